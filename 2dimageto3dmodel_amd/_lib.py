@@ -1,0 +1,65 @@
+"""ctypes binding of libm355.so (include/m355.h).  There is NO fallback: if the HIP extension is
+missing or a call fails, the op raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libm355.so")
+
+c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+
+class M355Error(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> (restype, argtypes); mirrors include/m355.h one to one (tests/test_abi.py checks both ways)
+_P = c_void_p
+SIGNATURES = {
+    "m355_last_error": (ctypes.c_char_p, []),
+    "m355_abi_version": (c_int, []),
+    "m355_proj_transform_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P]),
+    "m355_proj_transform_bwd": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, c_int, _P, c_int, c_int, c_float,
+                                        c_float, _P]),
+    "m355_smooth_taps": (c_int, [_P, c_int, c_int, _P, _P]),
+    "m355_proj_render_fwd": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "m355_proj_render_nparts": (c_int, [c_int]),
+    "m355_proj_render_bwd": (c_int, [_P, _P, _P, _P, c_int, _P, c_float, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "m355_sil_loss_ws_bytes": (c_size_t, [c_int, c_int]),
+    "m355_sil_loss_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise M355Error(
+                f"HIP extension {LIB_PATH} is missing -- build it with `python 2dimageto3dmodel_amd/build.py` "
+                "(there is no CPU/PyTorch fallback for the hot path)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().m355_last_error().decode("utf-8", "replace")
+        raise M355Error(f"{what} failed (status {rc}): {msg}")
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)"""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,192 @@
+"""torch.autograd bindings of the libm355 projection entry points (include/m355.h).
+
+Each Function's forward/backward launches HIP kernels on torch's current stream through ctypes; torch is
+used for device memory and stream plumbing only.  No op here has a CPU or PyTorch fallback.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream
+
+FIXED_WEIGHTS = 1
+TAPS_FROM_SIGMA = 2
+TRUE_GAUSSIAN = 4
+
+FOV = 1.875       # utils/effective_loss_function.py:69
+CAM_DIST = 2.0    # utils/effective_loss_function.py:70
+
+
+_TIMERS_ON = False
+_TIMER_EVENTS = []  # (name, start_event, end_event)
+
+
+def enable_kernel_timers(on):
+    """bench.py: bracket every libm355 launch with HIP events on the launch stream (torch's current stream)."""
+    global _TIMERS_ON
+    _TIMERS_ON = bool(on)
+    if on:
+        _TIMER_EVENTS.clear()
+
+
+def collect_kernel_timers():
+    """-> {entry point: (launches, total_ms)}; call after torch.cuda.synchronize()."""
+    out = {}
+    for name, e0, e1 in _TIMER_EVENTS:
+        c, t = out.get(name, (0, 0.0))
+        out[name] = (c + 1, t + e0.elapsed_time(e1))
+    _TIMER_EVENTS.clear()
+    return out
+
+
+def _launch(name, *args):
+    fn = getattr(lib(), "m355_" + name)
+    if _TIMERS_ON:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        _TIMER_EVENTS.append((name, e0, e1))
+    else:
+        rc = fn(*args)
+    check(rc, name)
+
+
+def _f32c(t, name):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.M355Error(f"{name} must be a CUDA(HIP) tensor; the hot path has no CPU implementation")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+class CameraTransform(torch.autograd.Function):
+    """CameraUtilities.transformation_3d_coord_to_camera_coord (camera/coordinate_system_transformation.py:20-39)."""
+
+    @staticmethod
+    def forward(ctx, pc, q, fov, dist):
+        pc, q = _f32c(pc.detach(), "point_cloud"), _f32c(q.detach(), "rotation")
+        B, N, _ = pc.shape
+        cam = torch.empty_like(pc)
+        _launch("proj_transform_fwd", ptr(pc), ptr(q), ptr(cam), None, B, N, 0, fov, dist, stream())
+        ctx.save_for_backward(pc, q)
+        ctx.fd = (fov, dist)
+        return cam
+
+    @staticmethod
+    def backward(ctx, dcam):
+        pc, q = ctx.saved_tensors
+        B, N, _ = pc.shape
+        dcam = _f32c(dcam, "grad")
+        dpc = torch.empty_like(pc)
+        dq = torch.empty_like(q)
+        _launch("proj_transform_bwd", ptr(pc), ptr(q), ptr(dcam), 1, 0, ptr(dpc), ptr(dq), None, 0, None, B, N,
+                                            ctx.fd[0], ctx.fd[1], stream())
+        return dpc, dq, None, None
+
+
+class ProjectSilhouette(torch.autograd.Function):
+    """EffectiveLossFunction.forward (utils/effective_loss_function.py:58-81), fused:
+    camera transform -> splat -> depth smoothing -> scale/clamp -> termination -> depth sum -> flip."""
+
+    @staticmethod
+    def forward(ctx, pc, q, scale, taps_or_sigma, ntaps, S, flags):
+        pc, q = _f32c(pc.detach(), "point_cloud"), _f32c(q.detach(), "rotation")
+        scale_shape = None if scale is None else tuple(scale.shape)
+        scale = None if scale is None else _f32c(scale.detach(), "scale").reshape(-1)
+        tp = _f32c(taps_or_sigma.detach(), "taps/sigma").reshape(-1)
+        B, N, _ = pc.shape
+        if q.shape[0] != B or (scale is not None and scale.numel() != B):
+            raise ValueError(f"batch mismatch: point_cloud {tuple(pc.shape)}, rotation {tuple(q.shape)}")
+        cam = torch.empty_like(pc)
+        key = torch.empty((B, N), dtype=torch.int32, device=pc.device)
+        proj = torch.empty((B, S, S), dtype=torch.float32, device=pc.device)
+        L, st = lib(), stream()
+        _launch("proj_transform_fwd", ptr(pc), ptr(q), ptr(cam), ptr(key), B, N, S, FOV, CAM_DIST, st)
+        _launch("proj_render_fwd", ptr(cam), ptr(key), ptr(scale), ptr(tp), ntaps, ptr(proj), B, N, S, flags, st)
+        ctx.save_for_backward(pc, q, cam, key, tp, *(() if scale is None else (scale,)))
+        ctx.cfg = (ntaps, S, flags, scale_shape)
+        return proj
+
+    @staticmethod
+    def backward(ctx, dproj):
+        return _project_backward(ctx, _f32c(dproj, "grad"), 1.0)
+
+
+def _project_backward(ctx, dproj, gmul):
+    ntaps, S, flags, scale_shape = ctx.cfg
+    has_scale = scale_shape is not None
+    if has_scale:
+        pc, q, cam, key, tp, scale = ctx.saved_tensors
+    else:
+        pc, q, cam, key, tp = ctx.saved_tensors
+        scale = None
+    B, N, _ = pc.shape
+    L, st = lib(), stream()
+    nparts = L.m355_proj_render_nparts(S)
+    slots = torch.empty((B, N, 4, 3), dtype=torch.float32, device=pc.device)
+    dsp = torch.empty((B, nparts), dtype=torch.float32, device=pc.device) if has_scale else None
+    _launch("proj_render_bwd", ptr(cam), ptr(key), ptr(scale), ptr(tp), ntaps, ptr(dproj), gmul, ptr(slots), ptr(dsp),
+                                 B, N, S, flags, st)
+    dpc = torch.empty_like(pc)
+    dq = torch.empty_like(q)
+    dscale = torch.empty((B,), dtype=torch.float32, device=pc.device) if has_scale else None
+    _launch("proj_transform_bwd", ptr(pc), ptr(q), ptr(slots), 4, 1, ptr(dpc), ptr(dq), ptr(dsp), nparts, ptr(dscale),
+                                    B, N, FOV, CAM_DIST, st)
+    return dpc, dq, (dscale.reshape(scale_shape) if has_scale else None), None, None, None, None
+
+
+class SilhouetteSSE(torch.autograd.Function):
+    """mask[B,2S,2S] -> bilinear 1/2 (align_corners) -> per-cloud and total squared error against proj[B,S,S]
+    (models/supervised_part.py:70-72, models/unsupervised_part.py:108-116).  Returns (total[1], sse[B])."""
+
+    @staticmethod
+    def forward(ctx, proj, mask, mask_repeat):
+        proj, mask = _f32c(proj.detach(), "projection"), _f32c(mask.detach(), "masks")
+        B, S, _ = proj.shape
+        if mask.dim() != 3 or mask.shape[0] * mask_repeat != B:
+            raise ValueError(f"masks {tuple(mask.shape)} x{mask_repeat} do not match projection {tuple(proj.shape)}")
+        Hin, Win = mask.shape[-2:]
+        L, st = lib(), stream()
+        diff = torch.empty_like(proj)
+        sse = torch.empty((B,), dtype=torch.float32, device=proj.device)
+        total = torch.empty((1,), dtype=torch.float32, device=proj.device)
+        ws = torch.empty((max(L.m355_sil_loss_ws_bytes(B, S), 8),), dtype=torch.uint8, device=proj.device)
+        _launch("sil_loss_fwd", ptr(proj), ptr(mask), Hin, Win, mask_repeat, ptr(diff), ptr(sse), ptr(total), ptr(ws), B, S, st)
+        ctx.save_for_backward(diff)
+        ctx.set_materialize_grads(False)
+        return total, sse
+
+    @staticmethod
+    def backward(ctx, gtotal, gsse):
+        (diff,) = ctx.saved_tensors
+        # d total/d proj = 2 diff ; d sse[b]/d proj[b] = 2 diff[b]
+        g = 2.0 * diff
+        out = None
+        if gtotal is not None:
+            out = g * gtotal.reshape(1, 1, 1)
+        if gsse is not None:
+            t = g * gsse.reshape(-1, 1, 1)
+            out = t if out is None else out + t
+        return out, None, None
+
+
+def camera_transform(pc, q, fov=FOV, dist=CAM_DIST):
+    return CameraTransform.apply(pc, q, float(fov), float(dist))
+
+
+def project_silhouette(pc, q, scale, taps_or_sigma, ntaps, S, flags):
+    return ProjectSilhouette.apply(pc, q, scale, taps_or_sigma, int(ntaps), int(S), int(flags))
+
+
+def silhouette_sse(proj, mask, mask_repeat=1):
+    return SilhouetteSSE.apply(proj, mask, int(mask_repeat))
+
+
+def smooth_taps(sigma, ntaps=21, true_gaussian=False):
+    """VoxelsSmooth.separate_kernels (utils/smooth_voxels.py:14-42) on device: sigma scalar tensor -> taps[ntaps]."""
+    sigma = _f32c(sigma.detach().reshape(-1), "sigma")
+    taps = torch.empty((ntaps,), dtype=torch.float32, device=sigma.device)
+    _launch("smooth_taps", ptr(sigma), ntaps, TRUE_GAUSSIAN if true_gaussian else 0, ptr(taps), stream())
+    return taps

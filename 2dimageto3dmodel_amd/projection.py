@@ -1,0 +1,110 @@
+"""Drop-in classes for the reference's point-cloud projection path, backed by libm355.
+
+Names, constructor arguments, forward signatures, buffers and return conventions follow the reference
+(file:line relative to /root/reference/code); keyword-only extras select the documented non-literal
+behaviours and default to the literal ones.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class CameraUtilities(object):
+    """camera/coordinate_system_transformation.py:16-39"""
+
+    def transformation_3d_coord_to_camera_coord(self, point_cloud, rotation, field_of_view, camera_view_distance):
+        return ops.camera_transform(point_cloud, rotation, field_of_view, camera_view_distance)
+
+
+class EffectiveLossFunction(nn.Module):
+    """utils/effective_loss_function.py:10-81.
+
+    forward(point_cloud[B,N,3], rotation[B,4], scale=None|[B,1]) -> silhouette [B,S,S].
+
+    Deviations from the file as committed, all documented in SURVEY.md section 8a ledger:
+      * D2 (shim S1): the smoothing kernels are built from the `sigma` buffer and `kernel_size`
+        (the reference passes kernels=() and raises);
+      * D6: `voxel_size` is honoured (the reference hard-wires 64); the default stays 64.
+    literal=True (default) keeps D3 (weights), D4 (inverted Gaussian) and D5 (depth-only smoothing).
+    """
+
+    def __init__(self, voxel_size=64, kernel_size=21, smooth_sigma=3.0, *, fixed_weights=False, true_gaussian=False):
+        super(EffectiveLossFunction, self).__init__()
+        self.voxel_size = voxel_size
+        self.kernel_size = kernel_size
+        self.register_buffer("sigma", torch.tensor(smooth_sigma))
+        self.fixed_weights = fixed_weights
+        self.true_gaussian = true_gaussian
+
+    def _flags(self):
+        f = ops.TAPS_FROM_SIGMA
+        if self.fixed_weights:
+            f |= ops.FIXED_WEIGHTS
+        if self.true_gaussian:
+            f |= ops.TRUE_GAUSSIAN
+        return f
+
+    def forward(self, point_cloud, rotation, scale=None):
+        sigma = self.sigma
+        if sigma.device != point_cloud.device or sigma.dtype != torch.float32:
+            sigma = sigma.to(device=point_cloud.device, dtype=torch.float32)
+        return ops.project_silhouette(point_cloud, rotation, scale, sigma, self.kernel_size, self.voxel_size,
+                                      self._flags())
+
+
+class SupervisedLoss(nn.Module):
+    """models/supervised_part.py:68-72: {"full_loss": sum((proj - bilinear_half(mask))^2) / (2B)}"""
+
+    def forward(self, projection, masks, **kwargs):
+        total, _ = ops.silhouette_sse(projection, masks)
+        return dict(full_loss=total.reshape(()) / (2 * projection.size(0)))
+
+
+def quaternion_multiplication(q1, q2):
+    """quaternions/operations.py:68-97 (tiny [.,4] tensors on the loss side; not a hot-path kernel)"""
+    a0, a1, a2, a3 = torch.unbind(q1, dim=-1)
+    b0, b1, b2, b3 = torch.unbind(q2, dim=-1)
+    return torch.stack([a0 * b0 - a1 * b1 - a2 * b2 - a3 * b3,
+                        a0 * b1 + a1 * b0 + a2 * b3 - a3 * b2,
+                        a0 * b2 + a2 * b0 + a3 * b1 - a1 * b3,
+                        a0 * b3 + a3 * b0 + a1 * b2 - a2 * b1], dim=-1)
+
+
+def quaternion_conjugate(q):
+    """quaternions/operations.py:120-136"""
+    return q * q.new_tensor([1.0, -1.0, -1.0, -1.0])
+
+
+class UnsupervisedLoss(nn.Module):
+    """models/unsupervised_part.py:90-143.  Defect D8 (`self.num_candidates` undefined) is restated with
+    `number_of_pose_predictor_candidates`, as SURVEY.md prescribes."""
+
+    def __init__(self, number_of_pose_predictor_candidates=4, student_weight=20.00):
+        super().__init__()
+        self.student_weight = student_weight
+        self.number_of_pose_predictor_candidates = number_of_pose_predictor_candidates
+        self.minimum_indexes = None
+
+    def forward(self, predictions, masks, training):
+        projection, *poses = predictions
+        K = self.number_of_pose_predictor_candidates
+        if not training:
+            total, _ = ops.silhouette_sse(projection, masks)
+            return dict(projection_loss=total.reshape(()) / projection.size(0))
+        ensemble_poses, student_poses = poses
+        # masks are repeated K times per element (unsup:113); the kernel indexes mask row b // K instead
+        _, sse = ops.silhouette_sse(projection, masks, mask_repeat=K)
+        projection_loss = sse.view(-1, K)
+        minimum_indexes = projection_loss.argmin(dim=-1).detach()
+        batch_indexes = torch.arange(minimum_indexes.size(0), device=minimum_indexes.device)
+        minimum_projection_loss = projection_loss[batch_indexes, minimum_indexes].sum() / minimum_indexes.size(0)
+        ensemble_poses = ensemble_poses.view(-1, K, 4)
+        best_poses = ensemble_poses[batch_indexes, minimum_indexes, :].detach()
+        poses_difference = torch.nn.functional.normalize(
+            quaternion_multiplication(best_poses, quaternion_conjugate(student_poses)), dim=-1)
+        angle_difference = poses_difference[:, 0]
+        student_loss = (1 - angle_difference ** 2).sum() / minimum_indexes.size(0)
+        self.minimum_indexes = minimum_indexes.detach()
+        total_loss = minimum_projection_loss + self.student_weight * student_loss
+        return dict(projection_loss=minimum_projection_loss, student_loss=student_loss, total_loss=total_loss)

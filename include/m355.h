@@ -1,0 +1,91 @@
+/*
+ * m355.h -- C-ABI of libm355.so, the MI355X (gfx950) hot path of 2dimageto3dmodel_amd.
+ *
+ * The reference (NikolaZubic/2dimageto3dmodel) is pure Python: its "FFI" for this path is the
+ * nn.Module / function surface listed in SURVEY.md section 8b.  Every entry point below replaces the
+ * body of one of those Python functions (file:line relative to /root/reference/code); the Python
+ * classes of the same name in 2dimageto3dmodel_amd/ bind them through ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative m355_status otherwise; m355_last_error()
+ *     returns a thread-local description.  Nothing throws across the boundary.
+ *   - no allocation, no ownership transfer: all pointers are caller-owned DEVICE pointers
+ *     (torch tensors' data_ptr()), fp32 contiguous unless stated; workspaces are sized by the
+ *     *_ws_bytes queries.
+ *   - asynchronous on the hipStream_t passed as `stream` (void* here so the header needs no HIP).
+ *   - re-entrant for distinct streams/devices; no global mutable state besides the error string.
+ */
+#ifndef M355_H
+#define M355_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    M355_OK = 0,
+    M355_ERR_BAD_ARG = -1,      /* null pointer / non-positive size / unsupported size */
+    M355_ERR_UNSUPPORTED = -2,  /* combination not handled by this kernel (caller picks another path) */
+    M355_ERR_LAUNCH = -3        /* HIP launch failure (message holds hipGetErrorString) */
+} m355_status;
+
+const char *m355_last_error(void);
+int m355_abi_version(void);
+
+/* flags for the projection entry points */
+#define M355_FIXED_WEIGHTS 1   /* w0 = 1-(g-floor g) instead of the literal 1-g-floor g (trilinear_interpolation.py:66) */
+#define M355_TAPS_FROM_SIGMA 2 /* `taps` points at the device scalar sigma; taps are built in-kernel (smooth_voxels.py:24-31) */
+#define M355_TRUE_GAUSSIAN 4   /* exp(-x^2/2s^2) instead of the literal exp(+x^2/2s^2) (smooth_voxels.py:29) */
+
+/* ---- P1+P2  CameraUtilities.transformation_3d_coord_to_camera_coord
+ *      camera/coordinate_system_transformation.py:20-39 (+ quaternions/points_quaternions.py:41-81,
+ *      quaternions/operations.py:68-97,120-136), fov 1.875, distance 2.0 passed explicitly.
+ *      pc[B,N,3], q[B,4] -> cam[B,N,3] in (z,y,x) order, bit-exact with the torch-CPU reference.
+ *      raykey (nullable, [B,N] int32): (floor g1 << 16 | floor g2) for grid side S, -1 when the point
+ *      fails the in-bounds test (trilinear_interpolation.py:24); consumed by m355_proj_render_*.  */
+int m355_proj_transform_fwd(const float *pc, const float *q, float *cam, int32_t *raykey, int B, int N, int S,
+                            float fov, float dist, void *stream);
+
+/*      backward: dcam[B,N,nslots,3] (slots summed in order) -> dpc[B,N,3], dq[B,4].
+ *      mask_oob != 0: points failing the in-bounds test get zero gradient and their slots are not read.
+ *      dscale_part[B,nparts] -> dscale[B] (deterministic second-stage reduce; both nullable). */
+int m355_proj_transform_bwd(const float *pc, const float *q, const float *dcam, int nslots, int mask_oob,
+                            float *dpc, float *dq, const float *dscale_part, int nparts, float *dscale, int B,
+                            int N, float fov, float dist, void *stream);
+
+/* ---- P4 taps  VoxelsSmooth.separate_kernels (utils/smooth_voxels.py:14-42): sigma (device scalar) -> taps[ntaps],
+ *      x = -ntaps//2+1 .. ntaps//2, exp(+x^2/(2 sigma^2)) / sum unless M355_TRUE_GAUSSIAN. */
+int m355_smooth_taps(const float *sigma, int ntaps, int flags, float *taps, void *stream);
+
+/* ---- P3..P6 fused  EffectiveLossFunction.forward  (utils/effective_loss_function.py:58-81 with shims S0/S1):
+ *      trilinear splat (utils/trilinear_interpolation.py:37-74) -> depth-axis smoothing
+ *      (utils/smooth_voxels.py:44-84, literal behaviour: only the last = depth kernel survives) ->
+ *      scale+clamp -> termination_probs (elf:18-56) -> sum over depth, flip y (elf:81).
+ *      The S^3 occupancy volume lives in LDS tiles only and never touches HBM.
+ *      cam[B,N,3] (from m355_proj_transform_fwd), raykey nullable, scale[B] nullable, taps[ntaps] (odd),
+ *      proj[B,S,S].  S <= 512. */
+int m355_proj_render_fwd(const float *cam, const int32_t *raykey, const float *scale, const float *taps, int ntaps,
+                         float *proj, int B, int N, int S, int flags, void *stream);
+
+/*      backward: dproj[B,S,S] * gmul -> dcam_slots[B,N,4,3] (one slot per ray (j,k) of the point, written
+ *      exactly once for in-bounds points), dscale_part[B,nparts] with nparts = m355_proj_render_nparts(S). */
+int m355_proj_render_nparts(int S);
+int m355_proj_render_bwd(const float *cam, const int32_t *raykey, const float *scale, const float *taps, int ntaps,
+                         const float *dproj, float gmul, float *dcam_slots, float *dscale_part, int B, int N, int S,
+                         int flags, void *stream);
+
+/* ---- P7/P8  SupervisedLoss.forward (models/supervised_part.py:68-72) and the per-cloud SSE used by
+ *      UnsupervisedLoss.forward (models/unsupervised_part.py:108-126):
+ *      mask[B/mask_repeat,Hin,Win] (row b/mask_repeat serves cloud b: batch_repetition.py:6-19)
+ *      -bilinear 1/2, align_corners- m[B,S,S]; diff = proj - m; sse[b] = sum diff^2;
+ *      total = sum_b sse[b].  ws >= m355_sil_loss_ws_bytes(B,S). */
+size_t m355_sil_loss_ws_bytes(int B, int S);
+int m355_sil_loss_fwd(const float *proj, const float *mask, int Hin, int Win, int mask_repeat, float *diff,
+                      float *sse, float *total, void *ws, int B, int S, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M355_H */
