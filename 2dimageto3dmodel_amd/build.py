@@ -24,6 +24,7 @@ SOURCES = [
     ("error.cpp", []),
     ("proj_transform.hip", STRICT),
     ("proj_render.hip", STRICT),
+    ("proj_render21.hip", STRICT),
     ("sil_loss.hip", STRICT),
 ]
 

@@ -26,6 +26,7 @@
 // the SAME fp32 values float(1 - o_j) promoted to fp64.  Agreement with the reference ~5e-7 relative per
 // pixel (its own fp32 rounding of L + log o), far inside the 1e-4 contract on the loss.
 #include "common.h"
+#include "proj_render21.h"
 
 namespace m355 {
 
@@ -448,7 +449,7 @@ struct TileCfg {
 
 static bool tile_cfg(int S, TileCfg &c)
 {
-    if (S <= 64) c = {1, 8, 16};
+    if (S <= 64) c = {1, 8, 8};  // same tile shapes as proj_render21.hip (nparts must agree)
     else if (S <= 128) c = {2, 8, 8};
     else if (S <= 256) c = {4, 4, 8};
     else if (S <= 512) c = {8, 4, 4};
@@ -468,7 +469,7 @@ static int launch_render(RenderArgs a, int B, hipStream_t st)
     a.tiles_y = (a.S + c.th - 1) / c.th;
     dim3 grid(a.tiles_x * a.tiles_y, B), block(kThreads);
     switch (c.R) {
-        case 1: hipLaunchKernelGGL((k_render<1, 8, 16, BWD>), grid, block, 0, st, a); break;
+        case 1: hipLaunchKernelGGL((k_render<1, 8, 8, BWD>), grid, block, 0, st, a); break;
         case 2: hipLaunchKernelGGL((k_render<2, 8, 8, BWD>), grid, block, 0, st, a); break;
         case 4: hipLaunchKernelGGL((k_render<4, 4, 8, BWD>), grid, block, 0, st, a); break;
         default: hipLaunchKernelGGL((k_render<8, 4, 4, BWD>), grid, block, 0, st, a); break;
@@ -504,6 +505,19 @@ extern "C" int m355_proj_render_fwd(const float *cam, const int32_t *raykey, con
                  ntaps, m355::kMaxTaps);
     M355_REQUIRE(B <= 65535, "proj_render_fwd: B=%d exceeds grid.y", B);
     if (B == 0) return M355_OK;
+    if (ntaps == 21 && !(flags & M355_TAPS_FROM_SIGMA)) {
+        m355::Render21Args r = {};
+        r.cam = cam;
+        r.raykey = raykey;
+        r.scale = scale;
+        r.taps = taps;
+        r.proj = proj;
+        r.empty_val = m355::render_empty_value(S);
+        r.N = N;
+        r.S = S;
+        r.fixed_weights = (flags & M355_FIXED_WEIGHTS) ? 1 : 0;
+        return m355::launch_render21<false>(r, B, (hipStream_t)stream);
+    }
     m355::RenderArgs a = {};
     a.cam = cam;
     a.raykey = raykey;
@@ -530,6 +544,21 @@ extern "C" int m355_proj_render_bwd(const float *cam, const int32_t *raykey, con
                  ntaps, m355::kMaxTaps);
     M355_REQUIRE(B <= 65535, "proj_render_bwd: B=%d exceeds grid.y", B);
     if (B == 0) return M355_OK;
+    if (ntaps == 21 && !(flags & M355_TAPS_FROM_SIGMA)) {
+        m355::Render21Args r = {};
+        r.cam = cam;
+        r.raykey = raykey;
+        r.scale = scale;
+        r.taps = taps;
+        r.dproj = dproj;
+        r.gmul = gmul;
+        r.dcam_slots = dcam_slots;
+        r.dscale_part = dscale_part;
+        r.N = N;
+        r.S = S;
+        r.fixed_weights = (flags & M355_FIXED_WEIGHTS) ? 1 : 0;
+        return m355::launch_render21<true>(r, B, (hipStream_t)stream);
+    }
     m355::RenderArgs a = {};
     a.cam = cam;
     a.raykey = raykey;

@@ -1,0 +1,27 @@
+// Interface between the C entry points (proj_render.hip) and the tuned 21-tap kernels (proj_render21.hip).
+#pragma once
+#include "common.h"
+
+namespace m355 {
+
+struct Render21Args {
+    const float *cam;
+    const int32_t *raykey;
+    const float *scale;  // nullable
+    const float *taps;   // NT taps, explicit
+    float *proj;         // fwd
+    const float *dproj;  // bwd
+    float gmul;
+    float *dcam_slots;   // bwd [B,N,4,3]
+    float *dscale_part;  // bwd [B,nparts]
+    int N, S, tiles_x, tiles_y;
+    int fixed_weights;
+    float empty_val;  // silhouette value of an untouched ray (render_empty_value(S))
+};
+
+template <bool BWD>
+int launch_render21(Render21Args a, int B, hipStream_t st);
+int render21_nparts(int S);
+float render_empty_value(int S);
+
+}  // namespace m355

@@ -103,6 +103,11 @@ class ProjectSilhouette(torch.autograd.Function):
         key = torch.empty((B, N), dtype=torch.int32, device=pc.device)
         proj = torch.empty((B, S, S), dtype=torch.float32, device=pc.device)
         L, st = lib(), stream()
+        if flags & TAPS_FROM_SIGMA:
+            # VoxelsSmooth.separate_kernels once per call (3 us) instead of once per workgroup inside the renderer
+            taps = torch.empty((ntaps,), dtype=torch.float32, device=pc.device)
+            _launch("smooth_taps", ptr(tp), ntaps, flags & TRUE_GAUSSIAN, ptr(taps), st)
+            tp, flags = taps, flags & ~(TAPS_FROM_SIGMA | TRUE_GAUSSIAN)
         _launch("proj_transform_fwd", ptr(pc), ptr(q), ptr(cam), ptr(key), B, N, S, FOV, CAM_DIST, st)
         _launch("proj_render_fwd", ptr(cam), ptr(key), ptr(scale), ptr(tp), ntaps, ptr(proj), B, N, S, flags, st)
         ctx.save_for_backward(pc, q, cam, key, tp, *(() if scale is None else (scale,)))
