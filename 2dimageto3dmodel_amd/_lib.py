@@ -20,12 +20,13 @@ _P = c_void_p
 SIGNATURES = {
     "m355_last_error": (ctypes.c_char_p, []),
     "m355_abi_version": (c_int, []),
-    "m355_proj_transform_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P]),
+    "m355_proj_transform_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, _P]),
+    "m355_proj_ntiles": (c_int, [c_int]),
+    "m355_proj_bin_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P]),
     "m355_proj_transform_bwd": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, c_int, _P, c_int, c_int, c_float,
                                         c_float, _P]),
     "m355_smooth_taps": (c_int, [_P, c_int, c_int, _P, _P]),
     "m355_proj_render_fwd": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
-    "m355_proj_render_nparts": (c_int, [c_int]),
     "m355_proj_render_bwd": (c_int, [_P, _P, _P, _P, c_int, _P, c_float, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "m355_sil_loss_ws_bytes": (c_size_t, [c_int, c_int]),
     "m355_sil_loss_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P]),

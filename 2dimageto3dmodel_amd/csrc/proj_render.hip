@@ -27,6 +27,7 @@
 // pixel (its own fp32 rounding of L + log o), far inside the 1e-4 contract on the loss.
 #include "common.h"
 #include "proj_render21.h"
+#include "tiles.h"
 
 namespace m355 {
 
@@ -70,9 +71,9 @@ __device__ __forceinline__ double wave_incl_sum_d(double x, int lane)
 }
 
 struct RenderArgs {
-    const float *cam;
-    const int32_t *raykey;
-    const float *scale;  // nullable
+    const int32_t *tile_start;  // [B, ntiles+1]   (m355_proj_bin_fwd)
+    const float *tile_pts;      // [B, 4N] float4 records (c0,c1,c2,n)
+    const float *scale;         // nullable
     const float *taps;
     int ntaps;
     float *proj;           // fwd
@@ -230,30 +231,15 @@ __global__ __launch_bounds__(kThreads) void k_render(RenderArgs a)
     }
     __syncthreads();
 
-    // ---- phase 2: splat.  Only points whose 2x2 ray footprint intersects the tile do any work.
-    const float *camb = a.cam + (size_t)b * N * 3;
-    const int32_t *keyb = a.raykey ? a.raykey + (size_t)b * N : nullptr;
-    for (int n = tid; n < N; n += kThreads) {
-        int f1, f2;
-        float c0, c1, c2;
-        if (keyb) {
-            const int key = keyb[n];
-            if (key < 0) continue;
-            f1 = key >> 16;
-            f2 = key & 0xffff;
-            if (f1 + 1 < y0 || f1 >= y0 + TH || f2 + 1 < x0 || f2 >= x0 + TW) continue;
-            c0 = camb[3 * n];
-            c1 = camb[3 * n + 1];
-            c2 = camb[3 * n + 2];
-        } else {
-            c0 = camb[3 * n];
-            c1 = camb[3 * n + 1];
-            c2 = camb[3 * n + 2];
-            if (!in_bounds3(c0, c1, c2)) continue;
-            f1 = (int)floorf(sm1 * (c1 + 0.5f));
-            f2 = (int)floorf(sm1 * (c2 + 0.5f));
-            if (f1 + 1 < y0 || f1 >= y0 + TH || f2 + 1 < x0 || f2 >= x0 + TW) continue;
-        }
+    // ---- phase 2: splat the records the binning kernel filed under this tile
+    const int ntiles = a.tiles_x * a.tiles_y;
+    const int *ts = a.tile_start + (size_t)b * (ntiles + 1) + blockIdx.x;
+    const int beg = ts[0], end = ts[1];
+    const float4 *pts = reinterpret_cast<const float4 *>(a.tile_pts) + (size_t)b * 4 * N;
+    for (int pi = beg + tid; pi < end; pi += kThreads) {
+        const float4 rec = pts[pi];
+        const float c0 = rec.x, c1 = rec.y, c2 = rec.z;
+        const int f1 = (int)floorf(sm1 * (c1 + 0.5f)), f2 = (int)floorf(sm1 * (c2 + 0.5f));
         const float g0 = sm1 * (c0 + 0.5f), g1 = sm1 * (c1 + 0.5f), g2 = sm1 * (c2 + 0.5f);  // tri:34
         const float fl0 = floorf(g0), fl1 = floorf(g1), fl2 = floorf(g2);
         const int f0 = (int)fl0;
@@ -379,27 +365,11 @@ __global__ __launch_bounds__(kThreads) void k_render(RenderArgs a)
     if (!any) return;
 
     // ---- phase 4: gather dV at the 8 corners of every point touching the tile
-    for (int n = tid; n < N; n += kThreads) {
-        int f1, f2;
-        float c0, c1, c2;
-        if (keyb) {
-            const int key = keyb[n];
-            if (key < 0) continue;
-            f1 = key >> 16;
-            f2 = key & 0xffff;
-            if (f1 + 1 < y0 || f1 >= y0 + TH || f2 + 1 < x0 || f2 >= x0 + TW) continue;
-            c0 = camb[3 * n];
-            c1 = camb[3 * n + 1];
-            c2 = camb[3 * n + 2];
-        } else {
-            c0 = camb[3 * n];
-            c1 = camb[3 * n + 1];
-            c2 = camb[3 * n + 2];
-            if (!in_bounds3(c0, c1, c2)) continue;
-            f1 = (int)floorf(sm1 * (c1 + 0.5f));
-            f2 = (int)floorf(sm1 * (c2 + 0.5f));
-            if (f1 + 1 < y0 || f1 >= y0 + TH || f2 + 1 < x0 || f2 >= x0 + TW) continue;
-        }
+    for (int pi = beg + tid; pi < end; pi += kThreads) {
+        const float4 rec = pts[pi];
+        const float c0 = rec.x, c1 = rec.y, c2 = rec.z;
+        const int n = __float_as_int(rec.w);
+        const int f1 = (int)floorf(sm1 * (c1 + 0.5f)), f2 = (int)floorf(sm1 * (c2 + 0.5f));
         const float g0 = sm1 * (c0 + 0.5f), g1 = sm1 * (c1 + 0.5f), g2 = sm1 * (c2 + 0.5f);
         const float fl0 = floorf(g0), fl1 = floorf(g1), fl2 = floorf(g2);
         const int f0 = (int)fl0;
@@ -443,32 +413,19 @@ __global__ __launch_bounds__(kThreads) void k_render(RenderArgs a)
     }
 }
 
-struct TileCfg {
-    int R, th, tw;
-};
-
-static bool tile_cfg(int S, TileCfg &c)
-{
-    if (S <= 64) c = {1, 8, 8};  // same tile shapes as proj_render21.hip (nparts must agree)
-    else if (S <= 128) c = {2, 8, 8};
-    else if (S <= 256) c = {4, 4, 8};
-    else if (S <= 512) c = {8, 4, 4};
-    else return false;
-    return true;
-}
-
 template <bool BWD>
 static int launch_render(RenderArgs a, int B, hipStream_t st)
 {
-    TileCfg c;
-    if (!tile_cfg(a.S, c)) {
+    TileShape c;
+    if (!tile_shape(a.S, c)) {
         set_error("proj_render: S=%d not supported by the fused kernel (max 512)", a.S);
         return M355_ERR_UNSUPPORTED;
     }
+    const int R = (a.S + 63) / 64 > 4 ? 8 : ((a.S + 63) / 64 > 2 ? 4 : (a.S + 63) / 64);
     a.tiles_x = (a.S + c.tw - 1) / c.tw;
     a.tiles_y = (a.S + c.th - 1) / c.th;
     dim3 grid(a.tiles_x * a.tiles_y, B), block(kThreads);
-    switch (c.R) {
+    switch (R) {
         case 1: hipLaunchKernelGGL((k_render<1, 8, 8, BWD>), grid, block, 0, st, a); break;
         case 2: hipLaunchKernelGGL((k_render<2, 8, 8, BWD>), grid, block, 0, st, a); break;
         case 4: hipLaunchKernelGGL((k_render<4, 4, 8, BWD>), grid, block, 0, st, a); break;
@@ -489,17 +446,11 @@ extern "C" int m355_smooth_taps(const float *sigma, int ntaps, int flags, float 
     return m355::check_launch("smooth_taps");
 }
 
-extern "C" int m355_proj_render_nparts(int S)
+extern "C" int m355_proj_render_fwd(const int32_t *tile_start, const float *tile_pts, const float *scale,
+                                    const float *taps, int ntaps, float *proj, int B, int N, int S, int flags,
+                                    void *stream)
 {
-    m355::TileCfg c;
-    if (!m355::tile_cfg(S, c)) return M355_ERR_UNSUPPORTED;
-    return ((S + c.tw - 1) / c.tw) * ((S + c.th - 1) / c.th);
-}
-
-extern "C" int m355_proj_render_fwd(const float *cam, const int32_t *raykey, const float *scale, const float *taps,
-                                    int ntaps, float *proj, int B, int N, int S, int flags, void *stream)
-{
-    M355_REQUIRE((cam || N == 0) && taps && proj, "proj_render_fwd: null pointer");
+    M355_REQUIRE(tile_start && (tile_pts || N == 0) && taps && proj, "proj_render_fwd: null pointer");
     M355_REQUIRE(B >= 0 && N >= 0 && S >= 2, "proj_render_fwd: bad size B=%d N=%d S=%d", B, N, S);
     M355_REQUIRE(ntaps >= 1 && ntaps <= m355::kMaxTaps && (ntaps & 1), "proj_render_fwd: ntaps=%d must be odd and <= %d",
                  ntaps, m355::kMaxTaps);
@@ -507,8 +458,8 @@ extern "C" int m355_proj_render_fwd(const float *cam, const int32_t *raykey, con
     if (B == 0) return M355_OK;
     if (ntaps == 21 && !(flags & M355_TAPS_FROM_SIGMA)) {
         m355::Render21Args r = {};
-        r.cam = cam;
-        r.raykey = raykey;
+        r.tile_start = tile_start;
+        r.tile_pts = tile_pts;
         r.scale = scale;
         r.taps = taps;
         r.proj = proj;
@@ -519,8 +470,8 @@ extern "C" int m355_proj_render_fwd(const float *cam, const int32_t *raykey, con
         return m355::launch_render21<false>(r, B, (hipStream_t)stream);
     }
     m355::RenderArgs a = {};
-    a.cam = cam;
-    a.raykey = raykey;
+    a.tile_start = tile_start;
+    a.tile_pts = tile_pts;
     a.scale = scale;
     a.taps = taps;
     a.ntaps = ntaps;
@@ -533,11 +484,11 @@ extern "C" int m355_proj_render_fwd(const float *cam, const int32_t *raykey, con
     return m355::launch_render<false>(a, B, (hipStream_t)stream);
 }
 
-extern "C" int m355_proj_render_bwd(const float *cam, const int32_t *raykey, const float *scale, const float *taps,
-                                    int ntaps, const float *dproj, float gmul, float *dcam_slots, float *dscale_part,
-                                    int B, int N, int S, int flags, void *stream)
+extern "C" int m355_proj_render_bwd(const int32_t *tile_start, const float *tile_pts, const float *scale,
+                                    const float *taps, int ntaps, const float *dproj, float gmul, float *dcam_slots,
+                                    float *dscale_part, int B, int N, int S, int flags, void *stream)
 {
-    M355_REQUIRE(((cam && dcam_slots) || N == 0) && taps && dproj, "proj_render_bwd: null pointer");
+    M355_REQUIRE(tile_start && ((tile_pts && dcam_slots) || N == 0) && taps && dproj, "proj_render_bwd: null pointer");
     M355_REQUIRE((scale == nullptr) == (dscale_part == nullptr), "proj_render_bwd: scale/dscale_part mismatch");
     M355_REQUIRE(B >= 0 && N >= 0 && S >= 2, "proj_render_bwd: bad size B=%d N=%d S=%d", B, N, S);
     M355_REQUIRE(ntaps >= 1 && ntaps <= m355::kMaxTaps && (ntaps & 1), "proj_render_bwd: ntaps=%d must be odd and <= %d",
@@ -546,8 +497,8 @@ extern "C" int m355_proj_render_bwd(const float *cam, const int32_t *raykey, con
     if (B == 0) return M355_OK;
     if (ntaps == 21 && !(flags & M355_TAPS_FROM_SIGMA)) {
         m355::Render21Args r = {};
-        r.cam = cam;
-        r.raykey = raykey;
+        r.tile_start = tile_start;
+        r.tile_pts = tile_pts;
         r.scale = scale;
         r.taps = taps;
         r.dproj = dproj;
@@ -560,8 +511,8 @@ extern "C" int m355_proj_render_bwd(const float *cam, const int32_t *raykey, con
         return m355::launch_render21<true>(r, B, (hipStream_t)stream);
     }
     m355::RenderArgs a = {};
-    a.cam = cam;
-    a.raykey = raykey;
+    a.tile_start = tile_start;
+    a.tile_pts = tile_pts;
     a.scale = scale;
     a.taps = taps;
     a.ntaps = ntaps;

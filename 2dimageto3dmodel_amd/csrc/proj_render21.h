@@ -5,8 +5,8 @@
 namespace m355 {
 
 struct Render21Args {
-    const float *cam;
-    const int32_t *raykey;
+    const int32_t *tile_start;  // [B, ntiles+1]   (m355_proj_bin_fwd)
+    const float *tile_pts;      // [B, 4N] float4 records (c0,c1,c2,n)
     const float *scale;  // nullable
     const float *taps;   // NT taps, explicit
     float *proj;         // fwd
@@ -21,7 +21,6 @@ struct Render21Args {
 
 template <bool BWD>
 int launch_render21(Render21Args a, int B, hipStream_t st);
-int render21_nparts(int S);
 float render_empty_value(int S);
 
 }  // namespace m355

@@ -17,6 +17,7 @@
 // exact fp64 recurrence (render_empty_value) and passes it in.
 #include "common.h"
 #include "proj_render21.h"
+#include "tiles.h"
 
 namespace m355 {
 
@@ -78,38 +79,15 @@ __device__ __forceinline__ double group_total(double x)
     return x;
 }
 
-// Scan the cloud's ray keys; for every point whose 2x2 ray footprint intersects the tile call f(n, f1, f2, c0,c1,c2).
-template <int TH, int TW, typename F>
-__device__ __forceinline__ void for_points_in_tile(const float *__restrict__ camb, const int32_t *__restrict__ keyb,
-                                                   int N, int y0, int x0, float sm1, int tid, F f)
+// Visit the records (c0,c1,c2,n) the binning kernel filed under this tile (proj_transform.hip k_bin).
+template <typename F>
+__device__ __forceinline__ void for_points_in_tile(const float4 *__restrict__ pts, int beg, int end, float sm1, int tid,
+                                                   F f)
 {
-    auto visit = [&](int n, int key) {
-        if (key < 0) return;
-        const int f1 = key >> 16, f2 = key & 0xffff;
-        if (f1 + 1 < y0 || f1 >= y0 + TH || f2 + 1 < x0 || f2 >= x0 + TW) return;
-        f(n, f1, f2, camb[3 * n], camb[3 * n + 1], camb[3 * n + 2]);
-    };
-    if (keyb) {
-        if ((N & 3) == 0) {  // rows are 16-byte aligned: 4 keys per load
-            const int4 *k4 = reinterpret_cast<const int4 *>(keyb);
-            for (int i = tid; i < N / 4; i += kThreads21) {
-                const int4 k = k4[i];
-                visit(4 * i, k.x);
-                visit(4 * i + 1, k.y);
-                visit(4 * i + 2, k.z);
-                visit(4 * i + 3, k.w);
-            }
-        } else {
-            for (int n = tid; n < N; n += kThreads21) visit(n, keyb[n]);
-        }
-    } else {
-        for (int n = tid; n < N; n += kThreads21) {
-            const float c0 = camb[3 * n], c1 = camb[3 * n + 1], c2 = camb[3 * n + 2];
-            if (!in_bounds3(c0, c1, c2)) continue;
-            const int f1 = (int)floorf(sm1 * (c1 + 0.5f)), f2 = (int)floorf(sm1 * (c2 + 0.5f));
-            if (f1 + 1 < y0 || f1 >= y0 + TH || f2 + 1 < x0 || f2 >= x0 + TW) continue;
-            f(n, f1, f2, c0, c1, c2);
-        }
+    for (int i = beg + tid; i < end; i += kThreads21) {
+        const float4 r = pts[i];
+        const int f1 = (int)floorf(sm1 * (r.y + 0.5f)), f2 = (int)floorf(sm1 * (r.z + 0.5f));
+        f(__float_as_int(r.w), f1, f2, r.x, r.y, r.z);
     }
 }
 
@@ -168,6 +146,23 @@ __global__ __launch_bounds__(kThreads21) void k_render21(Render21Args a)
     const float eps = 1e-5f, hi = (float)(1.0 - 1e-5);  // elf:18,32
     const double E = 1.0000100000500002;                 // exp(1e-5f): elf:40-41,48
 
+    // this tile's slice of the binned records; a tile nobody touches never looks at LDS
+    const int ntiles = a.tiles_x * a.tiles_y;
+    const int *ts = a.tile_start + (size_t)b * (ntiles + 1) + blockIdx.x;
+    const int beg = ts[0], end = ts[1];
+    const float4 *pts = reinterpret_cast<const float4 *>(a.tile_pts) + (size_t)b * 4 * N;
+    if (beg == end) {
+        if (BWD) {
+            if (tid == 0 && a.dscale_part) a.dscale_part[(size_t)b * ntiles + blockIdx.x] = 0.0f;
+        } else {
+            for (int r = tid; r < RAYS; r += kThreads21) {
+                const int yy = y0 + r / TW, xx = x0 + r % TW;
+                if (yy < S && xx < S) a.proj[((size_t)b * S + (S - 1 - yy)) * S + xx] = a.empty_val;
+            }
+        }
+        return;
+    }
+
     float tp[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) tp[t] = a.taps[t];
@@ -181,13 +176,8 @@ __global__ __launch_bounds__(kThreads21) void k_render21(Render21Args a)
     }
     __syncthreads();
 
-#if defined(M355_ABL) && M355_ABL == 2
-    return;
-#endif
     // ---- phase 2: splat (tri:37-60).  ds_add_f32 of (w_i*w_j)*w_k, evaluated left to right as tri:40-41
-    const float *camb = a.cam + (size_t)b * N * 3;
-    const int32_t *keyb = a.raykey ? a.raykey + (size_t)b * N : nullptr;
-    for_points_in_tile<TH, TW>(camb, keyb, N, y0, x0, sm1, tid, [&](int n, int f1, int f2, float c0, float c1, float c2) {
+    for_points_in_tile(pts, beg, end, sm1, tid, [&](int n, int f1, int f2, float c0, float c1, float c2) {
         const Corner k = corner_weights(c0, c1, c2, sm1, a.fixed_weights);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -207,9 +197,6 @@ __global__ __launch_bounds__(kThreads21) void k_render21(Render21Args a)
     });
     __syncthreads();
 
-#if defined(M355_ABL) && M355_ABL == 1
-    return;
-#endif
     // ---- phase 2.5: compact the touched rays (wave 0)
     if (wave == 0) {
         int count = 0;
@@ -224,10 +211,6 @@ __global__ __launch_bounds__(kThreads21) void k_render21(Render21Args a)
     }
     __syncthreads();
     const int ntouched = tcount;
-    if (BWD && ntouched == 0) {
-        if (tid == 0 && a.dscale_part) a.dscale_part[(size_t)b * (a.tiles_x * a.tiles_y) + blockIdx.x] = 0.0f;
-        return;
-    }
 
     // ---- phase 3: GPW rays per wave at a time, LPR lanes per ray, D depths per lane
     float ds_lane = 0.0f;
@@ -406,7 +389,7 @@ __global__ __launch_bounds__(kThreads21) void k_render21(Render21Args a)
     }
 
     // ---- phase 4: every point touching the tile gathers dV at its corners; one gradient slot per ray (j,k)
-    for_points_in_tile<TH, TW>(camb, keyb, N, y0, x0, sm1, tid, [&](int n, int f1, int f2, float c0, float c1, float c2) {
+    for_points_in_tile(pts, beg, end, sm1, tid, [&](int n, int f1, int f2, float c0, float c1, float c2) {
         const Corner k = corner_weights(c0, c1, c2, sm1, a.fixed_weights);
         const float dw[2] = {-1.0f, 1.0f};  // d w[0]/dg = -1, d w[1]/dg = +1 (floor has zero gradient)
 #pragma unroll
@@ -435,25 +418,11 @@ __global__ __launch_bounds__(kThreads21) void k_render21(Render21Args a)
     });
 }
 
-struct Tile21 {
-    int lpr, d, th, tw;
-};
-
-bool tile21_cfg(int S, Tile21 &c)
-{
-    if (S <= 64) c = {16, 4, 8, 8};
-    else if (S <= 128) c = {16, 8, 8, 8};
-    else if (S <= 256) c = {32, 8, 4, 8};
-    else if (S <= 512) c = {64, 8, 4, 4};
-    else return false;
-    return true;
-}
-
 template <bool BWD>
 int launch_render21(Render21Args a, int B, hipStream_t st)
 {
-    Tile21 c;
-    if (!tile21_cfg(a.S, c)) {
+    TileShape c;
+    if (!tile_shape(a.S, c)) {
         set_error("proj_render: S=%d not supported by the fused kernel (max 512)", a.S);
         return M355_ERR_UNSUPPORTED;
     }
@@ -484,13 +453,6 @@ float render_empty_value(int S)
         P *= (double)q;
     }
     return (float)sum;
-}
-
-int render21_nparts(int S)
-{
-    Tile21 c;
-    if (!tile21_cfg(S, c)) return M355_ERR_UNSUPPORTED;
-    return ((S + c.tw - 1) / c.tw) * ((S + c.th - 1) / c.th);
 }
 
 }  // namespace m355

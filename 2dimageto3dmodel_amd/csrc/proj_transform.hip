@@ -13,6 +13,7 @@
 //     sequential sum ((q0^2+q1^2)+q2^2)+q3^2.
 // Memory-bound and tiny (36 B/point): one thread per point, 12 B coalesced in, 12(+4) B out.
 #include "common.h"
+#include "tiles.h"
 
 namespace m355 {
 
@@ -49,45 +50,150 @@ __device__ __forceinline__ Quat normalize_quat(const float *q, float *norm_out)
     return r;
 }
 
+// one point through P1+P2; the reference's operation order, every op rounded (see header)
+__device__ __forceinline__ void transform_point(const Quat qn, const Quat qs, const float *__restrict__ p, float fov,
+                                                float dist, float &z_out, float &y_out, float &x_out)
+{
+    Quat p4;  // points_quaternions.py:33: pad -> (0, p0, p1, p2)
+    p4.w = 0.0f;
+    p4.x = p[0];
+    p4.y = p[1];
+    p4.z = p[2];
+    const Quat t = hamilton(qn, p4);  // points_quaternions.py:72-75
+    const Quat r = hamilton(t, qs);
+    const float z = r.x, y = r.y, x = r.z;  // cam:25  z,y,x = unbind(dim=2)
+    const float den = z + dist;
+    x_out = x * fov / den;  // cam:33
+    y_out = y * fov / den;  // cam:34
+    z_out = z;
+}
+
+__device__ __forceinline__ Quat conj_quat(const Quat qn)
+{
+    Quat qs;  // operations.py:131-136: q * (1,-1,-1,-1)
+    qs.w = qn.w * 1.0f;
+    qs.x = qn.x * -1.0f;
+    qs.y = qn.y * -1.0f;
+    qs.z = qn.z * -1.0f;
+    return qs;
+}
+
+// P1+P2 fused with the per-tile binning the renderer consumes.  One workgroup per cloud:
+//   pass 1: transform (or read) every point, count it into each tile its 2x2 ray footprint touches (LDS histogram)
+//   scan  : exclusive prefix over the tiles -> tile_start[b][0..ntiles]
+//   pass 2: scatter (c0,c1,c2,n) records into tile_pts[b][...] (<= 4N records)
+// The order of records inside a tile is whatever the LDS atomics produce; the renderer accumulates with LDS
+// atomics anyway.
+template <bool XFORM>
+__global__ __launch_bounds__(1024) void k_bin(const float *__restrict__ pc, const float *__restrict__ q,
+                                              float *__restrict__ cam, int32_t *__restrict__ raykey,
+                                              int *__restrict__ tile_start, float4 *__restrict__ tile_pts, int N, int S,
+                                              int TH, int TW, int tiles_x, int ntiles, float fov, float dist)
+{
+    extern __shared__ int cnt[];  // ntiles + 1
+    __shared__ int wave_tot[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float sm1 = (float)S - 1.0f;  // tri:34
+    for (int i = tid; i <= ntiles; i += 1024) cnt[i] = 0;
+    Quat qn = {1.f, 0.f, 0.f, 0.f}, qs = qn;
+    if (XFORM) {
+        float nrm;
+        qn = normalize_quat(q + 4 * b, &nrm);
+        qs = conj_quat(qn);
+    }
+    __syncthreads();
+    float *camb = cam + (size_t)b * N * 3;
+    auto tiles_of = [&](float c1, float c2, int (&t)[4]) -> int {
+        const int f1 = (int)floorf(sm1 * (c1 + 0.5f)), f2 = (int)floorf(sm1 * (c2 + 0.5f));
+        const int ty0 = f1 / TH, ty1 = (f1 + 1) / TH, tx0 = f2 / TW, tx1 = (f2 + 1) / TW;
+        int k = 0;
+        t[k++] = ty0 * tiles_x + tx0;
+        if (tx1 != tx0) t[k++] = ty0 * tiles_x + tx1;
+        if (ty1 != ty0) {
+            t[k++] = ty1 * tiles_x + tx0;
+            if (tx1 != tx0) t[k++] = ty1 * tiles_x + tx1;
+        }
+        return k;
+    };
+    for (int n = tid; n < N; n += 1024) {
+        float c0, c1, c2;
+        if (XFORM) {
+            transform_point(qn, qs, pc + ((size_t)b * N + n) * 3, fov, dist, c0, c1, c2);
+            camb[3 * n] = c0;
+            camb[3 * n + 1] = c1;
+            camb[3 * n + 2] = c2;
+        } else {
+            c0 = camb[3 * n];
+            c1 = camb[3 * n + 1];
+            c2 = camb[3 * n + 2];
+        }
+        const bool inb = in_bounds3(c0, c1, c2);
+        if (raykey) {
+            int32_t key = -1;
+            if (inb) key = ((int)floorf(sm1 * (c1 + 0.5f)) << 16) | (int)floorf(sm1 * (c2 + 0.5f));
+            raykey[(size_t)b * N + n] = key;
+        }
+        if (inb) {
+            int t[4];
+            const int k = tiles_of(c1, c2, t);
+            for (int i = 0; i < k; ++i) atomicAdd(&cnt[t[i]], 1);
+        }
+    }
+    __syncthreads();
+    // exclusive prefix over cnt[0..ntiles): each thread owns a chunk of consecutive tiles
+    const int chunk = (ntiles + 1023) / 1024;
+    const int lo = min(tid * chunk, ntiles), hi = min(lo + chunk, ntiles);
+    int local = 0;
+    for (int i = lo; i < hi; ++i) local += cnt[i];
+    int incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += y;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wave_tot[w];
+    int run = base + incl - local;
+    for (int i = lo; i < hi; ++i) {
+        const int c = cnt[i];
+        cnt[i] = run;
+        run += c;
+    }
+    if (tid == 1023) cnt[ntiles] = run;
+    __syncthreads();
+    int *ts = tile_start + (size_t)b * (ntiles + 1);
+    for (int i = tid; i <= ntiles; i += 1024) ts[i] = cnt[i];
+    __syncthreads();  // all starts published before the cursors move
+    float4 *pts = tile_pts + (size_t)b * 4 * N;
+    for (int n = tid; n < N; n += 1024) {
+        const float c0 = camb[3 * n], c1 = camb[3 * n + 1], c2 = camb[3 * n + 2];  // written by this thread above
+        if (!in_bounds3(c0, c1, c2)) continue;
+        int t[4];
+        const int k = tiles_of(c1, c2, t);
+        for (int i = 0; i < k; ++i) {
+            const int pos = atomicAdd(&cnt[t[i]], 1);
+            pts[pos] = make_float4(c0, c1, c2, __int_as_float(n));
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_transform_fwd(const float *__restrict__ pc, const float *__restrict__ q,
-                                                        float *__restrict__ cam, int32_t *__restrict__ raykey,
-                                                        int N, int S, float fov, float dist)
+                                                        float *__restrict__ cam, int N, float fov, float dist)
 {
     const int b = blockIdx.y;
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     float nrm;
     const Quat qn = normalize_quat(q + 4 * b, &nrm);
-    Quat qs;  // operations.py:131-136: q * (1,-1,-1,-1)
-    qs.w = qn.w * 1.0f;
-    qs.x = qn.x * -1.0f;
-    qs.y = qn.y * -1.0f;
-    qs.z = qn.z * -1.0f;
+    const Quat qs = conj_quat(qn);
     const size_t o = ((size_t)b * N + n) * 3;
-    Quat p4;  // points_quaternions.py:33: pad -> (0, p0, p1, p2)
-    p4.w = 0.0f;
-    p4.x = pc[o];
-    p4.y = pc[o + 1];
-    p4.z = pc[o + 2];
-    const Quat t = hamilton(qn, p4);  // points_quaternions.py:72-75
-    const Quat r = hamilton(t, qs);
-    const float z = r.x, y = r.y, x = r.z;  // cam:25  z,y,x = unbind(dim=2)
-    const float den = z + dist;
-    const float xo = x * fov / den;  // cam:33
-    const float yo = y * fov / den;  // cam:34
-    cam[o] = z;                      // cam:36-39 stack([z,y,x])
+    float z, yo, xo;
+    transform_point(qn, qs, pc + o, fov, dist, z, yo, xo);
+    cam[o] = z;  // cam:36-39 stack([z,y,x])
     cam[o + 1] = yo;
     cam[o + 2] = xo;
-    if (raykey) {
-        int32_t key = -1;
-        if (in_bounds3(z, yo, xo)) {
-            const float sm1 = (float)S - 1.0f;  // tri:34
-            const int f1 = (int)floorf(sm1 * (yo + 0.5f));
-            const int f2 = (int)floorf(sm1 * (xo + 0.5f));
-            key = (f1 << 16) | f2;
-        }
-        raykey[(size_t)b * N + n] = key;
-    }
 }
 
 // r = a (x) b ; dr -> da, db (accumulating)
@@ -192,19 +298,51 @@ __global__ __launch_bounds__(256) void k_transform_bwd(const float *__restrict__
 
 }  // namespace m355
 
-extern "C" int m355_proj_transform_fwd(const float *pc, const float *q, float *cam, int32_t *raykey, int B, int N,
-                                       int S, float fov, float dist, void *stream)
+extern "C" int m355_proj_transform_fwd(const float *pc, const float *q, float *cam, int B, int N, float fov, float dist,
+                                       void *stream)
 {
     M355_REQUIRE(B >= 0 && N >= 0, "proj_transform_fwd: negative size B=%d N=%d", B, N);
     if (B == 0 || N == 0) return M355_OK;  // empty cloud: nothing to write (pointers of empty tensors are null)
     M355_REQUIRE(pc && q && cam, "proj_transform_fwd: null pointer");
-    M355_REQUIRE(!raykey || (S >= 2 && S <= 32768), "proj_transform_fwd: raykey needs 2 <= S <= 32768 (S=%d)", S);
-    if (B == 0 || N == 0) return M355_OK;
     M355_REQUIRE(B <= 65535, "proj_transform_fwd: B=%d exceeds grid.y", B);
     dim3 grid((N + 255) / 256, B);
-    hipLaunchKernelGGL(m355::k_transform_fwd, grid, dim3(256), 0, (hipStream_t)stream, pc, q, cam, raykey, N, S, fov,
-                       dist);
+    hipLaunchKernelGGL(m355::k_transform_fwd, grid, dim3(256), 0, (hipStream_t)stream, pc, q, cam, N, fov, dist);
     return m355::check_launch("proj_transform_fwd");
+}
+
+extern "C" int m355_proj_ntiles(int S)
+{
+    const int n = m355::tile_count(S);
+    return n < 0 ? (int)M355_ERR_UNSUPPORTED : n;
+}
+
+extern "C" int m355_proj_bin_fwd(const float *pc, const float *q, float *cam, int32_t *raykey, int32_t *tile_start,
+                                 float *tile_pts, int B, int N, int S, float fov, float dist, void *stream)
+{
+    M355_REQUIRE(B >= 0 && N >= 0, "proj_bin_fwd: negative size B=%d N=%d", B, N);
+    m355::TileShape c;
+    if (!m355::tile_shape(S, c)) {
+        m355::set_error("proj_bin_fwd: S=%d not supported by the fused renderer (2..512)", S);
+        return M355_ERR_UNSUPPORTED;
+    }
+    if (B == 0) return M355_OK;
+    M355_REQUIRE(tile_start && (N == 0 || (cam && tile_pts)), "proj_bin_fwd: null pointer");
+    M355_REQUIRE(q == nullptr || pc != nullptr || N == 0, "proj_bin_fwd: q given without pc");
+    const int tiles_x = (S + c.tw - 1) / c.tw, ntiles = m355::tile_count(S);
+    const size_t lds = sizeof(int) * (size_t)(ntiles + 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (q) {  // transform + bin; q == NULL: cam is the input
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)m355::k_bin<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(m355::k_bin<true>, dim3(B), dim3(1024), lds, st, pc, q, cam, raykey, (int *)tile_start,
+                           (float4 *)tile_pts, N, S, c.th, c.tw, tiles_x, ntiles, fov, dist);
+    } else {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)m355::k_bin<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(m355::k_bin<false>, dim3(B), dim3(1024), lds, st, pc, q, cam, raykey, (int *)tile_start,
+                           (float4 *)tile_pts, N, S, c.th, c.tw, tiles_x, ntiles, fov, dist);
+    }
+    return m355::check_launch("proj_bin_fwd");
 }
 
 extern "C" int m355_proj_transform_bwd(const float *pc, const float *q, const float *dcam, int nslots, int mask_oob,

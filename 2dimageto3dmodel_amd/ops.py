@@ -69,7 +69,7 @@ class CameraTransform(torch.autograd.Function):
         pc, q = _f32c(pc.detach(), "point_cloud"), _f32c(q.detach(), "rotation")
         B, N, _ = pc.shape
         cam = torch.empty_like(pc)
-        _launch("proj_transform_fwd", ptr(pc), ptr(q), ptr(cam), None, B, N, 0, fov, dist, stream())
+        _launch("proj_transform_fwd", ptr(pc), ptr(q), ptr(cam), B, N, fov, dist, stream())
         ctx.save_for_backward(pc, q)
         ctx.fd = (fov, dist)
         return cam
@@ -99,18 +99,22 @@ class ProjectSilhouette(torch.autograd.Function):
         B, N, _ = pc.shape
         if q.shape[0] != B or (scale is not None and scale.numel() != B):
             raise ValueError(f"batch mismatch: point_cloud {tuple(pc.shape)}, rotation {tuple(q.shape)}")
-        cam = torch.empty_like(pc)
-        key = torch.empty((B, N), dtype=torch.int32, device=pc.device)
-        proj = torch.empty((B, S, S), dtype=torch.float32, device=pc.device)
         L, st = lib(), stream()
+        ntiles = L.m355_proj_ntiles(S)
+        if ntiles < 0:
+            raise _lib.M355Error(f"voxel_size={S} is not supported by the fused renderer (2..512)")
+        cam = torch.empty_like(pc)
+        tstart = torch.empty((B, ntiles + 1), dtype=torch.int32, device=pc.device)
+        tpts = torch.empty((B, 4 * N, 4), dtype=torch.float32, device=pc.device)
+        proj = torch.empty((B, S, S), dtype=torch.float32, device=pc.device)
         if flags & TAPS_FROM_SIGMA:
             # VoxelsSmooth.separate_kernels once per call (3 us) instead of once per workgroup inside the renderer
             taps = torch.empty((ntaps,), dtype=torch.float32, device=pc.device)
             _launch("smooth_taps", ptr(tp), ntaps, flags & TRUE_GAUSSIAN, ptr(taps), st)
             tp, flags = taps, flags & ~(TAPS_FROM_SIGMA | TRUE_GAUSSIAN)
-        _launch("proj_transform_fwd", ptr(pc), ptr(q), ptr(cam), ptr(key), B, N, S, FOV, CAM_DIST, st)
-        _launch("proj_render_fwd", ptr(cam), ptr(key), ptr(scale), ptr(tp), ntaps, ptr(proj), B, N, S, flags, st)
-        ctx.save_for_backward(pc, q, cam, key, tp, *(() if scale is None else (scale,)))
+        _launch("proj_bin_fwd", ptr(pc), ptr(q), ptr(cam), None, ptr(tstart), ptr(tpts), B, N, S, FOV, CAM_DIST, st)
+        _launch("proj_render_fwd", ptr(tstart), ptr(tpts), ptr(scale), ptr(tp), ntaps, ptr(proj), B, N, S, flags, st)
+        ctx.save_for_backward(pc, q, tstart, tpts, tp, *(() if scale is None else (scale,)))
         ctx.cfg = (ntaps, S, flags, scale_shape)
         return proj
 
@@ -123,16 +127,16 @@ def _project_backward(ctx, dproj, gmul):
     ntaps, S, flags, scale_shape = ctx.cfg
     has_scale = scale_shape is not None
     if has_scale:
-        pc, q, cam, key, tp, scale = ctx.saved_tensors
+        pc, q, tstart, tpts, tp, scale = ctx.saved_tensors
     else:
-        pc, q, cam, key, tp = ctx.saved_tensors
+        pc, q, tstart, tpts, tp = ctx.saved_tensors
         scale = None
     B, N, _ = pc.shape
     L, st = lib(), stream()
-    nparts = L.m355_proj_render_nparts(S)
+    nparts = L.m355_proj_ntiles(S)
     slots = torch.empty((B, N, 4, 3), dtype=torch.float32, device=pc.device)
     dsp = torch.empty((B, nparts), dtype=torch.float32, device=pc.device) if has_scale else None
-    _launch("proj_render_bwd", ptr(cam), ptr(key), ptr(scale), ptr(tp), ntaps, ptr(dproj), gmul, ptr(slots), ptr(dsp),
+    _launch("proj_render_bwd", ptr(tstart), ptr(tpts), ptr(scale), ptr(tp), ntaps, ptr(dproj), gmul, ptr(slots), ptr(dsp),
                                  B, N, S, flags, st)
     dpc = torch.empty_like(pc)
     dq = torch.empty_like(q)

@@ -41,12 +41,22 @@ int m355_abi_version(void);
 
 /* ---- P1+P2  CameraUtilities.transformation_3d_coord_to_camera_coord
  *      camera/coordinate_system_transformation.py:20-39 (+ quaternions/points_quaternions.py:41-81,
- *      quaternions/operations.py:68-97,120-136), fov 1.875, distance 2.0 passed explicitly.
- *      pc[B,N,3], q[B,4] -> cam[B,N,3] in (z,y,x) order, bit-exact with the torch-CPU reference.
- *      raykey (nullable, [B,N] int32): (floor g1 << 16 | floor g2) for grid side S, -1 when the point
- *      fails the in-bounds test (trilinear_interpolation.py:24); consumed by m355_proj_render_*.  */
-int m355_proj_transform_fwd(const float *pc, const float *q, float *cam, int32_t *raykey, int B, int N, int S,
-                            float fov, float dist, void *stream);
+ *      quaternions/operations.py:68-97,120-136); the reference passes fov 1.875, distance 2.0.
+ *      pc[B,N,3], q[B,4] -> cam[B,N,3] in (z,y,x) order, BIT-EXACT with the torch-CPU reference. */
+int m355_proj_transform_fwd(const float *pc, const float *q, float *cam, int B, int N, float fov, float dist,
+                            void *stream);
+
+/*      The same transform fused with the per-tile binning the fused renderer consumes (one launch).
+ *      A tile is a TH x TW block of rays (silhouette pixels); m355_proj_ntiles(S) tiles cover the S x S image.
+ *      pc/q both NULL: cam is an INPUT and only the binning runs.
+ *      raykey (nullable, [B,N] int32): (floor g1 << 16 | floor g2), or -1 when the point fails the in-bounds
+ *      test of trilinear_interpolation.py:24 -- the "index-exact bins" contract, exposed for the parity tests.
+ *      tile_start[B, ntiles+1] int32: exclusive prefix of the per-tile record counts.
+ *      tile_pts[B, 4N, 4] fp32: records (c0,c1,c2, bitcast(n)); a point is filed under every tile its 2x2 ray
+ *      footprint touches (1, 2 or 4 tiles). */
+int m355_proj_ntiles(int S);
+int m355_proj_bin_fwd(const float *pc, const float *q, float *cam, int32_t *raykey, int32_t *tile_start,
+                      float *tile_pts, int B, int N, int S, float fov, float dist, void *stream);
 
 /*      backward: dcam[B,N,nslots,3] (slots summed in order) -> dpc[B,N,3], dq[B,4].
  *      mask_oob != 0: points failing the in-bounds test get zero gradient and their slots are not read.
@@ -64,17 +74,16 @@ int m355_smooth_taps(const float *sigma, int ntaps, int flags, float *taps, void
  *      (utils/smooth_voxels.py:44-84, literal behaviour: only the last = depth kernel survives) ->
  *      scale+clamp -> termination_probs (elf:18-56) -> sum over depth, flip y (elf:81).
  *      The S^3 occupancy volume lives in LDS tiles only and never touches HBM.
- *      cam[B,N,3] (from m355_proj_transform_fwd), raykey nullable, scale[B] nullable, taps[ntaps] (odd),
- *      proj[B,S,S].  S <= 512. */
-int m355_proj_render_fwd(const float *cam, const int32_t *raykey, const float *scale, const float *taps, int ntaps,
-                         float *proj, int B, int N, int S, int flags, void *stream);
+ *      tile_start/tile_pts from m355_proj_bin_fwd, scale[B] nullable, taps[ntaps] (odd, <= 63; 21 takes the
+ *      tuned kernel), proj[B,S,S].  S <= 512. */
+int m355_proj_render_fwd(const int32_t *tile_start, const float *tile_pts, const float *scale, const float *taps,
+                         int ntaps, float *proj, int B, int N, int S, int flags, void *stream);
 
 /*      backward: dproj[B,S,S] * gmul -> dcam_slots[B,N,4,3] (one slot per ray (j,k) of the point, written
- *      exactly once for in-bounds points), dscale_part[B,nparts] with nparts = m355_proj_render_nparts(S). */
-int m355_proj_render_nparts(int S);
-int m355_proj_render_bwd(const float *cam, const int32_t *raykey, const float *scale, const float *taps, int ntaps,
-                         const float *dproj, float gmul, float *dcam_slots, float *dscale_part, int B, int N, int S,
-                         int flags, void *stream);
+ *      exactly once for in-bounds points, never for the others), dscale_part[B, m355_proj_ntiles(S)]. */
+int m355_proj_render_bwd(const int32_t *tile_start, const float *tile_pts, const float *scale, const float *taps,
+                         int ntaps, const float *dproj, float gmul, float *dcam_slots, float *dscale_part, int B,
+                         int N, int S, int flags, void *stream);
 
 /* ---- P7/P8  SupervisedLoss.forward (models/supervised_part.py:68-72) and the per-cloud SSE used by
  *      UnsupervisedLoss.forward (models/unsupervised_part.py:108-126):

@@ -16,6 +16,7 @@ pc = ((torch.rand(B, N, 3, generator=g) - 0.5) * 0.7).cuda()
 q = torch.randn(B, 4, generator=g).cuda()
 sc = torch.sigmoid(torch.randn(B, generator=g)).cuda()
 cam = torch.empty_like(pc); key = torch.empty(B, N, dtype=torch.int32, device="cuda")
+tstart = torch.empty(B, 257, dtype=torch.int32, device="cuda"); tpts = torch.empty(B, 4 * N, 4, device="cuda")
 proj = torch.empty(B, S, S, device="cuda"); dproj = torch.rand(B, S, S, device="cuda")
 slots = torch.empty(B, N, 4, 3, device="cuda"); dsp = torch.empty(B, 256, device="cuda")
 taps = torch.full((21,), 1 / 21.0, device="cuda")
@@ -23,12 +24,14 @@ P = ctypes.c_void_p
 for abl in [int(x) for x in sys.argv[1:]] or [0, 1, 2]:
     L = build(abl)
     st = P(torch.cuda.current_stream().cuda_stream)
-    L.m355_proj_transform_fwd(P(pc.data_ptr()), P(q.data_ptr()), P(cam.data_ptr()), P(key.data_ptr()), B, N, S, ctypes.c_float(1.875), ctypes.c_float(2.0), st)
+    def binf():
+        L.m355_proj_bin_fwd(P(pc.data_ptr()), P(q.data_ptr()), P(cam.data_ptr()), None, P(tstart.data_ptr()), P(tpts.data_ptr()), B, N, S, ctypes.c_float(1.875), ctypes.c_float(2.0), st)
+    binf()
     def fwd():
-        L.m355_proj_render_fwd(P(cam.data_ptr()), P(key.data_ptr()), P(sc.data_ptr()), P(taps.data_ptr()), 21, P(proj.data_ptr()), B, N, S, 0, st)
+        L.m355_proj_render_fwd(P(tstart.data_ptr()), P(tpts.data_ptr()), P(sc.data_ptr()), P(taps.data_ptr()), 21, P(proj.data_ptr()), B, N, S, 0, st)
     def bwd():
-        L.m355_proj_render_bwd(P(cam.data_ptr()), P(key.data_ptr()), P(sc.data_ptr()), P(taps.data_ptr()), 21, P(dproj.data_ptr()), ctypes.c_float(1.0), P(slots.data_ptr()), P(dsp.data_ptr()), B, N, S, 0, st)
-    for name, f in (("fwd", fwd), ("bwd", bwd)):
+        L.m355_proj_render_bwd(P(tstart.data_ptr()), P(tpts.data_ptr()), P(sc.data_ptr()), P(taps.data_ptr()), 21, P(dproj.data_ptr()), ctypes.c_float(1.0), P(slots.data_ptr()), P(dsp.data_ptr()), B, N, S, 0, st)
+    for name, f in (("bin", binf), ("fwd", fwd), ("bwd", bwd)):
         for _ in range(5): f()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -38,11 +38,11 @@ def test_ctypes_table_mirrors_header(pkg):
 def test_bad_arguments_report_errors_not_crashes(pkg):
     L = pkg._lib.lib()
     assert L.m355_abi_version() == 1
-    rc = L.m355_proj_transform_fwd(None, None, None, None, 1, 1, 0, 1.875, 2.0, None)
+    rc = L.m355_proj_transform_fwd(None, None, None, 1, 1, 1.875, 2.0, None)
     assert rc == -1 and b"null" in L.m355_last_error()
-    assert L.m355_proj_render_nparts(128) == 256
-    assert L.m355_proj_render_nparts(100000) == -2
-    rc = L.m355_proj_render_fwd(1, None, None, 1, 20, 1, 1, 1, 64, 0, None)  # even tap count
+    assert L.m355_proj_ntiles(128) == 256 and L.m355_proj_ntiles(64) == 64 and L.m355_proj_ntiles(512) == 16384
+    assert L.m355_proj_ntiles(100000) == -2
+    rc = L.m355_proj_render_fwd(1, 1, None, 1, 20, 1, 1, 1, 64, 0, None)  # even tap count
     assert rc == -1 and b"odd" in L.m355_last_error()
 
 

@@ -31,10 +31,34 @@ def test_camera_transform_bit_exact_and_bins(pkg, name):
     B, N, S = int(g["B"]), int(g["N"]), int(g["S"])
     pc, q = t(g["pc"]), t(g["q"])
     cam = torch.empty_like(pc)
+    cam2 = torch.empty_like(pc)
     key = torch.empty((B, N), dtype=torch.int32, device=DEV)
     L = pkg._lib.lib()
-    pkg._lib.check(L.m355_proj_transform_fwd(pc.data_ptr(), q.data_ptr(), cam.data_ptr(), key.data_ptr(), B, N, S,
-                                             1.875, 2.0, pkg._lib.stream()), "xform")
+    nt = L.m355_proj_ntiles(S)
+    tstart = torch.empty((B, nt + 1), dtype=torch.int32, device=DEV)
+    tpts = torch.empty((B, 4 * N, 4), dtype=torch.float32, device=DEV)
+    pkg._lib.check(L.m355_proj_bin_fwd(pc.data_ptr(), q.data_ptr(), cam.data_ptr(), key.data_ptr(), tstart.data_ptr(),
+                                       tpts.data_ptr(), B, N, S, 1.875, 2.0, pkg._lib.stream()), "bin")
+    pkg._lib.check(L.m355_proj_transform_fwd(pc.data_ptr(), q.data_ptr(), cam2.data_ptr(), B, N, 1.875, 2.0,
+                                             pkg._lib.stream()), "xform")
+    assert torch.equal(cam, cam2)
+    # every in-bounds point is filed under 1, 2 or 4 tiles; records carry its exact camera coordinates
+    ts, tp = tstart.cpu().numpy(), tpts.cpu().numpy()
+    assert (ts[:, 0] == 0).all() and (np.diff(ts, axis=1) >= 0).all()
+    th, tw = {32: (8, 8), 64: (8, 8), 128: (8, 8)}[S]
+    tiles_x = (S + tw - 1) // tw
+    for b in range(B):
+        rec = tp[b, : ts[b, -1]]
+        n = rec[:, 3].view(np.int32)
+        assert np.array_equal(rec[:, :3].view(np.uint32), g["cam"][b][n].view(np.uint32))
+        want = 0
+        for i in np.flatnonzero(g["inb"][b]):
+            f1, f2 = g["floor"][b, i, 1], g["floor"][b, i, 2]
+            tiles = {(y // th) * tiles_x + (x // tw) for y in (f1, f1 + 1) for x in (f2, f2 + 1)}
+            want += len(tiles)
+            for tl in tiles:
+                assert i in n[ts[b, tl]: ts[b, tl + 1]]
+        assert want == ts[b, -1]
     cam, key = cam.cpu().numpy(), key.cpu().numpy()
     assert np.array_equal(cam.view(np.uint32), g["cam"].view(np.uint32)), "camera coords must be bit-exact"
     inb = key >= 0
