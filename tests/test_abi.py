@@ -53,3 +53,17 @@ def test_hot_path_refuses_cpu_tensors(pkg):
     elf = pkg.EffectiveLossFunction()
     with pytest.raises(pkg._lib.M355Error):
         elf(torch.zeros(1, 4, 3), torch.ones(1, 4))
+
+
+def test_dropin_paths_resolve_to_the_hip_classes(pkg):
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path.insert(0, r'%s/2dimageto3dmodel_amd/dropin');"
+            "from utils.effective_loss_function import EffectiveLossFunction as E;"
+            "from models.supervised_part import SupervisedLoss;"
+            "from models.unsupervised_part import UnsupervisedLoss;"
+            "from camera.coordinate_system_transformation import CameraUtilities;"
+            "print(E.__module__)") % ROOT
+    out = subprocess.check_output([sys.executable, "-c", code]).decode()
+    assert "2dimageto3dmodel_amd.projection" in out
