@@ -30,7 +30,19 @@ SIGNATURES = {
     "m355_proj_render_bwd": (c_int, [_P, _P, _P, _P, c_int, _P, c_float, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "m355_sil_loss_ws_bytes": (c_size_t, [c_int, c_int]),
     "m355_sil_loss_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P]),
+    "m355_conv2d_out_hw": (c_int, [_P, _P, _P]),
+    "m355_conv2d_weight_elems": (c_size_t, [_P, c_int]),
+    "m355_conv2d_weight_prep": (c_int, [_P, _P, _P, _P, _P]),
+    "m355_conv2d_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P]),
+    "m355_conv2d_dgrad_ws_bytes": (c_size_t, [_P]),
+    "m355_conv2d_dgrad": (c_int, [_P, _P, _P, _P, _P, _P]),
 }
+
+
+class ConvDesc(ctypes.Structure):
+    """m355_conv_desc (include/m355.h)"""
+    _fields_ = [(n, c_int) for n in ("N", "H", "W", "Cin", "Cout", "kh", "kw", "stride", "pad_h", "pad_w",
+                                      "pad_w_mode", "upsample")]
 
 
 def lib():

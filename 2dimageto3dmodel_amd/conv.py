@@ -1,0 +1,70 @@
+"""Low-level bindings of the bf16 MFMA conv2d entry points (include/m355.h, csrc/conv_mfma.hip).
+
+Activations are NHWC bf16 tensors ([N,H,W,C] contiguous); weights are the fp32 [Cout,Cin,kh,kw] parameter,
+turned into bf16 GEMM views by `weight_prep`.  No fallback: CPU tensors raise."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check, lib, ptr, stream
+
+PAD_ZERO, PAD_REPLICATE, PAD_CIRCULAR = 0, 1, 2
+
+
+def _ceil(a, b):
+    return (a + b - 1) // b * b
+
+
+def make_desc(N, H, W, Cin, Cout, kh, kw, stride=1, pad_h=0, pad_w=0, pad_w_mode=PAD_ZERO, upsample=0):
+    return ConvDesc(N, H, W, Cin, Cout, kh, kw, stride, pad_h, pad_w, pad_w_mode, upsample)
+
+
+def out_hw(d):
+    ho, wo = ctypes.c_int(), ctypes.c_int()
+    check(lib().m355_conv2d_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), "conv2d_out_hw")
+    return ho.value, wo.value
+
+
+def _req(t, dtype, name):
+    if not t.is_cuda:
+        raise _lib.M355Error(f"{name} must be a CUDA(HIP) tensor; the conv path has no CPU implementation")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def weight_prep(d, w_oihw, want_dgrad=True):
+    w = _req(w_oihw.detach(), torch.float32, "weight")
+    L = lib()
+    wf = torch.empty((L.m355_conv2d_weight_elems(ctypes.byref(d), 0),), dtype=torch.bfloat16, device=w.device)
+    wd = None
+    if want_dgrad:
+        wd = torch.empty((L.m355_conv2d_weight_elems(ctypes.byref(d), 1),), dtype=torch.bfloat16, device=w.device)
+    check(L.m355_conv2d_weight_prep(ctypes.byref(d), ptr(w), ptr(wf), ptr(wd), stream()), "conv2d_weight_prep")
+    return wf, wd
+
+
+def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0):
+    x = _req(x, torch.bfloat16, "x")
+    assert tuple(x.shape) == (d.N, d.H, d.W, d.Cin), (tuple(x.shape), (d.N, d.H, d.W, d.Cin))
+    ho, wo = out_hw(d)
+    if out_f32_nchw:
+        y = torch.empty((d.N, d.Cout, ho, wo), dtype=torch.float32, device=x.device)
+    else:
+        y = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.bfloat16, device=x.device)
+    b = None if bias is None else _req(bias.detach(), torch.float32, "bias")
+    check(lib().m355_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(b), ptr(y), int(out_f32_nchw), float(slope),
+                                stream()), "conv2d_fwd")
+    return y
+
+
+def conv_dgrad(d, dy, w_dgrad):
+    dy = _req(dy, torch.bfloat16, "dy")
+    ho, wo = out_hw(d)
+    assert tuple(dy.shape) == (d.N, ho, wo, _ceil(d.Cout, 32)), tuple(dy.shape)
+    dx = torch.empty((d.N, d.H, d.W, d.Cin), dtype=torch.bfloat16, device=dy.device)
+    nws = lib().m355_conv2d_dgrad_ws_bytes(ctypes.byref(d))
+    ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device)
+    check(lib().m355_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(w_dgrad), ptr(dx), ptr(ws), stream()), "conv2d_dgrad")
+    return dx

@@ -1,0 +1,407 @@
+// G: conv2d of the GAN stacks as a bf16 MFMA implicit GEMM (fp32 accumulate) for gfx950.
+//
+// Replaces F.conv2d behind the nn.Conv2d layers of models/gan.py (ResBlockUp convs gan.py:294-302, heads
+// gan.py:359,364, TextureDiscriminator convs gan.py:163-177, MeshDiscriminator convs gan.py:57-65) together with
+// the pads the reference materialises before them (F.pad replicate gan.py:329, circpad rendering/utils.py:60-64)
+// and the nearest x2 upsample in front of a block (gan.py:319): all three are index arithmetic in the A-tile
+// loader here, no padded / upsampled tensor is ever written.
+//
+// GEMM view: M = N*Ho*Wo output pixels, Ncols = Cout, K = KH*KW*Cin ordered (kh,kw,ci).
+//   activations NHWC bf16 (K runs along the contiguous channel axis), weights [Cout_p][KH][KW][Cin] bf16.
+// Workgroup tile 256(M) x 64(N), K step 32; 4 waves, each 64x64 = 2x2 v_mfma_f32_32x32x16_bf16 accumulators.
+// A (gathered pixels) and B (weights) are staged global -> VGPR -> LDS (row pitch 80 B: ds_read_b128 fragment
+// reads are bank-conflict free), double buffered; loads of step s+1 are issued before the MFMAs of step s.
+//
+// The same kernel computes the data gradient: dgrad of a stride-1 conv is a forward conv of dy with flipped,
+// transposed weights; dgrad of a stride-2 conv splits into 4 output-parity classes, each a 2x2 forward conv
+// written with output stride 2 (k_weight_prep builds those weight views).  Gradients are produced in the padded
+// (and upsampled) input frame and folded back by k_fold_pad (W pad mode, H crop, 2x2 upsample sum).
+#include <hip/hip_bf16.h>
+
+#include "common.h"
+
+namespace m355 {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;  // 8 bf16 = one 16-byte granule
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int BM = 256, BN = 64, BK = 32;
+constexpr int LDP = BK + 8;  // LDS row pitch in bf16 (80 bytes)
+
+struct ConvArgs {
+    const unsigned short *x;  // bf16 NHWC [N,H,W,Cin]
+    const unsigned short *w;  // bf16 [Cout_p][KH][KW][Cin]
+    const float *bias;        // [Cout] or null
+    void *y;
+    int N, H, W, Cin;    // stored input
+    int Hl, Wl;          // logical input extent seen by the taps (after the optional x2 upsample)
+    int ups;             // 0/1: logical (h,w) reads stored (h>>ups, w>>ups)
+    int Ho, Wo, Cout;    // GEMM pixel grid, real output channels
+    int KH, KW, stride, pad_h, pad_w, pad_w_mode;  // W mode 0 zero, 1 replicate, 2 circular; H always zero
+    int OH, OW;          // physical output extent
+    int oy_mul, oy_off, ox_mul, ox_off;  // physical (oh,ow) = (ho*oy_mul+oy_off, wo*ox_mul+ox_off)
+    int y_f32_nchw;      // 0: bf16 NHWC with channel stride Cs; 1: fp32 NCHW
+    int Cs;
+    float slope;         // epilogue LeakyReLU slope (1 = identity)
+};
+
+__device__ __forceinline__ unsigned short f2bf(float f)
+{
+    // round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+
+__global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][BM * LDP];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BN * LDP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int M = a.N * a.Ho * a.Wo;
+    const int kg = tid & 3;  // which 8-channel granule of the 32-wide K step this thread stages
+
+    // ---- the 4 A rows (pixels) this thread stages: rows (tid>>2) + 64*i
+    int hi0[4], wi0[4];
+    const unsigned short *xb[4];
+    bool rok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + (tid >> 2) + 64 * i;
+        rok[i] = m < M;
+        const int mm = rok[i] ? m : 0;
+        const int n = mm / (a.Ho * a.Wo), r = mm - n * (a.Ho * a.Wo);
+        const int ho = r / a.Wo, wo = r - ho * a.Wo;
+        hi0[i] = ho * a.stride - a.pad_h;
+        wi0[i] = wo * a.stride - a.pad_w;
+        xb[i] = a.x + (size_t)n * a.H * a.W * a.Cin;
+    }
+    // B row (output channel) this thread stages
+    const unsigned short *wb = a.w + (size_t)(n0 + (tid >> 2)) * a.KH * a.KW * a.Cin + kg * 8;
+
+    const int csteps = a.Cin / BK;
+    const int nsteps = a.KH * a.KW * csteps;
+
+    bf16x8 ra[4], rb;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    auto load_step = [&](int s) {
+        const int tap = s / csteps, c0 = (s - tap * csteps) * BK;
+        const int kh = tap / a.KW, kw = tap - kh * a.KW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int hi = hi0[i] + kh;
+            int wi = wi0[i] + kw;
+            bool ok = rok[i] && hi >= 0 && hi < a.Hl;
+            if (a.pad_w_mode == 1) wi = min(max(wi, 0), a.Wl - 1);               // replicate (gan.py:329)
+            else if (a.pad_w_mode == 2) wi = wi < 0 ? wi + a.Wl : (wi >= a.Wl ? wi - a.Wl : wi);  // circpad
+            else ok = ok && wi >= 0 && wi < a.Wl;
+            const unsigned short *p = xb[i] + ((size_t)(hi >> a.ups) * a.W + (wi >> a.ups)) * a.Cin + c0 + kg * 8;
+            ra[i] = ok ? *reinterpret_cast<const bf16x8 *>(p) : zero8;
+        }
+        rb = *reinterpret_cast<const bf16x8 *>(wb + (size_t)tap * a.Cin + c0);
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<bf16x8 *>(&As[buf][((tid >> 2) + 64 * i) * LDP + kg * 8]) = ra[i];
+        *reinterpret_cast<bf16x8 *>(&Bs[buf][(tid >> 2) * LDP + kg * 8]) = rb;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) load_step(s + 1);  // global loads in flight under the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 16) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(&As[buf][(wave * 64 + frow) * LDP + kk + fk]);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(&As[buf][(wave * 64 + 32 + frow) * LDP + kk + fk]);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(&Bs[buf][frow * LDP + kk + fk]);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(&Bs[buf][(32 + frow) * LDP + kk + fk]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (s + 1 < nsteps) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wave * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m >= M) continue;
+            const int n = m / (a.Ho * a.Wo), rr = m - n * (a.Ho * a.Wo);
+            const int ho = rr / a.Wo, wo = rr - ho * a.Wo;
+            const int oh = ho * a.oy_mul + a.oy_off, ow = wo * a.ox_mul + a.ox_off;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int co = n0 + 32 * j + (lane & 31);
+                if (co >= a.Cout) continue;
+                float v = acc[i][j][r];
+                if (a.bias) v += a.bias[co];
+                v = v >= 0.0f ? v : v * a.slope;
+                if (a.y_f32_nchw)
+                    reinterpret_cast<float *>(a.y)[(((size_t)n * a.Cout + co) * a.OH + oh) * a.OW + ow] = v;
+                else
+                    reinterpret_cast<unsigned short *>(a.y)[(((size_t)n * a.OH + oh) * a.OW + ow) * a.Cs + co] = f2bf(v);
+            }
+        }
+    }
+}
+
+// ---- weights: fp32 torch layout [O][I][KH][KW]  ->  bf16 [Op][A][B][Ip] views used by the GEMMs
+//   transpose == 0:  out[o][a][b][i] = in[o][i][th0+ths*a][tw0+tws*b]        (forward)
+//   transpose == 1:  out[i][a][b][o] = in[o][i][th0+ths*a][tw0+tws*b]        (dgrad: flipped taps, swapped roles)
+// rows/channels beyond the real extents are zero filled.
+__global__ void k_weight_prep(const float *__restrict__ in, unsigned short *__restrict__ out, int O, int I, int KH,
+                              int KW, int transpose, int A, int B, int th0, int ths, int tw0, int tws, int Rp, int Cp)
+{
+    // out is [Rp][A][B][Cp]; R = transpose ? I : O, C = transpose ? O : I
+    const size_t total = (size_t)Rp * A * B * Cp;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = idx % Cp;
+        size_t t = idx / Cp;
+        const int b = t % B;
+        t /= B;
+        const int aa = t % A;
+        const int r = t / A;
+        const int o = transpose ? c : r, i = transpose ? r : c;
+        float v = 0.0f;
+        if (o < O && i < I) v = in[(((size_t)o * I + i) * KH + (th0 + ths * aa)) * KW + (tw0 + tws * b)];
+        out[idx] = f2bf(v);
+    }
+}
+
+// ---- fold a gradient given in the padded/upsampled input frame back onto the stored input:
+//   g[N, Hl(+0), Wl+2*pw, C] (W padded per mode; H already cropped to the logical rows)  ->  dx[N,H,W,C]
+//   sums the pad columns into their source columns and the 2x2 replicas of the nearest upsample.
+__global__ void k_fold_pad(const unsigned short *__restrict__ g, unsigned short *__restrict__ dx, int N, int H, int W,
+                           int C, int ups, int pw, int mode, int Hg, int hoff)
+{
+    const int Wl = W << ups, Wp = Wl + 2 * pw;
+    const size_t total = (size_t)N * H * W * C;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = idx % C;
+        size_t t = idx / C;
+        const int w = t % W;
+        t /= W;
+        const int h = t % H;
+        const int n = t / H;
+        float s = 0.0f;
+        for (int dy = 0; dy <= ups; ++dy)
+            for (int dxx = 0; dxx <= ups; ++dxx) {
+                const int hl = (h << ups) + dy, wl = (w << ups) + dxx;
+                const unsigned short *row = g + (((size_t)n * Hg + hl + hoff) * Wp) * C + c;
+                s += bf2f(row[(size_t)(wl + pw) * C]);
+                if (mode == 1) {  // replicate: all left pads read column 0, all right pads column Wl-1
+                    if (wl == 0)
+                        for (int p = 0; p < pw; ++p) s += bf2f(row[(size_t)p * C]);
+                    if (wl == Wl - 1)
+                        for (int p = 0; p < pw; ++p) s += bf2f(row[(size_t)(Wl + pw + p) * C]);
+                } else if (mode == 2) {  // circular: pad column p <-> source Wl-pw+p (left), Wl+pw+p <-> p (right)
+                    if (wl >= Wl - pw) s += bf2f(row[(size_t)(wl - (Wl - pw)) * C]);
+                    if (wl < pw) s += bf2f(row[(size_t)(Wl + pw + wl) * C]);
+                }
+            }
+        dx[idx] = f2bf(s);
+    }
+}
+
+static int launch_conv(const ConvArgs &a, int Cout_p, hipStream_t st)
+{
+    const int M = a.N * a.Ho * a.Wo;
+    dim3 grid((M + BM - 1) / BM, Cout_p / BN);
+    hipLaunchKernelGGL(k_conv_mfma, grid, dim3(256), 0, st, a);
+    return check_launch("conv2d");
+}
+
+}  // namespace m355
+
+using m355::ConvArgs;
+
+static int conv_out_hw(const m355_conv_desc *d, int *Ho, int *Wo)
+{
+    const int Hl = d->H << d->upsample, Wl = d->W << d->upsample;
+    *Ho = (Hl + 2 * d->pad_h - d->kh) / d->stride + 1;
+    *Wo = (Wl + 2 * d->pad_w - d->kw) / d->stride + 1;
+    return (*Ho > 0 && *Wo > 0) ? 0 : -1;
+}
+
+static int check_desc(const m355_conv_desc *d, const char *who)
+{
+    M355_REQUIRE(d, "%s: null descriptor", who);
+    M355_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "%s: non-positive size", who);
+    M355_REQUIRE(d->Cin % 32 == 0, "%s: Cin=%d must be a multiple of 32 (pad the channels)", who, d->Cin);
+    M355_REQUIRE(d->stride == 1 || d->stride == 2, "%s: stride %d", who, d->stride);
+    M355_REQUIRE(d->upsample == 0 || d->upsample == 1, "%s: upsample %d", who, d->upsample);
+    M355_REQUIRE(d->pad_w_mode >= 0 && d->pad_w_mode <= 2, "%s: pad_w_mode %d", who, d->pad_w_mode);
+    M355_REQUIRE(d->kh >= 1 && d->kw >= 1 && d->kh <= 7 && d->kw <= 7, "%s: kernel %dx%d", who, d->kh, d->kw);
+    int Ho, Wo;
+    M355_REQUIRE(conv_out_hw(d, &Ho, &Wo) == 0, "%s: empty output", who);
+    return 0;
+}
+
+extern "C" int m355_conv2d_out_hw(const m355_conv_desc *d, int *Ho, int *Wo)
+{
+    M355_REQUIRE(d && Ho && Wo, "conv2d_out_hw: null pointer");
+    return conv_out_hw(d, Ho, Wo) == 0 ? M355_OK : M355_ERR_BAD_ARG;
+}
+
+extern "C" size_t m355_conv2d_weight_elems(const m355_conv_desc *d, int which)
+{
+    // which 0: forward view [ceil64(Cout)][kh][kw][Cin]; 1: dgrad views (stride 1: one [ceil64(Cin)][kh][kw][Cout_p32];
+    // stride 2: four [ceil64(Cin)][kh/2][kw/2][Cout_p32])
+    if (!d) return 0;
+    const size_t cout64 = (size_t)((d->Cout + 63) / 64) * 64, cin64 = (size_t)((d->Cin + 63) / 64) * 64;
+    const size_t cout32 = (size_t)((d->Cout + 31) / 32) * 32;
+    if (which == 0) return cout64 * d->kh * d->kw * d->Cin;
+    return cin64 * d->kh * d->kw * cout32;  // the 4 stride-2 views together cover kh*kw taps
+}
+
+extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_oihw, void *w_fwd, void *w_dgrad,
+                                       void *stream)
+{
+    if (int rc = check_desc(d, "conv2d_weight_prep")) return rc;
+    M355_REQUIRE(w_oihw && (w_fwd || w_dgrad), "conv2d_weight_prep: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int cout64 = (d->Cout + 63) / 64 * 64, cin64 = (d->Cin + 63) / 64 * 64, cout32 = (d->Cout + 31) / 32 * 32;
+    if (w_fwd) {
+        const size_t total = (size_t)cout64 * d->kh * d->kw * d->Cin;
+        hipLaunchKernelGGL(m355::k_weight_prep, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),
+                           dim3(256), 0, st, w_oihw, (unsigned short *)w_fwd, d->Cout, d->Cin, d->kh, d->kw, 0, d->kh,
+                           d->kw, 0, 1, 0, 1, cout64, d->Cin);
+    }
+    if (w_dgrad) {
+        if (d->stride == 1) {
+            const size_t total = (size_t)cin64 * d->kh * d->kw * cout32;
+            hipLaunchKernelGGL(m355::k_weight_prep, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),
+                               dim3(256), 0, st, w_oihw, (unsigned short *)w_dgrad, d->Cout, d->Cin, d->kh, d->kw, 1,
+                               d->kh, d->kw, d->kh - 1, -1, d->kw - 1, -1, cin64, cout32);
+        } else {
+            M355_REQUIRE(d->kh % 2 == 0 && d->kw % 2 == 0, "conv2d_weight_prep: stride-2 dgrad needs even kernels");
+            const int A = d->kh / 2, B = d->kw / 2;
+            const size_t each = (size_t)cin64 * A * B * cout32;
+            for (int py = 0; py < 2; ++py)
+                for (int px = 0; px < 2; ++px)
+                    hipLaunchKernelGGL(m355::k_weight_prep, dim3((unsigned)((each + 255) / 256 > 4096 ? 4096 : (each + 255) / 256)),
+                                       dim3(256), 0, st, w_oihw, (unsigned short *)w_dgrad + (size_t)(py * 2 + px) * each,
+                                       d->Cout, d->Cin, d->kh, d->kw, 1, A, B, py + 2 * (A - 1), -2, px + 2 * (B - 1), -2,
+                                       cin64, cout32);
+        }
+    }
+    return m355::check_launch("conv2d_weight_prep");
+}
+
+extern "C" int m355_conv2d_fwd(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
+                               int y_f32_nchw, float lrelu_slope, void *stream)
+{
+    if (int rc = check_desc(d, "conv2d_fwd")) return rc;
+    M355_REQUIRE(x && w_fwd && y, "conv2d_fwd: null pointer");
+    ConvArgs a = {};
+    a.x = (const unsigned short *)x;
+    a.w = (const unsigned short *)w_fwd;
+    a.bias = bias;
+    a.y = y;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin;
+    a.ups = d->upsample;
+    a.Hl = d->H << d->upsample; a.Wl = d->W << d->upsample;
+    conv_out_hw(d, &a.Ho, &a.Wo);
+    a.Cout = d->Cout;
+    a.KH = d->kh; a.KW = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
+    a.pad_w_mode = d->pad_w_mode;
+    a.OH = a.Ho; a.OW = a.Wo; a.oy_mul = 1; a.ox_mul = 1; a.oy_off = 0; a.ox_off = 0;
+    a.y_f32_nchw = y_f32_nchw; a.Cs = d->Cout;
+    a.slope = lrelu_slope;
+    return m355::launch_conv(a, (d->Cout + 63) / 64 * 64, (hipStream_t)stream);
+}
+
+// dy[N,Ho,Wo,Cout_p32] bf16 (channel stride = ceil32(Cout), padding channels zero) -> dx[N,H,W,Cin] bf16.
+// ws >= m355_conv2d_dgrad_ws_bytes(d): the gradient in the padded / upsampled frame before folding.
+extern "C" size_t m355_conv2d_dgrad_ws_bytes(const m355_conv_desc *d)
+{
+    if (!d) return 0;
+    const size_t Hl = (size_t)d->H << d->upsample, Wl = (size_t)d->W << d->upsample;
+    return (size_t)d->N * (Hl + 2 * d->pad_h) * (Wl + 2 * d->pad_w) * d->Cin * 2;
+}
+
+extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, void *ws,
+                                 void *stream)
+{
+    if (int rc = check_desc(d, "conv2d_dgrad")) return rc;
+    M355_REQUIRE(dy && w_dgrad && dx, "conv2d_dgrad: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    int Ho, Wo;
+    conv_out_hw(d, &Ho, &Wo);
+    const int Hl = d->H << d->upsample, Wl = d->W << d->upsample;
+    const int cout32 = (d->Cout + 31) / 32 * 32, cin64 = (d->Cin + 63) / 64 * 64;
+    const bool need_fold = d->upsample || (d->pad_w_mode != 0 && d->pad_w > 0) || d->stride == 2;
+    M355_REQUIRE(!need_fold || ws, "conv2d_dgrad: workspace required");
+    // gradient frame: rows = logical rows only for stride 1 (H pad cropped via pad_h'), all padded rows for stride 2
+    ConvArgs a = {};
+    a.x = (const unsigned short *)dy;
+    a.N = d->N; a.H = Ho; a.W = Wo; a.Cin = cout32; a.Hl = Ho; a.Wl = Wo; a.ups = 0;
+    a.Cout = d->Cin; a.pad_w_mode = 0; a.stride = 1;
+    a.y_f32_nchw = 0; a.Cs = d->Cin; a.slope = 1.0f;
+    int rc = 0;
+    if (d->stride == 1) {
+        const int pw_keep = need_fold ? d->pad_w : 0;  // keep W pad columns in the frame only if they must be folded
+        a.w = (const unsigned short *)w_dgrad;
+        a.KH = d->kh; a.KW = d->kw;
+        a.pad_h = d->kh - 1 - d->pad_h;
+        a.pad_w = d->kw - 1 - (d->pad_w - pw_keep);
+        a.Ho = Hl; a.Wo = Wl + 2 * pw_keep;
+        a.OH = a.Ho; a.OW = a.Wo; a.oy_mul = a.ox_mul = 1; a.oy_off = a.ox_off = 0;
+        a.y = need_fold ? ws : dx;
+        rc = m355::launch_conv(a, cin64, st);
+        if (rc) return rc;
+        if (need_fold) {
+            const size_t total = (size_t)d->N * d->H * d->W * d->Cin;
+            hipLaunchKernelGGL(m355::k_fold_pad, dim3((unsigned)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256)),
+                               dim3(256), 0, st, (const unsigned short *)ws, (unsigned short *)dx, d->N, d->H, d->W, d->Cin,
+                               d->upsample, d->pad_w, d->pad_w_mode, Hl, 0);
+            rc = m355::check_launch("conv2d_dgrad fold");
+        }
+        return rc;
+    }
+    // stride 2: four parity classes of the padded frame, each a (kh/2 x kw/2) conv of dy written with stride 2
+    const int Hp = Hl + 2 * d->pad_h, Wp = Wl + 2 * d->pad_w;
+    M355_REQUIRE(Hp % 2 == 0 && Wp % 2 == 0, "conv2d_dgrad: stride-2 frame %dx%d must be even", Hp, Wp);
+    const int A = d->kh / 2, B = d->kw / 2;
+    const size_t each = (size_t)cin64 * A * B * cout32;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            a.w = (const unsigned short *)w_dgrad + (size_t)(py * 2 + px) * each;
+            a.KH = A; a.KW = B;
+            a.pad_h = A - 1; a.pad_w = B - 1;
+            a.Ho = Hp / 2; a.Wo = Wp / 2;
+            a.OH = Hp; a.OW = Wp; a.oy_mul = 2; a.ox_mul = 2; a.oy_off = py; a.ox_off = px;
+            a.y = ws;
+            rc = m355::launch_conv(a, cin64, st);
+            if (rc) return rc;
+        }
+    const size_t total = (size_t)d->N * d->H * d->W * d->Cin;
+    hipLaunchKernelGGL(m355::k_fold_pad, dim3((unsigned)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256)), dim3(256),
+                       0, st, (const unsigned short *)ws, (unsigned short *)dx, d->N, d->H, d->W, d->Cin, d->upsample,
+                       d->pad_w, d->pad_w_mode, Hp, d->pad_h);
+    return m355::check_launch("conv2d_dgrad fold");
+}

@@ -94,6 +94,35 @@ size_t m355_sil_loss_ws_bytes(int B, int S);
 int m355_sil_loss_fwd(const float *proj, const float *mask, int Hin, int Win, int mask_repeat, float *diff,
                       float *sse, float *total, void *ws, int B, int S, void *stream);
 
+/* ---- G  conv2d of the GAN stacks (models/gan.py:57-65,163-177,294-302,359,364 -> F.conv2d) as a bf16 MFMA
+ *      implicit GEMM with fp32 accumulation.  Activations are NHWC bf16, weights bf16 views built by
+ *      m355_conv2d_weight_prep from the fp32 [Cout][Cin][kh][kw] parameter.
+ *      The pads the reference materialises in front of the convs and the nearest x2 upsample are folded into
+ *      the loader: pad_w_mode 0 zero, 1 replicate (F.pad replicate, gan.py:329), 2 circular (circpad,
+ *      rendering/utils.py:60-64); H is always zero padded (Conv2d padding=(p,0), gan.py:294).
+ *      Cin must be a multiple of 32 (callers zero-pad the channels); dy carries ceil32(Cout) channels. */
+typedef struct {
+    int N, H, W, Cin;   /* stored input (before the optional upsample) */
+    int Cout, kh, kw;
+    int stride;         /* 1 or 2 */
+    int pad_h, pad_w;
+    int pad_w_mode;
+    int upsample;       /* 0 or 1: taps see the nearest x2 upsampled input (gan.py:319) */
+} m355_conv_desc;
+
+int m355_conv2d_out_hw(const m355_conv_desc *d, int *Ho, int *Wo);
+/*      elements (bf16) of the weight views: which 0 forward [ceil64(Cout)][kh][kw][Cin], 1 dgrad */
+size_t m355_conv2d_weight_elems(const m355_conv_desc *d, int which);
+int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_oihw, void *w_fwd, void *w_dgrad, void *stream);
+/*      y: bf16 NHWC [N,Ho,Wo,Cout] or (y_f32_nchw) fp32 [N,Cout,Ho,Wo]; epilogue: + bias[Cout] (nullable),
+ *      LeakyReLU(lrelu_slope) (1.0 = identity). */
+int m355_conv2d_fwd(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
+                    int y_f32_nchw, float lrelu_slope, void *stream);
+/*      dy[N,Ho,Wo,ceil32(Cout)] bf16 -> dx[N,H,W,Cin] bf16 (autograd of F.conv2d w.r.t. its input, through the
+ *      pad / upsample).  ws >= m355_conv2d_dgrad_ws_bytes(d). */
+size_t m355_conv2d_dgrad_ws_bytes(const m355_conv_desc *d);
+int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, void *ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

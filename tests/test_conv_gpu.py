@@ -1,0 +1,72 @@
+"""GPU: the bf16 MFMA conv2d (fwd / dgrad) against torch-CPU fp32 F.conv2d on the same bf16-rounded operands,
+with the reference's pads (F.pad replicate gan.py:329, circpad rendering/utils.py:60-64) and nearest x2
+upsample (gan.py:319) materialised on the CPU side.  Only the accumulation order differs -> tight tolerance."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def ref_conv(x_nchw, w, bias, stride, ph, pw, mode, ups):
+    if ups:
+        x_nchw = F.interpolate(x_nchw, scale_factor=2, mode="nearest")
+    if pw:
+        if mode == 1:
+            x_nchw = F.pad(x_nchw, (pw, pw, 0, 0), mode="replicate")
+        elif mode == 2:
+            x_nchw = torch.cat((x_nchw[..., -pw:], x_nchw, x_nchw[..., :pw]), dim=3)
+        else:
+            x_nchw = F.pad(x_nchw, (pw, pw, 0, 0))
+    return F.conv2d(x_nchw, w, bias, stride=stride, padding=(ph, 0))
+
+
+CASES = [
+    # N, H, W, Cin, Cout, k, stride, ph, pw, mode, ups
+    (2, 8, 4, 64, 64, 3, 1, 1, 1, 1, 0),      # ResBlockUp conv (replicate W pad), tiny
+    (2, 8, 4, 64, 128, 3, 1, 1, 1, 1, 1),     # with the x2 upsample folded in
+    (1, 16, 8, 128, 64, 1, 1, 0, 0, 0, 0),    # 1x1 shortcut
+    (2, 16, 16, 32, 64, 5, 1, 2, 2, 2, 0),    # D conv1-like: 5x5, circular
+    (2, 16, 16, 64, 128, 4, 2, 1, 1, 2, 0),   # D conv2-like: 4x4 stride 2, circular
+    (1, 8, 8, 64, 3, 5, 1, 2, 2, 1, 0),       # head: Cout=3
+    (3, 12, 6, 96, 96, 3, 1, 1, 1, 0, 0),     # zero W pad, Cout not a multiple of 64, M not a multiple of 256
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd_and_dgrad(pkg, case):
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    N, H, W, Cin, Cout, k, stride, ph, pw, mode, ups = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(N, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).bfloat16().float()
+    b = torch.randn(Cout, generator=g)
+    xr = x.clone().requires_grad_()
+    y_ref = ref_conv(xr, w, b, stride, ph, pw, mode, ups)
+    d = conv.make_desc(N, H, W, Cin, Cout, k, k, stride, ph, pw, mode, ups)
+    wf, wd = conv.weight_prep(d, w.to(DEV))
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    y = conv.conv_fwd(d, x_nhwc, wf, b.to(DEV))
+    assert tuple(y.shape) == (N, y_ref.shape[2], y_ref.shape[3], Cout)
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    err = (got - y_ref.detach()).abs().max().item() / y_ref.abs().max().item()
+    assert err < 6e-3, err  # bf16 rounding of the output (2^-9 relative) dominates
+    # fp32 NCHW epilogue (used by the heads) has no output rounding
+    y32 = conv.conv_fwd(d, x_nhwc, wf, b.to(DEV), out_f32_nchw=True).cpu()
+    assert (y32 - y_ref.detach()).abs().max().item() / y_ref.abs().max().item() < 2e-4
+    # LeakyReLU epilogue
+    yl = conv.conv_fwd(d, x_nhwc, wf, b.to(DEV), out_f32_nchw=True, slope=0.2).cpu()
+    assert (yl - F.leaky_relu(y_ref.detach(), 0.2)).abs().max().item() / y_ref.abs().max().item() < 2e-4
+    # dgrad
+    dy = torch.randn(y_ref.shape, generator=g).bfloat16().float()
+    y_ref.backward(dy)
+    c32 = (Cout + 31) // 32 * 32
+    dy_nhwc = torch.zeros(N, y_ref.shape[2], y_ref.shape[3], c32)
+    dy_nhwc[..., :Cout] = dy.permute(0, 2, 3, 1)
+    dx = conv.conv_dgrad(d, dy_nhwc.bfloat16().to(DEV), wd).float().cpu().permute(0, 3, 1, 2)
+    errg = (dx - xr.grad).abs().max().item() / xr.grad.abs().max().item()
+    assert errg < 1.2e-2, errg  # the padded-frame gradient is rounded to bf16 once before the fold
