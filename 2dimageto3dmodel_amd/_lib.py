@@ -36,6 +36,7 @@ SIGNATURES = {
     "m355_conv2d_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P]),
     "m355_conv2d_dgrad_ws_bytes": (c_size_t, [_P]),
     "m355_conv2d_dgrad": (c_int, [_P, _P, _P, _P, _P, _P]),
+    "m355_conv2d_wgrad": (c_int, [_P, _P, _P, _P, _P]),
 }
 
 

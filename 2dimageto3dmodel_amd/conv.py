@@ -68,3 +68,11 @@ def conv_dgrad(d, dy, w_dgrad):
     ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device)
     check(lib().m355_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(w_dgrad), ptr(dx), ptr(ws), stream()), "conv2d_dgrad")
     return dx
+
+
+def conv_wgrad(d, x, dy):
+    """-> dw fp32 in the parameter's layout [Cout,Cin,kh,kw]"""
+    x, dy = _req(x, torch.bfloat16, "x"), _req(dy, torch.bfloat16, "dy")
+    dw = torch.empty((d.Cout, d.kh, d.kw, d.Cin), dtype=torch.float32, device=x.device)
+    check(lib().m355_conv2d_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), stream()), "conv2d_wgrad")
+    return dw.permute(0, 3, 1, 2)

@@ -405,3 +405,139 @@ extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const 
                        d->pad_w, d->pad_w_mode, Hp, d->pad_h);
     return m355::check_launch("conv2d_dgrad fold");
 }
+
+// =====================================================================================================
+// wgrad: dw[co][kh][kw][ci] = sum over pixels p of dy[p][co] * xpatch[p][(kh,kw,ci)]       (fp32 accumulate)
+// GEMM with the PIXEL axis as K: both operands are stored pixel-major (channel contiguous), so each staged
+// 16-byte granule (8 channels of one pixel) is scattered into a channel-major LDS tile ([channel][32 pixels]),
+// from which the MFMA fragments (8 consecutive pixels of one channel) are plain ds_read_b128.
+// Tile: 64 output channels x 128 weight columns (one tap x 128 input channels, or several taps when Cin < 128),
+// split-K over the pixel range across gridDim.z, fp32 atomicAdd of the partial tiles into dw.
+namespace m355 {
+
+constexpr int WM = 64, WN = 128, WK = 32;
+constexpr int WLD = WK + 8;  // pixels per LDS row (+pad), bf16
+
+struct WgradArgs {
+    const unsigned short *x;   // bf16 NHWC [N,H,W,Cin]
+    const unsigned short *dy;  // bf16 NHWC [N,Ho,Wo,Cy]
+    float *dw;                 // fp32 [Cout][KH][KW][Cin], pre-zeroed
+    int N, H, W, Cin, Hl, Wl, ups;
+    int Ho, Wo, Cout, Cy;
+    int KH, KW, stride, pad_h, pad_w, pad_w_mode;
+    int chunk;  // pixels per z-slice (multiple of WK)
+};
+
+__global__ __launch_bounds__(256) void k_wgrad_mfma(WgradArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short At[WM * WLD];  // [co][pixel]
+    __shared__ __attribute__((aligned(16))) unsigned short Bt[WN * WLD];  // [col][pixel]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co0 = blockIdx.x * WM, col0 = blockIdx.y * WN;
+    const int P = a.N * a.Ho * a.Wo, K = a.KH * a.KW * a.Cin;
+    const int pbeg = blockIdx.z * a.chunk, pend = min(P, pbeg + a.chunk);
+    if (pbeg >= pend) return;
+
+    // staging roles: x granule (prow, cg) with prow = tid>>4 (+16), cg = tid&15 ; dy granule (prow2, cg2)
+    const int xg_col = col0 + (tid & 15) * 8;
+    const bool xcol_ok = xg_col < K;
+    const int tap = xcol_ok ? xg_col / a.Cin : 0, ci = xcol_ok ? xg_col - tap * a.Cin : 0;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const int yg_co = co0 + (tid & 7) * 8;
+    const bool yco_ok = yg_co < a.Cy;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    f32x16 acc[2];  // wave tile: 32 co x 64 cols  (waves 2 x 2)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+
+    for (int p0 = pbeg; p0 < pend; p0 += WK) {
+        // ---- stage x patches: 2 granules per thread
+        bf16x8 gx[2], gy;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = p0 + (tid >> 4) + 16 * i;
+            bool ok = xcol_ok && p < pend;
+            const int pp = ok ? p : 0;
+            const int n = pp / (a.Ho * a.Wo), r = pp - n * (a.Ho * a.Wo);
+            const int ho = r / a.Wo, wo = r - ho * a.Wo;
+            const int hi = ho * a.stride - a.pad_h + kh;
+            int wi = wo * a.stride - a.pad_w + kw;
+            ok = ok && hi >= 0 && hi < a.Hl;
+            if (a.pad_w_mode == 1) wi = min(max(wi, 0), a.Wl - 1);
+            else if (a.pad_w_mode == 2) wi = wi < 0 ? wi + a.Wl : (wi >= a.Wl ? wi - a.Wl : wi);
+            else ok = ok && wi >= 0 && wi < a.Wl;
+            const unsigned short *src = a.x + (((size_t)n * a.H + (hi >> a.ups)) * a.W + (wi >> a.ups)) * a.Cin + ci;
+            gx[i] = ok ? *reinterpret_cast<const bf16x8 *>(src) : zero8;
+        }
+        {
+            const int p = p0 + (tid >> 3);
+            const bool ok = yco_ok && p < pend;
+            gy = ok ? *reinterpret_cast<const bf16x8 *>(a.dy + (size_t)p * a.Cy + yg_co) : zero8;
+        }
+        __syncthreads();  // previous step's fragments consumed
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Bt[((tid & 15) * 8 + j) * WLD + (tid >> 4) + 16 * i] = (unsigned short)gx[i][j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) At[((tid & 7) * 8 + j) * WLD + (tid >> 3)] = (unsigned short)gy[j];
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < WK; kk += 16) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8 *>(&At[(wr * 32 + frow) * WLD + kk + fk]);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(&Bt[(wc * 64 + frow) * WLD + kk + fk]);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(&Bt[(wc * 64 + 32 + frow) * WLD + kk + fk]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[1], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: row = co, col = weight column
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int col = col0 + wc * 64 + 32 * j + (lane & 31);
+            if (co < a.Cout && col < K) atomicAdd(a.dw + (size_t)co * K + col, acc[j][r]);
+        }
+}
+
+}  // namespace m355
+
+// x[N,H,W,Cin] bf16, dy[N,Ho,Wo,ceil32(Cout)] bf16 -> dw fp32 [Cout][kh][kw][Cin] (overwritten).
+extern "C" int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const void *dy, float *dw, void *stream)
+{
+    if (int rc = check_desc(d, "conv2d_wgrad")) return rc;
+    M355_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    m355::WgradArgs a = {};
+    a.x = (const unsigned short *)x;
+    a.dy = (const unsigned short *)dy;
+    a.dw = dw;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ups = d->upsample;
+    a.Hl = d->H << d->upsample; a.Wl = d->W << d->upsample;
+    conv_out_hw(d, &a.Ho, &a.Wo);
+    a.Cout = d->Cout; a.Cy = (d->Cout + 31) / 32 * 32;
+    a.KH = d->kh; a.KW = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
+    a.pad_w_mode = d->pad_w_mode;
+    const int K = d->kh * d->kw * d->Cin, P = d->N * a.Ho * a.Wo;
+    const int gx = (d->Cout + m355::WM - 1) / m355::WM, gy = (K + m355::WN - 1) / m355::WN;
+    // split the pixel axis so that ~1024 workgroups are in flight, at least 4 K-steps each
+    int splits = (1024 + gx * gy - 1) / (gx * gy);
+    const int max_splits = (P + 4 * m355::WK - 1) / (4 * m355::WK);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    a.chunk = ((P + splits - 1) / splits + m355::WK - 1) / m355::WK * m355::WK;
+    splits = (P + a.chunk - 1) / a.chunk;
+    if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->Cout * K, st) != hipSuccess) {
+        m355::set_error("conv2d_wgrad: memset failed");
+        return M355_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(m355::k_wgrad_mfma, dim3(gx, gy, splits), dim3(256), 0, st, a);
+    return m355::check_launch("conv2d_wgrad");
+}

@@ -122,6 +122,9 @@ int m355_conv2d_fwd(const m355_conv_desc *d, const void *x, const void *w_fwd, c
  *      pad / upsample).  ws >= m355_conv2d_dgrad_ws_bytes(d). */
 size_t m355_conv2d_dgrad_ws_bytes(const m355_conv_desc *d);
 int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, void *ws, void *stream);
+/*      x[N,H,W,Cin], dy[N,Ho,Wo,ceil32(Cout)] -> dw fp32 [Cout][kh][kw][Cin] (overwritten; split-K partial tiles are
+ *      combined with fp32 atomics, so the last bits depend on arrival order). */
+int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const void *dy, float *dw, void *stream);
 
 #ifdef __cplusplus
 }

@@ -70,3 +70,9 @@ def test_conv_fwd_and_dgrad(pkg, case):
     dx = conv.conv_dgrad(d, dy_nhwc.bfloat16().to(DEV), wd).float().cpu().permute(0, 3, 1, 2)
     errg = (dx - xr.grad).abs().max().item() / xr.grad.abs().max().item()
     assert errg < 1.2e-2, errg  # the padded-frame gradient is rounded to bf16 once before the fold
+    # wgrad (fp32 accumulate, fp32 out): autograd of the same graph w.r.t. the weight
+    wr = w.clone().requires_grad_()
+    ref_conv(x, wr, b, stride, ph, pw, mode, ups).backward(dy)
+    dw = conv.conv_wgrad(d, x_nhwc, dy_nhwc.bfloat16().to(DEV)).cpu()
+    errw = (dw - wr.grad).abs().max().item() / wr.grad.abs().max().item()
+    assert errw < 2e-4, errw
