@@ -32,7 +32,7 @@ SIGNATURES = {
     "m355_sil_loss_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P]),
     "m355_conv2d_out_hw": (c_int, [_P, _P, _P]),
     "m355_conv2d_weight_elems": (c_size_t, [_P, c_int]),
-    "m355_conv2d_weight_prep": (c_int, [_P, _P, _P, _P, _P]),
+    "m355_conv2d_weight_prep": (c_int, [_P, _P, c_int, _P, _P, _P]),
     "m355_conv2d_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P]),
     "m355_conv2d_dgrad_ws_bytes": (c_size_t, [_P]),
     "m355_conv2d_dgrad": (c_int, [_P, _P, _P, _P, _P, _P]),

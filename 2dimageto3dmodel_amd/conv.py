@@ -41,7 +41,8 @@ def weight_prep(d, w_oihw, want_dgrad=True):
     wd = None
     if want_dgrad:
         wd = torch.empty((L.m355_conv2d_weight_elems(ctypes.byref(d), 1),), dtype=torch.bfloat16, device=w.device)
-    check(L.m355_conv2d_weight_prep(ctypes.byref(d), ptr(w), ptr(wf), ptr(wd), stream()), "conv2d_weight_prep")
+    check(L.m355_conv2d_weight_prep(ctypes.byref(d), ptr(w), int(w.shape[1]), ptr(wf), ptr(wd), stream()),
+          "conv2d_weight_prep")
     return wf, wd
 
 

@@ -278,24 +278,25 @@ extern "C" size_t m355_conv2d_weight_elems(const m355_conv_desc *d, int which)
     return cin64 * d->kh * d->kw * cout32;  // the 4 stride-2 views together cover kh*kw taps
 }
 
-extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_oihw, void *w_fwd, void *w_dgrad,
-                                       void *stream)
+extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_oihw, int cin_w, void *w_fwd,
+                                       void *w_dgrad, void *stream)
 {
     if (int rc = check_desc(d, "conv2d_weight_prep")) return rc;
     M355_REQUIRE(w_oihw && (w_fwd || w_dgrad), "conv2d_weight_prep: null pointer");
+    M355_REQUIRE(cin_w >= 1 && cin_w <= d->Cin, "conv2d_weight_prep: cin_w=%d outside 1..Cin=%d", cin_w, d->Cin);
     hipStream_t st = (hipStream_t)stream;
     const int cout64 = (d->Cout + 63) / 64 * 64, cin64 = (d->Cin + 63) / 64 * 64, cout32 = (d->Cout + 31) / 32 * 32;
     if (w_fwd) {
         const size_t total = (size_t)cout64 * d->kh * d->kw * d->Cin;
         hipLaunchKernelGGL(m355::k_weight_prep, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),
-                           dim3(256), 0, st, w_oihw, (unsigned short *)w_fwd, d->Cout, d->Cin, d->kh, d->kw, 0, d->kh,
+                           dim3(256), 0, st, w_oihw, (unsigned short *)w_fwd, d->Cout, cin_w, d->kh, d->kw, 0, d->kh,
                            d->kw, 0, 1, 0, 1, cout64, d->Cin);
     }
     if (w_dgrad) {
         if (d->stride == 1) {
             const size_t total = (size_t)cin64 * d->kh * d->kw * cout32;
             hipLaunchKernelGGL(m355::k_weight_prep, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),
-                               dim3(256), 0, st, w_oihw, (unsigned short *)w_dgrad, d->Cout, d->Cin, d->kh, d->kw, 1,
+                               dim3(256), 0, st, w_oihw, (unsigned short *)w_dgrad, d->Cout, cin_w, d->kh, d->kw, 1,
                                d->kh, d->kw, d->kh - 1, -1, d->kw - 1, -1, cin64, cout32);
         } else {
             M355_REQUIRE(d->kh % 2 == 0 && d->kw % 2 == 0, "conv2d_weight_prep: stride-2 dgrad needs even kernels");
@@ -305,7 +306,7 @@ extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_o
                 for (int px = 0; px < 2; ++px)
                     hipLaunchKernelGGL(m355::k_weight_prep, dim3((unsigned)((each + 255) / 256 > 4096 ? 4096 : (each + 255) / 256)),
                                        dim3(256), 0, st, w_oihw, (unsigned short *)w_dgrad + (size_t)(py * 2 + px) * each,
-                                       d->Cout, d->Cin, d->kh, d->kw, 1, A, B, py + 2 * (A - 1), -2, px + 2 * (B - 1), -2,
+                                       d->Cout, cin_w, d->kh, d->kw, 1, A, B, py + 2 * (A - 1), -2, px + 2 * (B - 1), -2,
                                        cin64, cout32);
         }
     }

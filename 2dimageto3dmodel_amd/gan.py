@@ -1,0 +1,446 @@
+"""Drop-in GAN modules (reference: code/models/gan.py, code/utils/losses.py, code/rendering/utils.py).
+
+Same class names, constructor arguments, forward signatures, parameter / buffer names and creation order as the
+reference, so `state_dict`s are interchangeable key for key and a module built under the same `torch.manual_seed`
+starts from the same weights.  What differs is the execution: activations live in NHWC bf16, every convolution
+runs as a bf16 MFMA implicit GEMM (csrc/conv_mfma.hip) with the reference's W pads (replicate / circular) and
+nearest x2 upsampling folded into its loader; inputs/outputs at the module boundary stay NCHW fp32.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import conv as C
+from . import gan_ops as G
+
+LRELU = 0.2  # nn.LeakyReLU(0.2) everywhere in models/gan.py
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def symmetrize_texture(x):
+    """rendering/utils.py:15-18: even symmetry along W (length N -> 2N) of an NCHW tensor"""
+    xf = torch.flip(x, (x.dim() - 1,))
+    h = xf.shape[3] // 2
+    return torch.cat((xf[:, :, :, h:], x, xf[:, :, :, :h]), dim=-1)
+
+
+def adjust_poles(tex):
+    """rendering/utils.py:21-26: replace the first / last row by their mean (mesh displacement map only)"""
+    top = tex[:, :, :1].mean(dim=3, keepdim=True).expand(-1, -1, -1, tex.shape[3])
+    bottom = tex[:, :, -1:].mean(dim=3, keepdim=True).expand(-1, -1, -1, tex.shape[3])
+    return torch.cat((top, tex[:, :, 1:-1], bottom), dim=2)
+
+
+def circpad(x, amount=1):
+    """rendering/utils.py:29-33 (kept for callers; the convolutions here wrap indices instead)"""
+    return torch.cat((x[:, :, :, -amount:], x, x[:, :, :, :amount]), dim=3)
+
+
+def positional_encoding(Ny, Nx):
+    """models/gan.py:9-20: cos/sin of the two sphere angles, x wrapping smoothly; half width when symmetric"""
+    symmetric = (Nx == Ny // 2)
+    n = Ny
+    ty = np.linspace(0, np.pi, n, endpoint=False)
+    tx = np.linspace(-np.pi, np.pi, n, endpoint=False)
+    Y, X = np.meshgrid(tx, ty)
+    enc = np.stack((np.cos(X), np.sin(X), np.cos(Y), np.sin(Y)))
+    return enc[:, :, n // 4:-(n // 4)] if symmetric else enc
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d parameters (so spectral_norm, init and state_dict keys are the reference's), MFMA execution.
+    Takes / returns NHWC bf16; `pad_w` columns are produced by index arithmetic in the kernel."""
+
+    def __init__(self, cin, cout, k, stride=1, pad_h=0, pad_w=0, pad_w_mode=C.PAD_ZERO, bias=True):
+        super().__init__(cin, cout, k, stride=stride, padding=(pad_h, 0), bias=bias)
+        self.m355 = (stride, pad_h, pad_w, pad_w_mode)
+
+    def forward(self, x, upsample=0, slope=1.0, out_f32_nchw=False):
+        stride, pad_h, pad_w, mode = self.m355
+        return G.conv2d(x, self.weight, self.bias, stride, pad_h, pad_w, mode, upsample, slope, out_f32_nchw)
+
+
+class _Identity(nn.Module):
+    def forward(self, x):
+        return x
+
+
+# ------------------------------------------------------------------------------------------------ generator
+class ConditionalBatchNorm2d(nn.Module):
+    """models/gan.py:264-286: BN(affine=False) then x*(1+fc_gamma(z)) + fc_beta(z); here fused with the
+    LeakyReLU that always follows it in ResBlockUp."""
+
+    def __init__(self, args, ch, emb_dim):
+        super().__init__()
+        if args.norm_g == 'syncbatch':
+            self.norm = G.SynchronizedBatchNorm2d(ch, affine=False)
+        elif args.norm_g == 'batch':
+            self.norm = G.BatchNorm2d(ch, affine=False)
+        elif args.norm_g == 'instance':
+            self.norm = G.InstanceNorm2d(ch)
+        elif args.norm_g == 'none':
+            self.norm = G.NoNorm()
+        else:
+            raise ValueError(f"norm_g={args.norm_g!r}")
+        self.fc_gamma = nn.Linear(emb_dim, ch)
+        self.fc_beta = nn.Linear(emb_dim, ch)
+
+    def forward(self, x, z, slope=1.0):
+        return self.norm(x, 1 + self.fc_gamma(z), self.fc_beta(z), slope)
+
+
+class ResBlockUp(nn.Module):
+    """models/gan.py:288-312"""
+
+    def __init__(self, args, ch_in, ch_out, emb_dim, pad_fn):
+        super().__init__()
+        ch_middle = min(ch_in, ch_out)
+        self.ch_out = ch_out
+        mode = pad_fn  # PAD_REPLICATE (symmetric generator, gan.py:329) or PAD_CIRCULAR (gan.py:331)
+        self.conv1 = nn.utils.spectral_norm(Conv2d(ch_in, ch_middle, 3, pad_h=1, pad_w=1, pad_w_mode=mode, bias=False))
+        self.conv2 = nn.utils.spectral_norm(Conv2d(ch_middle, ch_out, 3, pad_h=1, pad_w=1, pad_w_mode=mode, bias=False))
+        self.norm1 = ConditionalBatchNorm2d(args, ch_middle, emb_dim)
+        self.norm2 = ConditionalBatchNorm2d(args, ch_out, emb_dim)
+        self.relu = nn.LeakyReLU(LRELU, inplace=True)
+        self.pad = pad_fn
+        if ch_in != ch_out:
+            self.shortcut = nn.utils.spectral_norm(Conv2d(ch_in, ch_out, 1, bias=False))
+        else:
+            self.shortcut = _Identity()
+
+    def forward(self, x, z, upsample=0):
+        """x is the block input BEFORE the nearest x2 upsample that precedes the block in Generator.forward
+        (gan.py:386-404) when upsample=1; the upsample is folded into conv1 and the shortcut."""
+        if isinstance(self.shortcut, _Identity):
+            sc = G.upsample2x(x) if upsample else x
+        else:
+            sc = self.shortcut(x, upsample=upsample)
+        h = self.norm1(self.conv1(x, upsample=upsample), z, LRELU)
+        h = self.norm2(self.conv2(h), z, LRELU)
+        return h + sc
+
+
+class Generator(nn.Module):
+    """models/gan.py:314-426"""
+
+    def __init__(self, args, emb_dim, symmetric=True, mesh_head=True):
+        super().__init__()
+        self.relu = nn.LeakyReLU(LRELU, inplace=True)
+        self.width = 8
+        self.height = 8
+        self.args = args
+        self.symmetric = symmetric
+        if symmetric:
+            self.width //= 2
+            self.pad = C.PAD_REPLICATE  # even-mirror padding emulated with replication (gan.py:328-329)
+        else:
+            self.pad = C.PAD_CIRCULAR
+        if args.conditional_class and args.conditional_color:
+            self.emb_class = nn.Embedding(args.n_classes[0], emb_dim // 2)
+            self.emb_color = nn.Embedding(args.n_classes[1], emb_dim // 2)
+            emb_dim += emb_dim
+        elif args.conditional_class:
+            self.emb_class = nn.Embedding(args.n_classes[0], emb_dim)
+            emb_dim += emb_dim
+        self.fc = nn.Linear(emb_dim, self.height * self.width * 512)
+        self.blk1 = ResBlockUp(args, 512, 512, emb_dim, self.pad)
+        self.blk2 = ResBlockUp(args, 512, 256, emb_dim, self.pad)
+        for name, res in (("blk3a", 256), ("blk3b", 512), ("blk3c", 1024)):
+            if args.texture_resolution >= res:
+                setattr(self, name, ResBlockUp(args, 256, 256, emb_dim, self.pad))
+        if args.conditional_text:
+            self.att = SpatialAttention(256, args.text_embedding_dim)
+        self.blk4 = ResBlockUp(args, 256, 128, emb_dim, self.pad)
+        self.blk5 = ResBlockUp(args, 128, 128, emb_dim, self.pad)
+        self.blk6 = ResBlockUp(args, 128, 64, emb_dim, self.pad)
+        self.conv_final = Conv2d(64, 3, 5, pad_h=2, pad_w=2, pad_w_mode=self.pad)
+        self.mesh_head = mesh_head
+        if mesh_head:
+            self.blk3_mesh = ResBlockUp(args, 256, 64, emb_dim, self.pad)
+            self.conv_mesh = Conv2d(64, 3, 5, pad_h=2, pad_w=2, pad_w_mode=self.pad)
+            self.conv_mesh.weight.data[:] = 0  # zero-initialised for smoothness (gan.py:366-368)
+            self.conv_mesh.bias.data[:] = 0
+
+    def forward(self, z, c=None, caption=None, return_attention=False):
+        a = self.args
+        if a.conditional_class:
+            assert c is not None
+            parts = [z, self.emb_class(c[:, 0])]
+            if a.conditional_color:
+                parts.append(self.emb_color(c[:, 1]))
+            z = torch.cat(parts, dim=1)
+        x = self.fc(z).view(z.shape[0], -1, self.height, self.width)  # NCHW fp32 [B,512,8,4]
+        x = G.to_nhwc_bf16(x)
+        x = self.blk1(x, z)
+        x = self.blk2(x, z, upsample=1)
+        attention_map = None
+        if a.conditional_text:
+            att_out, attention_map = self.att(G.to_nchw_f32(x), *caption)
+            x = x + G.to_nhwc_bf16(att_out)
+        t = x  # every later stage starts with the x2 upsample of gan.py:391 / :395-404
+        for name in ("blk3a", "blk3b", "blk3c"):
+            if hasattr(self, name):
+                t = getattr(self, name)(t, z, upsample=1)
+        t = self.blk4(t, z, upsample=1)
+        t = self.blk5(t, z, upsample=1)
+        t = self.blk6(t, z, upsample=1)
+        t = G.leaky_relu(t, LRELU)
+        x_tex = torch.tanh(self.conv_final(t, out_f32_nchw=True))
+        x_mesh = None
+        if self.mesh_head:
+            m = G.leaky_relu(self.blk3_mesh(x, z, upsample=1), LRELU)
+            x_mesh = adjust_poles(self.conv_mesh(m, out_f32_nchw=True))
+        if self.symmetric:
+            x_tex = symmetrize_texture(x_tex)
+            if x_mesh is not None:
+                x_mesh = symmetrize_texture(x_mesh)
+            if attention_map is not None:
+                attention_map = symmetrize_texture(attention_map)
+        return (x_tex, x_mesh, attention_map) if return_attention else (x_tex, x_mesh)
+
+
+# ------------------------------------------------------------------------------------------------ discriminators
+def _d_norm(args, ch):
+    if args.norm_d == 'instance':
+        return nn.InstanceNorm2d(ch, affine=True), False
+    if args.norm_d == 'none':
+        return None, True
+    raise ValueError(f"norm_d={args.norm_d!r}")
+
+
+class _DiscBase(nn.Module):
+    def _pos(self, x):
+        """cached positional embedding [1,4,H,W] for an NCHW tensor (gan.py:87-90, 204-207)"""
+        if self.pos_emb is None:
+            self.pos_emb = torch.FloatTensor(positional_encoding(x.shape[2], x.shape[3])).unsqueeze(0)
+        return self.pos_emb.to(x.device).expand(x.shape[0], -1, -1, -1)
+
+    def _act(self, conv, norm, x):
+        """conv -> [InstanceNorm] -> LeakyReLU on NHWC bf16"""
+        if norm is None:
+            return conv(x, slope=LRELU)
+        y = G.to_nchw_f32(conv(x))
+        return G.to_nhwc_bf16(F.leaky_relu(norm(y), LRELU))
+
+    def _project(self, y, feat, c, caption):
+        """projection discriminator (gan.py:104-116, 216-228): y += sum_c feat * emb"""
+        a = self.args
+        if a.conditional_class:
+            c_emb = self.projector(c[:, 0])
+            if a.conditional_color:
+                c_emb = c_emb + self.projector_col1(c[:, 1])
+            y = y + torch.einsum("nhwc,nc->nhw", feat.float(), c_emb).unsqueeze(1)
+        elif a.conditional_text:
+            att_out, _ = self.att(G.to_nchw_f32(feat), *caption)
+            y = y + torch.sum(G.to_nchw_f32(feat) * att_out, dim=1, keepdim=True)
+        return y
+
+
+class MeshDiscriminator(_DiscBase):
+    """models/gan.py:23-121"""
+
+    def __init__(self, args, nc, circular=True, positional_embeddings=True):
+        super().__init__()
+        n2, bias = _d_norm(args, 128)
+        n3, _ = _d_norm(args, 256)
+        self.args = args
+        if args.conditional_text:
+            self.att = SpatialAttention(256, args.text_embedding_dim)
+        self.circular = circular
+        self.positional_embeddings = positional_embeddings
+        mode = C.PAD_CIRCULAR if circular else C.PAD_ZERO
+        if positional_embeddings:
+            self.pos_emb = None
+            nc += 4
+        self.conv1 = nn.utils.spectral_norm(Conv2d(nc, 64, 5, pad_h=2, pad_w=2, pad_w_mode=mode))
+        self.conv2 = nn.utils.spectral_norm(Conv2d(64, 128, 4, stride=2, pad_h=1, pad_w=1, pad_w_mode=mode, bias=bias))
+        if n2 is not None:
+            self.bn2 = n2
+        self.conv3 = nn.utils.spectral_norm(Conv2d(128, 256, 4, stride=2, pad_h=1, pad_w=1, pad_w_mode=mode, bias=bias))
+        if n3 is not None:
+            self.bn3 = n3
+        self.conv4 = nn.utils.spectral_norm(Conv2d(256, 1, 5, pad_h=2, pad_w=2, pad_w_mode=mode))
+        self.relu = nn.LeakyReLU(LRELU, inplace=True)
+        if args.conditional_class:
+            self.projector = nn.Embedding(args.n_classes[0], 256)
+            if args.conditional_color:
+                self.projector_col1 = nn.Embedding(args.n_classes[1], 256)
+
+    def forward(self, texture, mesh_map, c=None, caption=None):
+        x = F.avg_pool2d(texture, texture.shape[2] // mesh_map.shape[2])
+        parts = [x, mesh_map]
+        if self.positional_embeddings:
+            parts.append(self._pos(x))
+        x = torch.cat(parts, dim=1)
+        mask = None
+        if self.args.mask_output:
+            with torch.no_grad():
+                mask = F.avg_pool2d(x[:, 3:4], 4)
+        h = G.to_nhwc_bf16(x, pad_to=32)
+        h = self._act(self.conv1, None, h)
+        h = self._act(self.conv2, getattr(self, "bn2", None), h)
+        h = self._act(self.conv3, getattr(self, "bn3", None), h)
+        y = self.conv4(h, out_f32_nchw=True)
+        return self._project(y, h, c, caption), mask
+
+
+class TextureDiscriminator(_DiscBase):
+    """models/gan.py:123-233"""
+
+    def __init__(self, args, nc, downsample=1, circular=True, positional_embeddings=True):
+        super().__init__()
+        n2, bias = _d_norm(args, 128)
+        n3, _ = _d_norm(args, 256)
+        n4, _ = _d_norm(args, 512)
+        self.args = args
+        if args.conditional_text:
+            self.att = SpatialAttention(512, args.text_embedding_dim)
+        self.circular = circular
+        self.positional_embeddings = positional_embeddings
+        mode = C.PAD_CIRCULAR if circular else C.PAD_ZERO
+        if positional_embeddings:
+            self.pos_emb = None
+            nc += 4
+        self.stride_first = (downsample == 1 and args.texture_resolution >= 512) or args.texture_resolution >= 1024 \
+            or args.conditional_text
+        if self.stride_first:
+            self.conv1 = nn.utils.spectral_norm(Conv2d(nc, 64, 4, stride=2, pad_h=1, pad_w=1, pad_w_mode=mode))
+        else:
+            self.conv1 = nn.utils.spectral_norm(Conv2d(nc, 64, 5, pad_h=2, pad_w=2, pad_w_mode=mode))
+        self.conv2 = nn.utils.spectral_norm(Conv2d(64, 128, 4, stride=2, pad_h=1, pad_w=1, pad_w_mode=mode, bias=bias))
+        if n2 is not None:
+            self.bn2 = n2
+        self.conv3 = nn.utils.spectral_norm(Conv2d(128, 256, 4, stride=2, pad_h=1, pad_w=1, pad_w_mode=mode, bias=bias))
+        if n3 is not None:
+            self.bn3 = n3
+        self.conv4 = nn.utils.spectral_norm(Conv2d(256, 512, 4, stride=2, pad_h=1, pad_w=1, pad_w_mode=mode, bias=bias))
+        if n4 is not None:
+            self.bn4 = n4
+        self.conv5 = nn.utils.spectral_norm(Conv2d(512, 1, 5, pad_h=2, pad_w=2, pad_w_mode=mode))
+        self.relu = nn.LeakyReLU(LRELU, inplace=True)
+        self.downsample = downsample
+        if args.conditional_class:
+            self.projector = nn.Embedding(args.n_classes[0], 512)
+            if args.conditional_color:
+                self.projector_col1 = nn.Embedding(args.n_classes[1], 512)
+
+    def forward(self, x, c=None, caption=None):
+        if self.downsample > 1:
+            x = F.avg_pool2d(x, self.downsample)
+        mask = None
+        if self.args.mask_output:
+            with torch.no_grad():
+                mask = F.avg_pool2d(x[:, 3:4], 16 if self.stride_first else 8)
+        if self.positional_embeddings:
+            x = torch.cat((x, self._pos(x)), dim=1)
+        h = G.to_nhwc_bf16(x, pad_to=32)
+        h = self._act(self.conv1, None, h)
+        h = self._act(self.conv2, getattr(self, "bn2", None), h)
+        h = self._act(self.conv3, getattr(self, "bn3", None), h)
+        h = self._act(self.conv4, getattr(self, "bn4", None), h)
+        y = self.conv5(h, out_f32_nchw=True)
+        return self._project(y, h, c, caption), mask
+
+
+class MultiScaleDiscriminator(nn.Module):
+    """models/gan.py:235-260"""
+
+    def __init__(self, args, nc):
+        super().__init__()
+        self.args = args
+        self.d1 = TextureDiscriminator(args, nc, 1)
+        if not args.texture_only:
+            self.d2 = MeshDiscriminator(args, nc + 3)
+        else:
+            self.d2 = TextureDiscriminator(args, nc, 2)
+        if args.num_discriminators == 3:
+            self.d3 = TextureDiscriminator(args, nc, 4)
+        elif args.num_discriminators != 2:
+            raise ValueError(f"num_discriminators={args.num_discriminators}")
+
+    def forward(self, x, mesh_map=None, c=None, caption=None):
+        d1, m1 = self.d1(x, c, caption)
+        if self.args.texture_only:
+            d2, m2 = self.d2(x, c, caption)
+        else:
+            d2, m2 = self.d2(x, mesh_map, c, caption)
+        if self.args.num_discriminators == 3:
+            d3, m3 = self.d3(x, c, caption)
+            return [d1, d2, d3], [m1, m2, m3]
+        return [d1, d2], [m1, m2]
+
+
+class SpatialAttention(nn.Module):
+    """models/gan.py:433-481 (text conditioning; tiny bmm's on [B, <=512, <=18] -- plain torch, NCHW fp32)"""
+
+    def __init__(self, input_dim, context_dim):
+        super().__init__()
+        self.conv_context = nn.Conv2d(context_dim, input_dim, 1, stride=1, padding=0, bias=False)
+        self.sm = nn.Softmax(dim=1)
+
+    def forward(self, input, context, mask):
+        ih, iw = input.size(2), input.size(3)
+        B, L = context.size(0), context.size(2)
+        q = input.view(B, -1, ih * iw).transpose(1, 2)                     # B x queryL x idf
+        src = self.conv_context(context.unsqueeze(3)).squeeze(3)          # B x idf x sourceL
+        attn = torch.bmm(q, src).view(B * ih * iw, L)
+        if mask is not None:
+            attn = attn + mask.unsqueeze(1).expand(-1, ih * iw, -1).reshape(B * ih * iw, -1).float() * -10000
+        attn = self.sm(attn).view(B, ih * iw, L).transpose(1, 2)          # B x sourceL x queryL
+        out = torch.bmm(src, attn).view(B, -1, ih, iw)
+        return out, attn.reshape(B, -1, ih, iw)
+
+
+# ------------------------------------------------------------------------------------------------ loss
+class GANLoss(nn.Module):
+    """utils/losses.py:21-120 (hinge / ls / original / w, masked per-sample mean, per-discriminator weights).
+    Logits are [B,1,h,w] with h<=32: a few KB per call, evaluated with torch ops."""
+
+    def __init__(self, gan_mode, target_real_label=1.0, target_fake_label=0.0, tensor=torch.FloatTensor, opt=None):
+        super().__init__()
+        if gan_mode not in ('ls', 'original', 'w', 'hinge'):
+            raise ValueError('Unexpected gan_mode {}'.format(gan_mode))
+        self.real_label, self.fake_label = target_real_label, target_fake_label
+        self.Tensor, self.gan_mode, self.opt = tensor, gan_mode, opt
+
+    @staticmethod
+    def mean(x, mask=None, weight=None):
+        weight = 1 if weight is None else weight
+        if mask is None:
+            return torch.mean(x) * weight
+        assert x.shape == mask.shape, (x.shape, mask.shape)
+        per = torch.sum(x * mask, dim=[1, 2, 3]) / torch.sum(mask, dim=[1, 2, 3])  # NaN on an empty mask (D14)
+        return torch.mean(per) * weight
+
+    def loss(self, input, target_is_real, for_discriminator=True, mask=None, weight=None):
+        if self.gan_mode == 'original':
+            t = torch.full_like(input, self.real_label if target_is_real else self.fake_label)
+            return F.binary_cross_entropy_with_logits(input, t)
+        if self.gan_mode == 'ls':
+            t = torch.full_like(input, self.real_label if target_is_real else self.fake_label)
+            return F.mse_loss(input, t)
+        if self.gan_mode == 'hinge':
+            if for_discriminator:
+                v = torch.clamp_max((input if target_is_real else -input) - 1, 0)
+                return -self.mean(v, mask, weight)
+            assert target_is_real, "The generator's hinge loss must be aiming for real"
+            return -self.mean(input, mask, weight)
+        return -input.mean() if target_is_real else input.mean()
+
+    def __call__(self, input, target_is_real, for_discriminator=True, mask=None, weight=None):
+        if not isinstance(input, list):
+            return self.loss(input, target_is_real, for_discriminator, mask)
+        if mask is not None:
+            assert isinstance(mask, list) and len(input) == len(mask)
+        total = 0
+        for i, pred in enumerate(input):
+            if isinstance(pred, list):
+                pred = pred[-1]
+            t = self.loss(pred, target_is_real, for_discriminator, None if mask is None else mask[i],
+                          None if weight is None else weight[i])
+            bs = 1 if t.dim() == 0 else t.size(0)
+            total = total + torch.mean(t.view(bs, -1), dim=1)
+        return total / (len(input) if weight is None else sum(weight))

@@ -113,7 +113,9 @@ typedef struct {
 int m355_conv2d_out_hw(const m355_conv_desc *d, int *Ho, int *Wo);
 /*      elements (bf16) of the weight views: which 0 forward [ceil64(Cout)][kh][kw][Cin], 1 dgrad */
 size_t m355_conv2d_weight_elems(const m355_conv_desc *d, int which);
-int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_oihw, void *w_fwd, void *w_dgrad, void *stream);
+/*      w_oihw is the fp32 parameter [Cout][cin_w][kh][kw]; channels cin_w..Cin-1 of the views are zero. */
+int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_oihw, int cin_w, void *w_fwd, void *w_dgrad,
+                            void *stream);
 /*      y: bf16 NHWC [N,Ho,Wo,Cout] or (y_f32_nchw) fp32 [N,Cout,Ho,Wo]; epilogue: + bias[Cout] (nullable),
  *      LeakyReLU(lrelu_slope) (1.0 = identity). */
 int m355_conv2d_fwd(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
