@@ -68,6 +68,45 @@ def check(rc, what):
         raise M355Error(f"{what} failed (status {rc}): {msg}")
 
 
+# ---- per-launch HIP-event timers (bench.py): events are recorded on torch's current stream, which is the
+#      stream every libm355 kernel is launched on
+_TIMERS_ON = False
+_TIMER_EVENTS = []  # (name, start_event, end_event, algorithmic work of the launch)
+
+
+def enable_kernel_timers(on):
+    global _TIMERS_ON
+    _TIMERS_ON = bool(on)
+    if on:
+        _TIMER_EVENTS.clear()
+
+
+def collect_kernel_timers():
+    """-> {entry point: (launches, total_ms, total_work)}; call after torch.cuda.synchronize()."""
+    out = {}
+    for name, e0, e1, work in _TIMER_EVENTS:
+        c, t, w = out.get(name, (0, 0.0, 0.0))
+        out[name] = (c + 1, t + e0.elapsed_time(e1), w + work)
+    _TIMER_EVENTS.clear()
+    return out
+
+
+def launch(name, *args, work=0.0):
+    """call m355_<name>(*args), raise on a non-zero status; optionally bracket it with HIP events"""
+    fn = getattr(lib(), "m355_" + name)
+    if _TIMERS_ON:
+        import torch
+
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        _TIMER_EVENTS.append((name, e0, e1, float(work)))
+    else:
+        rc = fn(*args)
+    check(rc, name)
+
+
 def ptr(t):
     """device pointer of a tensor (None -> NULL)"""
     return None if t is None else t.data_ptr()

@@ -7,7 +7,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, check, lib, ptr, stream
+from ._lib import ConvDesc, check, launch, lib, ptr, stream
 
 PAD_ZERO, PAD_REPLICATE, PAD_CIRCULAR = 0, 1, 2
 
@@ -26,6 +26,13 @@ def out_hw(d):
     return ho.value, wo.value
 
 
+def flops(d, cin_real=None):
+    """algorithmic FLOPs of one pass (fwd, dgrad or wgrad) over the layer: 2*M*N*K with the REAL channel counts
+    (zero-padded input channels do not count)"""
+    ho, wo = out_hw(d)
+    return 2.0 * d.N * ho * wo * d.Cout * (cin_real or d.Cin) * d.kh * d.kw
+
+
 def _req(t, dtype, name):
     if not t.is_cuda:
         raise _lib.M355Error(f"{name} must be a CUDA(HIP) tensor; the conv path has no CPU implementation")
@@ -41,12 +48,11 @@ def weight_prep(d, w_oihw, want_dgrad=True):
     wd = None
     if want_dgrad:
         wd = torch.empty((L.m355_conv2d_weight_elems(ctypes.byref(d), 1),), dtype=torch.bfloat16, device=w.device)
-    check(L.m355_conv2d_weight_prep(ctypes.byref(d), ptr(w), int(w.shape[1]), ptr(wf), ptr(wd), stream()),
-          "conv2d_weight_prep")
+    launch("conv2d_weight_prep", ctypes.byref(d), ptr(w), int(w.shape[1]), ptr(wf), ptr(wd), stream())
     return wf, wd
 
 
-def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0):
+def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0, cin_real=None):
     x = _req(x, torch.bfloat16, "x")
     assert tuple(x.shape) == (d.N, d.H, d.W, d.Cin), (tuple(x.shape), (d.N, d.H, d.W, d.Cin))
     ho, wo = out_hw(d)
@@ -55,25 +61,25 @@ def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0):
     else:
         y = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.bfloat16, device=x.device)
     b = None if bias is None else _req(bias.detach(), torch.float32, "bias")
-    check(lib().m355_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(b), ptr(y), int(out_f32_nchw), float(slope),
-                                stream()), "conv2d_fwd")
+    launch("conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(b), ptr(y), int(out_f32_nchw), float(slope), stream(),
+           work=flops(d, cin_real))
     return y
 
 
-def conv_dgrad(d, dy, w_dgrad):
+def conv_dgrad(d, dy, w_dgrad, cin_real=None):
     dy = _req(dy, torch.bfloat16, "dy")
     ho, wo = out_hw(d)
     assert tuple(dy.shape) == (d.N, ho, wo, _ceil(d.Cout, 32)), tuple(dy.shape)
     dx = torch.empty((d.N, d.H, d.W, d.Cin), dtype=torch.bfloat16, device=dy.device)
     nws = lib().m355_conv2d_dgrad_ws_bytes(ctypes.byref(d))
     ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device)
-    check(lib().m355_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(w_dgrad), ptr(dx), ptr(ws), stream()), "conv2d_dgrad")
+    launch("conv2d_dgrad", ctypes.byref(d), ptr(dy), ptr(w_dgrad), ptr(dx), ptr(ws), stream(), work=flops(d, cin_real))
     return dx
 
 
-def conv_wgrad(d, x, dy):
+def conv_wgrad(d, x, dy, cin_real=None):
     """-> dw fp32 in the parameter's layout [Cout,Cin,kh,kw]"""
     x, dy = _req(x, torch.bfloat16, "x"), _req(dy, torch.bfloat16, "dy")
     dw = torch.empty((d.Cout, d.kh, d.kw, d.Cin), dtype=torch.float32, device=x.device)
-    check(lib().m355_conv2d_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), stream()), "conv2d_wgrad")
+    launch("conv2d_wgrad", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), stream(), work=flops(d, cin_real))
     return dw.permute(0, 3, 1, 2)

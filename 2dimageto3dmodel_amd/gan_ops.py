@@ -53,7 +53,7 @@ class Conv2dFn(torch.autograd.Function):
         d = C.make_desc(n, h, w, cx, cout, kh, kw, stride, pad_h, pad_w, mode, ups)
         need_dx = ctx.needs_input_grad[0]
         wf, wd = C.weight_prep(d, weight, want_dgrad=need_dx)
-        y = C.conv_fwd(d, x.detach(), wf, None if bias is None else bias.detach(), out_f32_nchw, slope)
+        y = C.conv_fwd(d, x.detach(), wf, None if bias is None else bias.detach(), out_f32_nchw, slope, cin_real=cw)
         ctx.d, ctx.cw, ctx.slope, ctx.f32 = d, cw, slope, out_f32_nchw
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x.detach(), wd, y if slope != 1.0 else None)
@@ -72,10 +72,10 @@ class Conv2dFn(torch.autograd.Function):
         if c32 != d.Cout:
             g = F.pad(g, (0, c32 - d.Cout))
         g = g.contiguous().to(torch.bfloat16)
-        dx = C.conv_dgrad(d, g, wd) if ctx.needs_input_grad[0] else None
+        dx = C.conv_dgrad(d, g, wd, cin_real=ctx.cw) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = C.conv_wgrad(d, x, g)[:, :ctx.cw].contiguous()
+            dw = C.conv_wgrad(d, x, g, cin_real=ctx.cw)[:, :ctx.cw].contiguous()
         return dx, dw, db, None, None, None, None, None, None, None
 
 

@@ -16,39 +16,9 @@ FOV = 1.875       # utils/effective_loss_function.py:69
 CAM_DIST = 2.0    # utils/effective_loss_function.py:70
 
 
-_TIMERS_ON = False
-_TIMER_EVENTS = []  # (name, start_event, end_event)
-
-
-def enable_kernel_timers(on):
-    """bench.py: bracket every libm355 launch with HIP events on the launch stream (torch's current stream)."""
-    global _TIMERS_ON
-    _TIMERS_ON = bool(on)
-    if on:
-        _TIMER_EVENTS.clear()
-
-
-def collect_kernel_timers():
-    """-> {entry point: (launches, total_ms)}; call after torch.cuda.synchronize()."""
-    out = {}
-    for name, e0, e1 in _TIMER_EVENTS:
-        c, t = out.get(name, (0, 0.0))
-        out[name] = (c + 1, t + e0.elapsed_time(e1))
-    _TIMER_EVENTS.clear()
-    return out
-
-
-def _launch(name, *args):
-    fn = getattr(lib(), "m355_" + name)
-    if _TIMERS_ON:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        rc = fn(*args)
-        e1.record()
-        _TIMER_EVENTS.append((name, e0, e1))
-    else:
-        rc = fn(*args)
-    check(rc, name)
+enable_kernel_timers = _lib.enable_kernel_timers
+collect_kernel_timers = _lib.collect_kernel_timers
+_launch = _lib.launch
 
 
 def _f32c(t, name):
@@ -113,7 +83,8 @@ class ProjectSilhouette(torch.autograd.Function):
             _launch("smooth_taps", ptr(tp), ntaps, flags & TRUE_GAUSSIAN, ptr(taps), st)
             tp, flags = taps, flags & ~(TAPS_FROM_SIGMA | TRUE_GAUSSIAN)
         _launch("proj_bin_fwd", ptr(pc), ptr(q), ptr(cam), None, ptr(tstart), ptr(tpts), B, N, S, FOV, CAM_DIST, st)
-        _launch("proj_render_fwd", ptr(tstart), ptr(tpts), ptr(scale), ptr(tp), ntaps, ptr(proj), B, N, S, flags, st)
+        _launch("proj_render_fwd", ptr(tstart), ptr(tpts), ptr(scale), ptr(tp), ntaps, ptr(proj), B, N, S, flags, st,
+                work=B * (12 * N + 20 + 8 * S ** 3 + 4 * S ** 2))
         ctx.save_for_backward(pc, q, tstart, tpts, tp, *(() if scale is None else (scale,)))
         ctx.cfg = (ntaps, S, flags, scale_shape)
         return proj
@@ -137,7 +108,7 @@ def _project_backward(ctx, dproj, gmul):
     slots = torch.empty((B, N, 4, 3), dtype=torch.float32, device=pc.device)
     dsp = torch.empty((B, nparts), dtype=torch.float32, device=pc.device) if has_scale else None
     _launch("proj_render_bwd", ptr(tstart), ptr(tpts), ptr(scale), ptr(tp), ntaps, ptr(dproj), gmul, ptr(slots), ptr(dsp),
-                                 B, N, S, flags, st)
+            B, N, S, flags, st, work=B * (4 * S ** 2 + 12 * S ** 3 + 24 * N + 20))
     dpc = torch.empty_like(pc)
     dq = torch.empty_like(q)
     dscale = torch.empty((B,), dtype=torch.float32, device=pc.device) if has_scale else None

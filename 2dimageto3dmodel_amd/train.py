@@ -1,0 +1,110 @@
+"""The GAN training iteration of code/main.py (ModelWrapper.forward :476-526 and the loop :691-723) on the drop-in
+modules: schedule 1 generator step : d_steps_per_g discriminator steps, Adam(betas=(0,0.9)), EMA generator.
+
+Not reproduced: the mesh smoothness regulariser of the G step (`loss_flat`, needs the Kaolin mesh template,
+SURVEY.md 8f row 1) and the text encoder."""
+import copy
+
+import torch
+
+from . import gan as G
+from . import parallel as P
+
+
+def divide_pred(pred):
+    """code/main.py:414-422: split the [fake; real] batch of every discriminator output"""
+    fake = [t[:t.size(0) // 2] for t in pred]
+    real = [t[t.size(0) // 2:] for t in pred]
+    return fake, real
+
+
+class GanTrainer(torch.nn.Module):
+    def __init__(self, args, latent_dim=64, lr_g=1e-4, lr_d=4e-4, d_steps_per_g=2, loss="hinge", device="cuda",
+                 symmetric_g=True, use_mesh=True, ema_alpha=0.999):
+        super().__init__()
+        self.args, self.latent_dim, self.d_steps_per_g, self.ema_alpha = args, latent_dim, d_steps_per_g, ema_alpha
+        self.generator = G.Generator(args, latent_dim, symmetric=symmetric_g, mesh_head=use_mesh)
+        self.generator_running_avg = copy.deepcopy(self.generator)          # main.py:453-457
+        for p in self.generator_running_avg.parameters():
+            p.requires_grad = False
+        self.discriminator = G.MultiScaleDiscriminator(args, 4)
+        self.criterion_gan = G.GANLoss(loss)
+        self.to(device)
+        for m in (self.generator, self.generator_running_avg, self.discriminator):
+            P.broadcast_parameters(m)
+        # betas=(0, 0.9) as main.py:588-589 (floats: torch >= 2.10 rejects the int/float mix)
+        self.optimizer_g = torch.optim.Adam(self.generator.parameters(), lr=lr_g, betas=(0.0, 0.9))
+        self.optimizer_d = torch.optim.Adam(self.discriminator.parameters(), lr=lr_d, betas=(0.0, 0.9))
+        self.reduce_g = P.FlatGradReducer(self.generator.parameters())
+        self.reduce_d = P.FlatGradReducer(self.discriminator.parameters())
+        self.total_it = 0
+
+    def _d_weight(self):
+        a = self.args
+        return [2, 1] if a.num_discriminators == 2 and a.texture_resolution >= 512 else None   # main.py:486-489
+
+    def forward(self, mode, X_tex, X_alpha, X_mesh=None, C=None, caption=None, noise=None):
+        """ModelWrapper.forward (main.py:476-526)"""
+        assert mode in ['g', 'd', 'inference']
+        if noise is None:
+            noise = torch.randn((X_alpha.shape[0], self.latent_dim), device=X_alpha.device)
+        w = self._d_weight()
+        if mode == 'g':
+            pred_tex, pred_mesh = self.generator(noise, C, caption)
+            X_fake = torch.cat((pred_tex * X_alpha, X_alpha), dim=1)
+            disc, mask = self.discriminator(X_fake, pred_mesh, C, caption)
+            loss = self.criterion_gan(disc, True, for_discriminator=False, mask=mask, weight=w)
+            return loss, pred_tex, pred_mesh
+        if mode == 'd':
+            with torch.no_grad():
+                pred_tex, pred_mesh = self.generator(noise, C, caption)
+                X_fake = torch.cat((pred_tex * X_alpha, X_alpha), dim=1)
+                X_real = torch.cat((X_tex, X_alpha), dim=1)
+                assert (X_mesh is None) == (pred_mesh is None)
+                X_comb = torch.cat((X_fake, X_real), dim=0)
+                C_comb = torch.cat((C, C), dim=0) if C is not None else None
+                M_comb = torch.cat((pred_mesh, X_mesh), dim=0) if pred_mesh is not None else None
+            disc, mask = self.discriminator(X_comb, M_comb, C_comb, caption)
+            d_fake, d_real = divide_pred(disc)
+            m_fake, m_real = divide_pred(mask)
+            loss_fake = self.criterion_gan(d_fake, False, for_discriminator=True, mask=m_fake, weight=w)
+            loss_real = self.criterion_gan(d_real, True, for_discriminator=True, mask=m_real, weight=w)
+            return loss_fake, loss_real, pred_tex, pred_mesh
+        with torch.no_grad():
+            return self.generator_running_avg(noise, C, caption, return_attention=True)
+
+    @torch.no_grad()
+    def update_generator_running_avg(self):
+        """main.py:431-447 (constant alpha; the reference ramps it over the first epochs)"""
+        src = self.generator.state_dict()
+        fl_dst, fl_src = [], []
+        for k, v in self.generator_running_avg.state_dict().items():
+            if torch.is_floating_point(v):
+                fl_dst.append(v)
+                fl_src.append(src[k])
+            else:
+                v.copy_(src[k])
+        torch._foreach_mul_(fl_dst, self.ema_alpha)
+        torch._foreach_add_(fl_dst, fl_src, alpha=1 - self.ema_alpha)
+
+    def iteration(self, X_tex, X_alpha, X_mesh, C, caption=None):
+        """one pass of the loop body main.py:691-723 on one loader batch; returns the scalar losses"""
+        if self.total_it % (1 + self.d_steps_per_g) == 0:
+            self.optimizer_g.zero_grad(set_to_none=True)
+            loss, _, _ = self('g', None, X_alpha, None, C, caption)
+            loss = loss.mean()
+            loss.backward()
+            self.reduce_g()
+            self.optimizer_g.step()
+            self.update_generator_running_avg()
+            out = {"g": loss.detach()}
+        else:
+            self.optimizer_d.zero_grad(set_to_none=True)
+            loss_fake, loss_real, _, _ = self('d', X_tex, X_alpha, X_mesh, C, caption)
+            loss_fake, loss_real = loss_fake.mean(), loss_real.mean()
+            (loss_fake + loss_real).backward()
+            self.reduce_d()
+            self.optimizer_d.step()
+            out = {"d_fake": loss_fake.detach(), "d_real": loss_real.detach()}
+        self.total_it += 1
+        return out

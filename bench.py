@@ -1,17 +1,21 @@
-"""Headline benchmark: projection + silhouette-loss train step (fwd + bwd) on N MI355X.
+"""Headline benchmark: train-step samples/sec (proj + loss + GAN fwd/bwd), batch 64 per GPU, N MI355X.
 
     python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
 
-A "step" is one pass of the hot path over one batch of synthetic clouds resident in HBM:
-  EffectiveLossFunction.forward -> SupervisedLoss.forward -> backward to (point_cloud, rotation, scale),
-called through the drop-in nn.Module API exactly as the reference's Learner.one_batch would
-(code/training_test_shape_net.py:69-100), minus the encoder/decoder (out of scope).
-Workload = BASELINE.json metric's configuration: batch 64 per GPU, 2048-point clouds, 128x128 silhouette
-(configs[1] shape at the metric's batch).  The path shards by cloud with no data-path collective
-(the projection has no parameters), so N > 1 is weak scaling.
+One "step" = one pass of BOTH hot paths over one batch of 64 synthetic samples resident in HBM:
+  (P) EffectiveLossFunction.forward -> SupervisedLoss.forward -> backward to (point_cloud, rotation, scale) on
+      64 clouds of 2048 points into a 128^3 grid (BASELINE configs[1] shape at the metric's batch), called
+      through the drop-in nn.Module API as Learner.one_batch does (code/training_test_shape_net.py:69-100);
+  (G) one GAN cycle of code/main.py:691-723 at batch 64, CUB-shaped 256x256 (BASELINE configs[2] shape at the
+      metric's batch): 1 generator step + 2 discriminator steps, each with its Adam step (+ EMA generator),
+      bf16 MFMA convolutions, fp32 master weights.
+`value` counts 64 samples per step (conservative: the GAN cycle alone consumes 3 loader batches = 192 textures);
+`proj_samples_per_s` and `gan_samples_per_s` give the two halves separately.
+Weak scaling: every rank runs the same per-GPU batch; (P) has no collective, (G) all-reduces gradients (one flat
+RCCL all-reduce per optimiser step) and SyncBN statistics.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed) and `cpu_baseline`
-(the CPU oracle = scalar C port of the reference path, timed on a bounded sample of the same workload).
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed over the same K steps) and
+`cpu_baseline` (the CPU oracle of the projection path, a scalar C port, on a bounded sample).
 """
 import argparse
 import importlib
@@ -27,10 +31,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (2:1-sparsity marketing figure excluded)
 
 
-def make_batch(B, N, S, seed, device):
+def make_clouds(B, N, S, seed, device):
     g = torch.Generator().manual_seed(seed)
     pc = (torch.rand(B, N, 3, generator=g) - 0.5) * 0.7
     q = torch.randn(B, 4, generator=g)
@@ -39,9 +44,19 @@ def make_batch(B, N, S, seed, device):
     return [x.to(device) for x in (pc, q, sc, mask)]
 
 
-def cpu_baseline(N, S, seconds_budget=20.0):
-    """oracle/p_oracle.c (scalar C port of the reference's literal arithmetic) on 1 host core, fwd+bwd,
-    on a bounded sample of the same workload (clouds of N points into an S^3 grid)."""
+def make_textures(B, R, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    x_tex = torch.rand(B, 3, R, R, generator=g) * 2 - 1
+    x_alpha = (torch.rand(B, 1, R, R, generator=g) > 0.4).float()
+    x_mesh = 0.05 * torch.randn(B, 3, 32, 32, generator=g)
+    c = torch.randint(0, 200, (B, 1), generator=g)
+    return [x.to(device) for x in (x_tex, x_alpha, x_mesh, c)]
+
+
+def cpu_baseline(N, S, seconds_budget=15.0):
+    """oracle/p_oracle.c (scalar C port of the reference's literal projection arithmetic) on 1 host core, fwd+bwd,
+    on a bounded sample of the same workload (clouds of N points into an S^3 grid).  The GAN half has no CPU leg
+    here: the reference's torch-CPU cycle at B=16 takes 12.75 s on 8 cores = 3.8 samples/s."""
     from oracle import p_oracle as po
 
     rs = np.random.RandomState(0)
@@ -60,112 +75,135 @@ def cpu_baseline(N, S, seconds_budget=20.0):
         if el > seconds_budget or done >= 64:
             break
     return {"value": done / el, "unit": "samples/s", "cores": 1, "kind": "port",
-            "sample": f"{done} clouds of {N} points -> {S}^3 grid, fwd+bwd, oracle/p_oracle.c, {el:.1f} s"}
+            "sample": f"projection half only: {done} clouds of {N} points -> {S}^3 grid, fwd+bwd, oracle/p_oracle.c, "
+                      f"{el:.1f} s"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=64, help="clouds per GPU")
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
     ap.add_argument("--points", type=int, default=2048)
     ap.add_argument("--grid", type=int, default=128)
+    ap.add_argument("--res", type=int, default=256, help="texture resolution of the GAN half")
+    ap.add_argument("--workload", choices=["both", "proj", "gan"], default="both")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    pkg = importlib.import_module("2dimageto3dmodel_amd")
+    par = importlib.import_module("2dimageto3dmodel_amd.parallel")
+    train = importlib.import_module("2dimageto3dmodel_amd.train")
+    rank, local_rank, world = par.init_from_env("cuda")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
 
-    pkg = importlib.import_module("2dimageto3dmodel_amd")
-    ops = pkg.ops
-    B, N, S = args.batch, args.points, args.grid
-    pc, q, sc, mask = make_batch(B, N, S, 1234 + 2 + rank, dev)
-    pc.requires_grad_()
-    q.requires_grad_()
-    sc.requires_grad_()
-    elf = pkg.EffectiveLossFunction(voxel_size=S).to(dev)
-    crit = pkg.SupervisedLoss()
+    B, N, S, R = args.batch, args.points, args.grid, args.res
+    do_p, do_g = args.workload in ("both", "proj"), args.workload in ("both", "gan")
+
+    if do_p:
+        pc, q, sc, mask = make_clouds(B, N, S, 1234 + 2 + 17 * rank, dev)
+        for t in (pc, q, sc):
+            t.requires_grad_()
+        elf = pkg.EffectiveLossFunction(voxel_size=S).to(dev)
+        crit = pkg.SupervisedLoss()
+    if do_g:
+        gargs = argparse.Namespace(norm_g="syncbatch", norm_d="none", conditional_class=True, conditional_color=False,
+                                   conditional_text=False, n_classes=[200], texture_resolution=R, mask_output=True,
+                                   num_discriminators=2, texture_only=False, text_embedding_dim=256)
+        torch.manual_seed(1234 + 3)
+        trainer = train.GanTrainer(gargs, device=dev)
+        trainer.train()
+        batches = [make_textures(B, R, 1234 + 3 + 17 * rank + i, dev) for i in range(3)]
+
+    last = {}
+
+    def step_p():
+        pc.grad = q.grad = sc.grad = None
+        loss = crit(elf(pc, q, sc), mask)["full_loss"]
+        loss.backward()
+        last["proj_loss"] = loss
+
+    def step_g():
+        for x_tex, x_alpha, x_mesh, c in batches:  # 1 G step + 2 D steps, one loader batch each
+            last.update(trainer.iteration(x_tex, x_alpha, x_mesh, c))
 
     def step():
-        pc.grad = q.grad = sc.grad = None
-        proj = elf(pc, q, sc)
-        loss = crit(proj, mask)["full_loss"]
-        loss.backward()
-        return loss
+        if do_p:
+            step_p()
+        if do_g:
+            step_g()
 
     def barrier():
-        if dist is not None:
+        if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(fn, k):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item()
+
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = tmax.item()
+    dt = timed(step, args.steps)
 
-    # ---- per-kernel HIP-event timing of the same K steps (events on the launch stream = torch's current
-    #      stream); a separate pass so that the event markers do not sit inside the timed region above
-    ops.enable_kernel_timers(True)
+    # ---- the two halves separately, and per-kernel HIP-event timing of the same K steps (events on the launch
+    #      stream = torch's current stream); separate passes so that no marker sits inside the timed region above
+    dt_p = timed(step_p, args.steps) if do_p else None
+    dt_g = timed(step_g, args.steps) if do_g else None
+    pkg._lib.enable_kernel_timers(True)
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    ktimes = ops.collect_kernel_timers()  # name -> (count, total_ms)
-    ops.enable_kernel_timers(False)
+    kt = pkg._lib.collect_kernel_timers()  # name -> (launches, total_ms, total algorithmic work)
+    pkg._lib.enable_kernel_timers(False)
 
     if rank == 0:
-        value = world * B * args.steps / dt
-        # dominant kernel + algorithmic bytes per launch (operator-granular definition)
-        dom = max(ktimes, key=lambda k: ktimes[k][1])
-        alg = {
-            "proj_render_fwd": B * (12 * N + 20 + 8 * S ** 3 + 4 * S ** 2),
-            "proj_render_bwd": B * (4 * S ** 2 + 12 * S ** 3 + 24 * N + 20),
-        }
-        compulsory = {
-            "proj_render_fwd": B * (16 * N + 4 * S ** 2 + 4),
-            "proj_render_bwd": B * (16 * N + 4 * S ** 2 + 48 * N + 4),
-        }
-        cnt, tot = ktimes[dom]
-        avg_s = tot / cnt / 1e3
-        ach = alg.get(dom, 0) / avg_s / 1e9
+        dom = max(kt, key=lambda k: kt[k][1])
+        cnt, tot_ms, work = kt[dom]
+        is_conv = dom.startswith("conv2d")
+        rate = work / (tot_ms * 1e-3) / (1e12 if is_conv else 1e9)
+        peak = MFMA_BF16_PEAK_TF if is_conv else HBM_PEAK_GBS
+        conv_ms = sum(v[1] for k, v in kt.items() if k.startswith("conv2d_") and k != "conv2d_weight_prep")
+        conv_fl = sum(v[2] for k, v in kt.items() if k.startswith("conv2d_") and k != "conv2d_weight_prep")
+        workload = []
+        if do_p:
+            workload.append(f"projection+silhouette-loss fwd/bwd on {B} clouds/GPU of {N} pts -> {S}x{S}")
+        if do_g:
+            workload.append(f"GAN cycle (1 G + 2 D steps, Adam) at batch {B}/GPU, {R}x{R}, nd=2, class-conditional, "
+                            f"syncbatch")
         out = {
-            "metric": "train-step samples/sec (proj+loss fwd/bwd)", "value": value, "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"projection+silhouette-loss fwd/bwd, batch {B}/GPU, {N}-pt clouds -> {S}x{S} "
-                                   f"(BASELINE configs[1] shape at the metric's batch)",
-                       "global_batch": world * B, "points": N, "grid": S, "parallelism": f"dp{world}",
-                       "loss": float(loss.item())},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                         "avg_kernel_us": avg_s * 1e6,
-                         "algorithmic_bytes": alg.get(dom, 0),
-                         "compulsory_io_bytes": compulsory.get(dom, 0),
-                         "note": "fused kernel keeps the S^3 volume in LDS: algorithmic (volume-based) bytes "
-                                 "exceed what actually moves, so frac may exceed 1 (SURVEY.md 8d)"},
-            "kernels_us": {k: v[1] / v[0] * 1e3 for k, v in ktimes.items()},
+            "metric": "train-step samples/sec (proj+loss+GAN fwd/bwd), batch 64", "value": world * B * args.steps / dt,
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if do_g else "f32", "data": "synthetic",
+            "config": {"workload": " + ".join(workload), "global_batch": world * B, "points": N, "grid": S,
+                       "texture_resolution": R, "parallelism": f"dp{world}",
+                       "losses": {k: float(v) for k, v in last.items()}},
+            "proj_samples_per_s": (world * B * args.steps / dt_p) if do_p else None,
+            "gan_samples_per_s": (world * 3 * B * args.steps / dt_g) if do_g else None,
+            "roofline": {"bound": "mfma" if is_conv else "hbm", "kernel": dom, "achieved": rate, "peak": peak,
+                         "unit": "TFLOP/s" if is_conv else "GB/s", "frac": rate / peak, "traffic": None,
+                         "avg_kernel_us": tot_ms / cnt * 1e3, "launches_per_step": cnt / args.steps,
+                         "share_of_kernel_time": tot_ms / sum(v[1] for v in kt.values()),
+                         "all_conv_tflops": (conv_fl / (conv_ms * 1e-3) / 1e12) if conv_ms else None,
+                         "note": "achieved = algorithmic work (2*M*N*K per conv pass; SURVEY 8d volume-based bytes "
+                                 "for the projection kernels, which keep the volume in LDS) / HIP-event kernel time"},
+            "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(kt.items(), key=lambda kv: -kv[1][1])},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, S)
         print(json.dumps(out), flush=True)
-    if dist is not None:
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
