@@ -409,15 +409,19 @@ extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const 
 
 // =====================================================================================================
 // wgrad: dw[co][kh][kw][ci] = sum over pixels p of dy[p][co] * xpatch[p][(kh,kw,ci)]       (fp32 accumulate)
-// GEMM with the PIXEL axis as K: both operands are stored pixel-major (channel contiguous), so each staged
-// 16-byte granule (8 channels of one pixel) is scattered into a channel-major LDS tile ([channel][32 pixels]),
-// from which the MFMA fragments (8 consecutive pixels of one channel) are plain ds_read_b128.
-// Tile: 64 output channels x 128 weight columns (one tap x 128 input channels, or several taps when Cin < 128),
-// split-K over the pixel range across gridDim.z, fp32 atomicAdd of the partial tiles into dw.
+// GEMM with the PIXEL axis as K.  Both operands are stored pixel-major (channels contiguous) while an MFMA fragment
+// needs 8 consecutive K (= pixels) of one channel, so every operand tile is transposed on its way into LDS:
+// a thread loads the same 8-channel granule of 4 consecutive pixels (4 x 16 B), transposes the 8x4 block in
+// registers with v_perm_b32 and writes 8 ds_write_b64 (one per channel, 4 pixels each) into a channel-major tile
+// [channel][64 pixels].  Lanes of a 16-lane group write 128 contiguous bytes of one row (conflict free); the 144-byte
+// row pitch keeps the ds_read_b128 fragment reads conflict free.
+// Tile: TM (64|128) output channels x 128 weight columns x 64 pixels per step; 4 waves as 2x2; the global loads of
+// step s+1 are in flight under the MFMAs of step s; split-K over the pixel axis across gridDim.z with fp32
+// atomicAdd of the partial tiles.
 namespace m355 {
 
-constexpr int WM = 64, WN = 128, WK = 32;
-constexpr int WLD = WK + 8;  // pixels per LDS row (+pad), bf16
+constexpr int WN = 128, WK = 64;
+constexpr int WLD = WK + 8;  // LDS row pitch in bf16 (144 bytes)
 
 struct WgradArgs {
     const unsigned short *x;   // bf16 NHWC [N,H,W,Cin]
@@ -429,43 +433,55 @@ struct WgradArgs {
     int chunk;  // pixels per z-slice (multiple of WK)
 };
 
+// 4 granules (pixels q..q+3, channels c..c+7) -> 8 x 8 bytes: for channel j the 4 pixel values
+__device__ __forceinline__ void transpose_store(const bf16x8 (&g)[4], unsigned short *row0 /* &T[c][4*pq] */)
+{
+    const unsigned int *w0 = reinterpret_cast<const unsigned int *>(&g[0]);
+    const unsigned int *w1 = reinterpret_cast<const unsigned int *>(&g[1]);
+    const unsigned int *w2 = reinterpret_cast<const unsigned int *>(&g[2]);
+    const unsigned int *w3 = reinterpret_cast<const unsigned int *>(&g[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // word k holds channels 2k (low half) and 2k+1 (high half)
+        uint2 lo, hi;
+        lo.x = __builtin_amdgcn_perm(w1[k], w0[k], 0x05040100u);  // (p0, p1) of channel 2k
+        lo.y = __builtin_amdgcn_perm(w3[k], w2[k], 0x05040100u);  // (p2, p3)
+        hi.x = __builtin_amdgcn_perm(w1[k], w0[k], 0x07060302u);  // channel 2k+1
+        hi.y = __builtin_amdgcn_perm(w3[k], w2[k], 0x07060302u);
+        *reinterpret_cast<uint2 *>(row0 + (2 * k) * WLD) = lo;
+        *reinterpret_cast<uint2 *>(row0 + (2 * k + 1) * WLD) = hi;
+    }
+}
+
+template <int TM>
 __global__ __launch_bounds__(256) void k_wgrad_mfma(WgradArgs a)
 {
-    __shared__ __attribute__((aligned(16))) unsigned short At[WM * WLD];  // [co][pixel]
+    __shared__ __attribute__((aligned(16))) unsigned short At[TM * WLD];  // [co][pixel]
     __shared__ __attribute__((aligned(16))) unsigned short Bt[WN * WLD];  // [col][pixel]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int co0 = blockIdx.x * WM, col0 = blockIdx.y * WN;
-    const int P = a.N * a.Ho * a.Wo, K = a.KH * a.KW * a.Cin;
+    const int co0 = blockIdx.x * TM, col0 = blockIdx.y * WN;
+    const int P = a.N * a.Ho * a.Wo, K = a.KH * a.KW * a.Cin, HW = a.Ho * a.Wo;
     const int pbeg = blockIdx.z * a.chunk, pend = min(P, pbeg + a.chunk);
     if (pbeg >= pend) return;
 
-    // staging roles: x granule (prow, cg) with prow = tid>>4 (+16), cg = tid&15 ; dy granule (prow2, cg2)
-    const int xg_col = col0 + (tid & 15) * 8;
-    const bool xcol_ok = xg_col < K;
-    const int tap = xcol_ok ? xg_col / a.Cin : 0, ci = xcol_ok ? xg_col - tap * a.Cin : 0;
+    // staging role: pixel quad pq (4 consecutive pixels) x 8-channel granule gi
+    const int pq = lane & 15, gi = wave * 4 + (lane >> 4);
+    const int xcol = col0 + gi * 8;
+    const bool xcol_ok = xcol < K;
+    const int tap = xcol_ok ? xcol / a.Cin : 0, ci = xcol_ok ? xcol - tap * a.Cin : 0;
     const int kh = tap / a.KW, kw = tap - kh * a.KW;
-    const int yg_co = co0 + (tid & 7) * 8;
-    const bool yco_ok = yg_co < a.Cy;
+    const int yco = co0 + gi * 8;
+    const bool y_ok = gi * 8 < TM && yco < a.Cy;
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    f32x16 acc[2];  // wave tile: 32 co x 64 cols  (waves 2 x 2)
+    bf16x8 gx[4], gy[4];
+    auto load_step = [&](int p0) {
+        int p = p0 + 4 * pq;
+        int n = p / HW, r = p - n * HW;
+        int ho = r / a.Wo, wo = r - ho * a.Wo;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int frow = lane & 31, fk = (lane >> 5) * 8;
-
-    for (int p0 = pbeg; p0 < pend; p0 += WK) {
-        // ---- stage x patches: 2 granules per thread
-        bf16x8 gx[2], gy;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int p = p0 + (tid >> 4) + 16 * i;
-            bool ok = xcol_ok && p < pend;
-            const int pp = ok ? p : 0;
-            const int n = pp / (a.Ho * a.Wo), r = pp - n * (a.Ho * a.Wo);
-            const int ho = r / a.Wo, wo = r - ho * a.Wo;
+        for (int i = 0; i < 4; ++i) {
+            const bool pin = p < pend;
+            bool ok = xcol_ok && pin;
             const int hi = ho * a.stride - a.pad_h + kh;
             int wi = wo * a.stride - a.pad_w + kw;
             ok = ok && hi >= 0 && hi < a.Hl;
@@ -474,38 +490,66 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgradArgs a)
             else ok = ok && wi >= 0 && wi < a.Wl;
             const unsigned short *src = a.x + (((size_t)n * a.H + (hi >> a.ups)) * a.W + (wi >> a.ups)) * a.Cin + ci;
             gx[i] = ok ? *reinterpret_cast<const bf16x8 *>(src) : zero8;
+            gy[i] = (y_ok && pin) ? *reinterpret_cast<const bf16x8 *>(a.dy + (size_t)p * a.Cy + yco) : zero8;
+            ++p;
+            if (++wo == a.Wo) {
+                wo = 0;
+                if (++ho == a.Ho) {
+                    ho = 0;
+                    ++n;
+                }
+            }
         }
-        {
-            const int p = p0 + (tid >> 3);
-            const bool ok = yco_ok && p < pend;
-            gy = ok ? *reinterpret_cast<const bf16x8 *>(a.dy + (size_t)p * a.Cy + yg_co) : zero8;
-        }
-        __syncthreads();  // previous step's fragments consumed
+    };
+    auto store_step = [&]() {
+        transpose_store(gx, &Bt[(gi * 8) * WLD + 4 * pq]);
+        if (gi * 8 < TM) transpose_store(gy, &At[(gi * 8) * WLD + 4 * pq]);
+    };
+
+    constexpr int MI = TM / 64;  // 32-row fragments per wave along co
+    f32x16 acc[MI][2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) Bt[((tid & 15) * 8 + j) * WLD + (tid >> 4) + 16 * i] = (unsigned short)gx[i][j];
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) At[((tid & 7) * 8 + j) * WLD + (tid >> 3)] = (unsigned short)gy[j];
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+
+    load_step(pbeg);
+    for (int p0 = pbeg; p0 < pend; p0 += WK) {
+        __syncthreads();  // the previous step's fragments are consumed
+        store_step();
         __syncthreads();
+        if (p0 + WK < pend) load_step(p0 + WK);  // in flight under the MFMAs
 #pragma unroll
         for (int kk = 0; kk < WK; kk += 16) {
-            const bf16x8 af = *reinterpret_cast<const bf16x8 *>(&At[(wr * 32 + frow) * WLD + kk + fk]);
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(&Bt[(wc * 64 + frow) * WLD + kk + fk]);
-            const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(&Bt[(wc * 64 + 32 + frow) * WLD + kk + fk]);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[1], 0, 0, 0);
+            bf16x8 af[MI], bfr[2];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                af[i] = *reinterpret_cast<const bf16x8 *>(&At[(wr * (TM / 2) + 32 * i + frow) * WLD + kk + fk]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8 *>(&Bt[(wc * 64 + 32 * j + frow) * WLD + kk + fk]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     }
     // ---- epilogue: row = co, col = weight column
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int col = col0 + wc * 64 + 32 * j + (lane & 31);
-            if (co < a.Cout && col < K) atomicAdd(a.dw + (size_t)co * K + col, acc[j][r]);
-        }
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wr * (TM / 2) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = col0 + wc * 64 + 32 * j + (lane & 31);
+                if (co < a.Cout && col < K) atomicAdd(a.dw + (size_t)co * K + col, acc[i][j][r]);
+            }
 }
 
 }  // namespace m355
@@ -527,10 +571,11 @@ extern "C" int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const v
     a.KH = d->kh; a.KW = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
     a.pad_w_mode = d->pad_w_mode;
     const int K = d->kh * d->kw * d->Cin, P = d->N * a.Ho * a.Wo;
-    const int gx = (d->Cout + m355::WM - 1) / m355::WM, gy = (K + m355::WN - 1) / m355::WN;
-    // split the pixel axis so that ~1024 workgroups are in flight, at least 4 K-steps each
+    const int TM = d->Cout > 64 ? 128 : 64;
+    const int gx = (d->Cout + TM - 1) / TM, gy = (K + m355::WN - 1) / m355::WN;
+    // split the pixel axis so that ~1024 workgroups are in flight, at least 2 K-steps each
     int splits = (1024 + gx * gy - 1) / (gx * gy);
-    const int max_splits = (P + 4 * m355::WK - 1) / (4 * m355::WK);
+    const int max_splits = (P + 2 * m355::WK - 1) / (2 * m355::WK);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     a.chunk = ((P + splits - 1) / splits + m355::WK - 1) / m355::WK * m355::WK;
@@ -539,6 +584,7 @@ extern "C" int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const v
         m355::set_error("conv2d_wgrad: memset failed");
         return M355_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(m355::k_wgrad_mfma, dim3(gx, gy, splits), dim3(256), 0, st, a);
+    if (TM == 128) hipLaunchKernelGGL(m355::k_wgrad_mfma<128>, dim3(gx, gy, splits), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(m355::k_wgrad_mfma<64>, dim3(gx, gy, splits), dim3(256), 0, st, a);
     return m355::check_launch("conv2d_wgrad");
 }
