@@ -27,6 +27,7 @@ SOURCES = [
     ("proj_render21.hip", STRICT),
     ("sil_loss.hip", STRICT),
     ("conv_mfma.hip", []),
+    ("gan_elem.hip", []),
 ]
 
 

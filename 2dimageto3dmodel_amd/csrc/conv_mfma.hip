@@ -198,32 +198,41 @@ __global__ void k_weight_prep(const float *__restrict__ in, unsigned short *__re
 __global__ void k_fold_pad(const unsigned short *__restrict__ g, unsigned short *__restrict__ dx, int N, int H, int W,
                            int C, int ups, int pw, int mode, int Hg, int hoff)
 {
-    const int Wl = W << ups, Wp = Wl + 2 * pw;
-    const size_t total = (size_t)N * H * W * C;
+    // one thread per 8-channel granule of dx
+    const int Wl = W << ups, Wp = Wl + 2 * pw, C8 = C >> 3;
+    const size_t total = (size_t)N * H * W * C8;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int c = idx % C;
-        size_t t = idx / C;
+        const int c = (int)(idx % C8) * 8;
+        size_t t = idx / C8;
         const int w = t % W;
         t /= W;
         const int h = t % H;
         const int n = t / H;
-        float s = 0.0f;
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        auto add = [&](const unsigned short *p) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(p);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += bf2f((unsigned short)v[j]);
+        };
         for (int dy = 0; dy <= ups; ++dy)
             for (int dxx = 0; dxx <= ups; ++dxx) {
                 const int hl = (h << ups) + dy, wl = (w << ups) + dxx;
                 const unsigned short *row = g + (((size_t)n * Hg + hl + hoff) * Wp) * C + c;
-                s += bf2f(row[(size_t)(wl + pw) * C]);
+                add(row + (size_t)(wl + pw) * C);
                 if (mode == 1) {  // replicate: all left pads read column 0, all right pads column Wl-1
                     if (wl == 0)
-                        for (int p = 0; p < pw; ++p) s += bf2f(row[(size_t)p * C]);
+                        for (int p = 0; p < pw; ++p) add(row + (size_t)p * C);
                     if (wl == Wl - 1)
-                        for (int p = 0; p < pw; ++p) s += bf2f(row[(size_t)(Wl + pw + p) * C]);
+                        for (int p = 0; p < pw; ++p) add(row + (size_t)(Wl + pw + p) * C);
                 } else if (mode == 2) {  // circular: pad column p <-> source Wl-pw+p (left), Wl+pw+p <-> p (right)
-                    if (wl >= Wl - pw) s += bf2f(row[(size_t)(wl - (Wl - pw)) * C]);
-                    if (wl < pw) s += bf2f(row[(size_t)(Wl + pw + wl) * C]);
+                    if (wl >= Wl - pw) add(row + (size_t)(wl - (Wl - pw)) * C);
+                    if (wl < pw) add(row + (size_t)(Wl + pw + wl) * C);
                 }
             }
-        dx[idx] = f2bf(s);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(s[j]);
+        *reinterpret_cast<bf16x8 *>(dx + idx * 8) = o;
     }
 }
 
@@ -376,7 +385,7 @@ extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const 
         rc = m355::launch_conv(a, cin64, st);
         if (rc) return rc;
         if (need_fold) {
-            const size_t total = (size_t)d->N * d->H * d->W * d->Cin;
+            const size_t total = (size_t)d->N * d->H * d->W * (d->Cin / 8);
             hipLaunchKernelGGL(m355::k_fold_pad, dim3((unsigned)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256)),
                                dim3(256), 0, st, (const unsigned short *)ws, (unsigned short *)dx, d->N, d->H, d->W, d->Cin,
                                d->upsample, d->pad_w, d->pad_w_mode, Hl, 0);
@@ -400,7 +409,7 @@ extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const 
             rc = m355::launch_conv(a, cin64, st);
             if (rc) return rc;
         }
-    const size_t total = (size_t)d->N * d->H * d->W * d->Cin;
+    const size_t total = (size_t)d->N * d->H * d->W * (d->Cin / 8);
     hipLaunchKernelGGL(m355::k_fold_pad, dim3((unsigned)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256)), dim3(256),
                        0, st, (const unsigned short *)ws, (unsigned short *)dx, d->N, d->H, d->W, d->Cin, d->upsample,
                        d->pad_w, d->pad_w_mode, Hp, d->pad_h);

@@ -1,0 +1,285 @@
+// G3 / G-bwd glue of the GAN stacks on NHWC bf16 activations (memory-bound, 16-byte vector accesses):
+//   * per-channel batch statistics                     (BatchNorm2d / SynchronizedBatchNorm2d of gan.py:268-271)
+//   * y = LeakyReLU(x * a[n,c] + b[n,c])                (BN normalisation + conditional affine gan.py:282-286 +
+//                                                        the LeakyReLU that follows it in ResBlockUp gan.py:309-310)
+//   * its backward: per-(n,c) reductions of dz and dz*x, then dx = dz*A[n,c] + x*B[c] + C[c]
+//   * LeakyReLU backward + bias gradient for convs with a fused activation epilogue (discriminators)
+// Reductions are two-stage and deterministic (fp32 partials per workgroup, then one finalising pass).
+// HBM roofline: stats 2 B/elem, apply 4 B/elem, bwd reduce 4 B/elem, bwd apply 6 B/elem.
+#include "common.h"
+
+namespace m355 {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8e;
+
+__device__ __forceinline__ float bf2f_e(short h) { return __uint_as_float(((unsigned int)(unsigned short)h) << 16); }
+__device__ __forceinline__ short f2bf_e(float f)
+{
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (short)(u >> 16);
+}
+
+constexpr int kMinPixPerBlock = 1024;  // pixels a workgroup reduces (more when that keeps the partial count <= 1024)
+
+static inline int pix_per_block(size_t P)
+{
+    size_t ppb = (P + 1023) / 1024;
+    if (ppb < (size_t)kMinPixPerBlock) ppb = kMinPixPerBlock;
+    return (int)((ppb + 63) / 64 * 64);
+}
+
+// ---- generic "sum over pixels of f(row)" skeleton: rows are [C] bf16, a thread owns one 8-channel vector and
+//      every (256 / (C/8))-th pixel of the workgroup's range; partials land in part[blk][NV][C].
+template <int NV, typename F>
+__device__ __forceinline__ void pixel_reduce(int C, size_t pix0, int npix, float *part_blk, F f)
+{
+    __shared__ float red[256 * 8];
+    const int tid = threadIdx.x;
+    const int vecs = C >> 3;                 // 8-channel vectors per pixel
+    const int lanes = 256 / vecs;            // pixel lanes
+    const int v = tid % vecs, pl = tid / vecs;
+    float acc[NV][8];
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[k][j] = 0.0f;
+    if (pl < lanes)
+        for (int p = pl; p < npix; p += lanes) f(pix0 + p, v * 8, acc);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid * 8 + j] = acc[k][j];
+        __syncthreads();
+        // thread t < C sums channel t over the pixel lanes
+        for (int c = tid; c < C; c += 256) {
+            const int vv = c >> 3, jj = c & 7;
+            float s = 0.0f;
+            for (int l = 0; l < lanes; ++l) s += red[(l * vecs + vv) * 8 + jj];
+            part_blk[(size_t)k * C + c] = s;
+        }
+    }
+}
+
+// x[P][C] -> part[blk][2][C] = (sum, sum of squares)
+__global__ __launch_bounds__(256) void k_chan_stats(const short *__restrict__ x, float *__restrict__ part, size_t P, int C,
+                                                    int ppb)
+{
+    const size_t pix0 = (size_t)blockIdx.x * ppb;
+    const int npix = (int)min((size_t)ppb, P - pix0);
+    pixel_reduce<2>(C, pix0, npix, part + (size_t)blockIdx.x * 2 * C, [&](size_t p, int c0, float (&acc)[2][8]) {
+        const bf16x8e v = *reinterpret_cast<const bf16x8e *>(x + p * C + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = bf2f_e(v[j]);
+            acc[0][j] += f;
+            acc[1][j] += f * f;
+        }
+    });
+}
+
+// part[G][nblk][W] -> out[G][W]: deterministic second stage.  A workgroup owns 32 outputs; 8 threads per output
+// each sum every 8th partial, then a fixed-order LDS combine.
+__global__ __launch_bounds__(256) void k_sum_partials(const float *__restrict__ part, float *__restrict__ out, int nblk,
+                                                      int W)
+{
+    __shared__ float red[8][32];
+    const int g = blockIdx.y;
+    const int i = blockIdx.x * 32 + (threadIdx.x & 31), l = threadIdx.x >> 5;
+    float s = 0.0f;
+    if (i < W)
+        for (int b = l; b < nblk; b += 8) s += part[((size_t)g * nblk + b) * W + i];
+    red[l][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (l == 0 && i < W) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x & 31];
+        out[(size_t)g * W + i] = t;
+    }
+}
+
+// y = lrelu(x * a[n,c] + b[n,c]);  x,y [N][HW][C]
+__global__ __launch_bounds__(256) void k_affine_act(const short *__restrict__ x, const float *__restrict__ a,
+                                                    const float *__restrict__ b, short *__restrict__ y, int HW, int C,
+                                                    float slope)
+{
+    const int n = blockIdx.y;
+    const int vecs = C >> 3;
+    const size_t total = (size_t)HW * vecs;
+    const short *xn = x + (size_t)n * HW * C;
+    short *yn = y + (size_t)n * HW * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c0 = (int)(i % vecs) * 8;
+        const bf16x8e v = *reinterpret_cast<const bf16x8e *>(xn + i * 8);
+        bf16x8e o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float z = bf2f_e(v[j]) * a[(size_t)n * C + c0 + j] + b[(size_t)n * C + c0 + j];
+            z = z >= 0.0f ? z : z * slope;
+            o[j] = f2bf_e(z);
+        }
+        *reinterpret_cast<bf16x8e *>(yn + i * 8) = o;
+    }
+}
+
+// dz = dy * lrelu'(x*a+b);  part[n][blk][2][C] = (sum dz, sum dz*x) over the workgroup's pixels of sample n
+__global__ __launch_bounds__(256) void k_act_bwd_reduce(const short *__restrict__ dy, const short *__restrict__ x,
+                                                        const float *__restrict__ a, const float *__restrict__ b,
+                                                        float *__restrict__ part, int HW, int C, float slope, int ppb)
+{
+    const int n = blockIdx.y, nblk = gridDim.x;
+    const size_t pix0 = (size_t)blockIdx.x * ppb;
+    const int npix = (int)min((size_t)ppb, (size_t)HW - pix0);
+    const size_t base = (size_t)n * HW;
+    pixel_reduce<2>(C, pix0, npix, part + ((size_t)n * nblk + blockIdx.x) * 2 * C,
+                    [&](size_t p, int c0, float (&acc)[2][8]) {
+                        const bf16x8e vx = *reinterpret_cast<const bf16x8e *>(x + (base + p) * C + c0);
+                        const bf16x8e vd = *reinterpret_cast<const bf16x8e *>(dy + (base + p) * C + c0);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float xf = bf2f_e(vx[j]);
+                            const float z = xf * a[(size_t)n * C + c0 + j] + b[(size_t)n * C + c0 + j];
+                            const float dz = bf2f_e(vd[j]) * (z >= 0.0f ? 1.0f : slope);
+                            acc[0][j] += dz;
+                            acc[1][j] += dz * xf;
+                        }
+                    });
+}
+
+// dx = dz * A[n,c] + x * B[c] + Cc[c]
+__global__ __launch_bounds__(256) void k_act_bwd_apply(const short *__restrict__ dy, const short *__restrict__ x,
+                                                       const float *__restrict__ a, const float *__restrict__ b,
+                                                       const float *__restrict__ A, const float *__restrict__ Bc,
+                                                       const float *__restrict__ Cc, short *__restrict__ dx, int HW,
+                                                       int C, float slope)
+{
+    const int n = blockIdx.y;
+    const int vecs = C >> 3;
+    const size_t total = (size_t)HW * vecs;
+    const size_t off = (size_t)n * HW * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c0 = (int)(i % vecs) * 8;
+        const bf16x8e vx = *reinterpret_cast<const bf16x8e *>(x + off + i * 8);
+        const bf16x8e vd = *reinterpret_cast<const bf16x8e *>(dy + off + i * 8);
+        bf16x8e o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j;
+            const float xf = bf2f_e(vx[j]);
+            const float z = xf * a[(size_t)n * C + c] + b[(size_t)n * C + c];
+            const float dz = bf2f_e(vd[j]) * (z >= 0.0f ? 1.0f : slope);
+            o[j] = f2bf_e(dz * A[(size_t)n * C + c] + xf * Bc[c] + Cc[c]);
+        }
+        *reinterpret_cast<bf16x8e *>(dx + off + i * 8) = o;
+    }
+}
+
+// g[P][Cp] = dy[P][C] * (y > 0 ? 1 : slope), channels C..Cp-1 zero;  part[blk][1][C] = sum over pixels of g
+__global__ __launch_bounds__(256) void k_lrelu_bwd(const short *__restrict__ dy, const short *__restrict__ y,
+                                                   short *__restrict__ g, float *__restrict__ part, size_t P, int C,
+                                                   float slope, int ppb)
+{
+    const size_t pix0 = (size_t)blockIdx.x * ppb;
+    const int npix = (int)min((size_t)ppb, P - pix0);
+    pixel_reduce<1>(C, pix0, npix, part + (size_t)blockIdx.x * C, [&](size_t p, int c0, float (&acc)[1][8]) {
+        const bf16x8e vy = *reinterpret_cast<const bf16x8e *>(y + p * C + c0);
+        const bf16x8e vd = *reinterpret_cast<const bf16x8e *>(dy + p * C + c0);
+        bf16x8e o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gz = bf2f_e(vd[j]) * (bf2f_e(vy[j]) > 0.0f ? 1.0f : slope);
+            o[j] = f2bf_e(gz);
+            acc[0][j] += bf2f_e(o[j]);
+        }
+        *reinterpret_cast<bf16x8e *>(g + p * C + c0) = o;
+    });
+}
+
+static int check_c(int C, const char *who)
+{
+    if (C < 8 || C % 8 != 0 || C > 2048 || 256 % (C / 8) != 0) {
+        set_error("%s: C=%d must be a multiple of 8 with C/8 dividing 256", who, C);
+        return M355_ERR_BAD_ARG;
+    }
+    return 0;
+}
+
+}  // namespace m355
+
+using namespace m355;
+
+extern "C" size_t m355_chan_reduce_ws_bytes(size_t pixels_per_group, int groups, int nvals, int C)
+{
+    const size_t ppb = pix_per_block(pixels_per_group);
+    const size_t nblk = (pixels_per_group + ppb - 1) / ppb;
+    return sizeof(float) * nblk * (size_t)groups * nvals * C;
+}
+
+extern "C" int m355_bn_stats(const void *x, float *sums /*[2][C]*/, void *ws, size_t P, int C, void *stream)
+{
+    M355_REQUIRE(x && sums && ws && P > 0, "bn_stats: null pointer / empty");
+    if (int rc = check_c(C, "bn_stats")) return rc;
+    const int ppb = pix_per_block(P);
+    const int nblk = (int)((P + ppb - 1) / ppb);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_chan_stats, dim3(nblk), dim3(256), 0, st, (const short *)x, (float *)ws, P, C, ppb);
+    hipLaunchKernelGGL(k_sum_partials, dim3((2 * C + 31) / 32, 1), dim3(256), 0, st, (const float *)ws, sums, nblk, 2 * C);
+    return check_launch("bn_stats");
+}
+
+extern "C" int m355_affine_act_fwd(const void *x, const float *a, const float *b, void *y, int N, int HW, int C,
+                                   float slope, void *stream)
+{
+    M355_REQUIRE(x && a && b && y && N > 0 && HW > 0, "affine_act_fwd: null pointer / empty");
+    if (int rc = check_c(C, "affine_act_fwd")) return rc;
+    const size_t total = (size_t)HW * (C / 8);
+    const unsigned gx = (unsigned)min((size_t)4096, (total + 255) / 256);
+    hipLaunchKernelGGL(k_affine_act, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, (const short *)x, a, b, (short *)y, HW,
+                       C, slope);
+    return check_launch("affine_act_fwd");
+}
+
+extern "C" int m355_affine_act_bwd_reduce(const void *dy, const void *x, const float *a, const float *b,
+                                          float *sums /*[N][2][C]*/, void *ws, int N, int HW, int C, float slope,
+                                          void *stream)
+{
+    M355_REQUIRE(dy && x && a && b && sums && ws && N > 0 && HW > 0, "affine_act_bwd_reduce: null pointer / empty");
+    if (int rc = check_c(C, "affine_act_bwd_reduce")) return rc;
+    const int ppb = pix_per_block((size_t)HW);
+    const int nblk = (HW + ppb - 1) / ppb;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_act_bwd_reduce, dim3(nblk, N), dim3(256), 0, st, (const short *)dy, (const short *)x, a, b,
+                       (float *)ws, HW, C, slope, ppb);
+    hipLaunchKernelGGL(k_sum_partials, dim3((2 * C + 31) / 32, N), dim3(256), 0, st, (const float *)ws, sums, nblk, 2 * C);
+    return check_launch("affine_act_bwd_reduce");
+}
+
+extern "C" int m355_affine_act_bwd_apply(const void *dy, const void *x, const float *a, const float *b, const float *A,
+                                         const float *Bc, const float *Cc, void *dx, int N, int HW, int C, float slope,
+                                         void *stream)
+{
+    M355_REQUIRE(dy && x && a && b && A && Bc && Cc && dx && N > 0 && HW > 0, "affine_act_bwd_apply: null pointer / empty");
+    if (int rc = check_c(C, "affine_act_bwd_apply")) return rc;
+    const size_t total = (size_t)HW * (C / 8);
+    const unsigned gx = (unsigned)min((size_t)4096, (total + 255) / 256);
+    hipLaunchKernelGGL(k_act_bwd_apply, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, (const short *)dy, (const short *)x,
+                       a, b, A, Bc, Cc, (short *)dx, HW, C, slope);
+    return check_launch("affine_act_bwd_apply");
+}
+
+extern "C" int m355_lrelu_bwd(const void *dy, const void *y, void *g, float *dbias /*[C]*/, void *ws, size_t P, int C,
+                              float slope, void *stream)
+{
+    M355_REQUIRE(dy && y && g && dbias && ws && P > 0, "lrelu_bwd: null pointer / empty");
+    if (int rc = check_c(C, "lrelu_bwd")) return rc;
+    const int ppb = pix_per_block(P);
+    const int nblk = (int)((P + ppb - 1) / ppb);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_lrelu_bwd, dim3(nblk), dim3(256), 0, st, (const short *)dy, (const short *)y, (short *)g,
+                       (float *)ws, P, C, slope, ppb);
+    hipLaunchKernelGGL(k_sum_partials, dim3((C + 31) / 32, 1), dim3(256), 0, st, (const float *)ws, dbias, nblk, C);
+    return check_launch("lrelu_bwd");
+}

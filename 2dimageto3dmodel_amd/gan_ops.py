@@ -11,6 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import conv as C
+from ._lib import launch, lib, ptr, stream
 
 
 def _ceil(a, b):
@@ -63,15 +64,21 @@ class Conv2dFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, wd, y = ctx.saved_tensors
         d = ctx.d
-        g = dy.permute(0, 2, 3, 1) if ctx.f32 else dy       # -> NHWC view
-        if ctx.slope != 1.0:
-            yy = y.permute(0, 2, 3, 1) if ctx.f32 else y
-            g = g * torch.where(yy > 0, 1.0, ctx.slope).to(g.dtype)
-        db = g.float().sum((0, 1, 2)) if ctx.has_bias and ctx.needs_input_grad[2] else None
         c32 = _ceil(d.Cout, 32)
-        if c32 != d.Cout:
-            g = F.pad(g, (0, c32 - d.Cout))
-        g = g.contiguous().to(torch.bfloat16)
+        if ctx.slope != 1.0 and not ctx.f32 and c32 == d.Cout and 256 % (d.Cout // 8) == 0:
+            # LeakyReLU epilogue backward + bias gradient in one pass (csrc/gan_elem.hip)
+            g, db = lrelu_bwd(dy.contiguous(), y, ctx.slope)
+            if not (ctx.has_bias and ctx.needs_input_grad[2]):
+                db = None
+        else:
+            g = dy.permute(0, 2, 3, 1) if ctx.f32 else dy       # -> NHWC view
+            if ctx.slope != 1.0:
+                yy = y.permute(0, 2, 3, 1) if ctx.f32 else y
+                g = g * torch.where(yy > 0, 1.0, ctx.slope).to(g.dtype)
+            db = g.float().sum((0, 1, 2)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+            if c32 != d.Cout:
+                g = F.pad(g, (0, c32 - d.Cout))
+            g = g.contiguous().to(torch.bfloat16)
         dx = C.conv_dgrad(d, g, wd, cin_real=ctx.cw) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
@@ -83,10 +90,95 @@ def conv2d(x, weight, bias, stride, pad_h, pad_w, mode, upsample=0, slope=1.0, o
     return Conv2dFn.apply(x, weight, bias, stride, pad_h, pad_w, mode, int(upsample), float(slope), bool(out_f32_nchw))
 
 
+# ------------------------------------------------------------------------------------------------ fused elementwise
+def _ws(pixels_per_group, groups, nvals, C, device):
+    n = lib().m355_chan_reduce_ws_bytes(pixels_per_group, groups, nvals, C)
+    return torch.empty((max(n, 8),), dtype=torch.uint8, device=device)
+
+
+def lrelu_bwd(dy, y, slope):
+    """g = dy * (y > 0 ? 1 : slope) (bf16) and its per-channel sum (fp32) in one pass"""
+    C_ = y.shape[-1]
+    P = y.numel() // C_
+    g = torch.empty_like(y)
+    db = torch.empty((C_,), dtype=torch.float32, device=y.device)
+    launch("lrelu_bwd", ptr(dy), ptr(y), ptr(g), ptr(db), ptr(_ws(P, 1, 1, C_, y.device)), P, C_, float(slope), stream())
+    return g, db
+
+
+def bn_sums(x):
+    """x [N,H,W,C] bf16 -> [2,C] fp32 (sum, sum of squares) over N*H*W"""
+    C_ = x.shape[-1]
+    P = x.numel() // C_
+    sums = torch.empty((2, C_), dtype=torch.float32, device=x.device)
+    launch("bn_stats", ptr(x), ptr(sums), ptr(_ws(P, 1, 2, C_, x.device)), P, C_, stream())
+    return sums
+
+
+class AffineActFn(torch.autograd.Function):
+    """y = LeakyReLU(((x - mean) * rstd) * scale[n,c] + shift[n,c]) on NHWC bf16, with the batch-norm backward
+    (mean / rstd are functions of x when `batch_stats`) folded into three per-channel coefficients."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, mean, rstd, slope, batch_stats, count, sync):
+        n, h, w, c = x.shape
+        x = x.contiguous()
+        a = (rstd * scale.float()).contiguous()            # [N,C]
+        b = (shift.float() - mean * a).contiguous()
+        y = torch.empty_like(x)
+        launch("affine_act_fwd", ptr(x), ptr(a), ptr(b), ptr(y), n, h * w, c, float(slope), stream())
+        ctx.save_for_backward(x, a, b, scale, mean, rstd)
+        ctx.cfg = (slope, batch_stats, count, sync)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, a, b, scale, mean, rstd = ctx.saved_tensors
+        slope, batch_stats, count, sync = ctx.cfg
+        n, h, w, c = x.shape
+        dy = dy.contiguous()
+        sums = torch.empty((n, 2, c), dtype=torch.float32, device=x.device)
+        launch("affine_act_bwd_reduce", ptr(dy), ptr(x), ptr(a), ptr(b), ptr(sums), ptr(_ws(h * w, n, 2, c, x.device)), n,
+               h * w, c, float(slope), stream())
+        s1, s2 = sums[:, 0], sums[:, 1]                    # sum dz, sum dz*x   per (n,c)
+        dxhat_xhat = rstd * (s2 - mean * s1)               # sum_hw dz * xhat
+        dshift = s1
+        dscale = dxhat_xhat
+        sc = scale.float()
+        A = (rstd * sc).contiguous()
+        if batch_stats:
+            m = torch.stack(((sc * s1).sum(0), (sc * dxhat_xhat).sum(0)))   # [2,C] sums over the local batch
+            if sync:
+                dist.all_reduce(m, op=dist.ReduceOp.SUM)
+            m1, m2 = m[0] / count, m[1] / count
+            Bc = (-rstd * rstd * m2).contiguous()
+            Cc = (-rstd * m1 + rstd * rstd * mean * m2).contiguous()
+        else:
+            Bc = torch.zeros(c, dtype=torch.float32, device=x.device)
+            Cc = Bc
+        dx = torch.empty_like(x)
+        launch("affine_act_bwd_apply", ptr(dy), ptr(x), ptr(a), ptr(b), ptr(A), ptr(Bc), ptr(Cc), ptr(dx), n, h * w, c,
+               float(slope), stream())
+        return dx, dscale.to(scale.dtype), dshift.to(scale.dtype), None, None, None, None, None, None
+
+
+def _fused_ok(x):
+    c = x.shape[-1]
+    return x.is_cuda and x.dtype == torch.bfloat16 and c % 8 == 0 and c <= 2048 and 256 % (c // 8) == 0
+
+
 # ------------------------------------------------------------------------------------------------ normalisation
+def _affine_act(xhat, scale, shift, slope):
+    """(torch path, CPU tests / odd channel counts) xhat fp32 [N,H,W,C]; scale/shift [N,C]"""
+    y = xhat * scale[:, None, None, :].float() + shift[:, None, None, :].float()
+    if slope != 1.0:
+        y = F.leaky_relu(y, slope)
+    return y.to(torch.bfloat16)
+
+
 class _SyncMoments(torch.autograd.Function):
-    """all-reduce (sum) of the per-channel [sum | sum of squares | count] vector; the backward all-reduces the
-    incoming gradient, which is the exact adjoint of a sum over ranks."""
+    """(torch path) all-reduce (sum) of the per-channel [sum | sum of squares | count] vector; the backward
+    all-reduces the incoming gradient, which is the exact adjoint of a sum over ranks."""
 
     @staticmethod
     def forward(ctx, v):
@@ -99,14 +191,6 @@ class _SyncMoments(torch.autograd.Function):
         g = g.clone()
         dist.all_reduce(g, op=dist.ReduceOp.SUM)
         return g
-
-
-def _affine_act(xhat, scale, shift, slope):
-    """xhat fp32 [N,H,W,C]; scale/shift [N,C] -> bf16 LeakyReLU(xhat*scale + shift)"""
-    y = xhat * scale[:, None, None, :].float() + shift[:, None, None, :].float()
-    if slope != 1.0:
-        y = F.leaky_relu(y, slope)
-    return y.to(torch.bfloat16)
 
 
 class BatchNorm2d(nn.Module):
@@ -123,22 +207,45 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(ch))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
+    def _is_sync(self):
+        return self.sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def _update_running(self, mean, var, cnt):
+        with torch.no_grad():
+            unbiased = var * (cnt / (cnt - 1)) if float(cnt) > 1 else var
+            self.running_mean.mul_(1 - self.momentum).add_(mean.detach(), alpha=self.momentum)
+            self.running_var.mul_(1 - self.momentum).add_(unbiased.detach(), alpha=self.momentum)
+            self.num_batches_tracked += 1
+
     def forward(self, x, scale, shift, slope=1.0):
+        if _fused_ok(x):
+            sync = self._is_sync()
+            if self.training:
+                cnt = float(x.shape[0] * x.shape[1] * x.shape[2])
+                with torch.no_grad():
+                    sums = bn_sums(x)
+                    if sync:  # one fused [sum | sumsq | count] message per layer
+                        v = torch.cat((sums.reshape(-1), sums.new_tensor([cnt])))
+                        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+                        sums, cnt = v[:-1].view(2, -1), float(v[-1])
+                    mean = sums[0] / cnt
+                    var = (sums[1] / cnt - mean * mean).clamp_min(0)
+                    rstd = torch.rsqrt(var + self.eps)
+                self._update_running(mean, var, cnt)
+                return AffineActFn.apply(x, scale, shift, mean, rstd, slope, True, cnt, sync)
+            rstd = torch.rsqrt(self.running_var + self.eps)
+            return AffineActFn.apply(x, scale, shift, self.running_mean, rstd, slope, False, 1.0, False)
         xf = x.float()
         if self.training:
             cnt = x.shape[0] * x.shape[1] * x.shape[2]
             s, ss = xf.sum((0, 1, 2)), (xf * xf).sum((0, 1, 2))
-            if self.sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if self._is_sync():
                 v = _SyncMoments.apply(torch.cat((s, ss, s.new_tensor([float(cnt)]))))
                 c = s.numel()
                 s, ss, cnt = v[:c], v[c:2 * c], v[2 * c]
             mean = s / cnt
             var = (ss / cnt - mean * mean).clamp_min(0)
-            with torch.no_grad():
-                unbiased = var * (cnt / (cnt - 1)) if float(cnt) > 1 else var
-                self.running_mean.mul_(1 - self.momentum).add_(mean.detach(), alpha=self.momentum)
-                self.running_var.mul_(1 - self.momentum).add_(unbiased.detach(), alpha=self.momentum)
-                self.num_batches_tracked += 1
+            self._update_running(mean, var, cnt)
         else:
             mean, var = self.running_mean, self.running_var
         return _affine_act((xf - mean) * torch.rsqrt(var + self.eps), scale, shift, slope)
@@ -163,4 +270,8 @@ class InstanceNorm2d(nn.Module):
 
 class NoNorm(nn.Module):
     def forward(self, x, scale, shift, slope=1.0):
+        if _fused_ok(x):
+            c = x.shape[-1]
+            zero = torch.zeros(c, dtype=torch.float32, device=x.device)
+            return AffineActFn.apply(x, scale, shift, zero, torch.ones_like(zero), slope, False, 1.0, False)
         return _affine_act(x.float(), scale, shift, slope)

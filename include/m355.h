@@ -128,6 +128,27 @@ int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const void *w_dgr
  *      combined with fp32 atomics, so the last bits depend on arrival order). */
 int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const void *dy, float *dw, void *stream);
 
+/* ---- G3 / G-bwd  normalisation + conditional affine + LeakyReLU on NHWC bf16 (models/gan.py:264-286, 306-312).
+ *      All reductions are two-stage and deterministic; ws >= m355_chan_reduce_ws_bytes(pixels per group, groups,
+ *      values per channel, C).  C must be a multiple of 8 with C/8 dividing 256. */
+size_t m355_chan_reduce_ws_bytes(size_t pixels_per_group, int groups, int nvals, int C);
+/*      x[P][C] -> sums[2][C] = (sum, sum of squares): the batch statistics of BatchNorm2d / SynchronizedBatchNorm2d */
+int m355_bn_stats(const void *x, float *sums, void *ws, size_t P, int C, void *stream);
+/*      y = LeakyReLU_slope(x * a[n,c] + b[n,c]);  x,y [N][HW][C];  a = rstd*(1+gamma), b = beta - mean*a */
+int m355_affine_act_fwd(const void *x, const float *a, const float *b, void *y, int N, int HW, int C, float slope,
+                        void *stream);
+/*      dz = dy * LeakyReLU'(x*a+b);  sums[N][2][C] = (sum_hw dz, sum_hw dz*x) */
+int m355_affine_act_bwd_reduce(const void *dy, const void *x, const float *a, const float *b, float *sums, void *ws,
+                               int N, int HW, int C, float slope, void *stream);
+/*      dx = dz * A[n,c] + x * Bc[c] + Cc[c]   (the batch-norm backward collapses into these three coefficients) */
+int m355_affine_act_bwd_apply(const void *dy, const void *x, const float *a, const float *b, const float *A,
+                              const float *Bc, const float *Cc, void *dx, int N, int HW, int C, float slope,
+                              void *stream);
+/*      backward of a conv epilogue LeakyReLU (discriminators, gan.py:92-94,210-213): g = dy * (y > 0 ? 1 : slope),
+ *      dbias[C] = sum over pixels of g */
+int m355_lrelu_bwd(const void *dy, const void *y, void *g, float *dbias, void *ws, size_t P, int C, float slope,
+                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif
