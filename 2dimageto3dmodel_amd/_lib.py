@@ -97,17 +97,24 @@ def collect_kernel_timers():
     return out
 
 
-def launch(name, *args, work=0.0):
+TIMER_TAGS = bool(os.environ.get("M355_TIMER_TAGS"))  # per-shape timer keys (scripts/layer_times.py)
+
+
+def launch(name, *args, work=0.0, tag=None):
     """call m355_<name>(*args), raise on a non-zero status; optionally bracket it with HIP events"""
     fn = getattr(lib(), "m355_" + name)
     if _TIMERS_ON:
+        if TIMER_TAGS and tag:
+            name_t = name + " " + tag
+        else:
+            name_t = name
         import torch
 
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = fn(*args)
         e1.record()
-        _TIMER_EVENTS.append((name, e0, e1, float(work)))
+        _TIMER_EVENTS.append((name_t, e0, e1, float(work)))
     else:
         rc = fn(*args)
     check(rc, name)

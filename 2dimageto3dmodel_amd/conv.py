@@ -33,6 +33,10 @@ def flops(d, cin_real=None):
     return 2.0 * d.N * ho * wo * d.Cout * (cin_real or d.Cin) * d.kh * d.kw
 
 
+def tag(d):
+    return (f"N{d.N} {d.H}x{d.W} {d.Cin}->{d.Cout} k{d.kh} s{d.stride} up{d.upsample}")
+
+
 def _req(t, dtype, name):
     if not t.is_cuda:
         raise _lib.M355Error(f"{name} must be a CUDA(HIP) tensor; the conv path has no CPU implementation")
@@ -62,7 +66,7 @@ def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0, cin_real=Non
         y = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.bfloat16, device=x.device)
     b = None if bias is None else _req(bias.detach(), torch.float32, "bias")
     launch("conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(b), ptr(y), int(out_f32_nchw), float(slope), stream(),
-           work=flops(d, cin_real))
+           work=flops(d, cin_real), tag=tag(d))
     return y
 
 
@@ -73,7 +77,7 @@ def conv_dgrad(d, dy, w_dgrad, cin_real=None):
     dx = torch.empty((d.N, d.H, d.W, d.Cin), dtype=torch.bfloat16, device=dy.device)
     nws = lib().m355_conv2d_dgrad_ws_bytes(ctypes.byref(d))
     ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device)
-    launch("conv2d_dgrad", ctypes.byref(d), ptr(dy), ptr(w_dgrad), ptr(dx), ptr(ws), stream(), work=flops(d, cin_real))
+    launch("conv2d_dgrad", ctypes.byref(d), ptr(dy), ptr(w_dgrad), ptr(dx), ptr(ws), stream(), work=flops(d, cin_real), tag=tag(d))
     return dx
 
 
@@ -81,5 +85,5 @@ def conv_wgrad(d, x, dy, cin_real=None):
     """-> dw fp32 in the parameter's layout [Cout,Cin,kh,kw]"""
     x, dy = _req(x, torch.bfloat16, "x"), _req(dy, torch.bfloat16, "dy")
     dw = torch.empty((d.Cout, d.kh, d.kw, d.Cin), dtype=torch.float32, device=x.device)
-    launch("conv2d_wgrad", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), stream(), work=flops(d, cin_real))
+    launch("conv2d_wgrad", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), stream(), work=flops(d, cin_real), tag=tag(d))
     return dw.permute(0, 3, 1, 2)

@@ -40,6 +40,7 @@ struct ConvArgs {
     int KH, KW, stride, pad_h, pad_w, pad_w_mode;  // W mode 0 zero, 1 replicate, 2 circular; H always zero
     int OH, OW;          // physical output extent
     int oy_mul, oy_off, ox_mul, ox_off;  // physical (oh,ow) = (ho*oy_mul+oy_off, wo*ox_mul+ox_off)
+    int Kp;              // flattened K = KH*KW*Cin rounded up to a multiple of 32 (weight row length)
     int y_f32_nchw;      // 0: bf16 NHWC with channel stride Cs; 1: fp32 NCHW
     int Cs;
     float slope;         // epilogue LeakyReLU slope (1 = identity)
@@ -82,29 +83,33 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
         xb[i] = a.x + (size_t)n * a.H * a.W * a.Cin;
     }
     // B row (output channel) this thread stages
-    const unsigned short *wb = a.w + (size_t)(n0 + (tid >> 2)) * a.KH * a.KW * a.Cin + kg * 8;
+    const unsigned short *wb = a.w + (size_t)(n0 + (tid >> 2)) * a.Kp + kg * 8;
 
-    const int csteps = a.Cin / BK;
-    const int nsteps = a.KH * a.KW * csteps;
+    // K is the flattened (kh, kw, ci) axis; one granule = 8 consecutive channels of one tap, so Cin only has to be a
+    // multiple of 8 (D conv1: 8 channels -> a 32-wide K step spans 4 taps).  The weight rows are zero beyond K.
+    const int Ktot = a.KH * a.KW * a.Cin;
+    const int nsteps = a.Kp / BK;
 
     bf16x8 ra[4], rb;
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
     auto load_step = [&](int s) {
-        const int tap = s / csteps, c0 = (s - tap * csteps) * BK;
+        const int k = s * BK + kg * 8;
+        const int tap = k / a.Cin, c0 = k - tap * a.Cin;
         const int kh = tap / a.KW, kw = tap - kh * a.KW;
+        const bool kok = k < Ktot;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int hi = hi0[i] + kh;
             int wi = wi0[i] + kw;
-            bool ok = rok[i] && hi >= 0 && hi < a.Hl;
+            bool ok = kok && rok[i] && hi >= 0 && hi < a.Hl;
             if (a.pad_w_mode == 1) wi = min(max(wi, 0), a.Wl - 1);               // replicate (gan.py:329)
             else if (a.pad_w_mode == 2) wi = wi < 0 ? wi + a.Wl : (wi >= a.Wl ? wi - a.Wl : wi);  // circpad
             else ok = ok && wi >= 0 && wi < a.Wl;
-            const unsigned short *p = xb[i] + ((size_t)(hi >> a.ups) * a.W + (wi >> a.ups)) * a.Cin + c0 + kg * 8;
+            const unsigned short *p = xb[i] + ((size_t)(hi >> a.ups) * a.W + (wi >> a.ups)) * a.Cin + c0;
             ra[i] = ok ? *reinterpret_cast<const bf16x8 *>(p) : zero8;
         }
-        rb = *reinterpret_cast<const bf16x8 *>(wb + (size_t)tap * a.Cin + c0);
+        rb = *reinterpret_cast<const bf16x8 *>(wb + (size_t)s * BK);
     };
     auto store_step = [&](int buf) {
 #pragma unroll
@@ -174,20 +179,21 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
 //   transpose == 1:  out[i][a][b][o] = in[o][i][th0+ths*a][tw0+tws*b]        (dgrad: flipped taps, swapped roles)
 // rows/channels beyond the real extents are zero filled.
 __global__ void k_weight_prep(const float *__restrict__ in, unsigned short *__restrict__ out, int O, int I, int KH,
-                              int KW, int transpose, int A, int B, int th0, int ths, int tw0, int tws, int Rp, int Cp)
+                              int KW, int transpose, int A, int B, int th0, int ths, int tw0, int tws, int Rp, int Cp,
+                              int Kp)
 {
-    // out is [Rp][A][B][Cp]; R = transpose ? I : O, C = transpose ? O : I
-    const size_t total = (size_t)Rp * A * B * Cp;
+    // out is [Rp][Kp], a row = (A x B taps) x Cp channels then zero fill; R = transpose ? I : O, C = transpose ? O : I
+    const size_t total = (size_t)Rp * Kp;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int c = idx % Cp;
-        size_t t = idx / Cp;
-        const int b = t % B;
-        t /= B;
-        const int aa = t % A;
-        const int r = t / A;
-        const int o = transpose ? c : r, i = transpose ? r : c;
+        const int k = idx % Kp;
+        const int r = idx / Kp;
         float v = 0.0f;
-        if (o < O && i < I) v = in[(((size_t)o * I + i) * KH + (th0 + ths * aa)) * KW + (tw0 + tws * b)];
+        if (k < A * B * Cp) {
+            const int c = k % Cp, t = k / Cp;
+            const int b = t % B, aa = t / B;
+            const int o = transpose ? c : r, i = transpose ? r : c;
+            if (o < O && i < I) v = in[(((size_t)o * I + i) * KH + (th0 + ths * aa)) * KW + (tw0 + tws * b)];
+        }
         out[idx] = f2bf(v);
     }
 }
@@ -260,7 +266,7 @@ static int check_desc(const m355_conv_desc *d, const char *who)
 {
     M355_REQUIRE(d, "%s: null descriptor", who);
     M355_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "%s: non-positive size", who);
-    M355_REQUIRE(d->Cin % 32 == 0, "%s: Cin=%d must be a multiple of 32 (pad the channels)", who, d->Cin);
+    M355_REQUIRE(d->Cin % 8 == 0, "%s: Cin=%d must be a multiple of 8 (pad the channels)", who, d->Cin);
     M355_REQUIRE(d->stride == 1 || d->stride == 2, "%s: stride %d", who, d->stride);
     M355_REQUIRE(d->upsample == 0 || d->upsample == 1, "%s: upsample %d", who, d->upsample);
     M355_REQUIRE(d->pad_w_mode >= 0 && d->pad_w_mode <= 2, "%s: pad_w_mode %d", who, d->pad_w_mode);
@@ -283,8 +289,8 @@ extern "C" size_t m355_conv2d_weight_elems(const m355_conv_desc *d, int which)
     if (!d) return 0;
     const size_t cout64 = (size_t)((d->Cout + 63) / 64) * 64, cin64 = (size_t)((d->Cin + 63) / 64) * 64;
     const size_t cout32 = (size_t)((d->Cout + 31) / 32) * 32;
-    if (which == 0) return cout64 * d->kh * d->kw * d->Cin;
-    return cin64 * d->kh * d->kw * cout32;  // the 4 stride-2 views together cover kh*kw taps
+    if (which == 0) return cout64 * (size_t)(((size_t)d->kh * d->kw * d->Cin + 31) / 32 * 32);
+    return cin64 * d->kh * d->kw * cout32;  // the 4 stride-2 views together cover kh*kw taps (cout32 keeps K % 32 == 0)
 }
 
 extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_oihw, int cin_w, void *w_fwd,
@@ -296,17 +302,18 @@ extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_o
     hipStream_t st = (hipStream_t)stream;
     const int cout64 = (d->Cout + 63) / 64 * 64, cin64 = (d->Cin + 63) / 64 * 64, cout32 = (d->Cout + 31) / 32 * 32;
     if (w_fwd) {
-        const size_t total = (size_t)cout64 * d->kh * d->kw * d->Cin;
+        const int Kp = (d->kh * d->kw * d->Cin + 31) / 32 * 32;
+        const size_t total = (size_t)cout64 * Kp;
         hipLaunchKernelGGL(m355::k_weight_prep, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),
                            dim3(256), 0, st, w_oihw, (unsigned short *)w_fwd, d->Cout, cin_w, d->kh, d->kw, 0, d->kh,
-                           d->kw, 0, 1, 0, 1, cout64, d->Cin);
+                           d->kw, 0, 1, 0, 1, cout64, d->Cin, Kp);
     }
     if (w_dgrad) {
         if (d->stride == 1) {
             const size_t total = (size_t)cin64 * d->kh * d->kw * cout32;
             hipLaunchKernelGGL(m355::k_weight_prep, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),
                                dim3(256), 0, st, w_oihw, (unsigned short *)w_dgrad, d->Cout, cin_w, d->kh, d->kw, 1,
-                               d->kh, d->kw, d->kh - 1, -1, d->kw - 1, -1, cin64, cout32);
+                               d->kh, d->kw, d->kh - 1, -1, d->kw - 1, -1, cin64, cout32, d->kh * d->kw * cout32);
         } else {
             M355_REQUIRE(d->kh % 2 == 0 && d->kw % 2 == 0, "conv2d_weight_prep: stride-2 dgrad needs even kernels");
             const int A = d->kh / 2, B = d->kw / 2;
@@ -316,7 +323,7 @@ extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_o
                     hipLaunchKernelGGL(m355::k_weight_prep, dim3((unsigned)((each + 255) / 256 > 4096 ? 4096 : (each + 255) / 256)),
                                        dim3(256), 0, st, w_oihw, (unsigned short *)w_dgrad + (size_t)(py * 2 + px) * each,
                                        d->Cout, cin_w, d->kh, d->kw, 1, A, B, py + 2 * (A - 1), -2, px + 2 * (B - 1), -2,
-                                       cin64, cout32);
+                                       cin64, cout32, A * B * cout32);
         }
     }
     return m355::check_launch("conv2d_weight_prep");
@@ -341,6 +348,7 @@ extern "C" int m355_conv2d_fwd(const m355_conv_desc *d, const void *x, const voi
     a.pad_w_mode = d->pad_w_mode;
     a.OH = a.Ho; a.OW = a.Wo; a.oy_mul = 1; a.ox_mul = 1; a.oy_off = 0; a.ox_off = 0;
     a.y_f32_nchw = y_f32_nchw; a.Cs = d->Cout;
+    a.Kp = (d->kh * d->kw * d->Cin + 31) / 32 * 32;
     a.slope = lrelu_slope;
     return m355::launch_conv(a, (d->Cout + 63) / 64 * 64, (hipStream_t)stream);
 }
@@ -377,6 +385,7 @@ extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const 
         const int pw_keep = need_fold ? d->pad_w : 0;  // keep W pad columns in the frame only if they must be folded
         a.w = (const unsigned short *)w_dgrad;
         a.KH = d->kh; a.KW = d->kw;
+        a.Kp = d->kh * d->kw * cout32;
         a.pad_h = d->kh - 1 - d->pad_h;
         a.pad_w = d->kw - 1 - (d->pad_w - pw_keep);
         a.Ho = Hl; a.Wo = Wl + 2 * pw_keep;
@@ -402,6 +411,7 @@ extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const 
         for (int px = 0; px < 2; ++px) {
             a.w = (const unsigned short *)w_dgrad + (size_t)(py * 2 + px) * each;
             a.KH = A; a.KW = B;
+            a.Kp = A * B * cout32;
             a.pad_h = A - 1; a.pad_w = B - 1;
             a.Ho = Hp / 2; a.Wo = Wp / 2;
             a.OH = Hp; a.OW = Wp; a.oy_mul = 2; a.ox_mul = 2; a.oy_off = py; a.ox_off = px;

@@ -279,7 +279,7 @@ class MeshDiscriminator(_DiscBase):
         if self.args.mask_output:
             with torch.no_grad():
                 mask = F.avg_pool2d(x[:, 3:4], 4)
-        h = G.to_nhwc_bf16(x, pad_to=32)
+        h = G.to_nhwc_bf16(x, pad_to=8)
         h = self._act(self.conv1, None, h)
         h = self._act(self.conv2, getattr(self, "bn2", None), h)
         h = self._act(self.conv3, getattr(self, "bn3", None), h)
@@ -336,7 +336,7 @@ class TextureDiscriminator(_DiscBase):
                 mask = F.avg_pool2d(x[:, 3:4], 16 if self.stride_first else 8)
         if self.positional_embeddings:
             x = torch.cat((x, self._pos(x)), dim=1)
-        h = G.to_nhwc_bf16(x, pad_to=32)
+        h = G.to_nhwc_bf16(x, pad_to=8)
         h = self._act(self.conv1, None, h)
         h = self._act(self.conv2, getattr(self, "bn2", None), h)
         h = self._act(self.conv3, getattr(self, "bn3", None), h)

@@ -49,8 +49,8 @@ class Conv2dFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, stride, pad_h, pad_w, mode, ups, slope, out_f32_nchw):
         n, h, w, cx = x.shape
         cout, cw, kh, kw = weight.shape
-        if cx % 32 or cx < cw:
-            raise ValueError(f"conv2d: input has {cx} channels (must be a multiple of 32 and >= {cw})")
+        if cx % 8 or cx < cw:
+            raise ValueError(f"conv2d: input has {cx} channels (must be a multiple of 8 and >= {cw})")
         d = C.make_desc(n, h, w, cx, cout, kh, kw, stride, pad_h, pad_w, mode, ups)
         need_dx = ctx.needs_input_grad[0]
         wf, wd = C.weight_prep(d, weight, want_dgrad=need_dx)

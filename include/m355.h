@@ -100,7 +100,7 @@ int m355_sil_loss_fwd(const float *proj, const float *mask, int Hin, int Win, in
  *      The pads the reference materialises in front of the convs and the nearest x2 upsample are folded into
  *      the loader: pad_w_mode 0 zero, 1 replicate (F.pad replicate, gan.py:329), 2 circular (circpad,
  *      rendering/utils.py:60-64); H is always zero padded (Conv2d padding=(p,0), gan.py:294).
- *      Cin must be a multiple of 32 (callers zero-pad the channels); dy carries ceil32(Cout) channels. */
+ *      Cin must be a multiple of 8 (callers zero-pad the channels); dy carries ceil32(Cout) channels. */
 typedef struct {
     int N, H, W, Cin;   /* stored input (before the optional upsample) */
     int Cout, kh, kw;
@@ -111,7 +111,7 @@ typedef struct {
 } m355_conv_desc;
 
 int m355_conv2d_out_hw(const m355_conv_desc *d, int *Ho, int *Wo);
-/*      elements (bf16) of the weight views: which 0 forward [ceil64(Cout)][kh][kw][Cin], 1 dgrad */
+/*      elements (bf16) of the weight views: which 0 forward [ceil64(Cout)][ceil32(kh*kw*Cin)], 1 dgrad */
 size_t m355_conv2d_weight_elems(const m355_conv_desc *d, int which);
 /*      w_oihw is the fp32 parameter [Cout][cin_w][kh][kw]; channels cin_w..Cin-1 of the views are zero. */
 int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_oihw, int cin_w, void *w_fwd, void *w_dgrad,

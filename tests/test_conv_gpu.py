@@ -34,6 +34,9 @@ CASES = [
     (2, 16, 16, 64, 128, 4, 2, 1, 1, 2, 0),   # D conv2-like: 4x4 stride 2, circular
     (1, 8, 8, 64, 3, 5, 1, 2, 2, 1, 0),       # head: Cout=3
     (3, 12, 6, 96, 96, 3, 1, 1, 1, 0, 0),     # zero W pad, Cout not a multiple of 64, M not a multiple of 256
+    (2, 16, 16, 8, 64, 5, 1, 2, 2, 2, 0),     # D conv1: 8 input channels (K step spans 4 taps, K=200 padded to 224)
+    (2, 16, 16, 16, 64, 4, 2, 1, 1, 2, 0),    # 16 input channels, stride 2
+    (2, 8, 8, 40, 32, 3, 1, 1, 1, 1, 1),      # Cin = 40 (multiple of 8 only), upsample
 ]
 
 
