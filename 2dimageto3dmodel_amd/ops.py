@@ -170,3 +170,25 @@ def smooth_taps(sigma, ntaps=21, true_gaussian=False):
     taps = torch.empty((ntaps,), dtype=torch.float32, device=sigma.device)
     _launch("smooth_taps", ptr(sigma), ntaps, TRUE_GAUSSIAN if true_gaussian else 0, ptr(taps), stream())
     return taps
+
+
+def chamfer_nn(a, b):
+    """a[B,N,3], b[B,M,3] -> (dist[B,N], idx[B,N] int32): squared distance to / index of the nearest point of b
+    (new capability, BASELINE configs[4]; no reference implementation exists)."""
+    a, b = _f32c(a.detach(), "a"), _f32c(b.detach(), "b")
+    B, N, _ = a.shape
+    M = b.shape[1]
+    dist = torch.empty((B, N), dtype=torch.float32, device=a.device)
+    idx = torch.empty((B, N), dtype=torch.int32, device=a.device)
+    _launch("chamfer_nn_fwd", ptr(a), ptr(b), ptr(dist), ptr(idx), B, N, M, stream(), work=8.0 * B * N * M)
+    return dist, idx
+
+
+def chamfer_distance(a, b):
+    """symmetric Chamfer distance mean_i min_j |a_i-b_j|^2 + mean_j min_i |b_j-a_i|^2, differentiable in a and b:
+    the nearest-neighbour search runs in HIP, the gradient flows through a gather of the matched pairs."""
+    _, ia = chamfer_nn(a, b)
+    _, ib = chamfer_nn(b, a)
+    nb = torch.gather(b, 1, ia.long().unsqueeze(-1).expand(-1, -1, 3))
+    na = torch.gather(a, 1, ib.long().unsqueeze(-1).expand(-1, -1, 3))
+    return ((a - nb) ** 2).sum(-1).mean(1) + ((b - na) ** 2).sum(-1).mean(1)

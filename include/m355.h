@@ -94,6 +94,12 @@ size_t m355_sil_loss_ws_bytes(int B, int S);
 int m355_sil_loss_fwd(const float *proj, const float *mask, int Hin, int Win, int mask_repeat, float *diff,
                       float *sse, float *total, void *ws, int B, int S, void *stream);
 
+/* ---- Chamfer nearest neighbour (BASELINE configs[4]).  NEW capability: the reference contains no Chamfer code
+ *      (SURVEY.md 0.3), parity is against the brute-force oracle only.
+ *      a[B,N,3], b[B,M,3] -> dist[B,N] = min_j |a_i-b_j|^2, idx[B,N] = argmin (lowest j on ties). */
+int m355_chamfer_nn_fwd(const float *a, const float *b, float *dist, int32_t *idx, int B, int N, int M,
+                        void *stream);
+
 /* ---- G  conv2d of the GAN stacks (models/gan.py:57-65,163-177,294-302,359,364 -> F.conv2d) as a bf16 MFMA
  *      implicit GEMM with fp32 accumulation.  Activations are NHWC bf16, weights bf16 views built by
  *      m355_conv2d_weight_prep from the fp32 [Cout][Cin][kh][kw] parameter.

@@ -1,0 +1,95 @@
+"""CPU, world_size 2 over gloo: the N > 1 path of the GAN half -- flat gradient all-reduce and SyncBN statistics
+(torch path of gan_ops.BatchNorm2d: same collectives as the HIP path, which needs a GPU)."""
+import importlib
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    par = importlib.import_module("2dimageto3dmodel_amd.parallel")
+    G = importlib.import_module("2dimageto3dmodel_amd.gan_ops")
+    r, _, w = par.init_from_env("cpu")
+    assert (r, w) == (rank, world) and par.world_size() == world
+    try:
+        # ---- broadcast_parameters + FlatGradReducer: gradients become the mean over ranks
+        torch.manual_seed(100 + rank)
+        lin = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+        par.broadcast_parameters(lin, src=0)
+        ref = [p.detach().clone() for p in lin.parameters()]
+        gathered = [torch.zeros_like(ref[0]) for _ in range(world)]
+        dist.all_gather(gathered, ref[0])
+        assert all(torch.equal(g, gathered[0]) for g in gathered)
+        x = torch.full((4, 5), float(rank + 1))
+        lin(x).sum().backward()
+        local = [p.grad.clone() for p in lin.parameters()]
+        par.FlatGradReducer(lin.parameters())()
+        for p, g in zip(lin.parameters(), local):
+            both = [torch.zeros_like(g) for _ in range(world)]
+            dist.all_gather(both, g)
+            assert torch.allclose(p.grad, sum(both) / world, atol=1e-6)
+        # ---- SynchronizedBatchNorm2d: statistics and gradients equal single-process BN over the global batch
+        torch.manual_seed(7)
+        full = torch.randn(2 * world, 6, 5, 16)                      # NHWC, global batch
+        scale = 1 + 0.1 * torch.randn(2 * world, 16)
+        shift = 0.1 * torch.randn(2 * world, 16)
+        sl = slice(2 * rank, 2 * rank + 2)
+        xs = full[sl].clone().requires_grad_()
+        sbn = G.SynchronizedBatchNorm2d(16)
+        y = sbn(xs, scale[sl], shift[sl], 0.2).float()
+        w_out = torch.linspace(0.5, 1.5, y.numel()).view_as(y)
+        (y * w_out).sum().backward()
+        xf = full.clone().requires_grad_()
+        bn = G.BatchNorm2d(16)
+        yf = bn(xf, scale, shift, 0.2).float()
+        wf = torch.zeros_like(yf)
+        wf[sl] = w_out
+        # every rank back-propagates its own shard's loss; the SyncBN backward sums the statistic gradients over ranks
+        allw = [torch.zeros_like(w_out) for _ in range(world)]
+        dist.all_gather(allw, w_out)
+        (yf * torch.cat(allw, 0)).sum().backward()
+        assert torch.allclose(y, yf[sl].detach(), atol=2e-2)          # bf16 outputs
+        assert torch.allclose(sbn.running_mean, bn.running_mean, atol=1e-6)
+        assert torch.allclose(sbn.running_var, bn.running_var, atol=1e-6)
+        assert torch.allclose(xs.grad, xf.grad[sl], atol=2e-2, rtol=2e-2)
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert sorted(r for r, _ in res) == [0, 1]
+    for r, msg in res:
+        assert msg == "ok", f"rank {r}:\n{msg}"

@@ -214,3 +214,27 @@ def test_size_independent_properties_full_size(pkg):
     # q and -q are the same rotation (every product pairs one factor from q with one from q*: exact)
     p4 = elf(tpc, -tq, tsc)
     assert frac_off(p4, p1) < 1e-3
+
+
+@pytest.mark.parametrize("B,N,M", [(2, 100, 70), (1, 1000, 2500), (3, 64, 1), (1, 16384, 4096)])
+def test_chamfer_nn_bit_exact_vs_oracle(pkg, B, N, M):
+    rs = np.random.RandomState(N + M)
+    a = rs.rand(B, N, 3).astype(np.float32)
+    b = rs.rand(B, M, 3).astype(np.float32)
+    b[:, M // 2] = b[:, 0]  # exact duplicate target: ties must resolve to the lowest index
+    d_o, i_o = po.chamfer_nn(a, b)
+    d, i = pkg.ops.chamfer_nn(t(a), t(b))
+    assert np.array_equal(i.cpu().numpy(), i_o)
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), d_o.view(np.uint32))
+
+
+def test_chamfer_distance_gradients(pkg):
+    torch.manual_seed(0)
+    a = torch.rand(2, 300, 3, device=DEV, requires_grad=True)
+    b = torch.rand(2, 200, 3, device=DEV, requires_grad=True)
+    cd = pkg.ops.chamfer_distance(a, b)
+    cd.sum().backward()
+    dm = torch.cdist(a.detach().cpu().double(), b.detach().cpu().double()) ** 2
+    want = dm.min(2)[0].mean(1) + dm.min(1)[0].mean(1)
+    assert (cd.detach().cpu().double() - want).abs().max().item() < 1e-6
+    assert a.grad.abs().sum().item() > 0 and b.grad.abs().sum().item() > 0
