@@ -6,4 +6,4 @@ or put `2dimageto3dmodel_amd/dropin` on sys.path and use the reference's own mod
 """
 from . import _lib, ops  # noqa: F401
 from .projection import (CameraUtilities, EffectiveLossFunction, SupervisedLoss,  # noqa: F401
-                         UnsupervisedLoss)
+                         TrilinearInterpolation, UnsupervisedLoss, VoxelsSmooth)

@@ -28,6 +28,12 @@ SIGNATURES = {
     "m355_smooth_taps": (c_int, [_P, c_int, c_int, _P, _P]),
     "m355_proj_render_fwd": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "m355_proj_render_bwd": (c_int, [_P, _P, _P, _P, c_int, _P, c_float, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "m355_trilinear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "m355_trilinear_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "m355_smooth_axis": (c_int, [_P, _P, _P, c_int, c_int, _P, c_int, c_int, c_int, _P]),
+    "m355_scale_clamp_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_size_t, _P]),
+    "m355_termination_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "m355_termination_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "m355_sil_loss_ws_bytes": (c_size_t, [c_int, c_int]),
     "m355_sil_loss_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P]),
     "m355_chamfer_nn_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),

@@ -26,6 +26,7 @@ SOURCES = [
     ("proj_render.hip", STRICT),
     ("proj_render21.hip", STRICT),
     ("sil_loss.hip", STRICT),
+    ("proj_dense.hip", STRICT),
     ("chamfer.hip", STRICT),
     ("conv_mfma.hip", []),
     ("gan_elem.hip", []),

@@ -192,3 +192,115 @@ def chamfer_distance(a, b):
     nb = torch.gather(b, 1, ia.long().unsqueeze(-1).expand(-1, -1, 3))
     na = torch.gather(a, 1, ib.long().unsqueeze(-1).expand(-1, -1, 3))
     return ((a - nb) ** 2).sum(-1).mean(1) + ((b - na) ** 2).sum(-1).mean(1)
+
+
+# ------------------------------------------------------------------------------------------------ dense stage API
+class Trilinear(torch.autograd.Function):
+    """TrilinearInterpolation.trilinear_interpolation (utils/trilinear_interpolation.py:62-74): cam -> clamped volume"""
+
+    @staticmethod
+    def forward(ctx, cam, S, flags):
+        cam = _f32c(cam.detach(), "point_cloud")
+        B, N, _ = cam.shape
+        L, st = lib(), stream()
+        ntiles = L.m355_proj_ntiles(S)
+        if ntiles < 0:
+            raise _lib.M355Error(f"size={S} is not supported (2..512)")
+        tstart = torch.empty((B, ntiles + 1), dtype=torch.int32, device=cam.device)
+        tpts = torch.empty((B, 4 * N, 4), dtype=torch.float32, device=cam.device)
+        vol = torch.empty((B, S, S, S), dtype=torch.float32, device=cam.device)
+        _launch("proj_bin_fwd", None, None, ptr(cam), None, ptr(tstart), ptr(tpts), B, N, S, FOV, CAM_DIST, st)
+        _launch("trilinear_fwd", ptr(tstart), ptr(tpts), ptr(vol), None, B, N, S, flags, st, work=B * (12 * N + 4 * S ** 3))
+        ctx.save_for_backward(tstart, tpts)
+        ctx.cfg = (B, N, S, flags)
+        return vol
+
+    @staticmethod
+    def backward(ctx, dvol):
+        tstart, tpts = ctx.saved_tensors
+        B, N, S, flags = ctx.cfg
+        dvol = _f32c(dvol, "grad")
+        dcam = torch.empty((B, N, 3), dtype=torch.float32, device=dvol.device)
+        _launch("trilinear_bwd", ptr(tstart), ptr(tpts), ptr(dvol), ptr(dcam), B, N, S, flags, stream())
+        return dcam, None, None
+
+
+class Smooth(torch.autograd.Function):
+    """VoxelsSmooth.smooth (utils/smooth_voxels.py:44-84) as a chain of 1-D convolutions + the scale/clamp epilogue"""
+
+    @staticmethod
+    def forward(ctx, vox, scale, taps, axes):
+        vox = _f32c(vox.detach(), "voxels")
+        B, S = vox.shape[0], vox.shape[1]
+        sc = None if scale is None else _f32c(scale.detach(), "scale").reshape(-1)
+        st = stream()
+        cur = vox
+        for i, (tp, ax) in enumerate(zip(taps, axes)):
+            last = i == len(axes) - 1
+            out = torch.empty_like(vox)
+            _launch("smooth_axis", ptr(cur), ptr(out), ptr(tp), tp.numel(), ax, ptr(sc) if last else None, 0, B, S, st,
+                    work=8.0 * vox.numel())
+            if last and sc is not None:
+                ctx.pre_in = cur  # the epilogue's input is recomputed in backward from this
+            cur = out
+        ctx.save_for_backward(*taps, *(() if sc is None else (sc,)))
+        ctx.cfg = (axes, sc is not None, None if scale is None else tuple(scale.shape))
+        return cur
+
+    @staticmethod
+    def backward(ctx, dout):
+        axes, has_scale, scale_shape = ctx.cfg
+        saved = ctx.saved_tensors
+        taps = saved[:len(axes)]
+        g = _f32c(dout, "grad")
+        B, S = g.shape[0], g.shape[1]
+        st = stream()
+        dscale = None
+        if has_scale:
+            sc = saved[-1]
+            pre = torch.empty_like(g)
+            _launch("smooth_axis", ptr(ctx.pre_in), ptr(pre), ptr(taps[-1]), taps[-1].numel(), axes[-1], None, 0, B, S, st)
+            dpre = torch.empty_like(g)
+            dscale = torch.empty((B,), dtype=torch.float32, device=g.device)
+            _launch("scale_clamp_bwd", ptr(pre), ptr(sc), ptr(g), ptr(dpre), ptr(dscale), B, S ** 3, st)
+            g, dscale = dpre, dscale.reshape(scale_shape)
+        for tp, ax in zip(reversed(taps), reversed(axes)):
+            out = torch.empty_like(g)
+            _launch("smooth_axis", ptr(g), ptr(out), ptr(tp), tp.numel(), ax, None, 1, B, S, st)
+            g = out
+        return g, dscale, None, None
+
+
+class Termination(torch.autograd.Function):
+    """EffectiveLossFunction.termination_probs (utils/effective_loss_function.py:18-56)"""
+
+    @staticmethod
+    def forward(ctx, vox, eps):
+        vox = _f32c(vox.detach(), "voxels")
+        B, D, H, W = vox.shape
+        T = torch.empty((B, D + 1, H, W), dtype=torch.float32, device=vox.device)
+        _launch("termination_fwd", ptr(vox), ptr(T), B, D, H, W, eps, stream(), work=8.0 * vox.numel())
+        ctx.save_for_backward(vox)
+        ctx.eps = eps
+        return T
+
+    @staticmethod
+    def backward(ctx, dT):
+        (vox,) = ctx.saved_tensors
+        B, D, H, W = vox.shape
+        dT = _f32c(dT, "grad")
+        dvol = torch.empty_like(vox)
+        _launch("termination_bwd", ptr(vox), ptr(dT), ptr(dvol), B, D, H, W, ctx.eps, stream())
+        return dvol, None
+
+
+def trilinear(cam, S, fixed_weights=False):
+    return Trilinear.apply(cam, int(S), FIXED_WEIGHTS if fixed_weights else 0)
+
+
+def smooth(vox, taps, axes, scale=None):
+    return Smooth.apply(vox, scale, tuple(taps), tuple(int(a) for a in axes))
+
+
+def termination_probs(vox, eps=1e-5):
+    return Termination.apply(vox, float(eps))

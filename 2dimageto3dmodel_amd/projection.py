@@ -17,6 +17,57 @@ class CameraUtilities(object):
         return ops.camera_transform(point_cloud, rotation, field_of_view, camera_view_distance)
 
 
+class TrilinearInterpolation(object):
+    """utils/trilinear_interpolation.py:11-74 (`size` is honoured; the reference module hard-wires 64 through its caller)"""
+
+    def __init__(self, epsilon=1e-6, size=64, *, fixed_weights=False):
+        self.epsilon = epsilon
+        self.size = size
+        self.fixed_weights = fixed_weights
+
+    def get_point_cloud_object_borders(self, point_cloud):
+        """tri:17-26"""
+        return ((point_cloud < 0.5 - self.epsilon) & (point_cloud > -0.5 + self.epsilon)).all(dim=-1).view(-1)
+
+    def get_grid(self, point_cloud, voxel_size):
+        """tri:28-35"""
+        return (voxel_size - 1) * (point_cloud + 0.5)
+
+    def trilinear_interpolation(self, point_cloud):
+        """tri:62-74: [B,N,3] camera-frame points (z,y,x) -> [B,S,S,S] occupancy in [0,1]"""
+        if self.epsilon != 1e-6:
+            raise ValueError("the HIP kernel implements the reference's epsilon=1e-6 in-bounds test")
+        return ops.trilinear(point_cloud, self.size, self.fixed_weights)
+
+
+class VoxelsSmooth(object):
+    """utils/smooth_voxels.py:10-84"""
+
+    def separate_kernels(self, std_dev, kernel_size=21, *, true_gaussian=False):
+        """sm:14-42: three views [1,1,1,1,K], [1,1,1,K,1], [1,1,K,1,1] of the normalised 1-D kernel
+        exp(+x^2/2s^2) (sign as written, defect D4) -- host arithmetic identical to the reference's."""
+        a, b = (-kernel_size // 2, kernel_size // 2)
+        x = torch.arange(a + 1.0, b + 1.0)
+        e = pow(-x, 2) / (2 * pow(std_dev, 2))
+        k = torch.exp(-e if true_gaussian else e)
+        k = k / k.sum()
+        return [k.view(1, 1, 1, 1, -1), k.view(1, 1, 1, -1, 1), k.view(1, 1, -1, 1, 1)]
+
+    def smooth(self, voxels, kernels, scale=None, *, chained=False):
+        """sm:44-84.  Literal behaviour (default): every kernel convolves the ORIGINAL volume and overwrites the
+        result, so only the last kernel of the list takes effect (defect D5); chained=True applies them in sequence."""
+        if len(kernels) == 0:
+            raise ValueError("smooth() needs at least one kernel (the reference raises AttributeError here, defect D2)")
+        items = []
+        for k in kernels:
+            shp = list(k.shape)
+            ax5 = max(range(len(shp)), key=lambda i: shp[i])          # np.argmax(kernel.shape)
+            items.append((k.reshape(-1).to(device=voxels.device, dtype=torch.float32).contiguous(), ax5 - 2))
+        if not chained:
+            items = items[-1:]
+        return ops.smooth(voxels, [t for t, _ in items], [a for _, a in items], scale)
+
+
 class EffectiveLossFunction(nn.Module):
     """utils/effective_loss_function.py:10-81.
 
@@ -44,6 +95,10 @@ class EffectiveLossFunction(nn.Module):
         if self.true_gaussian:
             f |= ops.TRUE_GAUSSIAN
         return f
+
+    def termination_probs(self, voxels, epsilon=1e-5):
+        """elf:18-56: occupancies [B,D,H,W] -> ray termination probabilities [B,D+1,H,W] (last = background)"""
+        return ops.termination_probs(voxels, epsilon)
 
     def forward(self, point_cloud, rotation, scale=None):
         sigma = self.sigma

@@ -85,6 +85,29 @@ int m355_proj_render_bwd(const int32_t *tile_start, const float *tile_pts, const
                          int ntaps, const float *dproj, float gmul, float *dcam_slots, float *dscale_part, int B,
                          int N, int S, int flags, void *stream);
 
+/* ---- P3 dense  TrilinearInterpolation.trilinear_interpolation (utils/trilinear_interpolation.py:62-74):
+ *      tile lists (m355_proj_bin_fwd with pc = q = NULL bins an existing cam) -> vol[B,S,S,S] = clamp(splat,0,1);
+ *      raw (nullable) receives the un-clamped sums. */
+int m355_trilinear_fwd(const int32_t *tile_start, const float *tile_pts, float *vol, float *raw, int B, int N, int S,
+                       int flags, void *stream);
+/*      dvol[B,S,S,S] -> dcam[B,N,3] (overwritten; the clamp mask is recomputed from the re-splatted sums) */
+int m355_trilinear_bwd(const int32_t *tile_start, const float *tile_pts, const float *dvol, float *dcam, int B, int N,
+                       int S, int flags, void *stream);
+
+/* ---- P4 dense  VoxelsSmooth.smooth (utils/smooth_voxels.py:44-84), one axis per call: axis 0 depth, 1 y, 2 x;
+ *      out = conv1d(in, taps, zero pad ntaps/2) [* scale[b], clamp(0,1) when scale != NULL]; transpose != 0 applies
+ *      the adjoint of the convolution (backward). */
+int m355_smooth_axis(const float *in, float *out, const float *taps, int ntaps, int axis, const float *scale,
+                     int transpose, int B, int S, void *stream);
+/*      backward of the scale/clamp epilogue: pre = conv output before scaling; dout -> dpre, dscale[B] */
+int m355_scale_clamp_bwd(const float *pre, const float *scale, const float *dout, float *dpre, float *dscale, int B,
+                         size_t per_sample, void *stream);
+
+/* ---- P5 dense  EffectiveLossFunction.termination_probs (elf:18-56): vol[B,D,H,W] -> T[B,D+1,H,W] */
+int m355_termination_fwd(const float *vol, float *T, int B, int D, int H, int W, float eps, void *stream);
+int m355_termination_bwd(const float *vol, const float *dT, float *dvol, int B, int D, int H, int W, float eps,
+                         void *stream);
+
 /* ---- P7/P8  SupervisedLoss.forward (models/supervised_part.py:68-72) and the per-cloud SSE used by
  *      UnsupervisedLoss.forward (models/unsupervised_part.py:108-126):
  *      mask[B/mask_repeat,Hin,Win] (row b/mask_repeat serves cloud b: batch_repetition.py:6-19)

@@ -238,3 +238,48 @@ def test_chamfer_distance_gradients(pkg):
     want = dm.min(2)[0].mean(1) + dm.min(1)[0].mean(1)
     assert (cd.detach().cpu().double() - want).abs().max().item() < 1e-6
     assert a.grad.abs().sum().item() > 0 and b.grad.abs().sum().item() > 0
+
+
+def test_stage_api_matches_reference_golden(pkg):
+    """The reference's stage-by-stage API (CameraUtilities -> TrilinearInterpolation -> VoxelsSmooth ->
+    termination_probs -> sum/flip), each stage a dense HIP kernel, against the goldens of every stage."""
+    for name in ("p_cfg1", "p_oob", "p_s128"):
+        g = load_golden(name)
+        S = int(g["S"])
+        pc, q = t(g["pc"]).requires_grad_(), t(g["q"]).requires_grad_()
+        sc = t(g["scale"]).requires_grad_()
+        cam = pkg.CameraUtilities().transformation_3d_coord_to_camera_coord(pc, q, 1.875, 2.0)
+        assert np.array_equal(cam.detach().cpu().numpy().view(np.uint32), g["cam"].view(np.uint32))
+        vox = pkg.TrilinearInterpolation(size=S).trilinear_interpolation(cam)
+        v = vox.detach().cpu().numpy().reshape(-1)
+        assert np.array_equal(np.flatnonzero(v), g["vox_idx"])
+        assert np.abs(v[g["vox_idx"]] - g["vox_val"]).max() < 2e-2   # LDS atomics: order-dependent last bits
+        vs = pkg.VoxelsSmooth()
+        kern = vs.separate_kernels(float(g["sigma"]), 21)
+        assert np.abs(kern[2].reshape(-1).numpy() / g["taps"] - 1).max() < 1e-6
+        sm = vs.smooth(vox, kern, sc)
+        ry, rx = g["ray_y"], g["ray_x"]
+        assert np.abs(sm.detach().cpu().numpy()[:, :, ry, rx] - g["sm_rays"]).max() < 2e-3
+        elf = pkg.EffectiveLossFunction(voxel_size=S).to(DEV)
+        probs = elf.termination_probs(sm)
+        assert np.abs(probs.detach().cpu().numpy()[:, :, ry, rx] - g["probs_rays"]).max() < 2e-3
+        proj = probs[:, :-1].sum(1).flip(1)
+        assert np.abs(proj.detach().cpu().numpy() / g["proj"] - 1).max() < 2e-3
+        loss = pkg.SupervisedLoss()(proj, t(g["mask"].astype(np.float32)))["full_loss"]
+        assert abs(loss.item() / float(g["loss"]) - 1) < 1e-4
+        loss.backward()
+        assert rel(pc.grad.cpu().numpy(), g["dpc"]) < 2e-3
+        assert rel(q.grad.cpu().numpy(), g["dq"]) < 2e-3
+        assert rel(sc.grad.cpu().numpy(), g["dscale"]) < 2e-3
+
+
+def test_smooth_three_axes_chained_vs_oracle(pkg):
+    rs = np.random.RandomState(5)
+    V = (rs.rand(2, 32, 32, 32) > 0.98).astype(np.float32) * rs.rand(2, 32, 32, 32).astype(np.float32)
+    taps = po.taps(2.0, 9, False)
+    sc = np.array([[0.7], [1.3]], np.float32)
+    want = po.smooth(V, taps, 7, sc)
+    k = torch.from_numpy(taps)
+    kern = [k.view(1, 1, 1, 1, -1), k.view(1, 1, 1, -1, 1), k.view(1, 1, -1, 1, 1)]
+    got = pkg.VoxelsSmooth().smooth(t(V), kern, t(sc), chained=True)
+    assert np.abs(got.cpu().numpy() - want).max() < 1e-5
