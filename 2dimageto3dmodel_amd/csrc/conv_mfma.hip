@@ -37,6 +37,7 @@ struct ConvArgs {
     int Hl, Wl;          // logical input extent seen by the taps (after the optional x2 upsample)
     int ups;             // 0/1: logical (h,w) reads stored (h>>ups, w>>ups)
     int Ho, Wo, Cout;    // GEMM pixel grid, real output channels
+    int CoutP;           // weight rows (Cout rounded up to the N tile)
     int KH, KW, stride, pad_h, pad_w, pad_w_mode;  // W mode 0 zero, 1 replicate, 2 circular; H always zero
     int OH, OW;          // physical output extent
     int oy_mul, oy_off, ox_mul, ox_off;  // physical (oh,ow) = (ho*oy_mul+oy_off, wo*ox_mul+ox_off)
@@ -174,6 +175,194 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     }
 }
 
+// =====================================================================================================
+// k_conv_glds: the main-line implicit GEMM.  Same GEMM view as k_conv_mfma, restructured around the LDS-DMA
+// (`buffer_load_dwordx4 ... lds`): no staging VGPRs, no ds_write pass, K step 64.
+//   * A (gathered pixels) and B (weight rows) tiles are LDS images of 128-byte rows (64 bf16 of K).  One
+//     wave-instruction fills 8 rows x 128 B; lane l lands at row l>>3, 16-byte slot l&7 (the DMA destination is
+//     lane-linear), and FETCHES source chunk (l&7) ^ ((row>>1)&7): the XOR swizzle lives on the source address
+//     and on the fragment read, never on the destination.  Fragment reads (ds_read_b128, rows = lane&31) are
+//     then bank-conflict free.
+//   * Padding (zero H pad, zero W pad, rows beyond M, K beyond taps*Cin) is an out-of-range buffer offset:
+//     the DMA writes zeros for those lanes (verified on gfx950: scripts/probes/blds_oob.hip).
+//   * Operands are swapped in the MFMA (A operand = weight rows, B operand = pixels), so a lane's 16 accumulator
+//     registers are 4 x 4 consecutive output CHANNELS of one pixel: the epilogue packs them to bf16, exchanges
+//     halves with v_permlane32_swap and issues 16-byte NHWC stores.
+//   * Workgroup tile BM x BN = 128x128 (2x2 waves) or 256x64 (4x1 waves), each wave 64x64 = 2x2 MFMA 32x32x16;
+//     2 LDS stages (64 / 80 KiB) -> 2 workgroups per CU; the DMA of step t+1 is issued before the MFMAs of step t.
+//   * blockIdx is remapped so that each XCD (private L2) owns a contiguous run of pixel tiles: neighbouring tiles
+//     share input halo rows and all tiles share the weights.
+// FAST (Cin % 64 == 0): a K step is one tap x 64 channels -> tap arithmetic is scalar.  Otherwise (Cin % 8 == 0,
+// D conv1's 8 channels, dgrad of the 1/3-channel heads) every 16-byte chunk derives its own tap.
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char *lds_dst, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)lds_dst, 16, voff, soff, 0, 0);
+}
+
+constexpr unsigned OOB = 0x80000000u;  // beyond num_records of every descriptor (tensors are < 2 GiB, checked on the host)
+
+template <int BM, int BN, bool FAST, int MODE>
+__global__ __launch_bounds__(256, 2) void k_conv_glds(ConvArgs a, unsigned xbytes, unsigned wbytes)
+{
+    constexpr int RA = BM / 32, RB = BN / 32;  // DMA instructions per wave per stage
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int WN = BN / 64;                // waves along N (1 or 2); waves along M = 4 / WN
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = a.N * a.Ho * a.Wo, HW = a.Ho * a.Wo;
+
+    // ---- XCD-aware tile id (bijective for any grid size): XCD x gets the tiles [start_x, start_x + count_x)
+    const int nwg = gridDim.x, nN = a.CoutP / BN;
+    const int q = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int sid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+    const int tn = sid % nN, tm = sid / nN;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, wbytes, 0x00020000);
+
+    // ---- per-lane staging roles.  DMA instruction i of wave w covers tile rows 8*(4i+w) .. +7, so that the
+    // swizzle term (row>>1)&7 = 4*(w&1) + (lane>>4) is the same for all of a lane's rows.
+    const int csrc = (lane & 7) ^ (((wave & 1) << 2) | ((lane >> 4) & 3));  // source chunk of this lane's LDS slot
+    int hi0[RA], wi0[RA];
+    unsigned nb[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + 8 * (4 * i + wave) + (lane >> 3);
+        if (m < M) {
+            const int n = m / HW, rr = m - n * HW;
+            const int ho = rr / a.Wo, wo = rr - ho * a.Wo;
+            hi0[i] = ho * a.stride - a.pad_h;
+            wi0[i] = wo * a.stride - a.pad_w;
+            nb[i] = (unsigned)n * (unsigned)(a.H * a.W * a.Cin * 2) + (FAST ? csrc * 16 : 0);
+        } else {
+            hi0[i] = -(1 << 20);  // never inside [0, Hl): the row stays zero
+            wi0[i] = 0;
+            nb[i] = 0;
+        }
+    }
+    unsigned wrow[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) wrow[j] = (unsigned)(n0 + 8 * (4 * j + wave) + (lane >> 3)) * (unsigned)(a.Kp * 2) + csrc * 16;
+
+    const int Cin2 = a.Cin * 2, nsteps = a.Kp / 64, Ktot = a.KH * a.KW * a.Cin;
+    const int cpt = a.Cin >> 6;       // FAST: 64-channel chunks per tap
+    int s_kh = 0, s_kw = 0, s_cc = 0;  // FAST: scalar tap cursor of the NEXT stage() call
+
+    auto stage = [&](int t, int buf) {
+        unsigned char *dstA = lds + buf * STAGE + wave * 1024, *dstB = dstA + BM * 128;
+        int kh, kw;
+        unsigned cb;
+        bool kok = true;
+        if (FAST) {
+            kh = s_kh; kw = s_kw; cb = (unsigned)s_cc * 128u;
+            kok = kh < a.KH;  // zero K steps beyond the last tap (Kp rounding) never occur when Cin % 64 == 0
+            if (++s_cc == cpt) { s_cc = 0; if (++s_kw == a.KW) { s_kw = 0; ++s_kh; } }
+        } else {
+            const int k = (t * 8 + csrc) * 8;
+            const int tap = k / a.Cin;
+            kh = tap / a.KW; kw = tap - kh * a.KW;
+            cb = (unsigned)(k - tap * a.Cin) * 2u;
+            kok = k < Ktot;
+        }
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int hi = hi0[i] + kh;
+            int wi = wi0[i] + kw;
+            bool ok = kok && (unsigned)hi < (unsigned)a.Hl;
+            if (MODE == 1) wi = min(max(wi, 0), a.Wl - 1);
+            else if (MODE == 2) wi = wi < 0 ? wi + a.Wl : (wi >= a.Wl ? wi - a.Wl : wi);
+            else ok = ok && (unsigned)wi < (unsigned)a.Wl;
+            unsigned off = nb[i] + (unsigned)(((hi >> a.ups) * a.W + (wi >> a.ups)) * Cin2);
+            if (!FAST) off += cb;
+            dma16(rx, dstA + i * 4096, ok ? off : OOB, FAST ? cb : 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) dma16(rw, dstB + j * 4096, wrow[j], (unsigned)t * 128u);
+    };
+
+    f32x16 acc[2][2];  // [co block j][pixel block i]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
+
+    const int wm = wave / WN, wn = wave % WN;
+    const int swz = (lane >> 1) & 7, half = lane >> 5;
+    const unsigned char *fa = lds + (wm * 64 + (lane & 31)) * 128;             // pixel rows of this wave
+    const unsigned char *fb = lds + BM * 128 + (wn * 64 + (lane & 31)) * 128;  // weight rows of this wave
+
+    stage(0, 0);
+    __syncthreads();  // (the barrier's fence drains the DMA: vmcnt(0))
+    for (int t = 0; t < nsteps; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nsteps) stage(t + 1, buf ^ 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int co16 = ((kk * 2 + half) ^ swz) << 4;
+            const bf16x8 p0 = *reinterpret_cast<const bf16x8 *>(fa + buf * STAGE + co16);
+            const bf16x8 p1 = *reinterpret_cast<const bf16x8 *>(fa + buf * STAGE + 32 * 128 + co16);
+            const bf16x8 w0 = *reinterpret_cast<const bf16x8 *>(fb + buf * STAGE + co16);
+            const bf16x8 w1 = *reinterpret_cast<const bf16x8 *>(fb + buf * STAGE + 32 * 128 + co16);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, p0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, p1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  acc[j][i][r]: channel n0 + wn*64 + 32j + 8*(r>>2) + 4*half + (r&3), pixel m0 + wm*64 + 32i + (lane&31)
+    unsigned short *yb = reinterpret_cast<unsigned short *>(a.y);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + 32 * i + (lane & 31);
+        const bool mok = m < M;
+        const int mm = mok ? m : 0;
+        const int n = mm / HW, rr = mm - n * HW;
+        const int ho = rr / a.Wo, wo = rr - ho * a.Wo;
+        const size_t pix = ((size_t)n * a.OH + (ho * a.oy_mul + a.oy_off)) * a.OW + (wo * a.ox_mul + a.ox_off);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int cbase = n0 + wn * 64 + 32 * j;
+            float4 b4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = cbase + 8 * g + 4 * half;
+                b4[g] = (a.bias && co < a.Cout) ? *reinterpret_cast<const float4 *>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            uint2 pk[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4] = {acc[j][i][4 * g] + b4[g].x, acc[j][i][4 * g + 1] + b4[g].y, acc[j][i][4 * g + 2] + b4[g].z,
+                              acc[j][i][4 * g + 3] + b4[g].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * a.slope;
+                pk[g].x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                pk[g].y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                // lanes < 32 end up with channels 8g..8g+7, lanes >= 32 with 8(g+1)..8(g+1)+7 of their pixel
+                auto sx = __builtin_amdgcn_permlane32_swap(pk[g].x, pk[g + 1].x, false, false);
+                auto sy = __builtin_amdgcn_permlane32_swap(pk[g].y, pk[g + 1].y, false, false);
+                const int co = cbase + 8 * (g + half);
+                if (mok && co < a.Cout) {
+                    uint4 o;
+                    o.x = sx[0]; o.y = sy[0]; o.z = sx[1]; o.w = sy[1];
+                    *reinterpret_cast<uint4 *>(yb + pix * a.Cs + co) = o;
+                }
+            }
+        }
+    }
+}
+
 // ---- weights: fp32 torch layout [O][I][KH][KW]  ->  bf16 [Op][A][B][Ip] views used by the GEMMs
 //   transpose == 0:  out[o][a][b][i] = in[o][i][th0+ths*a][tw0+tws*b]        (forward)
 //   transpose == 1:  out[i][a][b][o] = in[o][i][th0+ths*a][tw0+tws*b]        (dgrad: flipped taps, swapped roles)
@@ -242,10 +431,41 @@ __global__ void k_fold_pad(const unsigned short *__restrict__ g, unsigned short 
     }
 }
 
-static int launch_conv(const ConvArgs &a, int Cout_p, hipStream_t st)
+// rows of a weight view: a multiple of the N tile the launcher will pick for that many output channels
+static inline int rows_padded(int cout) { return cout <= 64 ? 64 : (cout + 127) / 128 * 128; }
+static inline int k_padded(int k) { return (k + 63) / 64 * 64; }
+
+static int launch_conv(ConvArgs a, hipStream_t st)
 {
     const int M = a.N * a.Ho * a.Wo;
-    dim3 grid((M + BM - 1) / BM, Cout_p / BN);
+    a.CoutP = rows_padded(a.Cout);
+    const size_t xbytes = (size_t)a.N * a.H * a.W * a.Cin * 2, wbytes = (size_t)a.CoutP * a.Kp * 2;
+    const bool dma_ok = !a.y_f32_nchw && a.Cout % 8 == 0 && a.Cs % 8 == 0 && a.Cin % 8 == 0 && a.Kp % 64 == 0 &&
+                        xbytes < (1ull << 31) && wbytes < (1ull << 31);
+    if (dma_ok) {
+        const bool fast = a.Cin % 64 == 0;
+        const unsigned xb = (unsigned)xbytes, wb = (unsigned)wbytes;
+#define M355_GO(BM_, BN_, F_, MD_) hipLaunchKernelGGL((k_conv_glds<BM_, BN_, F_, MD_>), grid, dim3(256), 0, st, a, xb, wb)
+#define M355_MODES(BM_, BN_, F_)                                \
+    do {                                                        \
+        if (a.pad_w_mode == 0) M355_GO(BM_, BN_, F_, 0);        \
+        else if (a.pad_w_mode == 1) M355_GO(BM_, BN_, F_, 1);   \
+        else M355_GO(BM_, BN_, F_, 2);                          \
+    } while (0)
+        if (a.CoutP == 64) {
+            dim3 grid((M + 255) / 256);
+            if (fast) M355_MODES(256, 64, true);
+            else M355_MODES(256, 64, false);
+        } else {
+            dim3 grid((unsigned)((M + 127) / 128) * (a.CoutP / 128));
+            if (fast) M355_MODES(128, 128, true);
+            else M355_MODES(128, 128, false);
+        }
+#undef M355_MODES
+#undef M355_GO
+        return check_launch("conv2d (dma)");
+    }
+    dim3 grid((M + BM - 1) / BM, a.CoutP / BN);
     hipLaunchKernelGGL(k_conv_mfma, grid, dim3(256), 0, st, a);
     return check_launch("conv2d");
 }
@@ -284,13 +504,14 @@ extern "C" int m355_conv2d_out_hw(const m355_conv_desc *d, int *Ho, int *Wo)
 
 extern "C" size_t m355_conv2d_weight_elems(const m355_conv_desc *d, int which)
 {
-    // which 0: forward view [ceil64(Cout)][kh][kw][Cin]; 1: dgrad views (stride 1: one [ceil64(Cin)][kh][kw][Cout_p32];
-    // stride 2: four [ceil64(Cin)][kh/2][kw/2][Cout_p32])
+    // which 0: forward view [rows_padded(Cout)][ceil64(kh*kw*Cin)]; 1: dgrad views (stride 1: one
+    // [rows_padded(Cin)][ceil64(kh*kw*Cout_p32)]; stride 2: four [rows_padded(Cin)][ceil64(kh/2*kw/2*Cout_p32)])
     if (!d) return 0;
-    const size_t cout64 = (size_t)((d->Cout + 63) / 64) * 64, cin64 = (size_t)((d->Cin + 63) / 64) * 64;
+    const size_t rows_f = m355::rows_padded(d->Cout), rows_d = m355::rows_padded(d->Cin);
     const size_t cout32 = (size_t)((d->Cout + 31) / 32) * 32;
-    if (which == 0) return cout64 * (size_t)(((size_t)d->kh * d->kw * d->Cin + 31) / 32 * 32);
-    return cin64 * d->kh * d->kw * cout32;  // the 4 stride-2 views together cover kh*kw taps (cout32 keeps K % 32 == 0)
+    if (which == 0) return rows_f * (size_t)m355::k_padded(d->kh * d->kw * d->Cin);
+    if (d->stride == 1) return rows_d * (size_t)m355::k_padded(d->kh * d->kw * (int)cout32);
+    return 4 * rows_d * (size_t)m355::k_padded((d->kh / 2) * (d->kw / 2) * (int)cout32);  // four parity-class views
 }
 
 extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_oihw, int cin_w, void *w_fwd,
@@ -300,9 +521,9 @@ extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_o
     M355_REQUIRE(w_oihw && (w_fwd || w_dgrad), "conv2d_weight_prep: null pointer");
     M355_REQUIRE(cin_w >= 1 && cin_w <= d->Cin, "conv2d_weight_prep: cin_w=%d outside 1..Cin=%d", cin_w, d->Cin);
     hipStream_t st = (hipStream_t)stream;
-    const int cout64 = (d->Cout + 63) / 64 * 64, cin64 = (d->Cin + 63) / 64 * 64, cout32 = (d->Cout + 31) / 32 * 32;
+    const int cout64 = m355::rows_padded(d->Cout), cin64 = m355::rows_padded(d->Cin), cout32 = (d->Cout + 31) / 32 * 32;
     if (w_fwd) {
-        const int Kp = (d->kh * d->kw * d->Cin + 31) / 32 * 32;
+        const int Kp = m355::k_padded(d->kh * d->kw * d->Cin);
         const size_t total = (size_t)cout64 * Kp;
         hipLaunchKernelGGL(m355::k_weight_prep, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),
                            dim3(256), 0, st, w_oihw, (unsigned short *)w_fwd, d->Cout, cin_w, d->kh, d->kw, 0, d->kh,
@@ -310,20 +531,22 @@ extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_o
     }
     if (w_dgrad) {
         if (d->stride == 1) {
-            const size_t total = (size_t)cin64 * d->kh * d->kw * cout32;
+            const int Kp = m355::k_padded(d->kh * d->kw * cout32);
+            const size_t total = (size_t)cin64 * Kp;
             hipLaunchKernelGGL(m355::k_weight_prep, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),
                                dim3(256), 0, st, w_oihw, (unsigned short *)w_dgrad, d->Cout, cin_w, d->kh, d->kw, 1,
-                               d->kh, d->kw, d->kh - 1, -1, d->kw - 1, -1, cin64, cout32, d->kh * d->kw * cout32);
+                               d->kh, d->kw, d->kh - 1, -1, d->kw - 1, -1, cin64, cout32, Kp);
         } else {
             M355_REQUIRE(d->kh % 2 == 0 && d->kw % 2 == 0, "conv2d_weight_prep: stride-2 dgrad needs even kernels");
             const int A = d->kh / 2, B = d->kw / 2;
-            const size_t each = (size_t)cin64 * A * B * cout32;
+            const int Kp = m355::k_padded(A * B * cout32);
+            const size_t each = (size_t)cin64 * Kp;
             for (int py = 0; py < 2; ++py)
                 for (int px = 0; px < 2; ++px)
                     hipLaunchKernelGGL(m355::k_weight_prep, dim3((unsigned)((each + 255) / 256 > 4096 ? 4096 : (each + 255) / 256)),
                                        dim3(256), 0, st, w_oihw, (unsigned short *)w_dgrad + (size_t)(py * 2 + px) * each,
                                        d->Cout, cin_w, d->kh, d->kw, 1, A, B, py + 2 * (A - 1), -2, px + 2 * (B - 1), -2,
-                                       cin64, cout32, A * B * cout32);
+                                       cin64, cout32, Kp);
         }
     }
     return m355::check_launch("conv2d_weight_prep");
@@ -348,9 +571,9 @@ extern "C" int m355_conv2d_fwd(const m355_conv_desc *d, const void *x, const voi
     a.pad_w_mode = d->pad_w_mode;
     a.OH = a.Ho; a.OW = a.Wo; a.oy_mul = 1; a.ox_mul = 1; a.oy_off = 0; a.ox_off = 0;
     a.y_f32_nchw = y_f32_nchw; a.Cs = d->Cout;
-    a.Kp = (d->kh * d->kw * d->Cin + 31) / 32 * 32;
+    a.Kp = m355::k_padded(d->kh * d->kw * d->Cin);
     a.slope = lrelu_slope;
-    return m355::launch_conv(a, (d->Cout + 63) / 64 * 64, (hipStream_t)stream);
+    return m355::launch_conv(a, (hipStream_t)stream);
 }
 
 // dy[N,Ho,Wo,Cout_p32] bf16 (channel stride = ceil32(Cout), padding channels zero) -> dx[N,H,W,Cin] bf16.
@@ -371,7 +594,7 @@ extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const 
     int Ho, Wo;
     conv_out_hw(d, &Ho, &Wo);
     const int Hl = d->H << d->upsample, Wl = d->W << d->upsample;
-    const int cout32 = (d->Cout + 31) / 32 * 32, cin64 = (d->Cin + 63) / 64 * 64;
+    const int cout32 = (d->Cout + 31) / 32 * 32, cin64 = m355::rows_padded(d->Cin);
     const bool need_fold = d->upsample || (d->pad_w_mode != 0 && d->pad_w > 0) || d->stride == 2;
     M355_REQUIRE(!need_fold || ws, "conv2d_dgrad: workspace required");
     // gradient frame: rows = logical rows only for stride 1 (H pad cropped via pad_h'), all padded rows for stride 2
@@ -385,13 +608,13 @@ extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const 
         const int pw_keep = need_fold ? d->pad_w : 0;  // keep W pad columns in the frame only if they must be folded
         a.w = (const unsigned short *)w_dgrad;
         a.KH = d->kh; a.KW = d->kw;
-        a.Kp = d->kh * d->kw * cout32;
+        a.Kp = m355::k_padded(d->kh * d->kw * cout32);
         a.pad_h = d->kh - 1 - d->pad_h;
         a.pad_w = d->kw - 1 - (d->pad_w - pw_keep);
         a.Ho = Hl; a.Wo = Wl + 2 * pw_keep;
         a.OH = a.Ho; a.OW = a.Wo; a.oy_mul = a.ox_mul = 1; a.oy_off = a.ox_off = 0;
         a.y = need_fold ? ws : dx;
-        rc = m355::launch_conv(a, cin64, st);
+        rc = m355::launch_conv(a, st);
         if (rc) return rc;
         if (need_fold) {
             const size_t total = (size_t)d->N * d->H * d->W * (d->Cin / 8);
@@ -406,17 +629,17 @@ extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const 
     const int Hp = Hl + 2 * d->pad_h, Wp = Wl + 2 * d->pad_w;
     M355_REQUIRE(Hp % 2 == 0 && Wp % 2 == 0, "conv2d_dgrad: stride-2 frame %dx%d must be even", Hp, Wp);
     const int A = d->kh / 2, B = d->kw / 2;
-    const size_t each = (size_t)cin64 * A * B * cout32;
+    const size_t each = (size_t)cin64 * m355::k_padded(A * B * cout32);
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
             a.w = (const unsigned short *)w_dgrad + (size_t)(py * 2 + px) * each;
             a.KH = A; a.KW = B;
-            a.Kp = A * B * cout32;
+            a.Kp = m355::k_padded(A * B * cout32);
             a.pad_h = A - 1; a.pad_w = B - 1;
             a.Ho = Hp / 2; a.Wo = Wp / 2;
             a.OH = Hp; a.OW = Wp; a.oy_mul = 2; a.ox_mul = 2; a.oy_off = py; a.ox_off = px;
             a.y = ws;
-            rc = m355::launch_conv(a, cin64, st);
+            rc = m355::launch_conv(a, st);
             if (rc) return rc;
         }
     const size_t total = (size_t)d->N * d->H * d->W * (d->Cin / 8);

@@ -37,6 +37,11 @@ CASES = [
     (2, 16, 16, 8, 64, 5, 1, 2, 2, 2, 0),     # D conv1: 8 input channels (K step spans 4 taps, K=200 padded to 224)
     (2, 16, 16, 16, 64, 4, 2, 1, 1, 2, 0),    # 16 input channels, stride 2
     (2, 8, 8, 40, 32, 3, 1, 1, 1, 1, 1),      # Cin = 40 (multiple of 8 only), upsample
+    (3, 20, 12, 128, 256, 3, 1, 1, 1, 1, 1),  # two 128-wide N tiles, M = 2880 (ragged last pixel tile), 2-chunk taps
+    (2, 24, 20, 64, 64, 3, 1, 1, 1, 0, 0),    # 256x64 tile, ragged M, zero W pad
+    (2, 32, 32, 128, 256, 4, 2, 1, 1, 2, 0),  # D conv3-like, stride-2 dgrad parity classes on the DMA path
+    (5, 16, 16, 8, 64, 5, 1, 2, 2, 2, 0),     # D conv1 on the per-chunk-tap path with several pixel tiles
+    (2, 16, 8, 256, 128, 3, 1, 1, 1, 1, 1),   # blk4 conv1 shape (upsample + replicate), 4-chunk taps
 ]
 
 
@@ -58,6 +63,9 @@ def test_conv_fwd_and_dgrad(pkg, case):
     got = y.float().cpu().permute(0, 3, 1, 2)
     err = (got - y_ref.detach()).abs().max().item() / y_ref.abs().max().item()
     assert err < 6e-3, err  # bf16 rounding of the output (2^-9 relative) dominates
+    # bf16 NHWC epilogue with LeakyReLU (the discriminators' conv -> LeakyReLU fusion)
+    ylb = conv.conv_fwd(d, x_nhwc, wf, b.to(DEV), slope=0.2).float().cpu().permute(0, 3, 1, 2)
+    assert (ylb - F.leaky_relu(y_ref.detach(), 0.2)).abs().max().item() / y_ref.abs().max().item() < 6e-3
     # fp32 NCHW epilogue (used by the heads) has no output rounding
     y32 = conv.conv_fwd(d, x_nhwc, wf, b.to(DEV), out_f32_nchw=True).cpu()
     assert (y32 - y_ref.detach()).abs().max().item() / y_ref.abs().max().item() < 2e-4
