@@ -794,6 +794,156 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgradArgs a)
             }
 }
 
+
+// -----------------------------------------------------------------------------------------------------
+// k_wgrad_dma: the same GEMM with both operand tiles filled by the LDS-DMA in their NATURAL pixel-major form
+// (a tile row = one pixel, channels contiguous) and the pixel-axis fragments produced by the gfx950 transpose
+// read ds_read_b64_tr_b16: a 16-lane group reads a [4 pixels][16 channels] block (lane q supplies the address of
+// pixel q>>2, channels 4(q&3)..+3) and lane i receives channel i of the 4 pixels (scripts/probes/tr16.hip) -- no
+// register transposes, no ds_write pass.  Two such reads (4 + 4 pixels) make one 8-deep MFMA operand; the
+// pixel <-> k-slot assignment is the same for both operands, which is all the contraction needs.
+//   * tile rows are 128 / 256 / 512 bytes; the 16-byte chunk index is XORed with 4*(pixel&3) (256/512-byte rows)
+//     or 4*((pixel>>1)&1) (128-byte rows) on the DMA SOURCE side and on the read side, which spreads the 32
+//     eight-byte pieces of a half-wave over all 64 banks.
+//   * a lane's x chunk is a fixed (tap, ci) for the whole kernel; only the pixel advances (64 per K step), and with
+//     Ho, Wo powers of two its (n, ho, wo) are shifts and masks.
+//   * tiles: Cout > 64: 128 (co) x 128 (weight columns), waves 2x2;  Cout <= 64: 64 x 256, waves 1x4; each wave
+//     64x64 = 2x2 MFMA 32x32x16; 2 LDS stages (64 / 80 KiB) -> 2 workgroups per CU; split-K over pixels (gridDim.z).
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s4v lds_s4v;
+
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char *p, int off0, int off1)
+{
+    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v *)(p + off0));
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v *)(p + off1));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+struct WgradDmaArgs {
+    WgradArgs w;
+    int lgWo, lgHo;
+    unsigned xbytes, ybytes;
+};
+
+template <int TM, int TN, int MODE>
+__global__ __launch_bounds__(256, 2) void k_wgrad_dma(WgradDmaArgs A)
+{
+    const WgradArgs &a = A.w;
+    constexpr int RBY = TM * 2, RBX = TN * 2;              // tile row bytes
+    constexpr int YB = 64 * RBY, XB = 64 * RBX, STAGE = YB + XB;
+    constexpr int NIY = YB / 4096, NIX = XB / 4096;        // DMA instructions per wave per stage
+    constexpr int CPY = RBY / 16, RPIY = 64 / CPY;         // chunks per row, rows per DMA instruction
+    constexpr int CPX = RBX / 16, RPIX = 64 / CPX;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co0 = blockIdx.x * TM, col0 = blockIdx.y * TN;
+    const int P = a.N * a.Ho * a.Wo, K = a.KH * a.KW * a.Cin;
+    const int pbeg = blockIdx.z * a.chunk, pend = min(P, pbeg + a.chunk);
+    if (pbeg >= pend) return;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, A.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, A.ybytes, 0x00020000);
+
+    // ---- DMA roles: instruction q = 4i + wave of a tile fills LDS bytes [1024q, 1024q + 1024)
+    const int ryl = lane / CPY, rxl = lane / CPX;  // row within the instruction's RPI rows
+    const int swzy = RBY == 128 ? 4 * ((ryl >> 1) & 1) : 4 * (ryl & 3);
+    const int swzx = RBX == 512 ? 4 * (2 * (wave & 1) + rxl) : 4 * (rxl & 3);
+    const int yco = co0 + ((lane % CPY) ^ swzy) * 8;
+    const bool yok = yco < a.Cy;
+    const int xcol = col0 + ((lane % CPX) ^ swzx) * 8;
+    const bool xok = xcol < K;
+    const int tap = xok ? xcol / a.Cin : 0;
+    const int ci = xok ? xcol - tap * a.Cin : 0;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const int hoff = kh - a.pad_h, woff = kw - a.pad_w;
+    const unsigned Cy2 = a.Cy * 2, Cin2 = a.Cin * 2;
+
+    auto stage = [&](int pb, int buf) {
+        unsigned char *dY = lds + buf * STAGE + wave * 1024, *dX = dY + YB;
+#pragma unroll
+        for (int i = 0; i < NIY; ++i) {
+            const int p = pb + RPIY * (4 * i + wave) + ryl;
+            const unsigned off = (unsigned)p * Cy2 + (unsigned)yco * 2u;
+            dma16(ry, dY + i * 4096, (yok && p < pend) ? off : OOB, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < NIX; ++i) {
+            const int p = pb + RPIX * (4 * i + wave) + rxl;
+            const int wo = p & (a.Wo - 1), ho = (p >> A.lgWo) & (a.Ho - 1), n = p >> (A.lgWo + A.lgHo);
+            const int hi = ho * a.stride + hoff;
+            int wi = wo * a.stride + woff;
+            bool ok = xok && p < pend && (unsigned)hi < (unsigned)a.Hl;
+            if (MODE == 1) wi = min(max(wi, 0), a.Wl - 1);
+            else if (MODE == 2) wi = wi < 0 ? wi + a.Wl : (wi >= a.Wl ? wi - a.Wl : wi);
+            else ok = ok && (unsigned)wi < (unsigned)a.Wl;
+            const unsigned off = (unsigned)((n * a.H + (hi >> a.ups)) * a.W + (wi >> a.ups)) * Cin2 + (unsigned)ci * 2u;
+            dma16(rx, dX + i * 4096, ok ? off : OOB, 0u);
+        }
+    };
+
+    f32x16 acc[2][2];  // [co block i][column block j]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // ---- fragment addressing.  Lane l: q = l&15 -> pixel (q>>2) of the 4-pixel group, channel quad q&3 of the
+    // 16-channel strip g16 = (l>>4)&1; half hh = l>>5 takes pixels 8hh..8hh+7 of each 16-pixel k group.
+    const int wr = TM == 128 ? wave >> 1 : 0, wc = TM == 128 ? wave & 1 : wave;
+    const int q = lane & 15, g16 = (lane >> 4) & 1, hh = lane >> 5;
+    const int rdswzy = RBY == 128 ? 4 * ((q >> 3) & 1) : 4 * (q >> 2);
+    const int rdswzx = 4 * (q >> 2);
+    const int rowl = hh * 8 + (q >> 2);
+    int ya[2], xb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        ya[i] = rowl * RBY + (((wr * 8 + 4 * i + g16 * 2 + ((q & 3) >> 1)) ^ rdswzy) << 4) + (q & 1) * 8;
+        xb[i] = YB + rowl * RBX + (((wc * 8 + 4 * i + g16 * 2 + ((q & 3) >> 1)) ^ rdswzx) << 4) + (q & 1) * 8;
+    }
+
+    stage(pbeg, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int pb = pbeg; pb < pend; pb += 64, buf ^= 1) {
+        if (pb + 64 < pend) stage(pb + 64, buf ^ 1);
+        const unsigned char *base = lds + buf * STAGE;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            const bf16x8 a0 = tr_pair(base + ya[0], kg * 16 * RBY, (kg * 16 + 4) * RBY);
+            const bf16x8 a1 = tr_pair(base + ya[1], kg * 16 * RBY, (kg * 16 + 4) * RBY);
+            const bf16x8 b0 = tr_pair(base + xb[0], kg * 16 * RBX, (kg * 16 + 4) * RBX);
+            const bf16x8 b1 = tr_pair(base + xb[1], kg * 16 * RBX, (kg * 16 + 4) * RBX);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wr * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = col0 + wc * 64 + 32 * j + (lane & 31);
+                if (co < a.Cout && col < K) atomicAdd(a.dw + (size_t)co * K + col, acc[i][j][r]);
+            }
+}
+
+static inline int ilog2_exact(int v)
+{
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
 }  // namespace m355
 
 // x[N,H,W,Cin] bf16, dy[N,Ho,Wo,ceil32(Cout)] bf16 -> dw fp32 [Cout][kh][kw][Cin] (overwritten).
@@ -813,6 +963,35 @@ extern "C" int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const v
     a.KH = d->kh; a.KW = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
     a.pad_w_mode = d->pad_w_mode;
     const int K = d->kh * d->kw * d->Cin, P = d->N * a.Ho * a.Wo;
+    if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->Cout * K, st) != hipSuccess) {
+        m355::set_error("conv2d_wgrad: memset failed");
+        return M355_ERR_LAUNCH;
+    }
+    const size_t xbytes = (size_t)d->N * d->H * d->W * d->Cin * 2, ybytes = (size_t)P * a.Cy * 2;
+    const int lgWo = m355::ilog2_exact(a.Wo), lgHo = m355::ilog2_exact(a.Ho);
+    if (d->Cout >= 64 && lgWo >= 0 && lgHo >= 0 && xbytes < (1ull << 31) && ybytes < (1ull << 31)) {
+        const int TM = d->Cout > 64 ? 128 : 64, TN = d->Cout > 64 ? 128 : 256;
+        const int gx = (d->Cout + TM - 1) / TM, gy = (K + TN - 1) / TN;
+        // split the pixel axis: ~1024 workgroups in flight (2 resident per CU), at least 4 K steps each
+        int splits = (1024 + gx * gy - 1) / (gx * gy);
+        const int max_splits = (P + 4 * 64 - 1) / (4 * 64);
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        a.chunk = ((P + splits - 1) / splits + 63) / 64 * 64;
+        splits = (P + a.chunk - 1) / a.chunk;
+        m355::WgradDmaArgs A = {a, lgWo, lgHo, (unsigned)xbytes, (unsigned)ybytes};
+        const dim3 grid(gx, gy, splits);
+#define M355_WG(TM_, TN_)                                                                                              \
+    do {                                                                                                               \
+        if (d->pad_w_mode == 0) hipLaunchKernelGGL((m355::k_wgrad_dma<TM_, TN_, 0>), grid, dim3(256), 0, st, A);       \
+        else if (d->pad_w_mode == 1) hipLaunchKernelGGL((m355::k_wgrad_dma<TM_, TN_, 1>), grid, dim3(256), 0, st, A);  \
+        else hipLaunchKernelGGL((m355::k_wgrad_dma<TM_, TN_, 2>), grid, dim3(256), 0, st, A);                          \
+    } while (0)
+        if (TM == 128) M355_WG(128, 128);
+        else M355_WG(64, 256);
+#undef M355_WG
+        return m355::check_launch("conv2d_wgrad (dma)");
+    }
     const int TM = d->Cout > 64 ? 128 : 64;
     const int gx = (d->Cout + TM - 1) / TM, gy = (K + m355::WN - 1) / m355::WN;
     // split the pixel axis so that ~1024 workgroups are in flight, at least 2 K-steps each
@@ -822,10 +1001,6 @@ extern "C" int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const v
     if (splits < 1) splits = 1;
     a.chunk = ((P + splits - 1) / splits + m355::WK - 1) / m355::WK * m355::WK;
     splits = (P + a.chunk - 1) / a.chunk;
-    if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->Cout * K, st) != hipSuccess) {
-        m355::set_error("conv2d_wgrad: memset failed");
-        return M355_ERR_LAUNCH;
-    }
     if (TM == 128) hipLaunchKernelGGL(m355::k_wgrad_mfma<128>, dim3(gx, gy, splits), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(m355::k_wgrad_mfma<64>, dim3(gx, gy, splits), dim3(256), 0, st, a);
     return m355::check_launch("conv2d_wgrad");
