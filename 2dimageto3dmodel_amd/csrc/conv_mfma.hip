@@ -45,6 +45,11 @@ struct ConvArgs {
     int y_f32_nchw;      // 0: bf16 NHWC with channel stride Cs; 1: fp32 NCHW
     int Cs;
     float slope;         // epilogue LeakyReLU slope (1 = identity)
+    // stride-2 dgrad in one launch (k_conv_glds only): blockIdx.y = output-parity class with its own weight view,
+    // pads and output offsets
+    int ncls;
+    int cpad_h[4], cpad_w[4], coy[4], cox[4];
+    unsigned cls_w_elems;
 };
 
 __device__ __forceinline__ unsigned short f2bf(float f)
@@ -222,8 +227,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_glds(ConvArgs a, unsigned xbyte
     const int tn = sid % nN, tm = sid / nN;
     const int m0 = tm * BM, n0 = tn * BN;
 
+    int pad_h = a.pad_h, pad_w = a.pad_w, oy_off = a.oy_off, ox_off = a.ox_off;
+    const unsigned short *wv = a.w;
+    if (a.ncls > 1) {
+        const int cls = blockIdx.y;
+        pad_h = a.cpad_h[cls]; pad_w = a.cpad_w[cls]; oy_off = a.coy[cls]; ox_off = a.cox[cls];
+        wv += (size_t)cls * a.cls_w_elems;
+    }
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)wv, 0, wbytes, 0x00020000);
 
     // ---- per-lane staging roles.  DMA instruction i of wave w covers tile rows 8*(4i+w) .. +7, so that the
     // swizzle term (row>>1)&7 = 4*(w&1) + (lane>>4) is the same for all of a lane's rows.
@@ -236,8 +248,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_glds(ConvArgs a, unsigned xbyte
         if (m < M) {
             const int n = m / HW, rr = m - n * HW;
             const int ho = rr / a.Wo, wo = rr - ho * a.Wo;
-            hi0[i] = ho * a.stride - a.pad_h;
-            wi0[i] = wo * a.stride - a.pad_w;
+            hi0[i] = ho * a.stride - pad_h;
+            wi0[i] = wo * a.stride - pad_w;
             nb[i] = (unsigned)n * (unsigned)(a.H * a.W * a.Cin * 2) + (FAST ? csrc * 16 : 0);
         } else {
             hi0[i] = -(1 << 20);  // never inside [0, Hl): the row stays zero
@@ -327,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_glds(ConvArgs a, unsigned xbyte
         const int mm = mok ? m : 0;
         const int n = mm / HW, rr = mm - n * HW;
         const int ho = rr / a.Wo, wo = rr - ho * a.Wo;
-        const size_t pix = ((size_t)n * a.OH + (ho * a.oy_mul + a.oy_off)) * a.OW + (wo * a.ox_mul + a.ox_off);
+        const size_t pix = ((size_t)n * a.OH + (ho * a.oy_mul + oy_off)) * a.OW + (wo * a.ox_mul + ox_off);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int cbase = n0 + wn * 64 + 32 * j;
@@ -435,13 +447,20 @@ __global__ void k_fold_pad(const unsigned short *__restrict__ g, unsigned short 
 static inline int rows_padded(int cout) { return cout <= 64 ? 64 : (cout + 127) / 128 * 128; }
 static inline int k_padded(int k) { return (k + 63) / 64 * 64; }
 
+static bool dma_eligible(const ConvArgs &a)
+{
+    const size_t xbytes = (size_t)a.N * a.H * a.W * a.Cin * 2, wbytes = (size_t)rows_padded(a.Cout) * a.Kp * 2;
+    return !a.y_f32_nchw && a.Cout % 8 == 0 && a.Cs % 8 == 0 && a.Cin % 8 == 0 && a.Kp % 64 == 0 &&
+           xbytes < (1ull << 31) && wbytes < (1ull << 31);
+}
+
 static int launch_conv(ConvArgs a, hipStream_t st)
 {
     const int M = a.N * a.Ho * a.Wo;
     a.CoutP = rows_padded(a.Cout);
+    if (a.ncls < 1) a.ncls = 1;
     const size_t xbytes = (size_t)a.N * a.H * a.W * a.Cin * 2, wbytes = (size_t)a.CoutP * a.Kp * 2;
-    const bool dma_ok = !a.y_f32_nchw && a.Cout % 8 == 0 && a.Cs % 8 == 0 && a.Cin % 8 == 0 && a.Kp % 64 == 0 &&
-                        xbytes < (1ull << 31) && wbytes < (1ull << 31);
+    const bool dma_ok = dma_eligible(a);
     if (dma_ok) {
         const bool fast = a.Cin % 64 == 0;
         const unsigned xb = (unsigned)xbytes, wb = (unsigned)wbytes;
@@ -453,17 +472,21 @@ static int launch_conv(ConvArgs a, hipStream_t st)
         else M355_GO(BM_, BN_, F_, 2);                          \
     } while (0)
         if (a.CoutP == 64) {
-            dim3 grid((M + 255) / 256);
+            dim3 grid((M + 255) / 256, a.ncls);
             if (fast) M355_MODES(256, 64, true);
             else M355_MODES(256, 64, false);
         } else {
-            dim3 grid((unsigned)((M + 127) / 128) * (a.CoutP / 128));
+            dim3 grid((unsigned)((M + 127) / 128) * (a.CoutP / 128), a.ncls);
             if (fast) M355_MODES(128, 128, true);
             else M355_MODES(128, 128, false);
         }
 #undef M355_MODES
 #undef M355_GO
         return check_launch("conv2d (dma)");
+    }
+    if (a.ncls != 1) {
+        set_error("conv2d: merged parity classes need the DMA kernel");
+        return M355_ERR_BAD_ARG;
     }
     dim3 grid((M + BM - 1) / BM, a.CoutP / BN);
     hipLaunchKernelGGL(k_conv_mfma, grid, dim3(256), 0, st, a);
@@ -595,15 +618,46 @@ extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const 
     conv_out_hw(d, &Ho, &Wo);
     const int Hl = d->H << d->upsample, Wl = d->W << d->upsample;
     const int cout32 = (d->Cout + 31) / 32 * 32, cin64 = m355::rows_padded(d->Cin);
-    const bool need_fold = d->upsample || (d->pad_w_mode != 0 && d->pad_w > 0) || d->stride == 2;
-    M355_REQUIRE(!need_fold || ws, "conv2d_dgrad: workspace required");
     // gradient frame: rows = logical rows only for stride 1 (H pad cropped via pad_h'), all padded rows for stride 2
     ConvArgs a = {};
     a.x = (const unsigned short *)dy;
     a.N = d->N; a.H = Ho; a.W = Wo; a.Cin = cout32; a.Hl = Ho; a.Wl = Wo; a.ups = 0;
     a.Cout = d->Cin; a.pad_w_mode = 0; a.stride = 1;
     a.y_f32_nchw = 0; a.Cs = d->Cin; a.slope = 1.0f;
+    // DIRECT form (no padded frame, no fold): without upsample and with a zero or circular W pad the adjoint of
+    // the padding is an index map on dy -- a circularly padded conv's dgrad is a circular conv of dy.
+    a.Kp = m355::k_padded((d->stride == 1 ? d->kh * d->kw : (d->kh / 2) * (d->kw / 2)) * cout32);
+    const bool direct = !d->upsample && d->pad_w_mode != 1 && m355::dma_eligible(a) &&
+                        (d->stride == 1 || (d->H % 2 == 0 && d->W % 2 == 0 && d->kh % 2 == 0 && d->kw % 2 == 0));
     int rc = 0;
+    if (direct && d->stride == 1) {
+        a.w = (const unsigned short *)w_dgrad;
+        a.KH = d->kh; a.KW = d->kw;
+        a.pad_h = d->kh - 1 - d->pad_h; a.pad_w = d->kw - 1 - d->pad_w;
+        a.pad_w_mode = d->pad_w_mode;
+        a.Ho = d->H; a.Wo = d->W; a.OH = a.Ho; a.OW = a.Wo; a.oy_mul = a.ox_mul = 1;
+        a.y = dx;
+        return m355::launch_conv(a, st);
+    }
+    if (direct) {
+        const int A = d->kh / 2, B = d->kw / 2;
+        a.w = (const unsigned short *)w_dgrad;
+        a.KH = A; a.KW = B;
+        a.pad_w_mode = d->pad_w_mode;
+        a.Ho = d->H / 2; a.Wo = d->W / 2; a.OH = d->H; a.OW = d->W; a.oy_mul = a.ox_mul = 2;
+        a.ncls = 4;
+        a.cls_w_elems = (unsigned)((size_t)cin64 * a.Kp);
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                const int c = py * 2 + px, ioff = (d->pad_h - py + 1) >> 1, joff = (d->pad_w - px + 1) >> 1;
+                a.cpad_h[c] = A - 1 - ioff; a.cpad_w[c] = B - 1 - joff;
+                a.coy[c] = 2 * ioff + py - d->pad_h; a.cox[c] = 2 * joff + px - d->pad_w;
+            }
+        a.y = dx;
+        return m355::launch_conv(a, st);
+    }
+    const bool need_fold = d->upsample || (d->pad_w_mode != 0 && d->pad_w > 0) || d->stride == 2;
+    M355_REQUIRE(!need_fold || ws, "conv2d_dgrad: workspace required");
     if (d->stride == 1) {
         const int pw_keep = need_fold ? d->pad_w : 0;  // keep W pad columns in the frame only if they must be folded
         a.w = (const unsigned short *)w_dgrad;
