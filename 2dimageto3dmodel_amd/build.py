@@ -29,6 +29,7 @@ SOURCES = [
     ("proj_dense.hip", STRICT),
     ("chamfer.hip", STRICT),
     ("conv_mfma.hip", []),
+    ("conv_small.hip", []),
     ("gan_elem.hip", []),
 ]
 

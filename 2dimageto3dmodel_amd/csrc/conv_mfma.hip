@@ -18,12 +18,9 @@
 // (and upsampled) input frame and folded back by k_fold_pad (W pad mode, H crop, 2x2 upsample sum).
 #include <hip/hip_bf16.h>
 
-#include "common.h"
+#include "conv_dma.h"
 
 namespace m355 {
-
-typedef __attribute__((ext_vector_type(8))) short bf16x8;  // 8 bf16 = one 16-byte granule
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int BM = 256, BN = 64, BK = 32;
 constexpr int LDP = BK + 8;  // LDS row pitch in bf16 (80 bytes)
@@ -51,17 +48,6 @@ struct ConvArgs {
     int cpad_h[4], cpad_w[4], coy[4], cox[4];
     unsigned cls_w_elems;
 };
-
-__device__ __forceinline__ unsigned short f2bf(float f)
-{
-    // round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
-    unsigned int u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-
-__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
 
 __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
 {
@@ -199,15 +185,6 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
 //     share input halo rows and all tiles share the weights.
 // FAST (Cin % 64 == 0): a K step is one tap x 64 channels -> tap arithmetic is scalar.  Otherwise (Cin % 8 == 0,
 // D conv1's 8 channels, dgrad of the 1/3-channel heads) every 16-byte chunk derives its own tap.
-typedef __attribute__((address_space(3))) void lds_void;
-
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char *lds_dst, unsigned voff, unsigned soff)
-{
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)lds_dst, 16, voff, soff, 0, 0);
-}
-
-constexpr unsigned OOB = 0x80000000u;  // beyond num_records of every descriptor (tensors are < 2 GiB, checked on the host)
-
 template <int BM, int BN, bool FAST, int MODE>
 __global__ __launch_bounds__(256, 2) void k_conv_glds(ConvArgs a, unsigned xbytes, unsigned wbytes)
 {
@@ -497,6 +474,12 @@ static int launch_conv(ConvArgs a, hipStream_t st)
 
 using m355::ConvArgs;
 
+namespace m355 {  // csrc/conv_small.hip
+bool conv_small_eligible(const m355_conv_desc *d, int y_f32_nchw);
+int conv_small_launch(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, float slope,
+                      int Kp, size_t wbytes, hipStream_t st);
+}  // namespace m355
+
 static int conv_out_hw(const m355_conv_desc *d, int *Ho, int *Wo)
 {
     const int Hl = d->H << d->upsample, Wl = d->W << d->upsample;
@@ -580,6 +563,11 @@ extern "C" int m355_conv2d_fwd(const m355_conv_desc *d, const void *x, const voi
 {
     if (int rc = check_desc(d, "conv2d_fwd")) return rc;
     M355_REQUIRE(x && w_fwd && y, "conv2d_fwd: null pointer");
+    if (m355::conv_small_eligible(d, y_f32_nchw)) {  // heads: 1..4 output channels, HBM-bound halo kernel
+        const int Kp = m355::k_padded(d->kh * d->kw * d->Cin);
+        return m355::conv_small_launch(d, x, w_fwd, bias, y, lrelu_slope, Kp, (size_t)m355::rows_padded(d->Cout) * Kp * 2,
+                                       (hipStream_t)stream);
+    }
     ConvArgs a = {};
     a.x = (const unsigned short *)x;
     a.w = (const unsigned short *)w_fwd;

@@ -15,6 +15,7 @@ LAYERS = [  # name, H, W (stored), Cin, Cout, k, stride, ph, pw, mode, ups
     ("D.conv2 64->128 4x4 s2", 256, 256, 64, 128, 4, 2, 1, 1, 2, 0),
     ("D.conv3 128->256 4x4 s2", 128, 128, 128, 256, 4, 2, 1, 1, 2, 0),
     ("D.conv4 256->512 4x4 s2", 64, 64, 256, 512, 4, 2, 1, 1, 2, 0),
+    ("D.conv5 512->1 5x5", 32, 32, 512, 1, 5, 1, 2, 2, 2, 0),
 ]
 def timeit(f, n=10):
     for _ in range(3): f()
@@ -32,7 +33,7 @@ for name, H, W, Cin, Cout, k, s, ph, pw, mode, ups in LAYERS:
     wf, wd = conv.weight_prep(d, w)
     dy = torch.randn(B, ho, wo, (Cout + 31) // 32 * 32, device="cuda").bfloat16()
     fl = 2.0 * B * ho * wo * Cout * Cin * k * k
-    tf = timeit(lambda: conv.conv_fwd(d, x, wf))
+    tf = timeit(lambda: conv.conv_fwd(d, x, wf, out_f32_nchw=Cout <= 4))
     td = timeit(lambda: conv.conv_dgrad(d, dy, wd))
     tw = timeit(lambda: conv.conv_wgrad(d, x, dy))
     print(f"{name:32s} {fl/1e9:7.1f} GF  fwd {tf*1e6:8.1f} us {fl/tf/1e12:6.1f} TF | dgrad {td*1e6:8.1f} us {fl/td/1e12:6.1f} TF | wgrad {tw*1e6:8.1f} us {fl/tw/1e12:6.1f} TF", flush=True)

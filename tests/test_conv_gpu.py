@@ -42,6 +42,10 @@ CASES = [
     (2, 32, 32, 128, 256, 4, 2, 1, 1, 2, 0),  # D conv3-like, stride-2 dgrad parity classes on the DMA path
     (5, 16, 16, 8, 64, 5, 1, 2, 2, 2, 0),     # D conv1 on the per-chunk-tap path with several pixel tiles
     (2, 16, 8, 256, 128, 3, 1, 1, 1, 1, 1),   # blk4 conv1 shape (upsample + replicate), 4-chunk taps
+    (2, 32, 32, 512, 1, 5, 1, 2, 2, 2, 0),    # TextureDiscriminator.conv5: halo kernel, 8 channel chunks, circular
+    (2, 40, 24, 64, 3, 5, 1, 2, 2, 1, 0),     # conv_final-like, image not a multiple of the 16x16 tile, replicate
+    (3, 8, 8, 256, 1, 5, 1, 2, 2, 2, 0),      # MeshDiscriminator.conv4: image narrower than the tile, circular
+    (2, 20, 20, 64, 2, 3, 1, 1, 1, 0, 0),     # 3x3, zero W pad, 2 output channels
 ]
 
 
