@@ -478,6 +478,8 @@ namespace m355 {  // csrc/conv_small.hip
 bool conv_small_eligible(const m355_conv_desc *d, int y_f32_nchw);
 int conv_small_launch(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, float slope,
                       int Kp, size_t wbytes, hipStream_t st);
+bool wgrad_small_eligible(const m355_conv_desc *d, int Cy);
+int wgrad_small_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, hipStream_t st);
 }  // namespace m355
 
 static int conv_out_hw(const m355_conv_desc *d, int *Ho, int *Wo)
@@ -1009,6 +1011,7 @@ extern "C" int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const v
         m355::set_error("conv2d_wgrad: memset failed");
         return M355_ERR_LAUNCH;
     }
+    if (m355::wgrad_small_eligible(d, a.Cy)) return m355::wgrad_small_launch(d, x, dy, a.Cy, dw, st);
     const size_t xbytes = (size_t)d->N * d->H * d->W * d->Cin * 2, ybytes = (size_t)P * a.Cy * 2;
     const int lgWo = m355::ilog2_exact(a.Wo), lgHo = m355::ilog2_exact(a.Ho);
     if (d->Cout >= 64 && lgWo >= 0 && lgHo >= 0 && xbytes < (1ull << 31) && ybytes < (1ull << 31)) {

@@ -142,6 +142,170 @@ __global__ __launch_bounds__(256, 2) void k_conv_smallco(SmallArgs a)
     }
 }
 
+// ---- weight gradient of the same heads: dw[co][kh][kw][ci] = sum over pixels dy[p][co] * xpad[p + (kh,kw)][ci].
+// M = Cout <= 4 rows: as a GEMM over 2 M pixels it is a long skinny reduction; the implicit-GEMM wgrad pads the rows
+// to 64 and re-gathers x per tap (1460 us for conv_final at batch 64).  Here, per 16x16 pixel tile and 64-channel
+// chunk, the x halo and the dy tile are DMA'd into LDS once; wave w owns input channels 16w..16w+15 of the chunk and
+// keeps all kh*kw accumulators (16x16 fp32 tiles, rows = out channels) in registers across the tiles the workgroup
+// visits; both operands have the pixel axis as K, so their fragments are ds_read_b64_tr_b16 transpose reads
+// (dy^T: [4 px][16 co] blocks, x: [4 px][16 ci] blocks).  One atomicAdd pass at the end.
+struct SmallWgArgs {
+    const unsigned short *x;   // bf16 NHWC [N,H,W,Cin]
+    const unsigned short *dy;  // bf16 NHWC [N,H,W,Cy]
+    float *dw;                 // fp32 [Cout][KS][KS][Cin], pre-zeroed
+    int N, H, W, Cin, Cout, Cy;
+    int tiles_x, tiles_y;
+    unsigned xbytes, ybytes;
+};
+
+typedef short s4w __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s4w lds_s4w;
+
+__device__ __forceinline__ bf16x8 tr8(const unsigned char *p0, const unsigned char *p1)
+{
+    const s4w lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4w *)p0);
+    const s4w hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4w *)p1);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// halo swizzle of the wgrad kernel: 8 pixels {x..x+3, x+8..x+11} must land on 8 distinct (parity, slot pair)
+__device__ __forceinline__ int wg_swz(int hx) { return (((hx >> 1) & 1) << 1) | (((hx >> 3) & 1) << 2); }
+
+template <int KS, int MODE>
+__global__ __launch_bounds__(256, 2) void k_wgrad_smallco(SmallWgArgs a)
+{
+    constexpr int HS = ST + KS - 1, HPIX = HS * HS, HINS = (HPIX + 7) / 8, HALO_B = HINS * 1024;
+    constexpr int TAPS = KS * KS;
+    constexpr int DY_B = ST * ST * 32;  // dy tile: 32 bytes (16 channel slots) per pixel
+    __shared__ __attribute__((aligned(16))) unsigned char lds[HALO_B + DY_B];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cc = blockIdx.z;  // 64-channel chunk of the input
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, a.ybytes, 0x00020000);
+
+    // ---- fragment roles (16x16x32, K = 32 pixels = 2 tile rows): lane group kgp = lane>>4 takes row kgp>>1,
+    // columns 8*(kgp&1) .. +7 of the pair of rows; inside the group lane q supplies pixel q>>2 of a 4-pixel run,
+    // channel quad q&3; the group's 16 lanes receive channel (lane&15) of those 4 pixels.
+    const int q = lane & 15, kgp = lane >> 4;
+    const int frow = kgp >> 1, fx = 8 * (kgp & 1) + (q >> 2);  // + 4*rd
+    // dy tile position of pixel (r, x): (r*16 + (x ^ ((x>>3)&1)<<2)) * 32 bytes
+    int dyo[2];
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+        const int x = fx + 4 * rd;
+        dyo[rd] = HALO_B + (frow * 16 + (x ^ (((x >> 3) & 1) << 2))) * 32 + (q & 3) * 8;
+    }
+    // x halo offsets per (kw, rd): pixel column fx + 4rd + kw, chunk = 2*wave + ((q&3)>>1), 8-byte half q&1
+    int xo[KS][2];
+#pragma unroll
+    for (int kw = 0; kw < KS; ++kw)
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int hx = fx + 4 * rd + kw;
+            xo[kw][rd] = (frow * HS + hx) * 128 + (((2 * wave + ((q & 3) >> 1)) ^ wg_swz(hx)) << 4) + (q & 1) * 8;
+        }
+
+    f32x4 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ntiles = a.tiles_x * a.tiles_y * a.N;
+    constexpr int HI = (HINS + 3) / 4;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / (a.tiles_x * a.tiles_y), tr_ = tile - n * (a.tiles_x * a.tiles_y);
+        const int ty = tr_ / a.tiles_x, tx = tr_ - ty * a.tiles_x;
+        const int y0 = ty * ST - KS / 2, x0 = tx * ST - KS / 2;
+        if (tile != (int)blockIdx.x) __syncthreads();  // the previous tile's fragments are consumed
+        // halo (as in k_conv_smallco, with this kernel's swizzle)
+#pragma unroll
+        for (int i = 0; i < HI; ++i) {
+            if (4 * i + wave < HINS) {
+                const int P = 8 * (4 * i + wave) + (lane >> 3);
+                const int hy = P / HS, hx = P - hy * HS;
+                const int gy = y0 + hy;
+                int gx = x0 + hx;
+                bool ok = P < HPIX && (unsigned)gy < (unsigned)a.H;
+                if (MODE == 1) gx = min(max(gx, 0), a.W - 1);
+                else if (MODE == 2) gx = gx < 0 ? gx + a.W : (gx >= a.W ? gx - a.W : gx);
+                ok = ok && (unsigned)gx < (unsigned)a.W;
+                const int chunk = (lane & 7) ^ wg_swz(hx);
+                const unsigned off = (unsigned)(((n * a.H + gy) * a.W + gx) * a.Cin * 2 + cc * 128 + chunk * 16);
+                dma16(rx, lds + (4 * i + wave) * 1024, ok ? off : OOB, 0u);
+            }
+        }
+        // dy tile: 512 16-byte slots (pixel position pp = e>>1, channel half e&1); 8 DMA instructions, 2 per wave
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = 64 * (4 * j + wave) + lane;
+            const int pp = e >> 1, hf = e & 1;
+            const int r = pp >> 4, xs = pp & 15, x = xs ^ (((xs >> 3) & 1) << 2);  // involution: position -> pixel column
+            const int gy = ty * ST + r, gx = tx * ST + x;
+            const bool ok = gy < a.H && gx < a.W && hf * 8 < a.Cy;
+            const unsigned off = (unsigned)(((n * a.H + gy) * a.W + gx) * a.Cy * 2 + hf * 16);
+            dma16(ry, lds + HALO_B + (4 * j + wave) * 1024, ok ? off : OOB, 0u);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int kb = 0; kb < ST / 2; ++kb) {  // K block = tile rows 2kb, 2kb+1
+            const bf16x8 dyf = tr8(lds + dyo[0] + kb * 2 * 16 * 32, lds + dyo[1] + kb * 2 * 16 * 32);
+            const unsigned char *hrow = lds + kb * (2 * HS * 128);
+#pragma unroll
+            for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < KS; ++kw) {
+                    const unsigned char *hb = hrow + kh * HS * 128;
+                    const bf16x8 xf = tr8(hb + xo[kw][0], hb + xo[kw][1]);
+                    acc[kh * KS + kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dyf, xf, acc[kh * KS + kw], 0, 0, 0);
+                }
+        }
+    }
+    // acc[tap][r]: out channel 4*kgp + r, input channel cc*64 + 16*wave + (lane&15)
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = 4 * kgp + r;
+            if (co < a.Cout)
+                atomicAdd(a.dw + ((size_t)co * TAPS + t) * a.Cin + cc * 64 + 16 * wave + (lane & 15), acc[t][r]);
+        }
+}
+
+bool wgrad_small_eligible(const m355_conv_desc *d, int Cy)
+{
+    return d->Cout <= SMAXCO && d->stride == 1 && d->upsample == 0 && d->kh == d->kw && (d->kh == 5 || d->kh == 3) &&
+           d->pad_h == d->kh / 2 && d->pad_w == d->kw / 2 && d->Cin % 64 == 0 && Cy % 8 == 0 &&
+           (size_t)d->N * d->H * d->W * d->Cin * 2 < (1ull << 31) && (size_t)d->N * d->H * d->W * Cy * 2 < (1ull << 31);
+}
+
+int wgrad_small_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, hipStream_t st)
+{
+    SmallWgArgs a = {};
+    a.x = (const unsigned short *)x;
+    a.dy = (const unsigned short *)dy;
+    a.dw = dw;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cy = Cy;
+    a.tiles_x = (d->W + ST - 1) / ST;
+    a.tiles_y = (d->H + ST - 1) / ST;
+    a.xbytes = (unsigned)((size_t)d->N * d->H * d->W * d->Cin * 2);
+    a.ybytes = (unsigned)((size_t)d->N * d->H * d->W * Cy * 2);
+    const int ntiles = a.tiles_x * a.tiles_y * d->N, nchunks = d->Cin / 64;
+    int gx = (512 + nchunks - 1) / nchunks;  // ~512 workgroups (2 per CU)
+    if (gx > ntiles) gx = ntiles;
+    const dim3 grid(gx, 1, nchunks);
+#define M355_SW(KS_)                                                                                               \
+    do {                                                                                                           \
+        if (d->pad_w_mode == 0) hipLaunchKernelGGL((k_wgrad_smallco<KS_, 0>), grid, dim3(256), 0, st, a);          \
+        else if (d->pad_w_mode == 1) hipLaunchKernelGGL((k_wgrad_smallco<KS_, 1>), grid, dim3(256), 0, st, a);     \
+        else hipLaunchKernelGGL((k_wgrad_smallco<KS_, 2>), grid, dim3(256), 0, st, a);                             \
+    } while (0)
+    if (d->kh == 5) M355_SW(5);
+    else M355_SW(3);
+#undef M355_SW
+    return check_launch("conv2d_wgrad (small Cout)");
+}
+
 // host side: eligibility + launch (called from m355_conv2d_fwd)
 bool conv_small_eligible(const m355_conv_desc *d, int y_f32_nchw)
 {
