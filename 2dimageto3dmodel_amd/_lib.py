@@ -38,6 +38,7 @@ SIGNATURES = {
     "m355_sil_loss_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P]),
     "m355_chamfer_nn_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "m355_conv2d_out_hw": (c_int, [_P, _P, _P]),
+    "m355_conv2d_dy_channels": (c_int, [c_int]),
     "m355_conv2d_weight_elems": (c_size_t, [_P, c_int]),
     "m355_conv2d_weight_prep": (c_int, [_P, _P, c_int, _P, _P, _P]),
     "m355_conv2d_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P]),

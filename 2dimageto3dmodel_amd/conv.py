@@ -26,6 +26,11 @@ def out_hw(d):
     return ho.value, wo.value
 
 
+def dy_channels(cout):
+    """channel stride the backward entry points expect of dy (8 for the 1..8-channel heads, else ceil32)"""
+    return lib().m355_conv2d_dy_channels(int(cout))
+
+
 def flops(d, cin_real=None):
     """algorithmic FLOPs of one pass (fwd, dgrad or wgrad) over the layer: 2*M*N*K with the REAL channel counts
     (zero-padded input channels do not count)"""
@@ -73,7 +78,7 @@ def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0, cin_real=Non
 def conv_dgrad(d, dy, w_dgrad, cin_real=None):
     dy = _req(dy, torch.bfloat16, "dy")
     ho, wo = out_hw(d)
-    assert tuple(dy.shape) == (d.N, ho, wo, _ceil(d.Cout, 32)), tuple(dy.shape)
+    assert tuple(dy.shape) == (d.N, ho, wo, dy_channels(d.Cout)), tuple(dy.shape)
     dx = torch.empty((d.N, d.H, d.W, d.Cin), dtype=torch.bfloat16, device=dy.device)
     nws = lib().m355_conv2d_dgrad_ws_bytes(ctypes.byref(d))
     ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device)

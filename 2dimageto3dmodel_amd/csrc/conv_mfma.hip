@@ -423,6 +423,9 @@ __global__ void k_fold_pad(const unsigned short *__restrict__ g, unsigned short 
 // rows of a weight view: a multiple of the N tile the launcher will pick for that many output channels
 static inline int rows_padded(int cout) { return cout <= 64 ? 64 : (cout + 127) / 128 * 128; }
 static inline int k_padded(int k) { return (k + 63) / 64 * 64; }
+// channel stride of the gradient tensor dy the backward entry points take: 8 for the 1..8-channel heads (so that the
+// dgrad GEMM's K is taps*8, not taps*32), otherwise Cout rounded up to 32
+static inline int dy_channels(int cout) { return cout <= 8 ? 8 : (cout + 31) / 32 * 32; }
 
 static bool dma_eligible(const ConvArgs &a)
 {
@@ -510,13 +513,15 @@ extern "C" int m355_conv2d_out_hw(const m355_conv_desc *d, int *Ho, int *Wo)
     return conv_out_hw(d, Ho, Wo) == 0 ? M355_OK : M355_ERR_BAD_ARG;
 }
 
+extern "C" int m355_conv2d_dy_channels(int cout) { return m355::dy_channels(cout); }
+
 extern "C" size_t m355_conv2d_weight_elems(const m355_conv_desc *d, int which)
 {
     // which 0: forward view [rows_padded(Cout)][ceil64(kh*kw*Cin)]; 1: dgrad views (stride 1: one
     // [rows_padded(Cin)][ceil64(kh*kw*Cout_p32)]; stride 2: four [rows_padded(Cin)][ceil64(kh/2*kw/2*Cout_p32)])
     if (!d) return 0;
     const size_t rows_f = m355::rows_padded(d->Cout), rows_d = m355::rows_padded(d->Cin);
-    const size_t cout32 = (size_t)((d->Cout + 31) / 32) * 32;
+    const size_t cout32 = (size_t)m355::dy_channels(d->Cout);
     if (which == 0) return rows_f * (size_t)m355::k_padded(d->kh * d->kw * d->Cin);
     if (d->stride == 1) return rows_d * (size_t)m355::k_padded(d->kh * d->kw * (int)cout32);
     return 4 * rows_d * (size_t)m355::k_padded((d->kh / 2) * (d->kw / 2) * (int)cout32);  // four parity-class views
@@ -529,7 +534,7 @@ extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_o
     M355_REQUIRE(w_oihw && (w_fwd || w_dgrad), "conv2d_weight_prep: null pointer");
     M355_REQUIRE(cin_w >= 1 && cin_w <= d->Cin, "conv2d_weight_prep: cin_w=%d outside 1..Cin=%d", cin_w, d->Cin);
     hipStream_t st = (hipStream_t)stream;
-    const int cout64 = m355::rows_padded(d->Cout), cin64 = m355::rows_padded(d->Cin), cout32 = (d->Cout + 31) / 32 * 32;
+    const int cout64 = m355::rows_padded(d->Cout), cin64 = m355::rows_padded(d->Cin), cout32 = m355::dy_channels(d->Cout);
     if (w_fwd) {
         const int Kp = m355::k_padded(d->kh * d->kw * d->Cin);
         const size_t total = (size_t)cout64 * Kp;
@@ -607,7 +612,7 @@ extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const 
     int Ho, Wo;
     conv_out_hw(d, &Ho, &Wo);
     const int Hl = d->H << d->upsample, Wl = d->W << d->upsample;
-    const int cout32 = (d->Cout + 31) / 32 * 32, cin64 = m355::rows_padded(d->Cin);
+    const int cout32 = m355::dy_channels(d->Cout), cin64 = m355::rows_padded(d->Cin);
     // gradient frame: rows = logical rows only for stride 1 (H pad cropped via pad_h'), all padded rows for stride 2
     ConvArgs a = {};
     a.x = (const unsigned short *)dy;
@@ -1003,7 +1008,7 @@ extern "C" int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const v
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ups = d->upsample;
     a.Hl = d->H << d->upsample; a.Wl = d->W << d->upsample;
     conv_out_hw(d, &a.Ho, &a.Wo);
-    a.Cout = d->Cout; a.Cy = (d->Cout + 31) / 32 * 32;
+    a.Cout = d->Cout; a.Cy = m355::dy_channels(d->Cout);
     a.KH = d->kh; a.KW = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
     a.pad_w_mode = d->pad_w_mode;
     const int K = d->kh * d->kw * d->Cin, P = d->N * a.Ho * a.Wo;

@@ -64,7 +64,7 @@ class Conv2dFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, wd, y = ctx.saved_tensors
         d = ctx.d
-        c32 = _ceil(d.Cout, 32)
+        c32 = C.dy_channels(d.Cout)
         if ctx.slope != 1.0 and not ctx.f32 and c32 == d.Cout and 256 % (d.Cout // 8) == 0:
             # LeakyReLU epilogue backward + bias gradient in one pass (csrc/gan_elem.hip)
             g, db = lrelu_bwd(dy.contiguous(), y, ctx.slope)

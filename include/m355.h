@@ -129,7 +129,8 @@ int m355_chamfer_nn_fwd(const float *a, const float *b, float *dist, int32_t *id
  *      The pads the reference materialises in front of the convs and the nearest x2 upsample are folded into
  *      the loader: pad_w_mode 0 zero, 1 replicate (F.pad replicate, gan.py:329), 2 circular (circpad,
  *      rendering/utils.py:60-64); H is always zero padded (Conv2d padding=(p,0), gan.py:294).
- *      Cin must be a multiple of 8 (callers zero-pad the channels); dy carries ceil32(Cout) channels. */
+ *      Cin must be a multiple of 8 (callers zero-pad the channels); dy carries m355_conv2d_dy_channels(Cout)
+ *      channels (8 when Cout <= 8, else Cout rounded up to 32; the extra channels are zero). */
 typedef struct {
     int N, H, W, Cin;   /* stored input (before the optional upsample) */
     int Cout, kh, kw;
@@ -140,6 +141,7 @@ typedef struct {
 } m355_conv_desc;
 
 int m355_conv2d_out_hw(const m355_conv_desc *d, int *Ho, int *Wo);
+int m355_conv2d_dy_channels(int cout);
 /*      elements (bf16) of the weight views: which 0 forward [ceil64(Cout)][ceil32(kh*kw*Cin)], 1 dgrad */
 size_t m355_conv2d_weight_elems(const m355_conv_desc *d, int which);
 /*      w_oihw is the fp32 parameter [Cout][cin_w][kh][kw]; channels cin_w..Cin-1 of the views are zero. */
@@ -149,11 +151,11 @@ int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_oihw, int ci
  *      LeakyReLU(lrelu_slope) (1.0 = identity). */
 int m355_conv2d_fwd(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
                     int y_f32_nchw, float lrelu_slope, void *stream);
-/*      dy[N,Ho,Wo,ceil32(Cout)] bf16 -> dx[N,H,W,Cin] bf16 (autograd of F.conv2d w.r.t. its input, through the
+/*      dy[N,Ho,Wo,dy_channels(Cout)] bf16 -> dx[N,H,W,Cin] bf16 (autograd of F.conv2d w.r.t. its input, through the
  *      pad / upsample).  ws >= m355_conv2d_dgrad_ws_bytes(d). */
 size_t m355_conv2d_dgrad_ws_bytes(const m355_conv_desc *d);
 int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, void *ws, void *stream);
-/*      x[N,H,W,Cin], dy[N,Ho,Wo,ceil32(Cout)] -> dw fp32 [Cout][kh][kw][Cin] (overwritten; split-K partial tiles are
+/*      x[N,H,W,Cin], dy[N,Ho,Wo,dy_channels(Cout)] -> dw fp32 [Cout][kh][kw][Cin] (overwritten; split-K partial tiles are
  *      combined with fp32 atomics, so the last bits depend on arrival order). */
 int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const void *dy, float *dw, void *stream);
 

@@ -31,7 +31,7 @@ for name, H, W, Cin, Cout, k, s, ph, pw, mode, ups in LAYERS:
     x = torch.randn(B, H, W, Cin, device="cuda").bfloat16()
     w = torch.randn(Cout, Cin, k, k, device="cuda") * 0.05
     wf, wd = conv.weight_prep(d, w)
-    dy = torch.randn(B, ho, wo, (Cout + 31) // 32 * 32, device="cuda").bfloat16()
+    dy = torch.randn(B, ho, wo, conv.dy_channels(Cout), device="cuda").bfloat16()
     fl = 2.0 * B * ho * wo * Cout * Cin * k * k
     tf = timeit(lambda: conv.conv_fwd(d, x, wf, out_f32_nchw=Cout <= 4))
     td = timeit(lambda: conv.conv_dgrad(d, dy, wd))

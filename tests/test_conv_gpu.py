@@ -79,7 +79,7 @@ def test_conv_fwd_and_dgrad(pkg, case):
     # dgrad
     dy = torch.randn(y_ref.shape, generator=g).bfloat16().float()
     y_ref.backward(dy)
-    c32 = (Cout + 31) // 32 * 32
+    c32 = conv.dy_channels(Cout)
     dy_nhwc = torch.zeros(N, y_ref.shape[2], y_ref.shape[3], c32)
     dy_nhwc[..., :Cout] = dy.permute(0, 2, 3, 1)
     dx = conv.conv_dgrad(d, dy_nhwc.bfloat16().to(DEV), wd).float().cpu().permute(0, 3, 1, 2)
