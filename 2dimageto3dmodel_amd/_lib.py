@@ -40,7 +40,7 @@ SIGNATURES = {
     "m355_conv2d_out_hw": (c_int, [_P, _P, _P]),
     "m355_conv2d_dy_channels": (c_int, [c_int]),
     "m355_conv2d_weight_elems": (c_size_t, [_P, c_int]),
-    "m355_conv2d_weight_prep": (c_int, [_P, _P, c_int, _P, _P, _P]),
+    "m355_conv2d_weight_prep": (c_int, [_P, _P, c_int, _P, _P, _P, _P]),
     "m355_conv2d_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P]),
     "m355_conv2d_dgrad_ws_bytes": (c_size_t, [_P]),
     "m355_conv2d_dgrad": (c_int, [_P, _P, _P, _P, _P, _P]),
@@ -51,6 +51,14 @@ SIGNATURES = {
     "m355_affine_act_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "m355_affine_act_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "m355_lrelu_bwd": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_float, _P]),
+    "m355_chan_reduce_nblk": (c_int, [c_size_t]),
+    "m355_bn_stats_partial": (c_int, [_P, _P, c_size_t, c_int, _P]),
+    "m355_affine_act_bwd_partial": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
+    "m355_sn_power_iter": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_float, _P]),
+    "m355_sn_wgrad_finish": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "m355_bn_finalize": (c_int, [_P, c_int, c_float, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P,
+                                 _P]),
+    "m355_bn_bwd_finalize": (c_int, [_P, c_int, c_float, _P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P]),
 }
 
 

@@ -31,6 +31,7 @@ SOURCES = [
     ("conv_mfma.hip", []),
     ("conv_small.hip", []),
     ("gan_elem.hip", []),
+    ("gan_glue.hip", []),
 ]
 
 

@@ -50,14 +50,15 @@ def _req(t, dtype, name):
     return t.contiguous()
 
 
-def weight_prep(d, w_oihw, want_dgrad=True):
+def weight_prep(d, w_oihw, want_dgrad=True, sigma=None):
+    """bf16 GEMM views of the fp32 parameter; `sigma` (1-element device tensor) divides it (spectral norm)"""
     w = _req(w_oihw.detach(), torch.float32, "weight")
     L = lib()
     wf = torch.empty((L.m355_conv2d_weight_elems(ctypes.byref(d), 0),), dtype=torch.bfloat16, device=w.device)
     wd = None
     if want_dgrad:
         wd = torch.empty((L.m355_conv2d_weight_elems(ctypes.byref(d), 1),), dtype=torch.bfloat16, device=w.device)
-    launch("conv2d_weight_prep", ctypes.byref(d), ptr(w), int(w.shape[1]), ptr(wf), ptr(wd), stream())
+    launch("conv2d_weight_prep", ctypes.byref(d), ptr(w), int(w.shape[1]), ptr(sigma), ptr(wf), ptr(wd), stream())
     return wf, wd
 
 
@@ -86,9 +87,20 @@ def conv_dgrad(d, dy, w_dgrad, cin_real=None):
     return dx
 
 
-def conv_wgrad(d, x, dy, cin_real=None):
-    """-> dw fp32 in the parameter's layout [Cout,Cin,kh,kw]"""
+def conv_wgrad(d, x, dy, cin_real=None, raw=False):
+    """-> dw fp32 in the parameter's layout [Cout,Cin,kh,kw] (a permuted view), or with raw=True the kernel's own
+    [Cout,kh,kw,Cin] buffer"""
     x, dy = _req(x, torch.bfloat16, "x"), _req(dy, torch.bfloat16, "dy")
     dw = torch.empty((d.Cout, d.kh, d.kw, d.Cin), dtype=torch.float32, device=x.device)
     launch("conv2d_wgrad", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), stream(), work=flops(d, cin_real), tag=tag(d))
-    return dw.permute(0, 3, 1, 2)
+    return dw if raw else dw.permute(0, 3, 1, 2)
+
+
+def wgrad_finish(d, g_khwc, cin_real, w_orig=None, u=None, v=None, sigma=None):
+    """[Cout][kh][kw][CinP] wgrad output -> the parameter's gradient [Cout][cin_real][kh][kw]; with spectral-norm
+    state, the gradient with respect to weight_orig (through sigma)"""
+    dw = torch.empty((d.Cout, cin_real, d.kh, d.kw), dtype=torch.float32, device=g_khwc.device)
+    part = torch.empty((256,), dtype=torch.float32, device=g_khwc.device) if sigma is not None else None
+    launch("sn_wgrad_finish", ptr(g_khwc), ptr(w_orig), ptr(u), ptr(v), ptr(sigma), ptr(part), ptr(dw), d.Cout, cin_real,
+           d.Cin, d.kh, d.kw, stream())
+    return dw

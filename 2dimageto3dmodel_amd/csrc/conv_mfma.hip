@@ -358,8 +358,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_glds(ConvArgs a, unsigned xbyte
 // rows/channels beyond the real extents are zero filled.
 __global__ void k_weight_prep(const float *__restrict__ in, unsigned short *__restrict__ out, int O, int I, int KH,
                               int KW, int transpose, int A, int B, int th0, int ths, int tw0, int tws, int Rp, int Cp,
-                              int Kp)
+                              int Kp, const float *__restrict__ sigma)
 {
+    const float wscale = sigma ? 1.0f / sigma[0] : 1.0f;  // spectral norm: W_sn = W_orig / sigma (gan_glue.hip)
     // out is [Rp][Kp], a row = (A x B taps) x Cp channels then zero fill; R = transpose ? I : O, C = transpose ? O : I
     const size_t total = (size_t)Rp * Kp;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -372,7 +373,7 @@ __global__ void k_weight_prep(const float *__restrict__ in, unsigned short *__re
             const int o = transpose ? c : r, i = transpose ? r : c;
             if (o < O && i < I) v = in[(((size_t)o * I + i) * KH + (th0 + ths * aa)) * KW + (tw0 + tws * b)];
         }
-        out[idx] = f2bf(v);
+        out[idx] = f2bf(v * wscale);
     }
 }
 
@@ -527,8 +528,8 @@ extern "C" size_t m355_conv2d_weight_elems(const m355_conv_desc *d, int which)
     return 4 * rows_d * (size_t)m355::k_padded((d->kh / 2) * (d->kw / 2) * (int)cout32);  // four parity-class views
 }
 
-extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_oihw, int cin_w, void *w_fwd,
-                                       void *w_dgrad, void *stream)
+extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_oihw, int cin_w, const float *sigma,
+                                       void *w_fwd, void *w_dgrad, void *stream)
 {
     if (int rc = check_desc(d, "conv2d_weight_prep")) return rc;
     M355_REQUIRE(w_oihw && (w_fwd || w_dgrad), "conv2d_weight_prep: null pointer");
@@ -540,7 +541,7 @@ extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_o
         const size_t total = (size_t)cout64 * Kp;
         hipLaunchKernelGGL(m355::k_weight_prep, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),
                            dim3(256), 0, st, w_oihw, (unsigned short *)w_fwd, d->Cout, cin_w, d->kh, d->kw, 0, d->kh,
-                           d->kw, 0, 1, 0, 1, cout64, d->Cin, Kp);
+                           d->kw, 0, 1, 0, 1, cout64, d->Cin, Kp, sigma);
     }
     if (w_dgrad) {
         if (d->stride == 1) {
@@ -548,7 +549,7 @@ extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_o
             const size_t total = (size_t)cin64 * Kp;
             hipLaunchKernelGGL(m355::k_weight_prep, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),
                                dim3(256), 0, st, w_oihw, (unsigned short *)w_dgrad, d->Cout, cin_w, d->kh, d->kw, 1,
-                               d->kh, d->kw, d->kh - 1, -1, d->kw - 1, -1, cin64, cout32, Kp);
+                               d->kh, d->kw, d->kh - 1, -1, d->kw - 1, -1, cin64, cout32, Kp, sigma);
         } else {
             M355_REQUIRE(d->kh % 2 == 0 && d->kw % 2 == 0, "conv2d_weight_prep: stride-2 dgrad needs even kernels");
             const int A = d->kh / 2, B = d->kw / 2;
@@ -559,7 +560,7 @@ extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_o
                     hipLaunchKernelGGL(m355::k_weight_prep, dim3((unsigned)((each + 255) / 256 > 4096 ? 4096 : (each + 255) / 256)),
                                        dim3(256), 0, st, w_oihw, (unsigned short *)w_dgrad + (size_t)(py * 2 + px) * each,
                                        d->Cout, cin_w, d->kh, d->kw, 1, A, B, py + 2 * (A - 1), -2, px + 2 * (B - 1), -2,
-                                       cin64, cout32, Kp);
+                                       cin64, cout32, Kp, sigma);
         }
     }
     return m355::check_launch("conv2d_weight_prep");

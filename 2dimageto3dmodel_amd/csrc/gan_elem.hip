@@ -218,6 +218,36 @@ extern "C" size_t m355_chan_reduce_ws_bytes(size_t pixels_per_group, int groups,
     return sizeof(float) * nblk * (size_t)groups * nvals * C;
 }
 
+extern "C" int m355_chan_reduce_nblk(size_t pixels_per_group)
+{
+    const size_t ppb = pix_per_block(pixels_per_group);
+    return (int)((pixels_per_group + ppb - 1) / ppb);
+}
+
+/* first stage only: part[nblk][2][C] (finalised by m355_bn_finalize, gan_glue.hip) */
+extern "C" int m355_bn_stats_partial(const void *x, float *part, size_t P, int C, void *stream)
+{
+    M355_REQUIRE(x && part && P > 0, "bn_stats_partial: null pointer / empty");
+    if (int rc = check_c(C, "bn_stats_partial")) return rc;
+    const int ppb = pix_per_block(P);
+    const int nblk = (int)((P + ppb - 1) / ppb);
+    hipLaunchKernelGGL(k_chan_stats, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const short *)x, part, P, C, ppb);
+    return check_launch("bn_stats_partial");
+}
+
+/* first stage only: part[N][nblk][2][C] (finalised by m355_bn_bwd_finalize) */
+extern "C" int m355_affine_act_bwd_partial(const void *dy, const void *x, const float *a, const float *b, float *part, int N,
+                                           int HW, int C, float slope, void *stream)
+{
+    M355_REQUIRE(dy && x && a && b && part && N > 0 && HW > 0, "affine_act_bwd_partial: null pointer / empty");
+    if (int rc = check_c(C, "affine_act_bwd_partial")) return rc;
+    const int ppb = pix_per_block((size_t)HW);
+    const int nblk = (HW + ppb - 1) / ppb;
+    hipLaunchKernelGGL(k_act_bwd_reduce, dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, (const short *)dy, (const short *)x,
+                       a, b, part, HW, C, slope, ppb);
+    return check_launch("affine_act_bwd_partial");
+}
+
 extern "C" int m355_bn_stats(const void *x, float *sums /*[2][C]*/, void *ws, size_t P, int C, void *stream)
 {
     M355_REQUIRE(x && sums && ws && P > 0, "bn_stats: null pointer / empty");

@@ -1,0 +1,313 @@
+// G9 / G3 glue of the GAN stacks: everything that sits BETWEEN the heavy kernels and used to be hundreds of 3-5 us
+// torch launches per forward (measured: 3400 launches = 19.7 ms of a 112 ms cycle).
+//   * spectral norm (torch.nn.utils.spectral_norm on 18 generator + 9 discriminator convs, gan.py:57-65,163-177,
+//     294-302): one power iteration per forward in train mode,  v = normalize(W^T u), u = normalize(W v),
+//     sigma = u . (W v),  W_sn = W / sigma.   Here ALL layers of a network advance in three launches
+//     (grid.y = layer) driven by a device-resident layer table; the division by sigma is folded into the bf16
+//     weight-view kernel and the backward through sigma into the kernel that lays out the weight gradient.
+//   * conditional batch norm (gan.py:264-286): from the per-workgroup partial sums to mean / rstd / running stats /
+//     the per-(sample, channel) affine coefficients in one launch; likewise the backward's coefficient algebra.
+#include "common.h"
+
+namespace m355 {
+
+// ------------------------------------------------------------------------------------------- spectral norm, forward
+// t = W^T u   (train only).  Block = 64 columns x 4 row groups.
+__global__ __launch_bounds__(256) void k_sn_wtu(const m355_sn_layer *__restrict__ tab, float *__restrict__ norms)
+{
+    __shared__ float red[4][64];
+    const m355_sn_layer L = tab[blockIdx.y];
+    const int c0 = blockIdx.x * 64;
+    if (c0 >= L.cols) return;
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = c0 + cl;
+    float acc = 0.0f;
+    if (c < L.cols)
+        for (int i = rg; i < L.rows; i += 4) acc += L.w[(size_t)i * L.cols + c] * L.u[i];
+    red[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0) {
+        const float t = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+        if (c < L.cols) L.t[c] = t;
+        float sq = c < L.cols ? t * t : 0.0f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        if (cl == 0) atomicAdd(norms + 2 * blockIdx.y, sq);
+    }
+}
+
+// s = W vhat, one wave per row (4 rows per block).  train: vhat = t / max(||t||, eps) (and v <- vhat, written by the
+// layer's first block); eval: vhat = v.   norms[2l+1] += s_i^2 (train) or u_i * s_i (eval).
+__global__ __launch_bounds__(256) void k_sn_wv(const m355_sn_layer *__restrict__ tab, float *__restrict__ norms, int training,
+                                               float eps)
+{
+    const m355_sn_layer L = tab[blockIdx.y];
+    const int r0 = blockIdx.x * 4;
+    if (r0 >= L.rows) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = r0 + wave;
+    float inv = 1.0f;
+    const float *vv = L.v;
+    if (training) {
+        inv = 1.0f / fmaxf(sqrtf(norms[2 * blockIdx.y]), eps);
+        vv = L.t;
+    }
+    float acc = 0.0f;
+    if (i < L.rows) {
+        const float *wr = L.w + (size_t)i * L.cols;
+        for (int j = lane; j < L.cols; j += 64) acc += wr[j] * vv[j];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    acc *= inv;
+    if (lane == 0 && i < L.rows) {
+        L.s[i] = acc;
+        atomicAdd(norms + 2 * blockIdx.y + 1, training ? acc * acc : acc * L.u[i]);
+    }
+    if (training && blockIdx.x == 0)
+        for (int j = threadIdx.x; j < L.cols; j += 256) {
+            const float vn = L.t[j] * inv;
+            L.v[j] = vn;
+            if (L.v_snap) L.v_snap[j] = vn;
+        }
+}
+
+// train: u = s / max(||s||, eps), sigma = ||s||^2 / max(||s||, eps);  eval: sigma = u . s.   Clears the norms.
+__global__ __launch_bounds__(256) void k_sn_final(const m355_sn_layer *__restrict__ tab, float *__restrict__ norms,
+                                                  float *__restrict__ sigma, int training, float eps)
+{
+    const m355_sn_layer L = tab[blockIdx.x];
+    const float n1 = norms[2 * blockIdx.x + 1];
+    __syncthreads();
+    if (training) {
+        const float inv = 1.0f / fmaxf(sqrtf(n1), eps);
+        for (int i = threadIdx.x; i < L.rows; i += 256) {
+            const float un = L.s[i] * inv;
+            L.u[i] = un;
+            if (L.u_snap) L.u_snap[i] = un;
+        }
+        if (threadIdx.x == 0) sigma[blockIdx.x] = n1 * inv;
+    } else {
+        if (L.u_snap)
+            for (int i = threadIdx.x; i < L.rows; i += 256) L.u_snap[i] = L.u[i];
+        if (L.v_snap)
+            for (int j = threadIdx.x; j < L.cols; j += 256) L.v_snap[j] = L.v[j];
+        if (threadIdx.x == 0) sigma[blockIdx.x] = n1;
+    }
+    if (threadIdx.x == 0) {
+        norms[2 * blockIdx.x] = 0.0f;
+        norms[2 * blockIdx.x + 1] = 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- spectral norm, backward
+// G = dL/dW_sn arrives from the wgrad kernel as [Cout][kh][kw][CinP]; the parameter is [Cout][Cin][kh][kw].
+//   dL/dW_orig = G / sigma - (<G, W_orig> / sigma^2) u v^T         (u, v constants of the power iteration)
+// stage 1: partial dot products; stage 2: every block sums the partials, then applies and re-lays-out.
+__global__ __launch_bounds__(256) void k_sn_bwd_dot(const float *__restrict__ g, const float *__restrict__ w, float *__restrict__ part,
+                                                    int Cout, int Cin, int CinP, int KK)
+{
+    __shared__ float red[4];
+    const size_t total = (size_t)Cout * Cin * KK;
+    float acc = 0.0f;
+    for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        // idx enumerates the parameter layout [co][ci][tap]
+        const int tap = (int)(idx % KK);
+        const size_t r = idx / KK;
+        const int ci = (int)(r % Cin), co = (int)(r / Cin);
+        acc += w[idx] * g[((size_t)co * KK + tap) * CinP + ci];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void k_sn_bwd_apply(const float *__restrict__ g, const float *__restrict__ u,
+                                                      const float *__restrict__ v, const float *__restrict__ sigma,
+                                                      const float *__restrict__ part, int npart, float *__restrict__ dw, int Cout,
+                                                      int Cin, int CinP, int KK)
+{
+    __shared__ float sh;
+    float inv = 1.0f, coef = 0.0f;
+    if (sigma) {
+        if (threadIdx.x < 64) {
+            float d = 0.0f;
+            for (int i = threadIdx.x; i < npart; i += 64) d += part[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+            if (threadIdx.x == 0) sh = d;
+        }
+        __syncthreads();
+        inv = 1.0f / sigma[0];
+        coef = sh * inv * inv;
+    }
+    const size_t total = (size_t)Cout * Cin * KK;
+    for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int tap = (int)(idx % KK);
+        const size_t r = idx / KK;
+        const int ci = (int)(r % Cin), co = (int)(r / Cin);
+        float val = g[((size_t)co * KK + tap) * CinP + ci] * inv;
+        if (sigma) val -= coef * u[co] * v[(size_t)ci * KK + tap];
+        dw[idx] = val;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- conditional batch norm
+// Block = 32 channels x 8 helper lanes.  part[nblk][2][C] -> mean, rstd (biased variance, eps inside the sqrt =
+// F.batch_norm, code/sync_batchnorm/batchnorm.py:71-73), running stats (unbiased variance, momentum), and
+// a[n,c] = rstd * (1 + gamma[n,c]),  b[n,c] = beta[n,c] - mean * a[n,c].
+__global__ __launch_bounds__(256) void k_bn_finalize(const float *__restrict__ part, int nblk, float count, const float *__restrict__ gamma,
+                                                     const float *__restrict__ beta, int gstride, int N, int C, float eps,
+                                                     float momentum, float *__restrict__ rmean, float *__restrict__ rvar,
+                                                     float *__restrict__ mean_o, float *__restrict__ rstd_o, float *__restrict__ a,
+                                                     float *__restrict__ b)
+{
+    __shared__ float red[2][8][32];
+    __shared__ float stat[2][32];
+    const int cl = threadIdx.x & 31, l = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    float s0 = 0.0f, s1 = 0.0f;
+    if (c < C)
+        for (int k = l; k < nblk; k += 8) {
+            s0 += part[((size_t)k * 2) * C + c];
+            s1 += part[((size_t)k * 2 + 1) * C + c];
+        }
+    red[0][l][cl] = s0;
+    red[1][l][cl] = s1;
+    __syncthreads();
+    if (l == 0 && c < C) {
+        float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            t0 += red[0][k][cl];
+            t1 += red[1][k][cl];
+        }
+        const float mean = t0 / count;
+        const float var = fmaxf(t1 / count - mean * mean, 0.0f);
+        const float rstd = rsqrtf(var + eps);
+        stat[0][cl] = mean;
+        stat[1][cl] = rstd;
+        mean_o[c] = mean;
+        rstd_o[c] = rstd;
+        if (rmean) {
+            const float unb = count > 1.0f ? var * (count / (count - 1.0f)) : var;
+            rmean[c] = rmean[c] * (1.0f - momentum) + mean * momentum;
+            rvar[c] = rvar[c] * (1.0f - momentum) + unb * momentum;
+        }
+    }
+    __syncthreads();
+    if (c < C) {
+        const float mean = stat[0][cl], rstd = stat[1][cl];
+        for (int n = l; n < N; n += 8) {
+            const float av = rstd * (1.0f + gamma[(size_t)n * gstride + c]);
+            a[(size_t)n * C + c] = av;
+            b[(size_t)n * C + c] = beta[(size_t)n * gstride + c] - mean * av;
+        }
+    }
+}
+
+// backward: part[N][nblk][2][C] = per-workgroup (sum dz, sum dz*x)  ->
+//   dgamma[n,c] = rstd (s2 - mean s1),  dbeta[n,c] = s1,  A[n,c] = rstd (1+gamma),
+//   m1 = sum_n (1+gamma) s1 / count,  m2 = sum_n (1+gamma) dgamma / count,
+//   Bc = -rstd^2 m2,  Cc = -rstd m1 + rstd^2 mean m2            (zeros when the statistics are not batch statistics)
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float *__restrict__ part, int nblk, float count,
+                                                         const float *__restrict__ gamma, int gstride, int N, int C,
+                                                         const float *__restrict__ mean_i, const float *__restrict__ rstd_i,
+                                                         int batch_stats, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                         float *__restrict__ A, float *__restrict__ Bc, float *__restrict__ Cc)
+{
+    __shared__ float red[2][8][32];
+    const int cl = threadIdx.x & 31, l = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    float m1 = 0.0f, m2 = 0.0f;
+    float mean = 0.0f, rstd = 1.0f;
+    if (c < C) {
+        mean = mean_i[c];
+        rstd = rstd_i[c];
+        for (int n = l; n < N; n += 8) {
+            float s1 = 0.0f, s2 = 0.0f;
+            const float *p = part + (size_t)n * nblk * 2 * C;
+            for (int k = 0; k < nblk; ++k) {
+                s1 += p[((size_t)k * 2) * C + c];
+                s2 += p[((size_t)k * 2 + 1) * C + c];
+            }
+            const float sc = 1.0f + gamma[(size_t)n * gstride + c];
+            const float dg = rstd * (s2 - mean * s1);
+            dgamma[(size_t)n * C + c] = dg;
+            dbeta[(size_t)n * C + c] = s1;
+            A[(size_t)n * C + c] = rstd * sc;
+            m1 += sc * s1;
+            m2 += sc * dg;
+        }
+    }
+    red[0][l][cl] = m1;
+    red[1][l][cl] = m2;
+    __syncthreads();
+    if (l == 0 && c < C) {
+        float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            t1 += red[0][k][cl];
+            t2 += red[1][k][cl];
+        }
+        if (batch_stats) {
+            t1 /= count;
+            t2 /= count;
+            Bc[c] = -rstd * rstd * t2;
+            Cc[c] = -rstd * t1 + rstd * rstd * mean * t2;
+        } else {
+            Bc[c] = 0.0f;
+            Cc[c] = 0.0f;
+        }
+    }
+}
+
+}  // namespace m355
+
+using namespace m355;
+
+extern "C" int m355_sn_power_iter(const m355_sn_layer *table_dev, int L, int max_rows, int max_cols, float *norms,
+                                  float *sigma, int training, float eps, void *stream)
+{
+    M355_REQUIRE(table_dev && norms && sigma && L > 0 && max_rows > 0 && max_cols > 0, "sn_power_iter: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (training) hipLaunchKernelGGL(k_sn_wtu, dim3((max_cols + 63) / 64, L), dim3(256), 0, st, table_dev, norms);
+    hipLaunchKernelGGL(k_sn_wv, dim3((max_rows + 3) / 4, L), dim3(256), 0, st, table_dev, norms, training, eps);
+    hipLaunchKernelGGL(k_sn_final, dim3(L), dim3(256), 0, st, table_dev, norms, sigma, training, eps);
+    return check_launch("sn_power_iter");
+}
+
+extern "C" int m355_sn_wgrad_finish(const float *g_khwc, const float *w_orig, const float *u, const float *v,
+                                    const float *sigma, float *part /*[256]*/, float *dw, int Cout, int Cin, int CinP,
+                                    int kh, int kw, void *stream)
+{
+    M355_REQUIRE(g_khwc && dw && Cout > 0 && Cin > 0 && CinP >= Cin, "sn_wgrad_finish: bad argument");
+    M355_REQUIRE(!sigma || (w_orig && u && v && part), "sn_wgrad_finish: spectral-norm state missing");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t total = (size_t)Cout * Cin * kh * kw;
+    const int nblk = (int)((total + 255) / 256 > 256 ? 256 : (total + 255) / 256);
+    if (sigma) hipLaunchKernelGGL(k_sn_bwd_dot, dim3(nblk), dim3(256), 0, st, g_khwc, w_orig, part, Cout, Cin, CinP, kh * kw);
+    const int nb2 = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(k_sn_bwd_apply, dim3(nb2), dim3(256), 0, st, g_khwc, u, v, sigma, part, nblk, dw, Cout, Cin, CinP,
+                       kh * kw);
+    return check_launch("sn_wgrad_finish");
+}
+
+extern "C" int m355_bn_finalize(const float *part, int nblk, float count, const float *gamma, const float *beta, int gstride,
+                                int N, int C, float eps, float momentum, float *running_mean, float *running_var,
+                                float *mean, float *rstd, float *a, float *b, void *stream)
+{
+    M355_REQUIRE(part && gamma && beta && mean && rstd && a && b && nblk > 0 && N > 0 && C > 0, "bn_finalize: bad argument");
+    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, part, nblk, count, gamma, beta,
+                       gstride, N, C, eps, momentum, running_mean, running_var, mean, rstd, a, b);
+    return check_launch("bn_finalize");
+}
+
+extern "C" int m355_bn_bwd_finalize(const float *part, int nblk, float count, const float *gamma, int gstride, int N, int C,
+                                    const float *mean, const float *rstd, int batch_stats, float *dgamma, float *dbeta,
+                                    float *A, float *Bc, float *Cc, void *stream)
+{
+    M355_REQUIRE(part && gamma && mean && rstd && dgamma && dbeta && A && Bc && Cc && nblk > 0 && N > 0 && C > 0,
+                 "bn_bwd_finalize: bad argument");
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, part, nblk, count, gamma,
+                       gstride, N, C, mean, rstd, batch_stats, dgamma, dbeta, A, Bc, Cc);
+    return check_launch("bn_bwd_finalize");
+}

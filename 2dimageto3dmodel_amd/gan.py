@@ -52,15 +52,41 @@ def positional_encoding(Ny, Nx):
 
 class Conv2d(nn.Conv2d):
     """nn.Conv2d parameters (so spectral_norm, init and state_dict keys are the reference's), MFMA execution.
-    Takes / returns NHWC bf16; `pad_w` columns are produced by index arithmetic in the kernel."""
+    Takes / returns NHWC bf16; `pad_w` columns are produced by index arithmetic in the kernel.  When wrapped by
+    `spectral_norm` below, the weight is weight_orig / sigma with sigma from the owning network's
+    SpectralNormGroup (one batched power iteration per forward) -- or from a private one-layer group when the
+    conv is called on its own."""
 
     def __init__(self, cin, cout, k, stride=1, pad_h=0, pad_w=0, pad_w_mode=C.PAD_ZERO, bias=True):
         super().__init__(cin, cout, k, stride=stride, padding=(pad_h, 0), bias=bias)
         self.m355 = (stride, pad_h, pad_w, pad_w_mode)
+        self._sn_state = None
+        self._sn_own = None
 
     def forward(self, x, upsample=0, slope=1.0, out_f32_nchw=False):
         stride, pad_h, pad_w, mode = self.m355
-        return G.conv2d(x, self.weight, self.bias, stride, pad_h, pad_w, mode, upsample, slope, out_f32_nchw)
+        sn, weight = None, None
+        if "weight_orig" in self._parameters:
+            sn, self._sn_state = self._sn_state, None
+            if sn is None:  # not driven by a network-level group
+                if self._sn_own is None:
+                    self._sn_own = G.SpectralNormGroup([self])
+                self._sn_own.step(self.training)
+                sn, self._sn_state = self._sn_state, None
+            weight = self.weight_orig
+        else:
+            weight = self.weight
+        return G.conv2d(x, weight, self.bias, stride, pad_h, pad_w, mode, upsample, slope, out_f32_nchw, sn)
+
+
+def spectral_norm(conv):
+    """torch.nn.utils.spectral_norm (same parameter / buffer names, initialisation and state_dict hooks) minus its
+    per-module forward pre-hook: sigma comes from the batched kernel (gan_ops.SpectralNormGroup)."""
+    return G.strip_sn_hook(nn.utils.spectral_norm(conv))
+
+
+def sn_convs(module):
+    return [m for m in module.modules() if isinstance(m, Conv2d) and "weight_orig" in m._parameters]
 
 
 class _Identity(nn.Module):
@@ -88,8 +114,10 @@ class ConditionalBatchNorm2d(nn.Module):
         self.fc_gamma = nn.Linear(emb_dim, ch)
         self.fc_beta = nn.Linear(emb_dim, ch)
 
-    def forward(self, x, z, slope=1.0):
-        return self.norm(x, 1 + self.fc_gamma(z), self.fc_beta(z), slope)
+    def forward(self, x, z, slope=1.0, gb=None):
+        """gb: (gamma, beta) of this layer when the owner evaluated all fc_gamma / fc_beta in one GEMM"""
+        gamma, beta = gb if gb is not None else (self.fc_gamma(z), self.fc_beta(z))
+        return self.norm(x, gamma, beta, slope)
 
 
 class ResBlockUp(nn.Module):
@@ -100,26 +128,29 @@ class ResBlockUp(nn.Module):
         ch_middle = min(ch_in, ch_out)
         self.ch_out = ch_out
         mode = pad_fn  # PAD_REPLICATE (symmetric generator, gan.py:329) or PAD_CIRCULAR (gan.py:331)
-        self.conv1 = nn.utils.spectral_norm(Conv2d(ch_in, ch_middle, 3, pad_h=1, pad_w=1, pad_w_mode=mode, bias=False))
-        self.conv2 = nn.utils.spectral_norm(Conv2d(ch_middle, ch_out, 3, pad_h=1, pad_w=1, pad_w_mode=mode, bias=False))
+        self.conv1 = spectral_norm(Conv2d(ch_in, ch_middle, 3, pad_h=1, pad_w=1, pad_w_mode=mode, bias=False))
+        self.conv2 = spectral_norm(Conv2d(ch_middle, ch_out, 3, pad_h=1, pad_w=1, pad_w_mode=mode, bias=False))
         self.norm1 = ConditionalBatchNorm2d(args, ch_middle, emb_dim)
         self.norm2 = ConditionalBatchNorm2d(args, ch_out, emb_dim)
         self.relu = nn.LeakyReLU(LRELU, inplace=True)
         self.pad = pad_fn
         if ch_in != ch_out:
-            self.shortcut = nn.utils.spectral_norm(Conv2d(ch_in, ch_out, 1, bias=False))
+            self.shortcut = spectral_norm(Conv2d(ch_in, ch_out, 1, bias=False))
         else:
             self.shortcut = _Identity()
 
-    def forward(self, x, z, upsample=0):
+    def forward(self, x, z, upsample=0, gb=None):
         """x is the block input BEFORE the nearest x2 upsample that precedes the block in Generator.forward
-        (gan.py:386-404) when upsample=1; the upsample is folded into conv1 and the shortcut."""
+        (gan.py:386-404) when upsample=1; the upsample is folded into conv1 and the shortcut.
+        gb: {norm module: (gamma, beta)} from the generator's batched conditioning GEMM."""
         if isinstance(self.shortcut, _Identity):
             sc = G.upsample2x(x) if upsample else x
         else:
             sc = self.shortcut(x, upsample=upsample)
-        h = self.norm1(self.conv1(x, upsample=upsample), z, LRELU)
-        h = self.norm2(self.conv2(h), z, LRELU)
+        g1 = gb.get(self.norm1) if gb is not None else None
+        g2 = gb.get(self.norm2) if gb is not None else None
+        h = self.norm1(self.conv1(x, upsample=upsample), z, LRELU, g1)
+        h = self.norm2(self.conv2(h), z, LRELU, g2)
         return h + sc
 
 
@@ -172,10 +203,12 @@ class Generator(nn.Module):
             if a.conditional_color:
                 parts.append(self.emb_color(c[:, 1]))
             z = torch.cat(parts, dim=1)
+        self._sn_group().step(self.training)   # one batched power iteration for all 18 spectral-normed convs
+        gb = self._conditioning(z)             # all fc_gamma / fc_beta in one GEMM
         x = self.fc(z).view(z.shape[0], -1, self.height, self.width)  # NCHW fp32 [B,512,8,4]
         x = G.to_nhwc_bf16(x)
-        x = self.blk1(x, z)
-        x = self.blk2(x, z, upsample=1)
+        x = self.blk1(x, z, gb=gb)
+        x = self.blk2(x, z, upsample=1, gb=gb)
         attention_map = None
         if a.conditional_text:
             att_out, attention_map = self.att(G.to_nchw_f32(x), *caption)
@@ -183,15 +216,15 @@ class Generator(nn.Module):
         t = x  # every later stage starts with the x2 upsample of gan.py:391 / :395-404
         for name in ("blk3a", "blk3b", "blk3c"):
             if hasattr(self, name):
-                t = getattr(self, name)(t, z, upsample=1)
-        t = self.blk4(t, z, upsample=1)
-        t = self.blk5(t, z, upsample=1)
-        t = self.blk6(t, z, upsample=1)
+                t = getattr(self, name)(t, z, upsample=1, gb=gb)
+        t = self.blk4(t, z, upsample=1, gb=gb)
+        t = self.blk5(t, z, upsample=1, gb=gb)
+        t = self.blk6(t, z, upsample=1, gb=gb)
         t = G.leaky_relu(t, LRELU)
         x_tex = torch.tanh(self.conv_final(t, out_f32_nchw=True))
         x_mesh = None
         if self.mesh_head:
-            m = G.leaky_relu(self.blk3_mesh(x, z, upsample=1), LRELU)
+            m = G.leaky_relu(self.blk3_mesh(x, z, upsample=1, gb=gb), LRELU)
             x_mesh = adjust_poles(self.conv_mesh(m, out_f32_nchw=True))
         if self.symmetric:
             x_tex = symmetrize_texture(x_tex)
@@ -199,7 +232,47 @@ class Generator(nn.Module):
                 x_mesh = symmetrize_texture(x_mesh)
             if attention_map is not None:
                 attention_map = symmetrize_texture(attention_map)
+        if self.training and self._nbt:
+            torch._foreach_add_(self._nbt, 1)  # num_batches_tracked of all the batch norms in one launch
         return (x_tex, x_mesh, attention_map) if return_attention else (x_tex, x_mesh)
+
+    # ---- network-level batching of the per-layer glue (csrc/gan_glue.hip); plain attributes, not sub-modules
+    def _sn_group(self):
+        g = self.__dict__.get("_sn")
+        if g is None:
+            g = self.__dict__["_sn"] = G.SpectralNormGroup(sn_convs(self))
+        return g
+
+    def _conditioning(self, z):
+        """{ConditionalBatchNorm2d: (gamma [B,C], beta [B,C])}: the 2 x 14 Linear(emb, C) of gan.py:279-280 as ONE
+        GEMM over the concatenated weights (views of its output; split's backward is a single cat)"""
+        layers = self.__dict__.get("_cbn")
+        if layers is None:
+            layers = self.__dict__["_cbn"] = [m for m in self.modules() if isinstance(m, ConditionalBatchNorm2d)]
+            self.__dict__["_nbt"] = []
+            for m in layers:
+                if isinstance(m.norm, G.BatchNorm2d):
+                    m.norm._defer_count = True
+                    self.__dict__["_nbt"].append(m.norm.num_batches_tracked)
+        if not layers:
+            return None
+        ws = [w for m in layers for w in (m.fc_gamma.weight, m.fc_beta.weight)]
+        bs = [b for m in layers for b in (m.fc_gamma.bias, m.fc_beta.bias)]
+        out = F.linear(z, torch.cat(ws), torch.cat(bs))
+        parts = out.split([w.shape[0] for w in ws], dim=1)
+        return {m: (parts[2 * i], parts[2 * i + 1]) for i, m in enumerate(layers)}
+
+    def __deepcopy__(self, memo):
+        # the batching caches hold device pointers / module references of THIS instance: rebuild them in the copy
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k in ("_sn", "_cbn", "_nbt"):
+                continue
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
 
 # ------------------------------------------------------------------------------------------------ discriminators
@@ -212,6 +285,25 @@ def _d_norm(args, ch):
 
 
 class _DiscBase(nn.Module):
+    _sn_external = False  # True when a MultiScaleDiscriminator steps the spectral norm of all its members at once
+
+    def _sn_step(self):
+        if self._sn_external:
+            return
+        g = self.__dict__.get("_sn")
+        if g is None:
+            g = self.__dict__["_sn"] = G.SpectralNormGroup(sn_convs(self))
+        g.step(self.training)
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k != "_sn":
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
     def _pos(self, x):
         """cached positional embedding [1,4,H,W] for an NCHW tensor (gan.py:87-90, 204-207)"""
         if self.pos_emb is None:
@@ -255,14 +347,14 @@ class MeshDiscriminator(_DiscBase):
         if positional_embeddings:
             self.pos_emb = None
             nc += 4
-        self.conv1 = nn.utils.spectral_norm(Conv2d(nc, 64, 5, pad_h=2, pad_w=2, pad_w_mode=mode))
-        self.conv2 = nn.utils.spectral_norm(Conv2d(64, 128, 4, stride=2, pad_h=1, pad_w=1, pad_w_mode=mode, bias=bias))
+        self.conv1 = spectral_norm(Conv2d(nc, 64, 5, pad_h=2, pad_w=2, pad_w_mode=mode))
+        self.conv2 = spectral_norm(Conv2d(64, 128, 4, stride=2, pad_h=1, pad_w=1, pad_w_mode=mode, bias=bias))
         if n2 is not None:
             self.bn2 = n2
-        self.conv3 = nn.utils.spectral_norm(Conv2d(128, 256, 4, stride=2, pad_h=1, pad_w=1, pad_w_mode=mode, bias=bias))
+        self.conv3 = spectral_norm(Conv2d(128, 256, 4, stride=2, pad_h=1, pad_w=1, pad_w_mode=mode, bias=bias))
         if n3 is not None:
             self.bn3 = n3
-        self.conv4 = nn.utils.spectral_norm(Conv2d(256, 1, 5, pad_h=2, pad_w=2, pad_w_mode=mode))
+        self.conv4 = spectral_norm(Conv2d(256, 1, 5, pad_h=2, pad_w=2, pad_w_mode=mode))
         self.relu = nn.LeakyReLU(LRELU, inplace=True)
         if args.conditional_class:
             self.projector = nn.Embedding(args.n_classes[0], 256)
@@ -270,6 +362,7 @@ class MeshDiscriminator(_DiscBase):
                 self.projector_col1 = nn.Embedding(args.n_classes[1], 256)
 
     def forward(self, texture, mesh_map, c=None, caption=None):
+        self._sn_step()
         x = F.avg_pool2d(texture, texture.shape[2] // mesh_map.shape[2])
         parts = [x, mesh_map]
         if self.positional_embeddings:
@@ -307,19 +400,19 @@ class TextureDiscriminator(_DiscBase):
         self.stride_first = (downsample == 1 and args.texture_resolution >= 512) or args.texture_resolution >= 1024 \
             or args.conditional_text
         if self.stride_first:
-            self.conv1 = nn.utils.spectral_norm(Conv2d(nc, 64, 4, stride=2, pad_h=1, pad_w=1, pad_w_mode=mode))
+            self.conv1 = spectral_norm(Conv2d(nc, 64, 4, stride=2, pad_h=1, pad_w=1, pad_w_mode=mode))
         else:
-            self.conv1 = nn.utils.spectral_norm(Conv2d(nc, 64, 5, pad_h=2, pad_w=2, pad_w_mode=mode))
-        self.conv2 = nn.utils.spectral_norm(Conv2d(64, 128, 4, stride=2, pad_h=1, pad_w=1, pad_w_mode=mode, bias=bias))
+            self.conv1 = spectral_norm(Conv2d(nc, 64, 5, pad_h=2, pad_w=2, pad_w_mode=mode))
+        self.conv2 = spectral_norm(Conv2d(64, 128, 4, stride=2, pad_h=1, pad_w=1, pad_w_mode=mode, bias=bias))
         if n2 is not None:
             self.bn2 = n2
-        self.conv3 = nn.utils.spectral_norm(Conv2d(128, 256, 4, stride=2, pad_h=1, pad_w=1, pad_w_mode=mode, bias=bias))
+        self.conv3 = spectral_norm(Conv2d(128, 256, 4, stride=2, pad_h=1, pad_w=1, pad_w_mode=mode, bias=bias))
         if n3 is not None:
             self.bn3 = n3
-        self.conv4 = nn.utils.spectral_norm(Conv2d(256, 512, 4, stride=2, pad_h=1, pad_w=1, pad_w_mode=mode, bias=bias))
+        self.conv4 = spectral_norm(Conv2d(256, 512, 4, stride=2, pad_h=1, pad_w=1, pad_w_mode=mode, bias=bias))
         if n4 is not None:
             self.bn4 = n4
-        self.conv5 = nn.utils.spectral_norm(Conv2d(512, 1, 5, pad_h=2, pad_w=2, pad_w_mode=mode))
+        self.conv5 = spectral_norm(Conv2d(512, 1, 5, pad_h=2, pad_w=2, pad_w_mode=mode))
         self.relu = nn.LeakyReLU(LRELU, inplace=True)
         self.downsample = downsample
         if args.conditional_class:
@@ -328,6 +421,7 @@ class TextureDiscriminator(_DiscBase):
                 self.projector_col1 = nn.Embedding(args.n_classes[1], 512)
 
     def forward(self, x, c=None, caption=None):
+        self._sn_step()
         if self.downsample > 1:
             x = F.avg_pool2d(x, self.downsample)
         mask = None
@@ -348,6 +442,15 @@ class TextureDiscriminator(_DiscBase):
 class MultiScaleDiscriminator(nn.Module):
     """models/gan.py:235-260"""
 
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k != "_sn":
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
     def __init__(self, args, nc):
         super().__init__()
         self.args = args
@@ -362,6 +465,13 @@ class MultiScaleDiscriminator(nn.Module):
             raise ValueError(f"num_discriminators={args.num_discriminators}")
 
     def forward(self, x, mesh_map=None, c=None, caption=None):
+        g = self.__dict__.get("_sn")
+        if g is None:
+            g = self.__dict__["_sn"] = G.SpectralNormGroup(sn_convs(self))
+            for m in self.children():
+                if isinstance(m, _DiscBase):
+                    m.__dict__["_sn_external"] = True
+        g.step(self.training)
         d1, m1 = self.d1(x, c, caption)
         if self.args.texture_only:
             d2, m2 = self.d2(x, c, caption)

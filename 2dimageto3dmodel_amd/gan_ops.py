@@ -43,26 +43,30 @@ def leaky_relu(x, slope):
 
 
 class Conv2dFn(torch.autograd.Function):
-    """F.conv2d(pad(up(x)), w, b) [+ LeakyReLU] on NHWC bf16 through libm355."""
+    """F.conv2d(pad(up(x)), w / sigma, b) [+ LeakyReLU] on NHWC bf16 through libm355.  `sn` is None or the
+    spectral-norm state of this forward (SpectralNormGroup.step): the division by sigma happens inside the bf16
+    weight-view kernel and the gradient with respect to weight_orig (through sigma) inside the kernel that lays
+    out the weight gradient."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad_h, pad_w, mode, ups, slope, out_f32_nchw):
+    def forward(ctx, x, weight, bias, stride, pad_h, pad_w, mode, ups, slope, out_f32_nchw, sn):
         n, h, w, cx = x.shape
         cout, cw, kh, kw = weight.shape
         if cx % 8 or cx < cw:
             raise ValueError(f"conv2d: input has {cx} channels (must be a multiple of 8 and >= {cw})")
         d = C.make_desc(n, h, w, cx, cout, kh, kw, stride, pad_h, pad_w, mode, ups)
         need_dx = ctx.needs_input_grad[0]
-        wf, wd = C.weight_prep(d, weight, want_dgrad=need_dx)
+        sigma = None if sn is None else sn.sigma
+        wf, wd = C.weight_prep(d, weight, want_dgrad=need_dx, sigma=sigma)
         y = C.conv_fwd(d, x.detach(), wf, None if bias is None else bias.detach(), out_f32_nchw, slope, cin_real=cw)
-        ctx.d, ctx.cw, ctx.slope, ctx.f32 = d, cw, slope, out_f32_nchw
+        ctx.d, ctx.cw, ctx.slope, ctx.f32, ctx.sn = d, cw, slope, out_f32_nchw, sn
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x.detach(), wd, y if slope != 1.0 else None)
+        ctx.save_for_backward(x.detach(), wd, y if slope != 1.0 else None, weight.detach() if sn is not None else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, wd, y = ctx.saved_tensors
+        x, wd, y, w_orig = ctx.saved_tensors
         d = ctx.d
         c32 = C.dy_channels(d.Cout)
         if ctx.slope != 1.0 and not ctx.f32 and c32 == d.Cout and 256 % (d.Cout // 8) == 0:
@@ -82,12 +86,99 @@ class Conv2dFn(torch.autograd.Function):
         dx = C.conv_dgrad(d, g, wd, cin_real=ctx.cw) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = C.conv_wgrad(d, x, g, cin_real=ctx.cw)[:, :ctx.cw].contiguous()
-        return dx, dw, db, None, None, None, None, None, None, None
+            graw = C.conv_wgrad(d, x, g, cin_real=ctx.cw, raw=True)
+            sn = ctx.sn
+            if sn is None:
+                dw = C.wgrad_finish(d, graw, ctx.cw)
+            else:
+                sn.check()
+                dw = C.wgrad_finish(d, graw, ctx.cw, w_orig, sn.u, sn.v, sn.sigma)
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias, stride, pad_h, pad_w, mode, upsample=0, slope=1.0, out_f32_nchw=False):
-    return Conv2dFn.apply(x, weight, bias, stride, pad_h, pad_w, mode, int(upsample), float(slope), bool(out_f32_nchw))
+def conv2d(x, weight, bias, stride, pad_h, pad_w, mode, upsample=0, slope=1.0, out_f32_nchw=False, sn=None):
+    return Conv2dFn.apply(x, weight, bias, stride, pad_h, pad_w, mode, int(upsample), float(slope), bool(out_f32_nchw), sn)
+
+
+# ------------------------------------------------------------------------------------------------ spectral norm
+class _SnState:
+    """what one conv needs from one SpectralNormGroup.step(): views of that step's sigma / u / v"""
+    __slots__ = ("sigma", "u", "v", "_slot", "_version")
+
+    def __init__(self, sigma, u, v, slot, version):
+        self.sigma, self.u, self.v, self._slot, self._version = sigma, u, v, slot, version
+
+    def check(self):
+        if self._slot["version"] != self._version:
+            raise RuntimeError("spectral norm: the power-iteration snapshot of this forward was overwritten by later "
+                               "forwards before its backward ran (more than %d forwards in flight)" % SpectralNormGroup.SLOTS)
+
+
+class SpectralNormGroup:
+    """torch.nn.utils.spectral_norm for all convs of a network at once (csrc/gan_glue.hip): one power iteration per
+    training forward, three launches for the whole group.  The convs keep torch's parametrisation
+    (weight_orig / weight_u / weight_v, same state_dict keys and initialisation); only the per-module forward
+    pre-hook is replaced by `step()`."""
+    SLOTS = 4
+    _ENTRY = 64  # sizeof(m355_sn_layer)
+
+    def __init__(self, convs, eps=1e-12):
+        self.convs = [c for c in convs if hasattr(c, "weight_orig")]
+        self.eps = eps
+        self._key = None
+        self._slots = None
+        self._next = 0
+
+    def _build(self, dev):
+        import struct
+        rows = [c.weight_orig.shape[0] for c in self.convs]
+        cols = [c.weight_orig[0].numel() for c in self.convs]
+        self._max = (max(rows), max(cols))
+        nr, nc = sum(rows), sum(cols)
+        self._scratch = torch.empty(nr + nc, dtype=torch.float32, device=dev)
+        self._norms = torch.zeros(2 * len(self.convs), dtype=torch.float32, device=dev)
+        self._slots = []
+        for _ in range(self.SLOTS):
+            snap = torch.empty(nr + nc, dtype=torch.float32, device=dev)
+            sigma = torch.empty(len(self.convs), dtype=torch.float32, device=dev)
+            raw = bytearray()
+            views = []
+            ro, co = 0, nr
+            for i, c in enumerate(self.convs):
+                u_s, v_s = snap[ro:ro + rows[i]], snap[co:co + cols[i]]
+                raw += struct.pack("<7Q2i", c.weight_orig.data_ptr(), c.weight_u.data_ptr(), c.weight_v.data_ptr(),
+                                   self._scratch[co:].data_ptr(), self._scratch[ro:].data_ptr(), u_s.data_ptr(),
+                                   v_s.data_ptr(), rows[i], cols[i])
+                views.append((sigma[i:i + 1], u_s, v_s))
+                ro += rows[i]
+                co += cols[i]
+            table = torch.frombuffer(raw, dtype=torch.uint8).to(dev)
+            self._slots.append({"table": table, "snap": snap, "sigma": sigma, "views": views, "version": 0})
+
+    def step(self, training):
+        """advance (training) / evaluate sigma for every conv of the group and hand each conv its state"""
+        if not self.convs:
+            return
+        key = tuple(t.data_ptr() for c in self.convs for t in (c.weight_orig, c.weight_u, c.weight_v))
+        if key != self._key:
+            self._build(self.convs[0].weight_orig.device)
+            self._key = key
+        slot = self._slots[self._next]
+        self._next = (self._next + 1) % self.SLOTS
+        slot["version"] += 1
+        launch("sn_power_iter", ptr(slot["table"]), len(self.convs), self._max[0], self._max[1], ptr(self._norms),
+               ptr(slot["sigma"]), int(bool(training)), float(self.eps), stream())
+        for c, (sg, u, v) in zip(self.convs, slot["views"]):
+            c._sn_state = _SnState(sg, u, v, slot, slot["version"])
+
+
+def strip_sn_hook(conv):
+    """nn.utils.spectral_norm registers a forward pre-hook that recomputes `weight` with ~13 tiny launches; the
+    group kernel replaces it (state_dict hooks, parameter and buffer names stay)."""
+    for k, h in list(conv._forward_pre_hooks.items()):
+        if type(h).__name__ == "SpectralNorm":
+            del conv._forward_pre_hooks[k]
+    return conv
 
 
 # ------------------------------------------------------------------------------------------------ fused elementwise
@@ -162,6 +253,52 @@ class AffineActFn(torch.autograd.Function):
         return dx, dscale.to(scale.dtype), dshift.to(scale.dtype), None, None, None, None, None, None
 
 
+class CbnActFn(torch.autograd.Function):
+    """y = LeakyReLU(BN_batch(x) * (1 + gamma[n,c]) + beta[n,c]) on NHWC bf16 with every piece of coefficient
+    algebra inside libm355 (csrc/gan_glue.hip): 3 launches forward (partial sums, finalise, apply), 3 backward.
+    gamma / beta are [N,C] views (unit channel stride) of the batched fc_gamma / fc_beta output."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope):
+        n, h, w, c = x.shape
+        x = x.contiguous()
+        assert gamma.stride(1) == 1 and beta.stride(1) == 1 and gamma.stride(0) == beta.stride(0)
+        dev = x.device
+        P = n * h * w
+        nblk = lib().m355_chan_reduce_nblk(P)
+        part = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev)
+        launch("bn_stats_partial", ptr(x), ptr(part), P, c, stream())
+        coef = torch.empty((2 * n + 2, c), dtype=torch.float32, device=dev)   # a[N,C] | b[N,C] | mean | rstd
+        a, b, mean, rstd = coef[:n], coef[n:2 * n], coef[2 * n], coef[2 * n + 1]
+        launch("bn_finalize", ptr(part), nblk, float(P), ptr(gamma), ptr(beta), int(gamma.stride(0)), n, c, float(eps),
+               float(momentum), ptr(running_mean), ptr(running_var), ptr(mean), ptr(rstd), ptr(a), ptr(b), stream())
+        y = torch.empty_like(x)
+        launch("affine_act_fwd", ptr(x), ptr(a), ptr(b), ptr(y), n, h * w, c, float(slope), stream())
+        ctx.save_for_backward(x, coef, gamma)
+        ctx.cfg = (slope, float(P))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, coef, gamma = ctx.saved_tensors
+        slope, count = ctx.cfg
+        n, h, w, c = x.shape
+        a, b, mean, rstd = coef[:n], coef[n:2 * n], coef[2 * n], coef[2 * n + 1]
+        dy = dy.contiguous()
+        dev = x.device
+        nblk = lib().m355_chan_reduce_nblk(h * w)
+        part = torch.empty((n, nblk, 2, c), dtype=torch.float32, device=dev)
+        launch("affine_act_bwd_partial", ptr(dy), ptr(x), ptr(a), ptr(b), ptr(part), n, h * w, c, float(slope), stream())
+        out = torch.empty((3 * n + 2, c), dtype=torch.float32, device=dev)   # dgamma | dbeta | A | Bc | Cc
+        dgamma, dbeta, A, Bc, Cc = out[:n], out[n:2 * n], out[2 * n:3 * n], out[3 * n], out[3 * n + 1]
+        launch("bn_bwd_finalize", ptr(part), nblk, count, ptr(gamma), int(gamma.stride(0)), n, c, ptr(mean), ptr(rstd), 1,
+               ptr(dgamma), ptr(dbeta), ptr(A), ptr(Bc), ptr(Cc), stream())
+        dx = torch.empty_like(x)
+        launch("affine_act_bwd_apply", ptr(dy), ptr(x), ptr(a), ptr(b), ptr(A), ptr(Bc), ptr(Cc), ptr(dx), n, h * w, c,
+               float(slope), stream())
+        return dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None, None, None, None, None
+
+
 def _fused_ok(x):
     c = x.shape[-1]
     return x.is_cuda and x.dtype == torch.bfloat16 and c % 8 == 0 and c <= 2048 and 256 % (c // 8) == 0
@@ -217,9 +354,18 @@ class BatchNorm2d(nn.Module):
             self.running_var.mul_(1 - self.momentum).add_(unbiased.detach(), alpha=self.momentum)
             self.num_batches_tracked += 1
 
-    def forward(self, x, scale, shift, slope=1.0):
+    def forward(self, x, gamma, beta, slope=1.0):
+        """LeakyReLU(BN(x) * (1 + gamma) + beta); gamma / beta [N,C]"""
         if _fused_ok(x):
             sync = self._is_sync()
+            if self.training and not sync and gamma.dtype == torch.float32:
+                # single-launch coefficient algebra (csrc/gan_glue.hip); num_batches_tracked is bumped by the owner
+                # (Generator.forward batches it over all layers) or here when used stand-alone
+                y = CbnActFn.apply(x, gamma, beta, self.running_mean, self.running_var, self.momentum, self.eps, slope)
+                if not getattr(self, "_defer_count", False):
+                    self.num_batches_tracked += 1
+                return y
+            scale = 1 + gamma
             if self.training:
                 cnt = float(x.shape[0] * x.shape[1] * x.shape[2])
                 with torch.no_grad():
@@ -232,9 +378,10 @@ class BatchNorm2d(nn.Module):
                     var = (sums[1] / cnt - mean * mean).clamp_min(0)
                     rstd = torch.rsqrt(var + self.eps)
                 self._update_running(mean, var, cnt)
-                return AffineActFn.apply(x, scale, shift, mean, rstd, slope, True, cnt, sync)
+                return AffineActFn.apply(x, scale, beta, mean, rstd, slope, True, cnt, sync)
             rstd = torch.rsqrt(self.running_var + self.eps)
-            return AffineActFn.apply(x, scale, shift, self.running_mean, rstd, slope, False, 1.0, False)
+            return AffineActFn.apply(x, scale, beta, self.running_mean, rstd, slope, False, 1.0, False)
+        scale = 1 + gamma
         xf = x.float()
         if self.training:
             cnt = x.shape[0] * x.shape[1] * x.shape[2]
@@ -248,7 +395,7 @@ class BatchNorm2d(nn.Module):
             self._update_running(mean, var, cnt)
         else:
             mean, var = self.running_mean, self.running_var
-        return _affine_act((xf - mean) * torch.rsqrt(var + self.eps), scale, shift, slope)
+        return _affine_act((xf - mean) * torch.rsqrt(var + self.eps), scale, beta, slope)
 
 
 class SynchronizedBatchNorm2d(BatchNorm2d):
@@ -261,17 +408,17 @@ class InstanceNorm2d(nn.Module):
         super().__init__()
         self.eps = eps
 
-    def forward(self, x, scale, shift, slope=1.0):
+    def forward(self, x, gamma, beta, slope=1.0):
         xf = x.float()
         mean = xf.mean((1, 2), keepdim=True)
         var = xf.var((1, 2), unbiased=False, keepdim=True)
-        return _affine_act((xf - mean) * torch.rsqrt(var + self.eps), scale, shift, slope)
+        return _affine_act((xf - mean) * torch.rsqrt(var + self.eps), 1 + gamma, beta, slope)
 
 
 class NoNorm(nn.Module):
-    def forward(self, x, scale, shift, slope=1.0):
+    def forward(self, x, gamma, beta, slope=1.0):
         if _fused_ok(x):
             c = x.shape[-1]
             zero = torch.zeros(c, dtype=torch.float32, device=x.device)
-            return AffineActFn.apply(x, scale, shift, zero, torch.ones_like(zero), slope, False, 1.0, False)
-        return _affine_act(x.float(), scale, shift, slope)
+            return AffineActFn.apply(x, 1 + gamma, beta, zero, torch.ones_like(zero), slope, False, 1.0, False)
+        return _affine_act(x.float(), 1 + gamma, beta, slope)

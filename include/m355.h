@@ -145,8 +145,10 @@ int m355_conv2d_dy_channels(int cout);
 /*      elements (bf16) of the weight views: which 0 forward [ceil64(Cout)][ceil32(kh*kw*Cin)], 1 dgrad */
 size_t m355_conv2d_weight_elems(const m355_conv_desc *d, int which);
 /*      w_oihw is the fp32 parameter [Cout][cin_w][kh][kw]; channels cin_w..Cin-1 of the views are zero. */
-int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_oihw, int cin_w, void *w_fwd, void *w_dgrad,
-                            void *stream);
+/*      sigma (nullable, 1 float on the device): the views hold w / sigma[0] -- the spectral-norm division
+ *      (torch.nn.utils.spectral_norm: weight = weight_orig / sigma) folded into the bf16 conversion. */
+int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_oihw, int cin_w, const float *sigma, void *w_fwd,
+                            void *w_dgrad, void *stream);
 /*      y: bf16 NHWC [N,Ho,Wo,Cout] or (y_f32_nchw) fp32 [N,Cout,Ho,Wo]; epilogue: + bias[Cout] (nullable),
  *      LeakyReLU(lrelu_slope) (1.0 = identity). */
 int m355_conv2d_fwd(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
@@ -179,6 +181,46 @@ int m355_affine_act_bwd_apply(const void *dy, const void *x, const float *a, con
  *      dbias[C] = sum over pixels of g */
 int m355_lrelu_bwd(const void *dy, const void *y, void *g, float *dbias, void *ws, size_t P, int C, float slope,
                    void *stream);
+
+/*      first stages only (the second stage is fused into m355_bn_finalize / m355_bn_bwd_finalize):
+ *      part[m355_chan_reduce_nblk(P)][2][C] resp. part[N][m355_chan_reduce_nblk(HW)][2][C] */
+int m355_chan_reduce_nblk(size_t pixels_per_group);
+int m355_bn_stats_partial(const void *x, float *part, size_t P, int C, void *stream);
+int m355_affine_act_bwd_partial(const void *dy, const void *x, const float *a, const float *b, float *part, int N, int HW,
+                                int C, float slope, void *stream);
+
+/* ---- G9  spectral normalisation (torch.nn.utils.spectral_norm, one power iteration per training forward:
+ *      v = normalize(W^T u), u = normalize(W v), sigma = u.(W v); gan.py:57-65,163-177,294-302) for ALL layers of
+ *      a network in three launches.  `table` is a device-resident array of L entries; norms[2L] must be zero on
+ *      entry and is zero again on exit; u, v are updated in place when training, u_snap / v_snap (nullable)
+ *      receive the values this forward used (what autograd needs in the backward). */
+typedef struct {
+    const float *w;          /* weight_orig viewed as [rows][cols] = [Cout][Cin*kh*kw] */
+    float *u, *v;            /* [rows], [cols] power-iteration state */
+    float *t, *s;            /* scratch [cols], [rows] */
+    float *u_snap, *v_snap;  /* [rows], [cols] or NULL */
+    int rows, cols;
+} m355_sn_layer;
+int m355_sn_power_iter(const m355_sn_layer *table, int L, int max_rows, int max_cols, float *norms, float *sigma,
+                       int training, float eps, void *stream);
+/*      weight gradient epilogue: g = dL/dW_sn as the wgrad kernel leaves it, [Cout][kh][kw][CinP] ->
+ *      dw [Cout][Cin][kh][kw] = g / sigma - (<g, w_orig> / sigma^2) u v^T   (sigma NULL: plain re-layout).
+ *      part: scratch of 256 floats. */
+int m355_sn_wgrad_finish(const float *g_khwc, const float *w_orig, const float *u, const float *v, const float *sigma,
+                         float *part, float *dw, int Cout, int Cin, int CinP, int kh, int kw, void *stream);
+
+/* ---- G3  conditional batch norm coefficient algebra (gan.py:264-286) in one launch each way.
+ *      forward:  part[nblk][2][C] (sum, sum of squares over `count` pixels) -> mean[C], rstd[C] (biased variance,
+ *      eps inside the sqrt), running stats (momentum, unbiased variance; nullable),
+ *      a[n,c] = rstd (1 + gamma[n,c]), b[n,c] = beta[n,c] - mean a[n,c];  gamma/beta rows are gstride floats apart.
+ *      backward: part[N][nblk][2][C] (sum dz, sum dz x) -> dgamma, dbeta [N][C], A[N][C], Bc[C], Cc[C] with
+ *      dx = dz A + x Bc + Cc. */
+int m355_bn_finalize(const float *part, int nblk, float count, const float *gamma, const float *beta, int gstride, int N,
+                     int C, float eps, float momentum, float *running_mean, float *running_var, float *mean, float *rstd,
+                     float *a, float *b, void *stream);
+int m355_bn_bwd_finalize(const float *part, int nblk, float count, const float *gamma, int gstride, int N, int C,
+                         const float *mean, const float *rstd, int batch_stats, float *dgamma, float *dbeta, float *A,
+                         float *Bc, float *Cc, void *stream);
 
 #ifdef __cplusplus
 }

@@ -37,7 +37,8 @@ def test_norm_affine_act_fwd_bwd(pkg, shape, mode):
         mod.running_mean.copy_(rm)
         mod.running_var.copy_(rv)
         mod.eval()
-    xd, sd, td = x.to(DEV).requires_grad_(), scale.to(DEV).requires_grad_(), shift.to(DEV).requires_grad_()
+    # the modules take gamma (the layer computes x_hat * (1 + gamma) + beta, gan.py:285); d/dgamma = d/dscale
+    xd, sd, td = x.to(DEV).requires_grad_(), (scale - 1).to(DEV).requires_grad_(), shift.to(DEV).requires_grad_()
     y = mod(xd, sd, td, 0.2)
     assert y.dtype == torch.bfloat16
     assert (y.float().cpu() - yr.detach()).abs().max().item() < 0.03 * yr.abs().max().item()
@@ -64,3 +65,47 @@ def test_lrelu_bwd(pkg):
     want = dy.float() * torch.where(y.float() > 0, 1.0, 0.2)
     assert (gg.float() - want).abs().max().item() < 1e-2
     assert (db - want.bfloat16().float().sum((0, 1, 2))).abs().max().item() < 1e-2 * want.abs().sum((0, 1, 2)).max().item()
+
+
+def test_spectral_norm_group_matches_torch(pkg):
+    """batched power iteration + sigma (csrc/gan_glue.hip) against torch.nn.utils.spectral_norm's own arithmetic, and
+    the weight-gradient epilogue against autograd through weight_orig / sigma(weight_orig)"""
+    gan = importlib.import_module("2dimageto3dmodel_amd.gan")
+    G = importlib.import_module("2dimageto3dmodel_amd.gan_ops")
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    torch.manual_seed(3)
+    convs = [gan.spectral_norm(gan.Conv2d(24, 40, 3, pad_h=1, pad_w=1, bias=False)),
+             gan.spectral_norm(gan.Conv2d(8, 64, 5, pad_h=2, pad_w=2)),
+             gan.spectral_norm(gan.Conv2d(512, 512, 3, pad_h=1, pad_w=1, bias=False))]
+    for c in convs:
+        c.to(DEV)
+    ref = [(c.weight_orig.detach().clone(), c.weight_u.clone(), c.weight_v.clone()) for c in convs]
+    grp = G.SpectralNormGroup(convs)
+    for training in (True, False):
+        grp.step(training)
+        states = [c._sn_state for c in convs]
+        new_ref = []
+        for c, st, (w, u, v) in zip(convs, states, ref):
+            wm = w.reshape(w.shape[0], -1)
+            if training:
+                v = F.normalize(torch.mv(wm.t(), u), dim=0, eps=1e-12)
+                u = F.normalize(torch.mv(wm, v), dim=0, eps=1e-12)
+            sigma = torch.dot(u, torch.mv(wm, v))
+            assert abs(st.sigma.item() / sigma.item() - 1) < 1e-5
+            assert (c.weight_u - u).abs().max().item() < 1e-5 and (c.weight_v - v).abs().max().item() < 1e-5
+            assert (st.u - u).abs().max().item() < 1e-5 and (st.v - v).abs().max().item() < 1e-5
+            new_ref.append((w, u, v))
+        ref = new_ref
+    # backward through sigma: dL/dW_orig for L = <Gmat, W_orig / sigma(W_orig)>, u and v held constant
+    for c, st, (w, u, v) in zip(convs, states, ref):
+        cout, cin, kh, kw = w.shape
+        cinp = (cin + 7) // 8 * 8
+        g_khwc = torch.randn(cout, kh, kw, cinp, device=DEV)
+        wr = w.clone().requires_grad_()
+        sigma = torch.dot(u, torch.mv(wr.reshape(cout, -1), v))
+        (g_khwc[..., :cin].permute(0, 3, 1, 2) * (wr / sigma)).sum().backward()
+        d = conv.make_desc(1, 8, 8, cinp, cout, kh, kw, 1, kh // 2, kw // 2, 0, 0)
+        got = conv.wgrad_finish(d, g_khwc, cin, w, st.u, st.v, st.sigma)
+        assert (got - wr.grad).abs().max().item() < 2e-4 * wr.grad.abs().max().item()
+        plain = conv.wgrad_finish(d, g_khwc, cin)
+        assert torch.equal(plain, g_khwc[..., :cin].permute(0, 3, 1, 2).contiguous())
