@@ -47,7 +47,7 @@ SIGNATURES = {
     "m355_conv2d_wgrad": (c_int, [_P, _P, _P, _P, _P]),
     "m355_chan_reduce_ws_bytes": (c_size_t, [c_size_t, c_int, c_int, c_int]),
     "m355_bn_stats": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
-    "m355_affine_act_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
+    "m355_affine_act_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "m355_affine_act_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "m355_affine_act_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "m355_lrelu_bwd": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_float, _P]),

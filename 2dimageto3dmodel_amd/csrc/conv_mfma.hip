@@ -44,6 +44,7 @@ struct ConvArgs {
     float slope;         // epilogue LeakyReLU slope (1 = identity)
     // stride-2 dgrad in one launch (k_conv_glds only): blockIdx.y = output-parity class with its own weight view,
     // pads and output offsets
+    int lgWo, lgHo;      // log2 of the GEMM pixel grid sides when both are powers of two (else -1): shift/mask decode
     int ncls;
     int cpad_h[4], cpad_w[4], coy[4], cox[4];
     unsigned cls_w_elems;
@@ -223,8 +224,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_glds(ConvArgs a, unsigned xbyte
     for (int i = 0; i < RA; ++i) {
         const int m = m0 + 8 * (4 * i + wave) + (lane >> 3);
         if (m < M) {
-            const int n = m / HW, rr = m - n * HW;
-            const int ho = rr / a.Wo, wo = rr - ho * a.Wo;
+            int n, ho, wo;
+            if (a.lgWo >= 0) {
+                wo = m & (a.Wo - 1); ho = (m >> a.lgWo) & (a.Ho - 1); n = m >> (a.lgWo + a.lgHo);
+            } else {
+                n = m / HW;
+                const int rr = m - n * HW;
+                ho = rr / a.Wo; wo = rr - ho * a.Wo;
+            }
             hi0[i] = ho * a.stride - pad_h;
             wi0[i] = wo * a.stride - pad_w;
             nb[i] = (unsigned)n * (unsigned)(a.H * a.W * a.Cin * 2) + (FAST ? csrc * 16 : 0);
@@ -314,8 +321,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_glds(ConvArgs a, unsigned xbyte
         const int m = m0 + wm * 64 + 32 * i + (lane & 31);
         const bool mok = m < M;
         const int mm = mok ? m : 0;
-        const int n = mm / HW, rr = mm - n * HW;
-        const int ho = rr / a.Wo, wo = rr - ho * a.Wo;
+        int n, ho, wo;
+        if (a.lgWo >= 0) {
+            wo = mm & (a.Wo - 1); ho = (mm >> a.lgWo) & (a.Ho - 1); n = mm >> (a.lgWo + a.lgHo);
+        } else {
+            n = mm / HW;
+            const int rr = mm - n * HW;
+            ho = rr / a.Wo; wo = rr - ho * a.Wo;
+        }
         const size_t pix = ((size_t)n * a.OH + (ho * a.oy_mul + oy_off)) * a.OW + (wo * a.ox_mul + ox_off);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -422,6 +435,13 @@ __global__ void k_fold_pad(const unsigned short *__restrict__ g, unsigned short 
 }
 
 // rows of a weight view: a multiple of the N tile the launcher will pick for that many output channels
+static inline int ilog2_exact(int v)
+{
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
 static inline int rows_padded(int cout) { return cout <= 64 ? 64 : (cout + 127) / 128 * 128; }
 static inline int k_padded(int k) { return (k + 63) / 64 * 64; }
 // channel stride of the gradient tensor dy the backward entry points take: 8 for the 1..8-channel heads (so that the
@@ -440,6 +460,9 @@ static int launch_conv(ConvArgs a, hipStream_t st)
     const int M = a.N * a.Ho * a.Wo;
     a.CoutP = rows_padded(a.Cout);
     if (a.ncls < 1) a.ncls = 1;
+    a.lgWo = ilog2_exact(a.Wo);
+    a.lgHo = ilog2_exact(a.Ho);
+    if (a.lgWo < 0 || a.lgHo < 0) a.lgWo = a.lgHo = -1;
     const size_t xbytes = (size_t)a.N * a.H * a.W * a.Cin * 2, wbytes = (size_t)a.CoutP * a.Kp * 2;
     const bool dma_ok = dma_eligible(a);
     if (dma_ok) {
@@ -985,13 +1008,6 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(WgradDmaArgs A)
                 const int col = col0 + wc * 64 + 32 * j + (lane & 31);
                 if (co < a.Cout && col < K) atomicAdd(a.dw + (size_t)co * K + col, acc[i][j][r]);
             }
-}
-
-static inline int ilog2_exact(int v)
-{
-    int l = 0;
-    while ((1 << l) < v) ++l;
-    return (1 << l) == v ? l : -1;
 }
 
 }  // namespace m355

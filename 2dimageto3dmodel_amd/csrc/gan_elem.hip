@@ -103,22 +103,28 @@ __global__ __launch_bounds__(256) void k_sum_partials(const float *__restrict__ 
 
 // y = lrelu(x * a[n,c] + b[n,c]);  x,y [N][HW][C]
 __global__ __launch_bounds__(256) void k_affine_act(const short *__restrict__ x, const float *__restrict__ a,
-                                                    const float *__restrict__ b, short *__restrict__ y, int HW, int C,
-                                                    float slope)
+                                                    const float *__restrict__ b, const short *__restrict__ res,
+                                                    short *__restrict__ y, int HW, int C, float slope)
 {
     const int n = blockIdx.y;
     const int vecs = C >> 3;
     const size_t total = (size_t)HW * vecs;
     const short *xn = x + (size_t)n * HW * C;
     short *yn = y + (size_t)n * HW * C;
+    const short *rn = res ? res + (size_t)n * HW * C : nullptr;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c0 = (int)(i % vecs) * 8;
         const bf16x8e v = *reinterpret_cast<const bf16x8e *>(xn + i * 8);
+        bf16x8e r = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (rn) r = *reinterpret_cast<const bf16x8e *>(rn + i * 8);
         bf16x8e o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float z = bf2f_e(v[j]) * a[(size_t)n * C + c0 + j] + b[(size_t)n * C + c0 + j];
             z = z >= 0.0f ? z : z * slope;
+            // residual branch of ResBlockUp (gan.py:312): the activation is rounded to bf16 first, as the
+            // separate bf16 add it replaces did
+            if (rn) z = bf2f_e(f2bf_e(z)) + bf2f_e(r[j]);
             o[j] = f2bf_e(z);
         }
         *reinterpret_cast<bf16x8e *>(yn + i * 8) = o;
@@ -260,15 +266,15 @@ extern "C" int m355_bn_stats(const void *x, float *sums /*[2][C]*/, void *ws, si
     return check_launch("bn_stats");
 }
 
-extern "C" int m355_affine_act_fwd(const void *x, const float *a, const float *b, void *y, int N, int HW, int C,
-                                   float slope, void *stream)
+extern "C" int m355_affine_act_fwd(const void *x, const float *a, const float *b, const void *res, void *y, int N, int HW,
+                                   int C, float slope, void *stream)
 {
     M355_REQUIRE(x && a && b && y && N > 0 && HW > 0, "affine_act_fwd: null pointer / empty");
     if (int rc = check_c(C, "affine_act_fwd")) return rc;
     const size_t total = (size_t)HW * (C / 8);
     const unsigned gx = (unsigned)min((size_t)4096, (total + 255) / 256);
-    hipLaunchKernelGGL(k_affine_act, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, (const short *)x, a, b, (short *)y, HW,
-                       C, slope);
+    hipLaunchKernelGGL(k_affine_act, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, (const short *)x, a, b,
+                       (const short *)res, (short *)y, HW, C, slope);
     return check_launch("affine_act_fwd");
 }
 

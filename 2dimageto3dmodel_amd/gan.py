@@ -114,10 +114,11 @@ class ConditionalBatchNorm2d(nn.Module):
         self.fc_gamma = nn.Linear(emb_dim, ch)
         self.fc_beta = nn.Linear(emb_dim, ch)
 
-    def forward(self, x, z, slope=1.0, gb=None):
-        """gb: (gamma, beta) of this layer when the owner evaluated all fc_gamma / fc_beta in one GEMM"""
+    def forward(self, x, z, slope=1.0, gb=None, res=None):
+        """gb: (gamma, beta) of this layer when the owner evaluated all fc_gamma / fc_beta in one GEMM;
+        res: tensor added after the activation (the block's shortcut branch), fused into the same pass"""
         gamma, beta = gb if gb is not None else (self.fc_gamma(z), self.fc_beta(z))
-        return self.norm(x, gamma, beta, slope)
+        return self.norm(x, gamma, beta, slope, res)
 
 
 class ResBlockUp(nn.Module):
@@ -150,8 +151,7 @@ class ResBlockUp(nn.Module):
         g1 = gb.get(self.norm1) if gb is not None else None
         g2 = gb.get(self.norm2) if gb is not None else None
         h = self.norm1(self.conv1(x, upsample=upsample), z, LRELU, g1)
-        h = self.norm2(self.conv2(h), z, LRELU, g2)
-        return h + sc
+        return self.norm2(self.conv2(h), z, LRELU, g2, sc)
 
 
 class Generator(nn.Module):

@@ -217,7 +217,7 @@ class AffineActFn(torch.autograd.Function):
         a = (rstd * scale.float()).contiguous()            # [N,C]
         b = (shift.float() - mean * a).contiguous()
         y = torch.empty_like(x)
-        launch("affine_act_fwd", ptr(x), ptr(a), ptr(b), ptr(y), n, h * w, c, float(slope), stream())
+        launch("affine_act_fwd", ptr(x), ptr(a), ptr(b), None, ptr(y), n, h * w, c, float(slope), stream())
         ctx.save_for_backward(x, a, b, scale, mean, rstd)
         ctx.cfg = (slope, batch_stats, count, sync)
         return y
@@ -259,9 +259,12 @@ class CbnActFn(torch.autograd.Function):
     gamma / beta are [N,C] views (unit channel stride) of the batched fc_gamma / fc_beta output."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope, res=None):
         n, h, w, c = x.shape
         x = x.contiguous()
+        if res is not None:
+            res = res.contiguous()
+            assert res.shape == x.shape and res.dtype == x.dtype
         assert gamma.stride(1) == 1 and beta.stride(1) == 1 and gamma.stride(0) == beta.stride(0)
         dev = x.device
         P = n * h * w
@@ -273,15 +276,15 @@ class CbnActFn(torch.autograd.Function):
         launch("bn_finalize", ptr(part), nblk, float(P), ptr(gamma), ptr(beta), int(gamma.stride(0)), n, c, float(eps),
                float(momentum), ptr(running_mean), ptr(running_var), ptr(mean), ptr(rstd), ptr(a), ptr(b), stream())
         y = torch.empty_like(x)
-        launch("affine_act_fwd", ptr(x), ptr(a), ptr(b), ptr(y), n, h * w, c, float(slope), stream())
+        launch("affine_act_fwd", ptr(x), ptr(a), ptr(b), ptr(res), ptr(y), n, h * w, c, float(slope), stream())
         ctx.save_for_backward(x, coef, gamma)
-        ctx.cfg = (slope, float(P))
+        ctx.cfg = (slope, float(P), res is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, coef, gamma = ctx.saved_tensors
-        slope, count = ctx.cfg
+        slope, count, has_res = ctx.cfg
         n, h, w, c = x.shape
         a, b, mean, rstd = coef[:n], coef[n:2 * n], coef[2 * n], coef[2 * n + 1]
         dy = dy.contiguous()
@@ -296,7 +299,7 @@ class CbnActFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         launch("affine_act_bwd_apply", ptr(dy), ptr(x), ptr(a), ptr(b), ptr(A), ptr(Bc), ptr(Cc), ptr(dx), n, h * w, c,
                float(slope), stream())
-        return dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None, None, None, None, None
+        return dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None, None, None, None, None, (dy if has_res else None)
 
 
 def _fused_ok(x):
@@ -354,17 +357,21 @@ class BatchNorm2d(nn.Module):
             self.running_var.mul_(1 - self.momentum).add_(unbiased.detach(), alpha=self.momentum)
             self.num_batches_tracked += 1
 
-    def forward(self, x, gamma, beta, slope=1.0):
-        """LeakyReLU(BN(x) * (1 + gamma) + beta); gamma / beta [N,C]"""
+    def forward(self, x, gamma, beta, slope=1.0, res=None):
+        """LeakyReLU(BN(x) * (1 + gamma) + beta) [+ res]; gamma / beta [N,C]; res: residual branch, same shape as x"""
         if _fused_ok(x):
             sync = self._is_sync()
             if self.training and not sync and gamma.dtype == torch.float32:
                 # single-launch coefficient algebra (csrc/gan_glue.hip); num_batches_tracked is bumped by the owner
                 # (Generator.forward batches it over all layers) or here when used stand-alone
-                y = CbnActFn.apply(x, gamma, beta, self.running_mean, self.running_var, self.momentum, self.eps, slope)
+                y = CbnActFn.apply(x, gamma, beta, self.running_mean, self.running_var, self.momentum, self.eps, slope, res)
                 if not getattr(self, "_defer_count", False):
                     self.num_batches_tracked += 1
                 return y
+        if res is not None:
+            return self.forward(x, gamma, beta, slope) + res
+        if _fused_ok(x):
+            sync = self._is_sync()
             scale = 1 + gamma
             if self.training:
                 cnt = float(x.shape[0] * x.shape[1] * x.shape[2])
@@ -408,7 +415,9 @@ class InstanceNorm2d(nn.Module):
         super().__init__()
         self.eps = eps
 
-    def forward(self, x, gamma, beta, slope=1.0):
+    def forward(self, x, gamma, beta, slope=1.0, res=None):
+        if res is not None:
+            return self.forward(x, gamma, beta, slope) + res
         xf = x.float()
         mean = xf.mean((1, 2), keepdim=True)
         var = xf.var((1, 2), unbiased=False, keepdim=True)
@@ -416,7 +425,9 @@ class InstanceNorm2d(nn.Module):
 
 
 class NoNorm(nn.Module):
-    def forward(self, x, gamma, beta, slope=1.0):
+    def forward(self, x, gamma, beta, slope=1.0, res=None):
+        if res is not None:
+            return self.forward(x, gamma, beta, slope) + res
         if _fused_ok(x):
             c = x.shape[-1]
             zero = torch.zeros(c, dtype=torch.float32, device=x.device)

@@ -167,9 +167,10 @@ int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const void *dy, fl
 size_t m355_chan_reduce_ws_bytes(size_t pixels_per_group, int groups, int nvals, int C);
 /*      x[P][C] -> sums[2][C] = (sum, sum of squares): the batch statistics of BatchNorm2d / SynchronizedBatchNorm2d */
 int m355_bn_stats(const void *x, float *sums, void *ws, size_t P, int C, void *stream);
-/*      y = LeakyReLU_slope(x * a[n,c] + b[n,c]);  x,y [N][HW][C];  a = rstd*(1+gamma), b = beta - mean*a */
-int m355_affine_act_fwd(const void *x, const float *a, const float *b, void *y, int N, int HW, int C, float slope,
-                        void *stream);
+/*      y = LeakyReLU_slope(x * a[n,c] + b[n,c]) [+ res];  x,y,res [N][HW][C];  a = rstd*(1+gamma), b = beta - mean*a;
+ *      res (nullable): the residual branch of ResBlockUp (gan.py:312) added in the same pass */
+int m355_affine_act_fwd(const void *x, const float *a, const float *b, const void *res, void *y, int N, int HW, int C,
+                        float slope, void *stream);
 /*      dz = dy * LeakyReLU'(x*a+b);  sums[N][2][C] = (sum_hw dz, sum_hw dz*x) */
 int m355_affine_act_bwd_reduce(const void *dy, const void *x, const float *a, const float *b, float *sums, void *ws,
                                int N, int HW, int C, float slope, void *stream);
