@@ -58,7 +58,9 @@ SIGNATURES = {
     "m355_sn_wgrad_finish": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "m355_bn_finalize": (c_int, [_P, c_int, c_float, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P,
                                  _P]),
-    "m355_bn_bwd_finalize": (c_int, [_P, c_int, c_float, _P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P]),
+    "m355_bn_bwd_finalize": (c_int, [_P, c_int, c_float, _P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P,
+                                     _P]),
+    "m355_bn_bwd_coeffs": (c_int, [_P, c_float, _P, _P, c_int, _P, _P, _P]),
 }
 
 

@@ -213,7 +213,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float *__restrict
                                                          const float *__restrict__ gamma, int gstride, int N, int C,
                                                          const float *__restrict__ mean_i, const float *__restrict__ rstd_i,
                                                          int batch_stats, float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                         float *__restrict__ A, float *__restrict__ Bc, float *__restrict__ Cc)
+                                                         float *__restrict__ A, float *__restrict__ Bc, float *__restrict__ Cc,
+                                                         float *__restrict__ m_out)
 {
     __shared__ float red[2][8][32];
     const int cl = threadIdx.x & 31, l = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
@@ -248,7 +249,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float *__restrict
             t1 += red[0][k][cl];
             t2 += red[1][k][cl];
         }
-        if (batch_stats) {
+        if (m_out) {  // SyncBN: the sums over the LOCAL samples; all-reduced, then m355_bn_bwd_coeffs
+            m_out[c] = t1;
+            m_out[C + c] = t2;
+        } else if (batch_stats) {
             t1 /= count;
             t2 /= count;
             Bc[c] = -rstd * rstd * t2;
@@ -258,6 +262,17 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float *__restrict
             Cc[c] = 0.0f;
         }
     }
+}
+
+// Bc, Cc from the (all-reduced) moment sums m[2][C] and the global pixel count
+__global__ void k_bn_bwd_coeffs(const float *__restrict__ m, float count, const float *__restrict__ mean_i,
+                                const float *__restrict__ rstd_i, int C, float *__restrict__ Bc, float *__restrict__ Cc)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float t1 = m[c] / count, t2 = m[C + c] / count, rstd = rstd_i[c], mean = mean_i[c];
+    Bc[c] = -rstd * rstd * t2;
+    Cc[c] = -rstd * t1 + rstd * rstd * mean * t2;
 }
 
 }  // namespace m355
@@ -303,11 +318,19 @@ extern "C" int m355_bn_finalize(const float *part, int nblk, float count, const 
 
 extern "C" int m355_bn_bwd_finalize(const float *part, int nblk, float count, const float *gamma, int gstride, int N, int C,
                                     const float *mean, const float *rstd, int batch_stats, float *dgamma, float *dbeta,
-                                    float *A, float *Bc, float *Cc, void *stream)
+                                    float *A, float *Bc, float *Cc, float *m_out, void *stream)
 {
     M355_REQUIRE(part && gamma && mean && rstd && dgamma && dbeta && A && Bc && Cc && nblk > 0 && N > 0 && C > 0,
                  "bn_bwd_finalize: bad argument");
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, part, nblk, count, gamma,
-                       gstride, N, C, mean, rstd, batch_stats, dgamma, dbeta, A, Bc, Cc);
+                       gstride, N, C, mean, rstd, batch_stats, dgamma, dbeta, A, Bc, Cc, m_out);
     return check_launch("bn_bwd_finalize");
+}
+
+extern "C" int m355_bn_bwd_coeffs(const float *m, float count, const float *mean, const float *rstd, int C, float *Bc,
+                                  float *Cc, void *stream)
+{
+    M355_REQUIRE(m && mean && rstd && Bc && Cc && C > 0, "bn_bwd_coeffs: bad argument");
+    hipLaunchKernelGGL(k_bn_bwd_coeffs, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, m, count, mean, rstd, C, Bc, Cc);
+    return check_launch("bn_bwd_coeffs");
 }

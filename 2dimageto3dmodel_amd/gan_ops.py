@@ -254,12 +254,14 @@ class AffineActFn(torch.autograd.Function):
 
 
 class CbnActFn(torch.autograd.Function):
-    """y = LeakyReLU(BN_batch(x) * (1 + gamma[n,c]) + beta[n,c]) on NHWC bf16 with every piece of coefficient
+    """y = LeakyReLU(BN_batch(x) * (1 + gamma[n,c]) + beta[n,c]) [+ res] on NHWC bf16 with every piece of coefficient
     algebra inside libm355 (csrc/gan_glue.hip): 3 launches forward (partial sums, finalise, apply), 3 backward.
-    gamma / beta are [N,C] views (unit channel stride) of the batched fc_gamma / fc_beta output."""
+    gamma / beta are [N,C] views (unit channel stride) of the batched fc_gamma / fc_beta output.
+    sync: statistics over all ranks (SynchronizedBatchNorm2d) -- one all-reduce of [sum | sumsq | count] forward and
+    one of the two moment sums backward (RCCL), replacing code/sync_batchnorm/batchnorm.py:110-131's pipes."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope, res=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope, res=None, sync=False):
         n, h, w, c = x.shape
         x = x.contiguous()
         if res is not None:
@@ -268,23 +270,28 @@ class CbnActFn(torch.autograd.Function):
         assert gamma.stride(1) == 1 and beta.stride(1) == 1 and gamma.stride(0) == beta.stride(0)
         dev = x.device
         P = n * h * w
+        count = float(P)
         nblk = lib().m355_chan_reduce_nblk(P)
         part = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev)
         launch("bn_stats_partial", ptr(x), ptr(part), P, c, stream())
+        if sync:
+            v = torch.cat((part.sum(0).reshape(-1), part.new_tensor([count])))
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            part, nblk, count = v[:-1].contiguous(), 1, float(v[-1])
         coef = torch.empty((2 * n + 2, c), dtype=torch.float32, device=dev)   # a[N,C] | b[N,C] | mean | rstd
         a, b, mean, rstd = coef[:n], coef[n:2 * n], coef[2 * n], coef[2 * n + 1]
-        launch("bn_finalize", ptr(part), nblk, float(P), ptr(gamma), ptr(beta), int(gamma.stride(0)), n, c, float(eps),
+        launch("bn_finalize", ptr(part), nblk, count, ptr(gamma), ptr(beta), int(gamma.stride(0)), n, c, float(eps),
                float(momentum), ptr(running_mean), ptr(running_var), ptr(mean), ptr(rstd), ptr(a), ptr(b), stream())
         y = torch.empty_like(x)
         launch("affine_act_fwd", ptr(x), ptr(a), ptr(b), ptr(res), ptr(y), n, h * w, c, float(slope), stream())
         ctx.save_for_backward(x, coef, gamma)
-        ctx.cfg = (slope, float(P), res is not None)
+        ctx.cfg = (slope, count, res is not None, sync)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, coef, gamma = ctx.saved_tensors
-        slope, count, has_res = ctx.cfg
+        slope, count, has_res, sync = ctx.cfg
         n, h, w, c = x.shape
         a, b, mean, rstd = coef[:n], coef[n:2 * n], coef[2 * n], coef[2 * n + 1]
         dy = dy.contiguous()
@@ -292,14 +299,19 @@ class CbnActFn(torch.autograd.Function):
         nblk = lib().m355_chan_reduce_nblk(h * w)
         part = torch.empty((n, nblk, 2, c), dtype=torch.float32, device=dev)
         launch("affine_act_bwd_partial", ptr(dy), ptr(x), ptr(a), ptr(b), ptr(part), n, h * w, c, float(slope), stream())
-        out = torch.empty((3 * n + 2, c), dtype=torch.float32, device=dev)   # dgamma | dbeta | A | Bc | Cc
+        out = torch.empty((3 * n + 4, c), dtype=torch.float32, device=dev)   # dgamma | dbeta | A | Bc | Cc | m[2]
         dgamma, dbeta, A, Bc, Cc = out[:n], out[n:2 * n], out[2 * n:3 * n], out[3 * n], out[3 * n + 1]
+        m = out[3 * n + 2:] if sync else None
         launch("bn_bwd_finalize", ptr(part), nblk, count, ptr(gamma), int(gamma.stride(0)), n, c, ptr(mean), ptr(rstd), 1,
-               ptr(dgamma), ptr(dbeta), ptr(A), ptr(Bc), ptr(Cc), stream())
+               ptr(dgamma), ptr(dbeta), ptr(A), ptr(Bc), ptr(Cc), ptr(m), stream())
+        if sync:
+            dist.all_reduce(m, op=dist.ReduceOp.SUM)
+            launch("bn_bwd_coeffs", ptr(m), count, ptr(mean), ptr(rstd), c, ptr(Bc), ptr(Cc), stream())
         dx = torch.empty_like(x)
         launch("affine_act_bwd_apply", ptr(dy), ptr(x), ptr(a), ptr(b), ptr(A), ptr(Bc), ptr(Cc), ptr(dx), n, h * w, c,
                float(slope), stream())
-        return dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None, None, None, None, None, (dy if has_res else None)
+        return (dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None, None, None, None, None,
+                (dy if has_res else None), None)
 
 
 def _fused_ok(x):
@@ -361,10 +373,11 @@ class BatchNorm2d(nn.Module):
         """LeakyReLU(BN(x) * (1 + gamma) + beta) [+ res]; gamma / beta [N,C]; res: residual branch, same shape as x"""
         if _fused_ok(x):
             sync = self._is_sync()
-            if self.training and not sync and gamma.dtype == torch.float32:
+            if self.training and gamma.dtype == torch.float32:
                 # single-launch coefficient algebra (csrc/gan_glue.hip); num_batches_tracked is bumped by the owner
                 # (Generator.forward batches it over all layers) or here when used stand-alone
-                y = CbnActFn.apply(x, gamma, beta, self.running_mean, self.running_var, self.momentum, self.eps, slope, res)
+                y = CbnActFn.apply(x, gamma, beta, self.running_mean, self.running_var, self.momentum, self.eps, slope, res,
+                                   sync)
                 if not getattr(self, "_defer_count", False):
                     self.num_batches_tracked += 1
                 return y

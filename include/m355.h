@@ -221,7 +221,13 @@ int m355_bn_finalize(const float *part, int nblk, float count, const float *gamm
                      float *a, float *b, void *stream);
 int m355_bn_bwd_finalize(const float *part, int nblk, float count, const float *gamma, int gstride, int N, int C,
                          const float *mean, const float *rstd, int batch_stats, float *dgamma, float *dbeta, float *A,
-                         float *Bc, float *Cc, void *stream);
+                         float *Bc, float *Cc, float *m_out, void *stream);
+/*      SyncBN (one process per GPU): m_out != NULL makes m355_bn_bwd_finalize emit the local moment sums
+ *      m[2][C] = (sum_n (1+gamma) s1, sum_n (1+gamma) dgamma) instead of Bc / Cc; after their all-reduce (RCCL)
+ *      this turns them into Bc, Cc with the global pixel count.  The forward side needs no extra entry point:
+ *      all-reduce the summed partials and call m355_bn_finalize with nblk = 1. */
+int m355_bn_bwd_coeffs(const float *m, float count, const float *mean, const float *rstd, int C, float *Bc, float *Cc,
+                       void *stream);
 
 #ifdef __cplusplus
 }
