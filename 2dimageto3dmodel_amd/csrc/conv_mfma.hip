@@ -18,6 +18,9 @@
 // (and upsampled) input frame and folded back by k_fold_pad (W pad mode, H crop, 2x2 upsample sum).
 #include <hip/hip_bf16.h>
 
+#include <stdlib.h>
+#include <string.h>
+
 #include "conv_dma.h"
 
 namespace m355 {
@@ -186,12 +189,14 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
 //     share input halo rows and all tiles share the weights.
 // FAST (Cin % 64 == 0): a K step is one tap x 64 channels -> tap arithmetic is scalar.  Otherwise (Cin % 8 == 0,
 // D conv1's 8 channels, dgrad of the 1/3-channel heads) every 16-byte chunk derives its own tap.
-template <int BM, int BN, bool FAST, int MODE>
-__global__ __launch_bounds__(256, 2) void k_conv_glds(ConvArgs a, unsigned xbytes, unsigned wbytes)
+template <int BM, int BN, int NW, int WGN, bool FAST, int MODE>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void k_conv_glds(ConvArgs a, unsigned xbytes, unsigned wbytes)
 {
-    constexpr int RA = BM / 32, RB = BN / 32;  // DMA instructions per wave per stage
+    // NW waves arranged (NW / WGN) x WGN over the BM x BN tile; each wave owns a WTM x WTN sub-tile
+    constexpr int WGM = NW / WGN, WTM = BM / WGM, WTN = BN / WGN, PI = WTM / 32, CJ = WTN / 32;
+    constexpr int RA = BM / (8 * NW), RB = BN / (8 * NW);  // DMA instructions per wave per stage
     constexpr int STAGE = (BM + BN) * 128;
-    constexpr int WN = BN / 64;                // waves along N (1 or 2); waves along M = 4 / WN
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0 && RA >= 1 && RB >= 1 && NW % 2 == 0, "tile shape");
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -215,14 +220,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_glds(ConvArgs a, unsigned xbyte
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)wv, 0, wbytes, 0x00020000);
 
-    // ---- per-lane staging roles.  DMA instruction i of wave w covers tile rows 8*(4i+w) .. +7, so that the
-    // swizzle term (row>>1)&7 = 4*(w&1) + (lane>>4) is the same for all of a lane's rows.
+    // ---- per-lane staging roles.  DMA instruction i of wave w covers tile rows 8*(NW*i+w) .. +7, so that the
+    // swizzle term (row>>1)&7 = 4*(w&1) + (lane>>4) is the same for all of a lane's rows (NW is even).
     const int csrc = (lane & 7) ^ (((wave & 1) << 2) | ((lane >> 4) & 3));  // source chunk of this lane's LDS slot
     int hi0[RA], wi0[RA];
     unsigned nb[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int m = m0 + 8 * (4 * i + wave) + (lane >> 3);
+        const int m = m0 + 8 * (NW * i + wave) + (lane >> 3);
         if (m < M) {
             int n, ho, wo;
             if (a.lgWo >= 0) {
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_glds(ConvArgs a, unsigned xbyte
     }
     unsigned wrow[RB];
 #pragma unroll
-    for (int j = 0; j < RB; ++j) wrow[j] = (unsigned)(n0 + 8 * (4 * j + wave) + (lane >> 3)) * (unsigned)(a.Kp * 2) + csrc * 16;
+    for (int j = 0; j < RB; ++j) wrow[j] = (unsigned)(n0 + 8 * (NW * j + wave) + (lane >> 3)) * (unsigned)(a.Kp * 2) + csrc * 16;
 
     const int Cin2 = a.Cin * 2, nsteps = a.Kp / 64, Ktot = a.KH * a.KW * a.Cin;
     const int cpt = a.Cin >> 6;       // FAST: 64-channel chunks per tap
@@ -275,24 +280,24 @@ __global__ __launch_bounds__(256, 2) void k_conv_glds(ConvArgs a, unsigned xbyte
             else ok = ok && (unsigned)wi < (unsigned)a.Wl;
             unsigned off = nb[i] + (unsigned)(((hi >> a.ups) * a.W + (wi >> a.ups)) * Cin2);
             if (!FAST) off += cb;
-            dma16(rx, dstA + i * 4096, ok ? off : OOB, FAST ? cb : 0u);
+            dma16(rx, dstA + i * (NW * 1024), ok ? off : OOB, FAST ? cb : 0u);
         }
 #pragma unroll
-        for (int j = 0; j < RB; ++j) dma16(rw, dstB + j * 4096, wrow[j], (unsigned)t * 128u);
+        for (int j = 0; j < RB; ++j) dma16(rw, dstB + j * (NW * 1024), wrow[j], (unsigned)t * 128u);
     };
 
-    f32x16 acc[2][2];  // [co block j][pixel block i]
+    f32x16 acc[CJ][PI];  // [co block j][pixel block i]
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < CJ; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < PI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
 
-    const int wm = wave / WN, wn = wave % WN;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int swz = (lane >> 1) & 7, half = lane >> 5;
-    const unsigned char *fa = lds + (wm * 64 + (lane & 31)) * 128;             // pixel rows of this wave
-    const unsigned char *fb = lds + BM * 128 + (wn * 64 + (lane & 31)) * 128;  // weight rows of this wave
+    const unsigned char *fa = lds + (wm * WTM + (lane & 31)) * 128;             // pixel rows of this wave
+    const unsigned char *fb = lds + BM * 128 + (wn * WTN + (lane & 31)) * 128;  // weight rows of this wave
 
     stage(0, 0);
     __syncthreads();  // (the barrier's fence drains the DMA: vmcnt(0))
@@ -302,23 +307,25 @@ __global__ __launch_bounds__(256, 2) void k_conv_glds(ConvArgs a, unsigned xbyte
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int co16 = ((kk * 2 + half) ^ swz) << 4;
-            const bf16x8 p0 = *reinterpret_cast<const bf16x8 *>(fa + buf * STAGE + co16);
-            const bf16x8 p1 = *reinterpret_cast<const bf16x8 *>(fa + buf * STAGE + 32 * 128 + co16);
-            const bf16x8 w0 = *reinterpret_cast<const bf16x8 *>(fb + buf * STAGE + co16);
-            const bf16x8 w1 = *reinterpret_cast<const bf16x8 *>(fb + buf * STAGE + 32 * 128 + co16);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, p0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, p1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p1, acc[1][1], 0, 0, 0);
+            bf16x8 pf[PI], wf[CJ];
+#pragma unroll
+            for (int i = 0; i < PI; ++i) pf[i] = *reinterpret_cast<const bf16x8 *>(fa + buf * STAGE + i * 32 * 128 + co16);
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) wf[j] = *reinterpret_cast<const bf16x8 *>(fb + buf * STAGE + j * 32 * 128 + co16);
+#pragma unroll
+            for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                for (int i = 0; i < PI; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], pf[i], acc[j][i], 0, 0, 0);
         }
         __syncthreads();
     }
 
-    // ---- epilogue.  acc[j][i][r]: channel n0 + wn*64 + 32j + 8*(r>>2) + 4*half + (r&3), pixel m0 + wm*64 + 32i + (lane&31)
+    // ---- epilogue.  acc[j][i][r]: channel n0 + wn*WTN + 32j + 8*(r>>2) + 4*half + (r&3), pixel m0 + wm*WTM + 32i + (lane&31)
     unsigned short *yb = reinterpret_cast<unsigned short *>(a.y);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 64 + 32 * i + (lane & 31);
+    for (int i = 0; i < PI; ++i) {
+        const int m = m0 + wm * WTM + 32 * i + (lane & 31);
         const bool mok = m < M;
         const int mm = mok ? m : 0;
         int n, ho, wo;
@@ -331,8 +338,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_glds(ConvArgs a, unsigned xbyte
         }
         const size_t pix = ((size_t)n * a.OH + (ho * a.oy_mul + oy_off)) * a.OW + (wo * a.ox_mul + ox_off);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int cbase = n0 + wn * 64 + 32 * j;
+        for (int j = 0; j < CJ; ++j) {
+            const int cbase = n0 + wn * WTN + 32 * j;
             float4 b4[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -468,22 +475,38 @@ static int launch_conv(ConvArgs a, hipStream_t st)
     if (dma_ok) {
         const bool fast = a.Cin % 64 == 0;
         const unsigned xb = (unsigned)xbytes, wb = (unsigned)wbytes;
-#define M355_GO(BM_, BN_, F_, MD_) hipLaunchKernelGGL((k_conv_glds<BM_, BN_, F_, MD_>), grid, dim3(256), 0, st, a, xb, wb)
-#define M355_MODES(BM_, BN_, F_)                                \
-    do {                                                        \
-        if (a.pad_w_mode == 0) M355_GO(BM_, BN_, F_, 0);        \
-        else if (a.pad_w_mode == 1) M355_GO(BM_, BN_, F_, 1);   \
-        else M355_GO(BM_, BN_, F_, 2);                          \
+#define M355_GO(BM_, BN_, NW_, WGN_, F_, MD_) \
+    hipLaunchKernelGGL((k_conv_glds<BM_, BN_, NW_, WGN_, F_, MD_>), grid, dim3(NW_ * 64), 0, st, a, xb, wb)
+#define M355_MODES(BM_, BN_, NW_, WGN_, F_)                                   \
+    do {                                                                      \
+        if (a.pad_w_mode == 0) M355_GO(BM_, BN_, NW_, WGN_, F_, 0);           \
+        else if (a.pad_w_mode == 1) M355_GO(BM_, BN_, NW_, WGN_, F_, 1);      \
+        else M355_GO(BM_, BN_, NW_, WGN_, F_, 2);                             \
     } while (0)
-        if (a.CoutP == 64) {
-            dim3 grid((M + 255) / 256, a.ncls);
-            if (fast) M355_MODES(256, 64, true);
-            else M355_MODES(256, 64, false);
-        } else {
-            dim3 grid((unsigned)((M + 127) / 128) * (a.CoutP / 128), a.ncls);
-            if (fast) M355_MODES(128, 128, true);
-            else M355_MODES(128, 128, false);
+#define M355_TILE(BM_, BN_, NW_, WGN_)                                        \
+    do {                                                                      \
+        grid = dim3((unsigned)((M + BM_ - 1) / BM_) * (a.CoutP / BN_), a.ncls); \
+        if (fast) M355_MODES(BM_, BN_, NW_, WGN_, true);                      \
+        else M355_MODES(BM_, BN_, NW_, WGN_, false);                          \
+    } while (0)
+        // Tile choice (measured at batch 64, profiles/r01_conv_tiles.txt): 256x256 (8 waves, 128x64 per wave: half the
+        // LDS-DMA instructions and L2->LDS bytes per flop) wins by 15-20 % wherever Cout is a multiple of 256 and
+        // there are >= 4 tiles per CU; 256x128 (8 waves, one workgroup per CU) never beats two co-resident 128x128
+        // workgroups, so it is only reachable through M355_CONV_TILE.
+        dim3 grid;
+        const long tiles128 = (long)((M + 127) / 128) * (a.CoutP / 128) * a.ncls;
+        const char *force = getenv("M355_CONV_TILE");  // tests / tuning: "128x128", "256x128", "256x256"
+        int pick = a.CoutP == 64 ? 0 : (a.CoutP % 256 == 0 && tiles128 >= 4 * 1024) ? 3 : 1;
+        if (force && a.CoutP != 64) {
+            if (!strcmp(force, "128x128")) pick = 1;
+            else if (!strcmp(force, "256x128")) pick = 2;
+            else if (!strcmp(force, "256x256") && a.CoutP % 256 == 0) pick = 3;
         }
+        if (pick == 0) M355_TILE(256, 64, 4, 1);
+        else if (pick == 3) M355_TILE(256, 256, 8, 4);
+        else if (pick == 2) M355_TILE(256, 128, 8, 2);
+        else M355_TILE(128, 128, 4, 2);
+#undef M355_TILE
 #undef M355_MODES
 #undef M355_GO
         return check_launch("conv2d (dma)");

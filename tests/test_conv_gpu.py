@@ -91,3 +91,31 @@ def test_conv_fwd_and_dgrad(pkg, case):
     dw = conv.conv_wgrad(d, x_nhwc, dy_nhwc.bfloat16().to(DEV)).cpu()
     errw = (dw - wr.grad).abs().max().item() / wr.grad.abs().max().item()
     assert errw < 2e-4, errw
+
+
+@pytest.mark.parametrize("tile", ["128x128", "256x128", "256x256"])
+@pytest.mark.parametrize("case", [(3, 20, 12, 128, 256, 3, 1, 1, 1, 1, 1), (2, 32, 32, 128, 256, 4, 2, 1, 1, 2, 0),
+                                  (2, 16, 16, 64, 128, 4, 2, 1, 1, 2, 0), (3, 12, 6, 96, 96, 3, 1, 1, 1, 0, 0)])
+def test_conv_tile_variants(pkg, case, tile, monkeypatch):
+    """every workgroup tile of the DMA kernel (the launcher picks by problem size; forced here) on fwd + dgrad"""
+    monkeypatch.setenv("M355_CONV_TILE", tile)
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    N, H, W, Cin, Cout, k, stride, ph, pw, mode, ups = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).bfloat16().float()
+    b = torch.randn(Cout, generator=g)
+    xr = x.clone().requires_grad_()
+    y_ref = ref_conv(xr, w, b, stride, ph, pw, mode, ups)
+    d = conv.make_desc(N, H, W, Cin, Cout, k, k, stride, ph, pw, mode, ups)
+    wf, wd = conv.weight_prep(d, w.to(DEV))
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    y = conv.conv_fwd(d, x_nhwc, wf, b.to(DEV), slope=0.2).float().cpu().permute(0, 3, 1, 2)
+    assert (y - F.leaky_relu(y_ref.detach(), 0.2)).abs().max().item() / y_ref.abs().max().item() < 6e-3
+    dy = torch.randn(y_ref.shape, generator=g).bfloat16().float()
+    y_ref.backward(dy)
+    c32 = conv.dy_channels(Cout)
+    dy_nhwc = torch.zeros(N, y_ref.shape[2], y_ref.shape[3], c32)
+    dy_nhwc[..., :Cout] = dy.permute(0, 2, 3, 1)
+    dx = conv.conv_dgrad(d, dy_nhwc.bfloat16().to(DEV), wd).float().cpu().permute(0, 3, 1, 2)
+    assert (dx - xr.grad).abs().max().item() / xr.grad.abs().max().item() < 1.2e-2
