@@ -43,10 +43,12 @@ SIGNATURES = {
     "m355_conv2d_weight_prep": (c_int, [_P, _P, c_int, _P, _P, _P, _P]),
     "m355_conv2d_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P]),
     "m355_conv2d_dgrad_ws_bytes": (c_size_t, [_P]),
-    "m355_conv2d_dgrad": (c_int, [_P, _P, _P, _P, _P, _P]),
-    "m355_conv2d_wgrad": (c_int, [_P, _P, _P, _P, _P]),
+    "m355_conv2d_dgrad": (c_int, [_P, _P, _P, _P, _P, _P, c_float, _P]),
+    "m355_conv2d_wgrad_fuses_dbias": (c_int, [_P]),
+    "m355_conv2d_wgrad": (c_int, [_P, _P, _P, _P, _P, _P]),
     "m355_chan_reduce_ws_bytes": (c_size_t, [c_size_t, c_int, c_int, c_int]),
     "m355_bn_stats": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
+    "m355_chan_sum": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
     "m355_affine_act_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "m355_affine_act_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "m355_affine_act_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),

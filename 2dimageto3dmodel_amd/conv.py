@@ -76,23 +76,30 @@ def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0, cin_real=Non
     return y
 
 
-def conv_dgrad(d, dy, w_dgrad, cin_real=None):
+def conv_dgrad(d, dy, w_dgrad, cin_real=None, mask_x=None, mask_slope=1.0):
+    """mask_x: this conv's input x when it is the output of a fused conv+LeakyReLU(mask_slope): the returned gradient
+    is then already multiplied by that activation's derivative"""
     dy = _req(dy, torch.bfloat16, "dy")
     ho, wo = out_hw(d)
     assert tuple(dy.shape) == (d.N, ho, wo, dy_channels(d.Cout)), tuple(dy.shape)
     dx = torch.empty((d.N, d.H, d.W, d.Cin), dtype=torch.bfloat16, device=dy.device)
     nws = lib().m355_conv2d_dgrad_ws_bytes(ctypes.byref(d))
     ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device)
-    launch("conv2d_dgrad", ctypes.byref(d), ptr(dy), ptr(w_dgrad), ptr(dx), ptr(ws), stream(), work=flops(d, cin_real), tag=tag(d))
+    launch("conv2d_dgrad", ctypes.byref(d), ptr(dy), ptr(w_dgrad), ptr(dx), ptr(ws), ptr(mask_x), float(mask_slope), stream(),
+           work=flops(d, cin_real), tag=tag(d))
     return dx
 
 
-def conv_wgrad(d, x, dy, cin_real=None, raw=False):
+def wgrad_fuses_dbias(d):
+    return bool(lib().m355_conv2d_wgrad_fuses_dbias(ctypes.byref(d)))
+
+
+def conv_wgrad(d, x, dy, cin_real=None, raw=False, dbias=None):
     """-> dw fp32 in the parameter's layout [Cout,Cin,kh,kw] (a permuted view), or with raw=True the kernel's own
     [Cout,kh,kw,Cin] buffer"""
     x, dy = _req(x, torch.bfloat16, "x"), _req(dy, torch.bfloat16, "dy")
     dw = torch.empty((d.Cout, d.kh, d.kw, d.Cin), dtype=torch.float32, device=x.device)
-    launch("conv2d_wgrad", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), stream(), work=flops(d, cin_real), tag=tag(d))
+    launch("conv2d_wgrad", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), stream(), work=flops(d, cin_real), tag=tag(d))
     return dw if raw else dw.permute(0, 3, 1, 2)
 
 

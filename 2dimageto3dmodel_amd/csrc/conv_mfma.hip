@@ -47,6 +47,8 @@ struct ConvArgs {
     float slope;         // epilogue LeakyReLU slope (1 = identity)
     // stride-2 dgrad in one launch (k_conv_glds only): blockIdx.y = output-parity class with its own weight view,
     // pads and output offsets
+    const unsigned short *mask_x;  // dgrad only (k_conv_glds): tensor of the output's shape; y *= (mask_x > 0 ? 1 : mask_slope)
+    float mask_slope;              //   = the backward of the LeakyReLU that produced this conv's input, folded in
     int lgWo, lgHo;      // log2 of the GEMM pixel grid sides when both are powers of two (else -1): shift/mask decode
     int ncls;
     int cpad_h[4], cpad_w[4], coy[4], cox[4];
@@ -346,6 +348,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void k_conv_glds(ConvArgs
                 const int co = cbase + 8 * g + 4 * half;
                 b4[g] = (a.bias && co < a.Cout) ? *reinterpret_cast<const float4 *>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            // LeakyReLU backward of the layer below (its output = this conv's input, same shape as this output):
+            // this lane's 4 x 4 channels of its pixel, fetched before the conversions so the latency overlaps them
+            uint2 mk[4];
+            if (a.mask_x) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = cbase + 8 * g + 4 * half;
+                    mk[g] = (mok && co < a.Cout) ? *reinterpret_cast<const uint2 *>(a.mask_x + pix * a.Cs + co) : make_uint2(0u, 0u);
+                }
+            }
             uint2 pk[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -353,6 +365,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void k_conv_glds(ConvArgs
                               acc[j][i][4 * g + 3] + b4[g].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * a.slope;
+                if (a.mask_x) {
+                    const float x0 = __uint_as_float(mk[g].x << 16), x1 = __uint_as_float(mk[g].x & 0xffff0000u);
+                    const float x2 = __uint_as_float(mk[g].y << 16), x3 = __uint_as_float(mk[g].y & 0xffff0000u);
+                    v[0] = x0 > 0.0f ? v[0] : v[0] * a.mask_slope;
+                    v[1] = x1 > 0.0f ? v[1] : v[1] * a.mask_slope;
+                    v[2] = x2 > 0.0f ? v[2] : v[2] * a.mask_slope;
+                    v[3] = x3 > 0.0f ? v[3] : v[3] * a.mask_slope;
+                }
                 pk[g].x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
                 pk[g].y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
             }
@@ -643,15 +663,29 @@ extern "C" int m355_conv2d_fwd(const m355_conv_desc *d, const void *x, const voi
 
 // dy[N,Ho,Wo,Cout_p32] bf16 (channel stride = ceil32(Cout), padding channels zero) -> dx[N,H,W,Cin] bf16.
 // ws >= m355_conv2d_dgrad_ws_bytes(d): the gradient in the padded / upsampled frame before folding.
+// does the dgrad of this layer run in the direct form (writes dx itself: no padded frame, no fold pass)?
+static bool dgrad_direct(const m355_conv_desc *d)
+{
+    int Ho, Wo;
+    if (conv_out_hw(d, &Ho, &Wo) != 0) return false;
+    const int cy = m355::dy_channels(d->Cout);
+    ConvArgs a = {};
+    a.N = d->N; a.H = Ho; a.W = Wo; a.Cin = cy; a.Cout = d->Cin; a.Cs = d->Cin;
+    a.Kp = m355::k_padded((d->stride == 1 ? d->kh * d->kw : (d->kh / 2) * (d->kw / 2)) * cy);
+    return !d->upsample && d->pad_w_mode != 1 && m355::dma_eligible(a) &&
+           (d->stride == 1 || (d->H % 2 == 0 && d->W % 2 == 0 && d->kh % 2 == 0 && d->kw % 2 == 0));
+}
+
 extern "C" size_t m355_conv2d_dgrad_ws_bytes(const m355_conv_desc *d)
 {
     if (!d) return 0;
+    if (dgrad_direct(d)) return 0;
     const size_t Hl = (size_t)d->H << d->upsample, Wl = (size_t)d->W << d->upsample;
     return (size_t)d->N * (Hl + 2 * d->pad_h) * (Wl + 2 * d->pad_w) * d->Cin * 2;
 }
 
 extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, void *ws,
-                                 void *stream)
+                                 const void *mask_x, float mask_slope, void *stream)
 {
     if (int rc = check_desc(d, "conv2d_dgrad")) return rc;
     M355_REQUIRE(dy && w_dgrad && dx, "conv2d_dgrad: null pointer");
@@ -669,8 +703,11 @@ extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const 
     // DIRECT form (no padded frame, no fold): without upsample and with a zero or circular W pad the adjoint of
     // the padding is an index map on dy -- a circularly padded conv's dgrad is a circular conv of dy.
     a.Kp = m355::k_padded((d->stride == 1 ? d->kh * d->kw : (d->kh / 2) * (d->kw / 2)) * cout32);
-    const bool direct = !d->upsample && d->pad_w_mode != 1 && m355::dma_eligible(a) &&
-                        (d->stride == 1 || (d->H % 2 == 0 && d->W % 2 == 0 && d->kh % 2 == 0 && d->kw % 2 == 0));
+    const bool direct = dgrad_direct(d);
+    M355_REQUIRE(!mask_x || direct, "conv2d_dgrad: the fused activation backward needs the direct form (no upsample, "
+                                    "no replicate pad, tensors < 2 GiB)");
+    a.mask_x = (const unsigned short *)mask_x;
+    a.mask_slope = mask_slope;
     int rc = 0;
     if (direct && d->stride == 1) {
         a.w = (const unsigned short *)w_dgrad;
@@ -765,6 +802,7 @@ struct WgradArgs {
     const unsigned short *x;   // bf16 NHWC [N,H,W,Cin]
     const unsigned short *dy;  // bf16 NHWC [N,Ho,Wo,Cy]
     float *dw;                 // fp32 [Cout][KH][KW][Cin], pre-zeroed
+    float *db;                 // k_wgrad_dma only, nullable: fp32 [Cout] += column sums of dy (bias gradient), pre-zeroed
     int N, H, W, Cin, Hl, Wl, ups;
     int Ho, Wo, Cout, Cy;
     int KH, KW, stride, pad_h, pad_w, pad_w_mode;
@@ -1001,12 +1039,27 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(WgradDmaArgs A)
         xb[i] = YB + rowl * RBX + (((wc * 8 + 4 * i + g16 * 2 + ((q & 3) >> 1)) ^ rdswzx) << 4) + (q & 1) * 8;
     }
 
+    // bias gradient for free: the workgroups of the first column tile also sum the dy tile they stage anyway
+    // (thread -> channel tid % TM, pixel group tid / TM); rows beyond pend were zero-filled by the DMA
+    const bool do_db = a.db != nullptr && blockIdx.y == 0;
+    constexpr int DBG = 256 / TM, DBP = 64 / DBG;
+    const int dbc = tid % TM, dbq = tid / TM;
+    float dbacc = 0.0f;
+
     stage(pbeg, 0);
     __syncthreads();
     int buf = 0;
     for (int pb = pbeg; pb < pend; pb += 64, buf ^= 1) {
         if (pb + 64 < pend) stage(pb + 64, buf ^ 1);
         const unsigned char *base = lds + buf * STAGE;
+        if (do_db) {
+#pragma unroll 8
+            for (int pp = 0; pp < DBP; ++pp) {
+                const int prow = dbq * DBP + pp;
+                const int sw = RBY == 128 ? 4 * ((prow >> 1) & 1) : 4 * (prow & 3);
+                dbacc += bf2f(*reinterpret_cast<const unsigned short *>(base + prow * RBY + (((dbc >> 3) ^ sw) << 4) + (dbc & 7) * 2));
+            }
+        }
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
             const bf16x8 a0 = tr_pair(base + ya[0], kg * 16 * RBY, (kg * 16 + 4) * RBY);
@@ -1031,20 +1084,37 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(WgradDmaArgs A)
                 const int col = col0 + wc * 64 + 32 * j + (lane & 31);
                 if (co < a.Cout && col < K) atomicAdd(a.dw + (size_t)co * K + col, acc[i][j][r]);
             }
+    if (do_db && co0 + dbc < a.Cout) atomicAdd(a.db + co0 + dbc, dbacc);
 }
 
 }  // namespace m355
 
-// x[N,H,W,Cin] bf16, dy[N,Ho,Wo,ceil32(Cout)] bf16 -> dw fp32 [Cout][kh][kw][Cin] (overwritten).
-extern "C" int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const void *dy, float *dw, void *stream)
+// x[N,H,W,Cin] bf16, dy[N,Ho,Wo,dy_channels(Cout)] bf16 -> dw fp32 [Cout][kh][kw][Cin] (overwritten).
+static bool wgrad_dma_ok(const m355_conv_desc *d)
+{
+    int Ho, Wo;
+    if (conv_out_hw(d, &Ho, &Wo) != 0) return false;
+    const size_t xbytes = (size_t)d->N * d->H * d->W * d->Cin * 2;
+    const size_t ybytes = (size_t)d->N * Ho * Wo * m355::dy_channels(d->Cout) * 2;
+    return d->Cout >= 64 && m355::ilog2_exact(Wo) >= 0 && m355::ilog2_exact(Ho) >= 0 && xbytes < (1ull << 31) &&
+           ybytes < (1ull << 31);
+}
+
+/* 1 when m355_conv2d_wgrad can also produce the bias gradient (column sums of dy) for this layer */
+extern "C" int m355_conv2d_wgrad_fuses_dbias(const m355_conv_desc *d) { return d && wgrad_dma_ok(d) ? 1 : 0; }
+
+extern "C" int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias,
+                                 void *stream)
 {
     if (int rc = check_desc(d, "conv2d_wgrad")) return rc;
     M355_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
+    M355_REQUIRE(!dbias || wgrad_dma_ok(d), "conv2d_wgrad: dbias is only fused on the DMA path (m355_conv2d_wgrad_fuses_dbias)");
     hipStream_t st = (hipStream_t)stream;
     m355::WgradArgs a = {};
     a.x = (const unsigned short *)x;
     a.dy = (const unsigned short *)dy;
     a.dw = dw;
+    a.db = dbias;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ups = d->upsample;
     a.Hl = d->H << d->upsample; a.Wl = d->W << d->upsample;
     conv_out_hw(d, &a.Ho, &a.Wo);
@@ -1056,10 +1126,14 @@ extern "C" int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const v
         m355::set_error("conv2d_wgrad: memset failed");
         return M355_ERR_LAUNCH;
     }
+    if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)d->Cout, st) != hipSuccess) {
+        m355::set_error("conv2d_wgrad: memset failed");
+        return M355_ERR_LAUNCH;
+    }
     if (m355::wgrad_small_eligible(d, a.Cy)) return m355::wgrad_small_launch(d, x, dy, a.Cy, dw, st);
     const size_t xbytes = (size_t)d->N * d->H * d->W * d->Cin * 2, ybytes = (size_t)P * a.Cy * 2;
     const int lgWo = m355::ilog2_exact(a.Wo), lgHo = m355::ilog2_exact(a.Ho);
-    if (d->Cout >= 64 && lgWo >= 0 && lgHo >= 0 && xbytes < (1ull << 31) && ybytes < (1ull << 31)) {
+    if (wgrad_dma_ok(d)) {
         const int TM = d->Cout > 64 ? 128 : 64, TN = d->Cout > 64 ? 128 : 256;
         const int gx = (d->Cout + TM - 1) / TM, gy = (K + TN - 1) / TN;
         // split the pixel axis: ~1024 workgroups in flight (2 resident per CU), at least 4 K steps each

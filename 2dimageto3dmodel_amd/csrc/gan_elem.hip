@@ -80,6 +80,18 @@ __global__ __launch_bounds__(256) void k_chan_stats(const short *__restrict__ x,
     });
 }
 
+// x[P][C] -> part[blk][1][C] = sum over pixels (bias gradient of a conv whose incoming gradient is already masked)
+__global__ __launch_bounds__(256) void k_chan_sum(const short *__restrict__ x, float *__restrict__ part, size_t P, int C, int ppb)
+{
+    const size_t pix0 = (size_t)blockIdx.x * ppb;
+    const int npix = (int)min((size_t)ppb, P - pix0);
+    pixel_reduce<1>(C, pix0, npix, part + (size_t)blockIdx.x * C, [&](size_t p, int c0, float (&acc)[1][8]) {
+        const bf16x8e v = *reinterpret_cast<const bf16x8e *>(x + p * C + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[0][j] += bf2f_e(v[j]);
+    });
+}
+
 // part[G][nblk][W] -> out[G][W]: deterministic second stage.  A workgroup owns 32 outputs; 8 threads per output
 // each sum every 8th partial, then a fixed-order LDS combine.
 __global__ __launch_bounds__(256) void k_sum_partials(const float *__restrict__ part, float *__restrict__ out, int nblk,
@@ -252,6 +264,18 @@ extern "C" int m355_affine_act_bwd_partial(const void *dy, const void *x, const 
     hipLaunchKernelGGL(k_act_bwd_reduce, dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, (const short *)dy, (const short *)x,
                        a, b, part, HW, C, slope, ppb);
     return check_launch("affine_act_bwd_partial");
+}
+
+extern "C" int m355_chan_sum(const void *x, float *sums /*[C]*/, void *ws, size_t P, int C, void *stream)
+{
+    M355_REQUIRE(x && sums && ws && P > 0, "chan_sum: null pointer / empty");
+    if (int rc = check_c(C, "chan_sum")) return rc;
+    const int ppb = pix_per_block(P);
+    const int nblk = (int)((P + ppb - 1) / ppb);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_chan_sum, dim3(nblk), dim3(256), 0, st, (const short *)x, (float *)ws, P, C, ppb);
+    hipLaunchKernelGGL(k_sum_partials, dim3((C + 31) / 32, 1), dim3(256), 0, st, (const float *)ws, sums, nblk, C);
+    return check_launch("chan_sum");
 }
 
 extern "C" int m355_bn_stats(const void *x, float *sums /*[2][C]*/, void *ws, size_t P, int C, void *stream)

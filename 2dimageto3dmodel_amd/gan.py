@@ -63,7 +63,7 @@ class Conv2d(nn.Conv2d):
         self._sn_state = None
         self._sn_own = None
 
-    def forward(self, x, upsample=0, slope=1.0, out_f32_nchw=False):
+    def forward(self, x, upsample=0, slope=1.0, out_f32_nchw=False, in_slope=1.0, premasked=False):
         stride, pad_h, pad_w, mode = self.m355
         sn, weight = None, None
         if "weight_orig" in self._parameters:
@@ -76,7 +76,8 @@ class Conv2d(nn.Conv2d):
             weight = self.weight_orig
         else:
             weight = self.weight
-        return G.conv2d(x, weight, self.bias, stride, pad_h, pad_w, mode, upsample, slope, out_f32_nchw, sn)
+        return G.conv2d(x, weight, self.bias, stride, pad_h, pad_w, mode, upsample, slope, out_f32_nchw, sn, in_slope,
+                        premasked)
 
 
 def spectral_norm(conv):
@@ -310,10 +311,15 @@ class _DiscBase(nn.Module):
             self.pos_emb = torch.FloatTensor(positional_encoding(x.shape[2], x.shape[3])).unsqueeze(0)
         return self.pos_emb.to(x.device).expand(x.shape[0], -1, -1, -1)
 
-    def _act(self, conv, norm, x):
-        """conv -> [InstanceNorm] -> LeakyReLU on NHWC bf16"""
+    def _act(self, conv, norm, x, in_act=False, sole_consumer_masks=False):
+        """conv -> [InstanceNorm] -> LeakyReLU on NHWC bf16.  With the activation in the conv epilogue (no norm):
+        in_act = x is the previous layer's fused conv+LeakyReLU output and this conv is its only consumer -> this
+        conv's dgrad applies that activation's backward; sole_consumer_masks = the same arrangement one layer up,
+        i.e. this layer's incoming gradient is already masked."""
         if norm is None:
-            return conv(x, slope=LRELU)
+            fuse = x.is_cuda and conv.m355[3] != C.PAD_REPLICATE
+            return conv(x, slope=LRELU, in_slope=LRELU if (in_act and fuse) else 1.0,
+                        premasked=sole_consumer_masks and fuse)
         y = G.to_nchw_f32(conv(x))
         return G.to_nhwc_bf16(F.leaky_relu(norm(y), LRELU))
 
@@ -373,9 +379,12 @@ class MeshDiscriminator(_DiscBase):
             with torch.no_grad():
                 mask = F.avg_pool2d(x[:, 3:4], 4)
         h = G.to_nhwc_bf16(x, pad_to=8)
-        h = self._act(self.conv1, None, h)
-        h = self._act(self.conv2, getattr(self, "bn2", None), h)
-        h = self._act(self.conv3, getattr(self, "bn3", None), h)
+        # conv1 -> conv2 -> conv3 are single-consumer chains when norm_d == 'none': each dgrad carries the LeakyReLU
+        # backward of the layer below (conv3's output also feeds the projection term, so it keeps its own)
+        n2, n3 = getattr(self, "bn2", None), getattr(self, "bn3", None)
+        h = self._act(self.conv1, None, h, False, n2 is None)
+        h = self._act(self.conv2, n2, h, True, n3 is None)
+        h = self._act(self.conv3, n3, h, n2 is None and True, False)
         y = self.conv4(h, out_f32_nchw=True)
         return self._project(y, h, c, caption), mask
 
@@ -431,10 +440,11 @@ class TextureDiscriminator(_DiscBase):
         if self.positional_embeddings:
             x = torch.cat((x, self._pos(x)), dim=1)
         h = G.to_nhwc_bf16(x, pad_to=8)
-        h = self._act(self.conv1, None, h)
-        h = self._act(self.conv2, getattr(self, "bn2", None), h)
-        h = self._act(self.conv3, getattr(self, "bn3", None), h)
-        h = self._act(self.conv4, getattr(self, "bn4", None), h)
+        n2, n3, n4 = getattr(self, "bn2", None), getattr(self, "bn3", None), getattr(self, "bn4", None)
+        h = self._act(self.conv1, None, h, False, n2 is None)
+        h = self._act(self.conv2, n2, h, True, n3 is None)
+        h = self._act(self.conv3, n3, h, n2 is None, n4 is None)
+        h = self._act(self.conv4, n4, h, n3 is None, False)
         y = self.conv5(h, out_f32_nchw=True)
         return self._project(y, h, c, caption), mask
 

@@ -49,7 +49,8 @@ class Conv2dFn(torch.autograd.Function):
     out the weight gradient."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad_h, pad_w, mode, ups, slope, out_f32_nchw, sn):
+    def forward(ctx, x, weight, bias, stride, pad_h, pad_w, mode, ups, slope, out_f32_nchw, sn, in_slope=1.0,
+                premasked=False):
         n, h, w, cx = x.shape
         cout, cw, kh, kw = weight.shape
         if cx % 8 or cx < cw:
@@ -60,8 +61,10 @@ class Conv2dFn(torch.autograd.Function):
         wf, wd = C.weight_prep(d, weight, want_dgrad=need_dx, sigma=sigma)
         y = C.conv_fwd(d, x.detach(), wf, None if bias is None else bias.detach(), out_f32_nchw, slope, cin_real=cw)
         ctx.d, ctx.cw, ctx.slope, ctx.f32, ctx.sn = d, cw, slope, out_f32_nchw, sn
+        ctx.in_slope, ctx.premasked = in_slope, premasked
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x.detach(), wd, y if slope != 1.0 else None, weight.detach() if sn is not None else None)
+        ctx.save_for_backward(x.detach(), wd, y if (slope != 1.0 and not premasked) else None,
+                              weight.detach() if sn is not None else None)
         return y
 
     @staticmethod
@@ -69,7 +72,17 @@ class Conv2dFn(torch.autograd.Function):
         x, wd, y, w_orig = ctx.saved_tensors
         d = ctx.d
         c32 = C.dy_channels(d.Cout)
-        if ctx.slope != 1.0 and not ctx.f32 and c32 == d.Cout and 256 % (d.Cout // 8) == 0:
+        if ctx.premasked:
+            # the consumer's dgrad already applied this layer's LeakyReLU derivative (mask_x below): dy IS g
+            assert not ctx.f32 and c32 == d.Cout
+            g = dy.contiguous()
+            db = None
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                if ctx.needs_input_grad[1] and C.wgrad_fuses_dbias(d):
+                    db = torch.empty((d.Cout,), dtype=torch.float32, device=g.device)   # filled by the wgrad kernel
+                else:
+                    db = chan_sum(g)
+        elif ctx.slope != 1.0 and not ctx.f32 and c32 == d.Cout and 256 % (d.Cout // 8) == 0:
             # LeakyReLU epilogue backward + bias gradient in one pass (csrc/gan_elem.hip)
             g, db = lrelu_bwd(dy.contiguous(), y, ctx.slope)
             if not (ctx.has_bias and ctx.needs_input_grad[2]):
@@ -83,21 +96,32 @@ class Conv2dFn(torch.autograd.Function):
             if c32 != d.Cout:
                 g = F.pad(g, (0, c32 - d.Cout))
             g = g.contiguous().to(torch.bfloat16)
-        dx = C.conv_dgrad(d, g, wd, cin_real=ctx.cw) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.in_slope != 1.0:   # fold the LeakyReLU backward of the layer that produced x into the epilogue
+                dx = C.conv_dgrad(d, g, wd, cin_real=ctx.cw, mask_x=x, mask_slope=ctx.in_slope)
+            else:
+                dx = C.conv_dgrad(d, g, wd, cin_real=ctx.cw)
         dw = None
         if ctx.needs_input_grad[1]:
-            graw = C.conv_wgrad(d, x, g, cin_real=ctx.cw, raw=True)
+            fused_db = db if (ctx.premasked and db is not None and C.wgrad_fuses_dbias(d)) else None
+            graw = C.conv_wgrad(d, x, g, cin_real=ctx.cw, raw=True, dbias=fused_db)
             sn = ctx.sn
             if sn is None:
                 dw = C.wgrad_finish(d, graw, ctx.cw)
             else:
                 sn.check()
                 dw = C.wgrad_finish(d, graw, ctx.cw, w_orig, sn.u, sn.v, sn.sigma)
-        return dx, dw, db, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias, stride, pad_h, pad_w, mode, upsample=0, slope=1.0, out_f32_nchw=False, sn=None):
-    return Conv2dFn.apply(x, weight, bias, stride, pad_h, pad_w, mode, int(upsample), float(slope), bool(out_f32_nchw), sn)
+def conv2d(x, weight, bias, stride, pad_h, pad_w, mode, upsample=0, slope=1.0, out_f32_nchw=False, sn=None, in_slope=1.0,
+           premasked=False):
+    """in_slope != 1: x is the output of a fused conv+LeakyReLU(in_slope) whose ONLY consumer is this conv: the
+    returned grad_x is pre-multiplied by that activation's derivative, and that producer must be called with
+    premasked=True (it then skips its own activation backward).  Both flags are set by the discriminators."""
+    return Conv2dFn.apply(x, weight, bias, stride, pad_h, pad_w, mode, int(upsample), float(slope), bool(out_f32_nchw), sn,
+                          float(in_slope), bool(premasked))
 
 
 # ------------------------------------------------------------------------------------------------ spectral norm
@@ -195,6 +219,15 @@ def lrelu_bwd(dy, y, slope):
     db = torch.empty((C_,), dtype=torch.float32, device=y.device)
     launch("lrelu_bwd", ptr(dy), ptr(y), ptr(g), ptr(db), ptr(_ws(P, 1, 1, C_, y.device)), P, C_, float(slope), stream())
     return g, db
+
+
+def chan_sum(x):
+    """x [..., C] bf16 -> [C] fp32 sum over all leading dims"""
+    C_ = x.shape[-1]
+    P = x.numel() // C_
+    out = torch.empty((C_,), dtype=torch.float32, device=x.device)
+    launch("chan_sum", ptr(x), ptr(out), ptr(_ws(P, 1, 1, C_, x.device)), P, C_, stream())
+    return out
 
 
 def bn_sums(x):

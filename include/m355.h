@@ -156,10 +156,17 @@ int m355_conv2d_fwd(const m355_conv_desc *d, const void *x, const void *w_fwd, c
 /*      dy[N,Ho,Wo,dy_channels(Cout)] bf16 -> dx[N,H,W,Cin] bf16 (autograd of F.conv2d w.r.t. its input, through the
  *      pad / upsample).  ws >= m355_conv2d_dgrad_ws_bytes(d). */
 size_t m355_conv2d_dgrad_ws_bytes(const m355_conv_desc *d);
-int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, void *ws, void *stream);
+/*      mask_x (nullable; same shape as dx, i.e. this conv's input x): dx *= (mask_x > 0 ? 1 : mask_slope) in the
+ *      epilogue -- the backward of the LeakyReLU that produced x (fused conv+LeakyReLU layer below), so that layer's
+ *      gradient arrives already masked.  Only with the direct form (no upsample, zero/circular W pad). */
+int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, void *ws,
+                      const void *mask_x, float mask_slope, void *stream);
 /*      x[N,H,W,Cin], dy[N,Ho,Wo,dy_channels(Cout)] -> dw fp32 [Cout][kh][kw][Cin] (overwritten; split-K partial tiles are
  *      combined with fp32 atomics, so the last bits depend on arrival order). */
-int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const void *dy, float *dw, void *stream);
+/*      dbias (nullable, [Cout] fp32): column sums of dy = the bias gradient, accumulated by the workgroups that stage
+ *      the dy tiles anyway; only where m355_conv2d_wgrad_fuses_dbias(d) != 0. */
+int m355_conv2d_wgrad_fuses_dbias(const m355_conv_desc *d);
+int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias, void *stream);
 
 /* ---- G3 / G-bwd  normalisation + conditional affine + LeakyReLU on NHWC bf16 (models/gan.py:264-286, 306-312).
  *      All reductions are two-stage and deterministic; ws >= m355_chan_reduce_ws_bytes(pixels per group, groups,
@@ -167,6 +174,8 @@ int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const void *dy, fl
 size_t m355_chan_reduce_ws_bytes(size_t pixels_per_group, int groups, int nvals, int C);
 /*      x[P][C] -> sums[2][C] = (sum, sum of squares): the batch statistics of BatchNorm2d / SynchronizedBatchNorm2d */
 int m355_bn_stats(const void *x, float *sums, void *ws, size_t P, int C, void *stream);
+/*      x[P][C] -> sums[C] (bias gradient) */
+int m355_chan_sum(const void *x, float *sums, void *ws, size_t P, int C, void *stream);
 /*      y = LeakyReLU_slope(x * a[n,c] + b[n,c]) [+ res];  x,y,res [N][HW][C];  a = rstd*(1+gamma), b = beta - mean*a;
  *      res (nullable): the residual branch of ResBlockUp (gan.py:312) added in the same pass */
 int m355_affine_act_fwd(const void *x, const float *a, const float *b, const void *res, void *y, int N, int HW, int C,

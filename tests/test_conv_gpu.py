@@ -91,6 +91,17 @@ def test_conv_fwd_and_dgrad(pkg, case):
     dw = conv.conv_wgrad(d, x_nhwc, dy_nhwc.bfloat16().to(DEV)).cpu()
     errw = (dw - wr.grad).abs().max().item() / wr.grad.abs().max().item()
     assert errw < 2e-4, errw
+    # bias gradient fused into the wgrad kernel (column sums of dy)
+    if conv.wgrad_fuses_dbias(d):
+        db = torch.empty(Cout, device=DEV)
+        conv.conv_wgrad(d, x_nhwc, dy_nhwc.bfloat16().to(DEV), dbias=db)
+        want = dy.sum((0, 2, 3))
+        assert (db.cpu() - want).abs().max().item() < 1e-3 * max(1.0, want.abs().max().item())
+    # LeakyReLU backward of the producer of x folded into the dgrad epilogue (direct-form layers only)
+    if mode != 1 and not ups:
+        dxm = conv.conv_dgrad(d, dy_nhwc.bfloat16().to(DEV), wd, mask_x=x_nhwc, mask_slope=0.2).float().cpu()
+        want = xr.grad * torch.where(x > 0, 1.0, 0.2)
+        assert (dxm.permute(0, 3, 1, 2) - want).abs().max().item() / want.abs().max().item() < 1.2e-2
 
 
 @pytest.mark.parametrize("tile", ["128x128", "256x128", "256x256"])
