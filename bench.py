@@ -33,6 +33,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (2:1-sparsity marketing figure excluded)
+# entry point -> kernel family (what rocprofv3 lists; csrc/conv_mfma.hip)
+FAMILY = {"conv2d_fwd": "k_conv_glds (conv2d_fwd + conv2d_dgrad)", "conv2d_dgrad": "k_conv_glds (conv2d_fwd + conv2d_dgrad)",
+          "conv2d_wgrad": "k_wgrad_dma (conv2d_wgrad)"}
 
 
 def make_clouds(B, N, S, seed, device):
@@ -168,9 +171,19 @@ def main():
     pkg._lib.enable_kernel_timers(False)
 
     if rank == 0:
-        dom = max(kt, key=lambda k: kt[k][1])
-        cnt, tot_ms, work = kt[dom]
-        is_conv = dom.startswith("conv2d")
+        # conv2d_fwd and conv2d_dgrad launch the same implicit-GEMM kernel (k_conv_glds): one roofline family
+        fam = {}
+        for k, v in kt.items():
+            f = FAMILY.get(k, k)
+            c0, t0, w0 = fam.get(f, (0, 0.0, 0.0))
+            fam[f] = (c0 + v[0], t0 + v[1], w0 + v[2])
+        dom = max(fam, key=lambda k: fam[k][1])
+        cnt, tot_ms, work = fam[dom]
+        is_conv = dom.startswith("k_conv") or dom.startswith("k_wgrad")
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):  # measured by separate rocprofv3 --pmc passes (scripts/make_profile.sh)
+            traffic = json.load(open(tpath)).get(dom.split(" ")[0], {}).get("hbm_bytes_per_launch")
         rate = work / (tot_ms * 1e-3) / (1e12 if is_conv else 1e9)
         peak = MFMA_BF16_PEAK_TF if is_conv else HBM_PEAK_GBS
         conv_ms = sum(v[1] for k, v in kt.items() if k.startswith("conv2d_") and k != "conv2d_weight_prep")
@@ -192,12 +205,17 @@ def main():
             "proj_samples_per_s": (world * B * args.steps / dt_p) if do_p else None,
             "gan_samples_per_s": (world * 3 * B * args.steps / dt_g) if do_g else None,
             "roofline": {"bound": "mfma" if is_conv else "hbm", "kernel": dom, "achieved": rate, "peak": peak,
-                         "unit": "TFLOP/s" if is_conv else "GB/s", "frac": rate / peak, "traffic": None,
+                         "unit": "TFLOP/s" if is_conv else "GB/s", "frac": rate / peak, "traffic": traffic,
                          "avg_kernel_us": tot_ms / cnt * 1e3, "launches_per_step": cnt / args.steps,
                          "share_of_kernel_time": tot_ms / sum(v[1] for v in kt.values()),
                          "all_conv_tflops": (conv_fl / (conv_ms * 1e-3) / 1e12) if conv_ms else None,
-                         "note": "achieved = algorithmic work (2*M*N*K per conv pass; SURVEY 8d volume-based bytes "
-                                 "for the projection kernels, which keep the volume in LDS) / HIP-event kernel time"},
+                         "work_per_launch": work / cnt,
+                         "note": "kernel = the family of template instantiations behind the named entry points; "
+                                 "achieved = algorithmic work (2*M*N*K per conv pass with the real channel counts; "
+                                 "SURVEY 8d volume-based bytes for the projection kernels, which keep the volume in "
+                                 "LDS) / HIP-event time on the launch stream; traffic = HBM bytes per launch from "
+                                 "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/pmc_traffic.json, "
+                                 "(2*FETCH+WRITE)*1024, gfx950 fetch correction), null if not collected"},
             "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(kt.items(), key=lambda kv: -kv[1][1])},
         }
         if not args.no_cpu_baseline:
