@@ -30,6 +30,7 @@ SOURCES = [
     ("chamfer.hip", STRICT),
     ("conv_mfma.hip", []),
     ("conv_small.hip", []),
+    ("conv_halo.hip", []),
     ("gan_elem.hip", []),
     ("gan_glue.hip", []),
 ]

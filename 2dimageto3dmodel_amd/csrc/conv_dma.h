@@ -29,4 +29,32 @@ __device__ __forceinline__ unsigned short f2bf(float f)
 
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
 
+// launch description shared by the implicit-GEMM kernels (csrc/conv_mfma.hip, csrc/conv_halo.hip)
+struct ConvArgs {
+    const unsigned short *x;  // bf16 NHWC [N,H,W,Cin]
+    const unsigned short *w;  // bf16 [Cout_p][KH][KW][Cin]
+    const float *bias;        // [Cout] or null
+    void *y;
+    int N, H, W, Cin;    // stored input
+    int Hl, Wl;          // logical input extent seen by the taps (after the optional x2 upsample)
+    int ups;             // 0/1: logical (h,w) reads stored (h>>ups, w>>ups)
+    int Ho, Wo, Cout;    // GEMM pixel grid, real output channels
+    int CoutP;           // weight rows (Cout rounded up to the N tile)
+    int KH, KW, stride, pad_h, pad_w, pad_w_mode;  // W mode 0 zero, 1 replicate, 2 circular; H always zero
+    int OH, OW;          // physical output extent
+    int oy_mul, oy_off, ox_mul, ox_off;  // physical (oh,ow) = (ho*oy_mul+oy_off, wo*ox_mul+ox_off)
+    int Kp;              // flattened K = KH*KW*Cin rounded up to a multiple of 32 (weight row length)
+    int y_f32_nchw;      // 0: bf16 NHWC with channel stride Cs; 1: fp32 NCHW
+    int Cs;
+    float slope;         // epilogue LeakyReLU slope (1 = identity)
+    // stride-2 dgrad in one launch (k_conv_glds only): blockIdx.y = output-parity class with its own weight view,
+    // pads and output offsets
+    const unsigned short *mask_x;  // dgrad only (k_conv_glds): tensor of the output's shape; y *= (mask_x > 0 ? 1 : mask_slope)
+    float mask_slope;              //   = the backward of the LeakyReLU that produced this conv's input, folded in
+    int lgWo, lgHo;      // log2 of the GEMM pixel grid sides when both are powers of two (else -1): shift/mask decode
+    int ncls;
+    int cpad_h[4], cpad_w[4], coy[4], cox[4];
+    unsigned cls_w_elems;
+};
+
 }  // namespace m355

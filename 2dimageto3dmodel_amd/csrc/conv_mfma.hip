@@ -28,32 +28,6 @@ namespace m355 {
 constexpr int BM = 256, BN = 64, BK = 32;
 constexpr int LDP = BK + 8;  // LDS row pitch in bf16 (80 bytes)
 
-struct ConvArgs {
-    const unsigned short *x;  // bf16 NHWC [N,H,W,Cin]
-    const unsigned short *w;  // bf16 [Cout_p][KH][KW][Cin]
-    const float *bias;        // [Cout] or null
-    void *y;
-    int N, H, W, Cin;    // stored input
-    int Hl, Wl;          // logical input extent seen by the taps (after the optional x2 upsample)
-    int ups;             // 0/1: logical (h,w) reads stored (h>>ups, w>>ups)
-    int Ho, Wo, Cout;    // GEMM pixel grid, real output channels
-    int CoutP;           // weight rows (Cout rounded up to the N tile)
-    int KH, KW, stride, pad_h, pad_w, pad_w_mode;  // W mode 0 zero, 1 replicate, 2 circular; H always zero
-    int OH, OW;          // physical output extent
-    int oy_mul, oy_off, ox_mul, ox_off;  // physical (oh,ow) = (ho*oy_mul+oy_off, wo*ox_mul+ox_off)
-    int Kp;              // flattened K = KH*KW*Cin rounded up to a multiple of 32 (weight row length)
-    int y_f32_nchw;      // 0: bf16 NHWC with channel stride Cs; 1: fp32 NCHW
-    int Cs;
-    float slope;         // epilogue LeakyReLU slope (1 = identity)
-    // stride-2 dgrad in one launch (k_conv_glds only): blockIdx.y = output-parity class with its own weight view,
-    // pads and output offsets
-    const unsigned short *mask_x;  // dgrad only (k_conv_glds): tensor of the output's shape; y *= (mask_x > 0 ? 1 : mask_slope)
-    float mask_slope;              //   = the backward of the LeakyReLU that produced this conv's input, folded in
-    int lgWo, lgHo;      // log2 of the GEMM pixel grid sides when both are powers of two (else -1): shift/mask decode
-    int ncls;
-    int cpad_h[4], cpad_w[4], coy[4], cox[4];
-    unsigned cls_w_elems;
-};
 
 __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
 {
@@ -475,6 +449,9 @@ static inline int k_padded(int k) { return (k + 63) / 64 * 64; }
 // dgrad GEMM's K is taps*8, not taps*32), otherwise Cout rounded up to 32
 static inline int dy_channels(int cout) { return cout <= 8 ? 8 : (cout + 31) / 32 * 32; }
 
+bool conv_halo_eligible(const ConvArgs &a);  // csrc/conv_halo.hip
+int conv_halo_launch(const ConvArgs &a, unsigned xb, unsigned wb, hipStream_t st);
+
 static bool dma_eligible(const ConvArgs &a)
 {
     const size_t xbytes = (size_t)a.N * a.H * a.W * a.Cin * 2, wbytes = (size_t)rows_padded(a.Cout) * a.Kp * 2;
@@ -495,6 +472,10 @@ static int launch_conv(ConvArgs a, hipStream_t st)
     if (dma_ok) {
         const bool fast = a.Cin % 64 == 0;
         const unsigned xb = (unsigned)xbytes, wb = (unsigned)wbytes;
+        {
+            const char *h = getenv("M355_CONV_HALO");  // "0": keep everything on k_conv_glds (A/B runs)
+            if (!(h && h[0] == '0') && conv_halo_eligible(a)) return conv_halo_launch(a, xb, wb, st);
+        }
 #define M355_GO(BM_, BN_, NW_, WGN_, F_, MD_) \
     hipLaunchKernelGGL((k_conv_glds<BM_, BN_, NW_, WGN_, F_, MD_>), grid, dim3(NW_ * 64), 0, st, a, xb, wb)
 #define M355_MODES(BM_, BN_, NW_, WGN_, F_)                                   \

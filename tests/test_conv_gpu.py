@@ -46,6 +46,15 @@ CASES = [
     (2, 40, 24, 64, 3, 5, 1, 2, 2, 1, 0),     # conv_final-like, image not a multiple of the 16x16 tile, replicate
     (3, 8, 8, 256, 1, 5, 1, 2, 2, 2, 0),      # MeshDiscriminator.conv4: image narrower than the tile, circular
     (2, 20, 20, 64, 2, 3, 1, 1, 1, 0, 0),     # 3x3, zero W pad, 2 output channels
+    # ---- halo kernel (conv_halo.hip): Wo % 32 == 0, Ho % 8 == 0, Cin % 64 == 0
+    (2, 16, 32, 64, 64, 3, 1, 1, 1, 1, 0),    # 3x3 replicate, Cout 64 (4-wave variant), one channel chunk
+    (2, 16, 32, 128, 128, 3, 1, 1, 1, 1, 0),  # 3x3 replicate, Cout 128 (8-wave variant), two chunks (halo double buffer)
+    (2, 8, 16, 256, 128, 3, 1, 1, 1, 1, 1),   # upsample folded into the halo (6 x 18 stored pixels), 4 chunks
+    (1, 16, 16, 128, 64, 3, 1, 1, 1, 1, 1),   # upsample, Cout 64
+    (2, 24, 64, 192, 256, 3, 1, 1, 1, 0, 0),  # zero W pad, 3 chunks, two N tiles, two pixel tiles across W
+    (2, 32, 64, 128, 256, 4, 2, 1, 1, 2, 0),  # stride-2 dgrad: four 2x2 classes of dy on the halo kernel, circular
+    (2, 32, 64, 64, 128, 4, 2, 1, 1, 0, 0),   # stride-2 dgrad with zero W pad, dx has 64 channels (4-wave variant)
+    (1, 16, 32, 64, 64, 3, 1, 1, 1, 2, 0),    # 3x3 circular
 ]
 
 
