@@ -45,8 +45,11 @@ __device__ __forceinline__ void pixel_reduce(int C, size_t pix0, int npix, float
     for (int k = 0; k < NV; ++k)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[k][j] = 0.0f;
-    if (pl < lanes)
+    if (pl < lanes) {
+        // 4 independent 16-byte loads in flight per thread (the un-unrolled loop was latency bound at ~1.5 TB/s)
+#pragma unroll 4
         for (int p = pl; p < npix; p += lanes) f(pix0 + p, v * 8, acc);
+    }
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         __syncthreads();
@@ -113,7 +116,9 @@ __global__ __launch_bounds__(256) void k_sum_partials(const float *__restrict__ 
     }
 }
 
-// y = lrelu(x * a[n,c] + b[n,c]);  x,y [N][HW][C]
+// y = lrelu(x * a[n,c] + b[n,c]) [+ res];  x,y [N][HW][C].  A thread keeps ONE 8-channel group for its whole loop
+// (the grid stride is a multiple of C/8), so its 16 coefficients live in registers: the kernel is pure 16-byte
+// streaming (the first version re-read a/b per element and ran at a third of the HBM rate).
 __global__ __launch_bounds__(256) void k_affine_act(const short *__restrict__ x, const float *__restrict__ a,
                                                     const float *__restrict__ b, const short *__restrict__ res,
                                                     short *__restrict__ y, int HW, int C, float slope)
@@ -124,15 +129,22 @@ __global__ __launch_bounds__(256) void k_affine_act(const short *__restrict__ x,
     const short *xn = x + (size_t)n * HW * C;
     short *yn = y + (size_t)n * HW * C;
     const short *rn = res ? res + (size_t)n * HW * C : nullptr;
+    const int c0 = (int)(threadIdx.x % vecs) * 8;   // (blockIdx.x * 256 + k * gridDim.x * 256) % vecs == 0
+    float av[8], bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        av[j] = a[(size_t)n * C + c0 + j];
+        bv[j] = b[(size_t)n * C + c0 + j];
+    }
+#pragma unroll 4
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c0 = (int)(i % vecs) * 8;
         const bf16x8e v = *reinterpret_cast<const bf16x8e *>(xn + i * 8);
         bf16x8e r = {0, 0, 0, 0, 0, 0, 0, 0};
         if (rn) r = *reinterpret_cast<const bf16x8e *>(rn + i * 8);
         bf16x8e o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float z = bf2f_e(v[j]) * a[(size_t)n * C + c0 + j] + b[(size_t)n * C + c0 + j];
+            float z = bf2f_e(v[j]) * av[j] + bv[j];
             z = z >= 0.0f ? z : z * slope;
             // residual branch of ResBlockUp (gan.py:312): the activation is rounded to bf16 first, as the
             // separate bf16 add it replaces did
@@ -152,6 +164,13 @@ __global__ __launch_bounds__(256) void k_act_bwd_reduce(const short *__restrict_
     const size_t pix0 = (size_t)blockIdx.x * ppb;
     const int npix = (int)min((size_t)ppb, (size_t)HW - pix0);
     const size_t base = (size_t)n * HW;
+    const int cg = (int)(threadIdx.x % (C >> 3)) * 8;  // the 8-channel group pixel_reduce gives this thread
+    float av[8], bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        av[j] = a[(size_t)n * C + cg + j];
+        bv[j] = b[(size_t)n * C + cg + j];
+    }
     pixel_reduce<2>(C, pix0, npix, part + ((size_t)n * nblk + blockIdx.x) * 2 * C,
                     [&](size_t p, int c0, float (&acc)[2][8]) {
                         const bf16x8e vx = *reinterpret_cast<const bf16x8e *>(x + (base + p) * C + c0);
@@ -159,7 +178,7 @@ __global__ __launch_bounds__(256) void k_act_bwd_reduce(const short *__restrict_
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const float xf = bf2f_e(vx[j]);
-                            const float z = xf * a[(size_t)n * C + c0 + j] + b[(size_t)n * C + c0 + j];
+                            const float z = xf * av[j] + bv[j];
                             const float dz = bf2f_e(vd[j]) * (z >= 0.0f ? 1.0f : slope);
                             acc[0][j] += dz;
                             acc[1][j] += dz * xf;
@@ -167,7 +186,7 @@ __global__ __launch_bounds__(256) void k_act_bwd_reduce(const short *__restrict_
                     });
 }
 
-// dx = dz * A[n,c] + x * B[c] + Cc[c]
+// dx = dz * A[n,c] + x * B[c] + Cc[c]   (coefficients of the thread's 8-channel group in registers, as above)
 __global__ __launch_bounds__(256) void k_act_bwd_apply(const short *__restrict__ dy, const short *__restrict__ x,
                                                        const float *__restrict__ a, const float *__restrict__ b,
                                                        const float *__restrict__ A, const float *__restrict__ Bc,
@@ -178,18 +197,27 @@ __global__ __launch_bounds__(256) void k_act_bwd_apply(const short *__restrict__
     const int vecs = C >> 3;
     const size_t total = (size_t)HW * vecs;
     const size_t off = (size_t)n * HW * C;
+    const int c0 = (int)(threadIdx.x % vecs) * 8;
+    float av[8], bv[8], Av[8], Bv[8], Cv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        av[j] = a[(size_t)n * C + c0 + j];
+        bv[j] = b[(size_t)n * C + c0 + j];
+        Av[j] = A[(size_t)n * C + c0 + j];
+        Bv[j] = Bc[c0 + j];
+        Cv[j] = Cc[c0 + j];
+    }
+#pragma unroll 4
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c0 = (int)(i % vecs) * 8;
         const bf16x8e vx = *reinterpret_cast<const bf16x8e *>(x + off + i * 8);
         const bf16x8e vd = *reinterpret_cast<const bf16x8e *>(dy + off + i * 8);
         bf16x8e o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = c0 + j;
             const float xf = bf2f_e(vx[j]);
-            const float z = xf * a[(size_t)n * C + c] + b[(size_t)n * C + c];
+            const float z = xf * av[j] + bv[j];
             const float dz = bf2f_e(vd[j]) * (z >= 0.0f ? 1.0f : slope);
-            o[j] = f2bf_e(dz * A[(size_t)n * C + c] + xf * Bc[c] + Cc[c]);
+            o[j] = f2bf_e(dz * Av[j] + xf * Bv[j] + Cv[j]);
         }
         *reinterpret_cast<bf16x8e *>(dx + off + i * 8) = o;
     }
@@ -296,7 +324,8 @@ extern "C" int m355_affine_act_fwd(const void *x, const float *a, const float *b
     M355_REQUIRE(x && a && b && y && N > 0 && HW > 0, "affine_act_fwd: null pointer / empty");
     if (int rc = check_c(C, "affine_act_fwd")) return rc;
     const size_t total = (size_t)HW * (C / 8);
-    const unsigned gx = (unsigned)min((size_t)4096, (total + 255) / 256);
+    // ~8 vectors per thread (its coefficients are loaded once), still thousands of workgroups with N in grid.y
+    const unsigned gx = (unsigned)min((size_t)4096, (total + 2047) / 2048);
     hipLaunchKernelGGL(k_affine_act, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, (const short *)x, a, b,
                        (const short *)res, (short *)y, HW, C, slope);
     return check_launch("affine_act_fwd");
@@ -324,7 +353,8 @@ extern "C" int m355_affine_act_bwd_apply(const void *dy, const void *x, const fl
     M355_REQUIRE(dy && x && a && b && A && Bc && Cc && dx && N > 0 && HW > 0, "affine_act_bwd_apply: null pointer / empty");
     if (int rc = check_c(C, "affine_act_bwd_apply")) return rc;
     const size_t total = (size_t)HW * (C / 8);
-    const unsigned gx = (unsigned)min((size_t)4096, (total + 255) / 256);
+    // ~8 vectors per thread (its coefficients are loaded once), still thousands of workgroups with N in grid.y
+    const unsigned gx = (unsigned)min((size_t)4096, (total + 2047) / 2048);
     hipLaunchKernelGGL(k_act_bwd_apply, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, (const short *)dy, (const short *)x,
                        a, b, A, Bc, Cc, (short *)dx, HW, C, slope);
     return check_launch("affine_act_bwd_apply");
