@@ -18,6 +18,8 @@
 // Used for: the generator's 3x3 convs (fwd, with and without upsample; dgrad in the padded frame) and every
 // stride-2 dgrad of the discriminators (four 2x2 stride-1 convs of dy).  Needs Cin % 64 == 0, Wo % 32 == 0,
 // Ho % 8 == 0; everything else stays on k_conv_glds.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "conv_dma.h"
@@ -61,15 +63,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // ---- tile id: XCD-aware, then (pixel tile, N tile)
-    const int nwg = gridDim.x, nN = a.CoutP / BN;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int sid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    const int tn = sid % nN, tp = sid / nN;
-    const int tpx = a.Wo / TW, tpy = a.Ho / TH;
-    const int n = tp / (tpx * tpy), trem = tp - n * (tpx * tpy);
-    const int oy0 = (trem / tpx) * TH, ox0 = (trem % tpx) * TW;
+    // ---- persistent workgroup: N tile tn and (blockIdx.y) parity class are fixed, the pixel tiles bp, bp + PS, ...
+    // are visited in turn; the stream of (tile, channel chunk) pairs is continuous, so the NEXT tile's first halo is
+    // prefetched by the same slice mechanism and the weight ring simply wraps around (same weights for every tile).
+    const int nN = a.CoutP / BN;
+    const int tn = blockIdx.x % nN, bp = blockIdx.x / nN, PS = gridDim.x / nN;
+    const int tpx = a.Wo / TW, tpy = a.Ho / TH, tiles_p = a.N * tpx * tpy;
     const int n0 = tn * BN;
+    if (bp >= tiles_p) return;
 
     int pad_h = a.pad_h, pad_w = a.pad_w, oy_off = a.oy_off, ox_off = a.ox_off;
     const unsigned short *wv = a.w;
@@ -81,46 +82,56 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)wv, 0, wbytes, 0x00020000);
 
-    // ---- halo DMA offsets, once per tile.  Slot k of wave w is DMA instruction q = NW*k + w = halo rows 8q .. 8q+7;
+    // ---- halo DMA offsets of a tile.  Slot k of wave w is DMA instruction q = NW*k + w = halo rows 8q .. 8q+7;
     // lane l -> row 8q + (l>>3), LDS chunk slot l&7, source chunk (l&7) ^ ((row>>1)&7)  [(row>>1)&7 = 4(w&1) + (l>>4)&3]
     const int csrc = (lane & 7) ^ (((wave & 1) << 2) | ((lane >> 4) & 3));
-    const int Y0 = UPS ? (oy0 - pad_h) >> 1 : oy0 - pad_h, X0 = UPS ? (ox0 - pad_w) >> 1 : ox0 - pad_w;
     unsigned aoff[NAW];
+    auto tile_origin = [&](int tp, int &n, int &oy0, int &ox0) {
+        n = tp / (tpx * tpy);
+        const int trem = tp - n * (tpx * tpy);
+        oy0 = (trem / tpx) * TH;
+        ox0 = (trem % tpx) * TW;
+    };
+    auto compute_aoff = [&](int tp) {
+        int n, oy0, ox0;
+        tile_origin(tp, n, oy0, ox0);
+        const int Y0 = UPS ? (oy0 - pad_h) >> 1 : oy0 - pad_h, X0 = UPS ? (ox0 - pad_w) >> 1 : ox0 - pad_w;
 #pragma unroll
-    for (int k = 0; k < NAW; ++k) {
-        const int rho = 8 * (NW * k + wave) + (lane >> 3);
-        const int hy = rho / HWD, hx = rho - hy * HWD;
-        const int iy = Y0 + hy;
-        int ix = X0 + hx;
-        bool ok = rho < HR && (unsigned)iy < (unsigned)a.H;
-        if (MODE == 1) ix = min(max(ix, 0), a.W - 1);
-        else if (MODE == 2) ix = ix < 0 ? ix + a.W : (ix >= a.W ? ix - a.W : ix);
-        ok = ok && (unsigned)ix < (unsigned)a.W;
-        aoff[k] = ok ? (unsigned)(((n * a.H + iy) * a.W + ix) * a.Cin * 2 + csrc * 16) : OOB;
-    }
+        for (int k = 0; k < NAW; ++k) {
+            const int rho = 8 * (NW * k + wave) + (lane >> 3);
+            const int hy = rho / HWD, hx = rho - hy * HWD;
+            const int iy = Y0 + hy;
+            int ix = X0 + hx;
+            bool ok = rho < HR && (unsigned)iy < (unsigned)a.H;
+            if (MODE == 1) ix = min(max(ix, 0), a.W - 1);
+            else if (MODE == 2) ix = ix < 0 ? ix + a.W : (ix >= a.W ? ix - a.W : ix);
+            ok = ok && (unsigned)ix < (unsigned)a.W;
+            aoff[k] = ok ? (unsigned)(((n * a.H + iy) * a.W + ix) * a.Cin * 2 + csrc * 16) : OOB;
+        }
+    };
     unsigned wrow[NBW];
 #pragma unroll
     for (int j = 0; j < NBW; ++j) wrow[j] = (unsigned)(n0 + 8 * (NW * j + wave) + (lane >> 3)) * (unsigned)(a.Kp * 2) + csrc * 16;
 
     const int ncc = a.Cin >> 6, S = ncc * T;
 
-    // weights of global step s (= chunk s / T, tap s % T) -> ring slot; beyond the last step: zeros (harmless refill)
+    // weights of step s of a tile (= chunk s / T, tap s % T) -> ring slot; steps >= S are the next tile's first ones
     auto issue_B = [&](int s, int slot) {
+        if (s >= S) s -= S;
         const int cc = s / T, tap = s - cc * T;
         const unsigned so = (unsigned)((tap * a.Cin + cc * 64) * 2);
 #pragma unroll
-        for (int j = 0; j < NBW; ++j)
-            dma16(rw, ldsB + slot * BBUF + (NW * j + wave) * 1024, wrow[j], s < S ? so : 0u);  // (beyond S: a harmless re-read)
+        for (int j = 0; j < NBW; ++j) dma16(rw, ldsB + slot * BBUF + (NW * j + wave) * 1024, wrow[j], so);
     };
-    // halo slice of tap `tap` (slots tap*NAS .. +NAS-1, as far as they exist) of chunk cc+1 into the other halo buffer.
-    // Every step must issue a COMPILE-TIME-KNOWN number of DMAs (the counted wait below depends on it), so after the
-    // last chunk the slices simply re-load the last chunk into the idle buffer instead of being skipped.
-    auto issue_A = [&](int cc_next, int tap) {
-        const int cs = min(cc_next, ncc - 1);
+    // halo slice `tap` (slots tap*NAS .. +NAS-1, as far as they exist) of the NEXT (tile, chunk) into halo buffer hbuf.
+    // Every step issues a COMPILE-TIME-KNOWN number of DMAs (the counted wait depends on it): when there is no next
+    // chunk the slices re-load the current one into the idle buffer instead of being skipped.
+    auto issue_A = [&](int hbuf, int chunk, auto tapc) {
+        constexpr int tap = decltype(tapc)::value;
 #pragma unroll
         for (int k = 0; k < NAW; ++k)
             if (k >= tap * NAS && k < (tap + 1) * NAS && tap <= T - 3)
-                dma16(rx, lds + (cc_next & 1) * ABUF + (NW * k + wave) * 1024, aoff[k], (unsigned)cs * 128u);
+                dma16(rx, lds + hbuf * ABUF + (NW * k + wave) * 1024, aoff[k], (unsigned)chunk * 128u);
     };
 
     f32x16 acc[CJ][PI];
@@ -134,121 +145,145 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
     // ---- fragment roles: wave (wm, wn): tile rows 2wm, 2wm+1 x channels 64wn..; lane -> pixel column tx = lane&31
     const int wm = wave / WGN, wn = wave % WGN;
     const int tx = lane & 31, half = lane >> 5;
-    const int ey = UPS ? ((oy0 - pad_h) & 1) : 0, ex = UPS ? ((ox0 - pad_w) & 1) : 0;
+    const int ey = UPS ? ((0 - pad_h) & 1) : 0, ex = UPS ? ((0 - pad_w) & 1) : 0;  // tile origins are even
     const unsigned char *fb = ldsB + (wn * 64 + (lane & 31)) * 128;
     const int swzb = (lane >> 1) & 7;
+    unsigned short *yb = reinterpret_cast<unsigned short *>(a.y);
 
-    // ---- prologue: the whole first halo, then the two weight steps the loop expects in flight (with their dummies)
+    // ---- prologue: the whole first halo of the first tile, then the two weight steps the loop expects in flight
+    int tp = bp;
+    compute_aoff(tp);
 #pragma unroll
     for (int k = 0; k < NAW; ++k) dma16(rx, lds + (NW * k + wave) * 1024, aoff[k], 0u);
     issue_B(0, 0);
     issue_B(1, 1);
 
-    int slot = 0;  // ring slot of step s
-    for (int cc = 0; cc < ncc; ++cc) {
-        const unsigned char *ha = lds + (cc & 1) * ABUF;
-        static_for<0, T>([&](auto tapc) {
-            constexpr int tap = decltype(tapc)::value;
-            const int s = cc * T + tap;
-            // DMAs younger than the weights of step s: the halo slices of the two previous steps and the weights of
-            // step s+1 -- their number is a compile-time function of the tap.  Everything older has landed in THIS
-            // wave's rows; and this wave's fragment reads of step s-1 have returned (their ring slot is refilled next).
-            constexpr int t1 = (tap + T - 1) % T, t2 = (tap + T - 2) % T;
-            constexpr int nA1 = t1 <= T - 3 ? (NAW - t1 * NAS < 0 ? 0 : (NAW - t1 * NAS > NAS ? NAS : NAW - t1 * NAS)) : 0;
-            constexpr int nA2 = t2 <= T - 3 ? (NAW - t2 * NAS < 0 ? 0 : (NAW - t2 * NAS > NAS ? NAS : NAW - t2 * NAS)) : 0;
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NBW + nA1 + nA2) : "memory");
-            __builtin_amdgcn_s_barrier();      // ... the same holds for every wave
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const int ns = slot == 0 ? 2 : slot - 1;  // (slot + 2) % 3: the slot read at step s-1
-                issue_B(s + 2, ns);
-                issue_A(cc + 1, tap);  // taps T-2, T-1 issue none
+    int slot = 0;  // ring slot of the current step
+    int hb = 0;    // halo buffer of the current chunk
+    for (;;) {
+        int n, oy0, ox0;
+        tile_origin(tp, n, oy0, ox0);
+        const int tp_next = tp + PS;
+        const bool has_next = tp_next < tiles_p;
+        for (int cc = 0; cc < ncc; ++cc) {
+            const unsigned char *ha = lds + hb * ABUF;
+            // what the slices of this chunk prefetch: the tile's next chunk, else the next tile's chunk 0 (new offsets:
+            // this tile's own halo loads have all been issued by now), else (nothing left) the current chunk again
+            int chunk_next = cc + 1;
+            if (cc == ncc - 1) {
+                chunk_next = has_next ? 0 : cc;
+                if (has_next) compute_aoff(tp_next);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            const int kh = tap / KS, kw = tap - kh * KS;
-            int rowa[PI], swa[PI];
+            static_for<0, T>([&](auto tapc) {
+                constexpr int tap = decltype(tapc)::value;
+                const int s = cc * T + tap;
+                // DMAs younger than the weights of step s: the halo slices of the two previous steps and the weights
+                // of step s+1 -- their number is a compile-time function of the tap.  Everything older has landed in
+                // THIS wave's rows; and this wave's fragment reads of step s-1 have returned (their ring slot is
+                // refilled next).  (Epilogue loads / stores of the previous tile are younger still: they only make the
+                // wait stricter.)
+                constexpr int t1 = (tap + T - 1) % T, t2 = (tap + T - 2) % T;
+                constexpr int nA1 = t1 <= T - 3 ? (NAW - t1 * NAS < 0 ? 0 : (NAW - t1 * NAS > NAS ? NAS : NAW - t1 * NAS)) : 0;
+                constexpr int nA2 = t2 <= T - 3 ? (NAW - t2 * NAS < 0 ? 0 : (NAW - t2 * NAS > NAS ? NAS : NAW - t2 * NAS)) : 0;
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NBW + nA1 + nA2) : "memory");
+                __builtin_amdgcn_s_barrier();      // ... the same holds for every wave
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const int ns = slot == 0 ? 2 : slot - 1;  // (slot + 2) % 3: the slot read at step s-1
+                    issue_B(s + 2, ns);
+                    issue_A(hb ^ 1, chunk_next, tapc);  // taps T-2, T-1 issue none
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int kh = tap / KS, kw = tap - kh * KS;
+                int rowa[PI], swa[PI];
 #pragma unroll
-            for (int i = 0; i < PI; ++i) {
-                const int ly = 2 * wm + i + kh, lx = tx + kw;
-                const int rho = UPS ? ((ly + ey) >> 1) * HWD + ((lx + ex) >> 1) : ly * HWD + lx;
-                rowa[i] = rho * 128;
-                swa[i] = (rho >> 1) & 7;
-            }
-            const unsigned char *bs = fb + slot * BBUF;
+                for (int i = 0; i < PI; ++i) {
+                    const int ly = 2 * wm + i + kh, lx = tx + kw;
+                    const int rho = UPS ? ((ly + ey) >> 1) * HWD + ((lx + ex) >> 1) : ly * HWD + lx;
+                    rowa[i] = rho * 128;
+                    swa[i] = (rho >> 1) & 7;
+                }
+                const unsigned char *bs = fb + slot * BBUF;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                bf16x8 pf[PI], wf[CJ];
-#pragma unroll
-                for (int i = 0; i < PI; ++i)
-                    pf[i] = *reinterpret_cast<const bf16x8 *>(ha + rowa[i] + (((kk * 2 + half) ^ swa[i]) << 4));
-#pragma unroll
-                for (int j = 0; j < CJ; ++j)
-                    wf[j] = *reinterpret_cast<const bf16x8 *>(bs + j * 32 * 128 + (((kk * 2 + half) ^ swzb) << 4));
-#pragma unroll
-                for (int j = 0; j < CJ; ++j)
+                for (int kk = 0; kk < 4; ++kk) {
+                    bf16x8 pf[PI], wf[CJ];
 #pragma unroll
                     for (int i = 0; i < PI; ++i)
-                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], pf[i], acc[j][i], 0, 0, 0);
-            }
-            slot = slot == 2 ? 0 : slot + 1;
-        });
-    }
-    wait_vm<0>();  // the trailing (unused) prefetches
+                        pf[i] = *reinterpret_cast<const bf16x8 *>(ha + rowa[i] + (((kk * 2 + half) ^ swa[i]) << 4));
+#pragma unroll
+                    for (int j = 0; j < CJ; ++j)
+                        wf[j] = *reinterpret_cast<const bf16x8 *>(bs + j * 32 * 128 + (((kk * 2 + half) ^ swzb) << 4));
+#pragma unroll
+                    for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                        for (int i = 0; i < PI; ++i)
+                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], pf[i], acc[j][i], 0, 0, 0);
+                }
+                slot = slot == 2 ? 0 : slot + 1;
+            });
+            hb ^= 1;
+        }
 
-    // ---- epilogue (as k_conv_glds): acc[j][i][r] = channel n0 + 64wn + 32j + 8(r>>2) + 4half + (r&3), pixel (2wm+i, tx)
-    unsigned short *yb = reinterpret_cast<unsigned short *>(a.y);
+        // ---- epilogue of this tile (as k_conv_glds), while the next tile's halo and first weights are in flight:
+        // acc[j][i][r] = channel n0 + 64wn + 32j + 8(r>>2) + 4half + (r&3), pixel (2wm+i, tx)
 #pragma unroll
-    for (int i = 0; i < PI; ++i) {
-        const int ho = oy0 + 2 * wm + i, wo = ox0 + tx;
-        const size_t pix = ((size_t)n * a.OH + (ho * a.oy_mul + oy_off)) * a.OW + (wo * a.ox_mul + ox_off);
+        for (int i = 0; i < PI; ++i) {
+            const int ho = oy0 + 2 * wm + i, wo = ox0 + tx;
+            const size_t pix = ((size_t)n * a.OH + (ho * a.oy_mul + oy_off)) * a.OW + (wo * a.ox_mul + ox_off);
 #pragma unroll
-        for (int j = 0; j < CJ; ++j) {
-            const int cbase = n0 + wn * 64 + 32 * j;
-            float4 b4[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = cbase + 8 * g + 4 * half;
-                b4[g] = (a.bias && co < a.Cout) ? *reinterpret_cast<const float4 *>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            uint2 mk[4];
-            if (a.mask_x) {
+            for (int j = 0; j < CJ; ++j) {
+                const int cbase = n0 + wn * 64 + 32 * j;
+                float4 b4[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int co = cbase + 8 * g + 4 * half;
-                    mk[g] = co < a.Cout ? *reinterpret_cast<const uint2 *>(a.mask_x + pix * a.Cs + co) : make_uint2(0u, 0u);
+                    b4[g] = (a.bias && co < a.Cout) ? *reinterpret_cast<const float4 *>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-            }
-            uint2 pk[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v[4] = {acc[j][i][4 * g] + b4[g].x, acc[j][i][4 * g + 1] + b4[g].y, acc[j][i][4 * g + 2] + b4[g].z,
-                              acc[j][i][4 * g + 3] + b4[g].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * a.slope;
+                uint2 mk[4];
                 if (a.mask_x) {
-                    const float x0 = __uint_as_float(mk[g].x << 16), x1 = __uint_as_float(mk[g].x & 0xffff0000u);
-                    const float x2 = __uint_as_float(mk[g].y << 16), x3 = __uint_as_float(mk[g].y & 0xffff0000u);
-                    v[0] = x0 > 0.0f ? v[0] : v[0] * a.mask_slope;
-                    v[1] = x1 > 0.0f ? v[1] : v[1] * a.mask_slope;
-                    v[2] = x2 > 0.0f ? v[2] : v[2] * a.mask_slope;
-                    v[3] = x3 > 0.0f ? v[3] : v[3] * a.mask_slope;
-                }
-                pk[g].x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                pk[g].y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-            }
 #pragma unroll
-            for (int g = 0; g < 4; g += 2) {
-                auto sx = __builtin_amdgcn_permlane32_swap(pk[g].x, pk[g + 1].x, false, false);
-                auto sy = __builtin_amdgcn_permlane32_swap(pk[g].y, pk[g + 1].y, false, false);
-                const int co = cbase + 8 * (g + half);
-                if (co < a.Cout) {
-                    uint4 o;
-                    o.x = sx[0]; o.y = sy[0]; o.z = sx[1]; o.w = sy[1];
-                    *reinterpret_cast<uint4 *>(yb + pix * a.Cs + co) = o;
+                    for (int g = 0; g < 4; ++g) {
+                        const int co = cbase + 8 * g + 4 * half;
+                        mk[g] = co < a.Cout ? *reinterpret_cast<const uint2 *>(a.mask_x + pix * a.Cs + co) : make_uint2(0u, 0u);
+                    }
                 }
+                uint2 pk[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4] = {acc[j][i][4 * g] + b4[g].x, acc[j][i][4 * g + 1] + b4[g].y, acc[j][i][4 * g + 2] + b4[g].z,
+                                  acc[j][i][4 * g + 3] + b4[g].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * a.slope;
+                    if (a.mask_x) {
+                        const float x0 = __uint_as_float(mk[g].x << 16), x1 = __uint_as_float(mk[g].x & 0xffff0000u);
+                        const float x2 = __uint_as_float(mk[g].y << 16), x3 = __uint_as_float(mk[g].y & 0xffff0000u);
+                        v[0] = x0 > 0.0f ? v[0] : v[0] * a.mask_slope;
+                        v[1] = x1 > 0.0f ? v[1] : v[1] * a.mask_slope;
+                        v[2] = x2 > 0.0f ? v[2] : v[2] * a.mask_slope;
+                        v[3] = x3 > 0.0f ? v[3] : v[3] * a.mask_slope;
+                    }
+                    pk[g].x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                    pk[g].y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    auto sx = __builtin_amdgcn_permlane32_swap(pk[g].x, pk[g + 1].x, false, false);
+                    auto sy = __builtin_amdgcn_permlane32_swap(pk[g].y, pk[g + 1].y, false, false);
+                    const int co = cbase + 8 * (g + half);
+                    if (co < a.Cout) {
+                        uint4 o;
+                        o.x = sx[0]; o.y = sy[0]; o.z = sx[1]; o.w = sy[1];
+                        *reinterpret_cast<uint4 *>(yb + pix * a.Cs + co) = o;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
             }
         }
+        if (!has_next) break;
+        tp = tp_next;
     }
+    wait_vm<0>();  // the trailing (unused) prefetches
 }
 
 // host side (called from launch_conv, conv_mfma.hip)
@@ -264,13 +299,23 @@ bool conv_halo_eligible(const ConvArgs &a)
             if (a.ups) return false;
     // measured (profiles/r01_conv_halo_ab.txt): the 4-wave variant (Cout <= 64: one workgroup of 4 waves per CU, nothing
     // to hide its prologue / epilogue behind) only pays when a tile carries enough work -- 3x3 with >= 2 channel chunks
-    if (rows_le64(a.Cout) && !(a.KH == 3 && a.Cin >= 128)) return false;
+    if (rows_le64(a.Cout) && !(a.KH == 3 && a.Cin >= 128) && !getenv("M355_HALO_ALL")) return false;
     return true;
 }
 
 int conv_halo_launch(const ConvArgs &a, unsigned xb, unsigned wb, hipStream_t st)
 {
+    // persistent workgroups: one per CU (the LDS footprint allows no more), each walking a strided list of pixel tiles
     const int tiles = a.N * (a.Ho / 8) * (a.Wo / 32);
+    const int nN = a.CoutP == 64 ? 1 : a.CoutP / 128;
+    const char *wgs = getenv("M355_HALO_WGS");       // tests: force few workgroups so that each walks several tiles
+    // (the 4-wave variant with the upsample folded in needs only 56 KiB of LDS -> two workgroups per CU, and measured
+    // best with one tile per workgroup: 963 vs 798 TF on G.blk6.conv1 -- the dispatcher staggers them for free)
+    const int resident = (a.CoutP == 64 && a.ups) ? tiles : 256;
+    int per = (wgs ? atoi(wgs) : resident) / (nN * a.ncls);  // workgroups along the pixel-tile axis
+    if (per < 1) per = 1;
+    if (per > tiles) per = tiles;
+    per = (tiles + (tiles + per - 1) / per - 1) / ((tiles + per - 1) / per);  // same tiles-per-workgroup, fewer idle ones
 #define M355_HL(BN_, NW_, KS_, UPS_, MD_) \
     hipLaunchKernelGGL((k_conv_halo<BN_, NW_, KS_, UPS_, MD_>), grid, dim3(NW_ * 64), 0, st, a, xb, wb)
 #define M355_HM(BN_, NW_, KS_, UPS_)                                   \
@@ -285,13 +330,9 @@ int conv_halo_launch(const ConvArgs &a, unsigned xb, unsigned wb, hipStream_t st
         else if (a.ups) M355_HM(BN_, NW_, 3, 1);                       \
         else M355_HM(BN_, NW_, 3, 0);                                  \
     } while (0)
-    if (a.CoutP == 64) {
-        const dim3 grid(tiles, a.ncls);
-        M355_HK(64, 4);
-    } else {
-        const dim3 grid((unsigned)tiles * (a.CoutP / 128), a.ncls);
-        M355_HK(128, 8);
-    }
+    const dim3 grid((unsigned)per * nN, a.ncls);
+    if (a.CoutP == 64) M355_HK(64, 4);
+    else M355_HK(128, 8);
 #undef M355_HK
 #undef M355_HM
 #undef M355_HL

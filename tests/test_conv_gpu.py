@@ -139,3 +139,34 @@ def test_conv_tile_variants(pkg, case, tile, monkeypatch):
     dy_nhwc[..., :Cout] = dy.permute(0, 2, 3, 1)
     dx = conv.conv_dgrad(d, dy_nhwc.bfloat16().to(DEV), wd).float().cpu().permute(0, 3, 1, 2)
     assert (dx - xr.grad).abs().max().item() / xr.grad.abs().max().item() < 1.2e-2
+
+
+@pytest.mark.parametrize("wgs", ["3", "8"])
+@pytest.mark.parametrize("case", [(3, 16, 64, 128, 128, 3, 1, 1, 1, 1, 0), (2, 16, 16, 128, 64, 3, 1, 1, 1, 1, 1),
+                                  (2, 32, 64, 128, 256, 4, 2, 1, 1, 2, 0), (3, 24, 32, 64, 64, 3, 1, 1, 1, 2, 0)])
+def test_conv_halo_persistent_tiles(pkg, case, wgs, monkeypatch):
+    """k_conv_halo with few persistent workgroups: each walks several pixel tiles (cross-tile halo prefetch, weight
+    ring wrap-around, uneven tile counts per workgroup)"""
+    monkeypatch.setenv("M355_HALO_WGS", wgs)
+    monkeypatch.setenv("M355_HALO_ALL", "1")
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    N, H, W, Cin, Cout, k, stride, ph, pw, mode, ups = case
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).bfloat16().float()
+    b = torch.randn(Cout, generator=g)
+    xr = x.clone().requires_grad_()
+    y_ref = ref_conv(xr, w, b, stride, ph, pw, mode, ups)
+    d = conv.make_desc(N, H, W, Cin, Cout, k, k, stride, ph, pw, mode, ups)
+    wf, wd = conv.weight_prep(d, w.to(DEV))
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    for _ in range(3):
+        y = conv.conv_fwd(d, x_nhwc, wf, b.to(DEV)).float().cpu().permute(0, 3, 1, 2)
+        assert (y - y_ref.detach()).abs().max().item() / y_ref.abs().max().item() < 6e-3
+    dy = torch.randn(y_ref.shape, generator=g).bfloat16().float()
+    y_ref.backward(dy)
+    dy_nhwc = torch.zeros(N, y_ref.shape[2], y_ref.shape[3], conv.dy_channels(Cout))
+    dy_nhwc[..., :Cout] = dy.permute(0, 2, 3, 1)
+    for _ in range(3):
+        dx = conv.conv_dgrad(d, dy_nhwc.bfloat16().to(DEV), wd).float().cpu().permute(0, 3, 1, 2)
+        assert (dx - xr.grad).abs().max().item() / xr.grad.abs().max().item() < 1.2e-2
