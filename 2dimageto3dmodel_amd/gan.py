@@ -309,7 +309,12 @@ class _DiscBase(nn.Module):
         """cached positional embedding [1,4,H,W] for an NCHW tensor (gan.py:87-90, 204-207)"""
         if self.pos_emb is None:
             self.pos_emb = torch.FloatTensor(positional_encoding(x.shape[2], x.shape[3])).unsqueeze(0)
-        return self.pos_emb.to(x.device).expand(x.shape[0], -1, -1, -1)
+        # (the reference re-uploads the CPU tensor on every forward; the device copy is kept here: one H2D copy per
+        # device instead of one blocking copy per call, and the forward becomes hipGraph-capturable)
+        dev = self.__dict__.get("_pos_dev")
+        if dev is None or dev.device != x.device:
+            dev = self.__dict__["_pos_dev"] = self.pos_emb.to(x.device)
+        return dev.expand(x.shape[0], -1, -1, -1)
 
     def _act(self, conv, norm, x, in_act=False, sole_consumer_masks=False):
         """conv -> [InstanceNorm] -> LeakyReLU on NHWC bf16.  With the activation in the conv epilogue (no norm):

@@ -20,7 +20,7 @@ def divide_pred(pred):
 
 class GanTrainer(torch.nn.Module):
     def __init__(self, args, latent_dim=64, lr_g=1e-4, lr_d=4e-4, d_steps_per_g=2, loss="hinge", device="cuda",
-                 symmetric_g=True, use_mesh=True, ema_alpha=0.999):
+                 symmetric_g=True, use_mesh=True, ema_alpha=0.999, capturable=False):
         super().__init__()
         self.args, self.latent_dim, self.d_steps_per_g, self.ema_alpha = args, latent_dim, d_steps_per_g, ema_alpha
         self.generator = G.Generator(args, latent_dim, symmetric=symmetric_g, mesh_head=use_mesh)
@@ -33,8 +33,9 @@ class GanTrainer(torch.nn.Module):
         for m in (self.generator, self.generator_running_avg, self.discriminator):
             P.broadcast_parameters(m)
         # betas=(0, 0.9) as main.py:588-589 (floats: torch >= 2.10 rejects the int/float mix)
-        self.optimizer_g = torch.optim.Adam(self.generator.parameters(), lr=lr_g, betas=(0.0, 0.9))
-        self.optimizer_d = torch.optim.Adam(self.discriminator.parameters(), lr=lr_d, betas=(0.0, 0.9))
+        # capturable: the step counters live on the device, so a whole cycle can be recorded into a hipGraph
+        self.optimizer_g = torch.optim.Adam(self.generator.parameters(), lr=lr_g, betas=(0.0, 0.9), capturable=capturable)
+        self.optimizer_d = torch.optim.Adam(self.discriminator.parameters(), lr=lr_d, betas=(0.0, 0.9), capturable=capturable)
         self.reduce_g = P.FlatGradReducer(self.generator.parameters())
         self.reduce_d = P.FlatGradReducer(self.discriminator.parameters())
         self.total_it = 0
