@@ -529,6 +529,9 @@ namespace m355 {  // csrc/conv_small.hip
 bool conv_small_eligible(const m355_conv_desc *d, int y_f32_nchw);
 int conv_small_launch(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, float slope,
                       int Kp, size_t wbytes, hipStream_t st);
+bool conv_c8_eligible(const m355_conv_desc *d, int y_f32_nchw);
+int conv_c8_launch(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, float slope, int Kp,
+                   size_t wbytes, hipStream_t st);
 bool wgrad_small_eligible(const m355_conv_desc *d, int Cy);
 int wgrad_small_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, hipStream_t st);
 }  // namespace m355
@@ -622,6 +625,11 @@ extern "C" int m355_conv2d_fwd(const m355_conv_desc *d, const void *x, const voi
         const int Kp = m355::k_padded(d->kh * d->kw * d->Cin);
         return m355::conv_small_launch(d, x, w_fwd, bias, y, lrelu_slope, Kp, (size_t)m355::rows_padded(d->Cout) * Kp * 2,
                                        (hipStream_t)stream);
+    }
+    if (m355::conv_c8_eligible(d, y_f32_nchw) && !getenv("M355_NO_C8")) {  // TextureDiscriminator.conv1: 8 input channels
+        const int Kp = m355::k_padded(d->kh * d->kw * d->Cin);
+        return m355::conv_c8_launch(d, x, w_fwd, bias, y, lrelu_slope, Kp, (size_t)m355::rows_padded(d->Cout) * Kp * 2,
+                                    (hipStream_t)stream);
     }
     ConvArgs a = {};
     a.x = (const unsigned short *)x;

@@ -306,6 +306,190 @@ int wgrad_small_launch(const m355_conv_desc *d, const void *x, const void *dy, i
     return check_launch("conv2d_wgrad (small Cout)");
 }
 
+// ---- the OTHER thin layer: 8 input channels -> 64*k output channels, 5x5 (TextureDiscriminator.conv1 on the
+// [texture(3) | alpha(1) | positional(4)] image, gan.py:163).  K = 25 taps x 8 channels = 200: as an implicit GEMM the
+// k_conv_glds launch spends its time in per-tile prologues / epilogues (4 K steps per tile) and runs at 260 TF,
+// 3.5x off the HBM floor (1.07 GB of bf16 output per launch at batch 128).  Here:
+//   * a pixel is ONE 16-byte chunk; the (8+4) x (32+4) halo of an 8 x 32 output tile is 6.9 KB, double buffered and
+//     prefetched one tile ahead; the whole weight matrix [64][26 taps x 8] stays in LDS (row pitch 432 B = 16 x odd:
+//     conflict-free fragment reads) for the lifetime of the persistent workgroup;
+//   * one MFMA 32x32x16 K step = two taps: lane half h reads the pixel chunk of tap 2ks+h -- a single ds_read_b128;
+//     13 K steps, 52 MFMAs per wave and tile; epilogue = k_conv_glds's (bias, LeakyReLU, permlane32 16-byte stores).
+struct C8Args {
+    const unsigned short *x;  // bf16 NHWC [N,H,W,8]
+    const unsigned short *w;  // bf16 forward view [rows][Kp], K ordered (kh, kw, ci): 200 real columns
+    const float *bias;
+    unsigned short *y;        // bf16 NHWC [N,H,W,Cout]
+    int N, H, W, Cout, Kp;
+    float slope;
+    unsigned xbytes, wbytes;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
+{
+    constexpr int TH = 8, TW = 32, KS = 5, HS_Y = TH + KS - 1, HS_X = TW + KS - 1;  // 12 x 36 halo
+    constexpr int HPIX = HS_Y * HS_X, HINS = (HPIX + 63) / 64;                      // 432 chunks, 7 DMA instructions
+    constexpr int HBUF = HINS * 1024;
+    constexpr int WPITCH = 432, WCH = 26;                                            // weight row: 26 chunks (taps 0..25)
+    constexpr int WINS = (64 * 27 + 63) / 64;                                        // 27 DMA instructions ([co][27-chunk] image)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HBUF + WINS * 1024];
+    unsigned char *const ldsW = lds + 2 * HBUF;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nN = a.Cout / 64, tn = blockIdx.x % nN, bp = blockIdx.x / nN, PS = gridDim.x / nN;
+    const int tpx = a.W / TW, tpy = a.H / TH, tiles = a.N * tpx * tpy;
+    if (bp >= tiles) return;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.wbytes, 0x00020000);
+
+    // weights: chunk e = 64 j + lane -> (co, c) = (e / 26, e % 26) -> LDS co*432 + c*16.  The DMA destination is
+    // lane-linear (1 KB per instruction), so the 432-byte pitch is produced by giving every (co, c) its own instruction
+    // slot in a [co][27-chunk] image: e' = co*27 + c, chunk 26 of each row is padding (never read).
+    for (int j = wave; j < WINS; j += 4) {
+        const int e = 64 * j + lane, co = e / 27, c = e - co * 27;
+        const bool ok = co < 64 && c < WCH;
+        dma16(rw, ldsW + j * 1024, ok ? (unsigned)(((tn * 64 + co) * a.Kp) * 2 + c * 16) : OOB, 0u);
+    }
+
+    auto origin = [&](int tp, int &n, int &oy0, int &ox0) {
+        n = tp / (tpx * tpy);
+        const int r = tp - n * (tpx * tpy);
+        oy0 = (r / tpx) * TH;
+        ox0 = (r % tpx) * TW;
+    };
+    // halo chunk P = 64 q + lane of tile tp -> image pixel; instructions q = wave, wave + 4
+    auto issue_halo = [&](int tp, int buf) {
+        int n, oy0, ox0;
+        origin(tp, n, oy0, ox0);
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+            const int q = wave + 4 * qi;
+            if (q < HINS) {
+                const int P = 64 * q + lane;
+                const int hy = P / HS_X, hx = P - hy * HS_X;
+                const int gy = oy0 - KS / 2 + hy;
+                int gx = ox0 - KS / 2 + hx;
+                bool ok = P < HPIX && (unsigned)gy < (unsigned)a.H;
+                if (MODE == 1) gx = min(max(gx, 0), a.W - 1);
+                else if (MODE == 2) gx = gx < 0 ? gx + a.W : (gx >= a.W ? gx - a.W : gx);
+                ok = ok && (unsigned)gx < (unsigned)a.W;
+                dma16(rx, lds + buf * HBUF + q * 1024, ok ? (unsigned)(((n * a.H + gy) * a.W + gx) * 16) : OOB, 0u);
+            }
+        }
+    };
+
+    // fragment roles: lane -> pixel column tx / output channel row (lane & 31), half -> which of the step's two taps
+    const int tx = lane & 31, half = lane >> 5;
+    int poff[13];  // byte offset of this lane's tap inside the halo, relative to its pixel, per K step
+#pragma unroll
+    for (int ks = 0; ks < 13; ++ks) {
+        const int tap = min(2 * ks + half, 24);  // (tap 25 multiplies zero weights)
+        poff[ks] = ((tap / KS) * HS_X + tap % KS) * 16;
+    }
+    const unsigned char *wfrag = ldsW + (lane & 31) * WPITCH + half * 16;
+
+    f32x16 acc[2][2];  // [co block j][pixel row i]
+    int tp = bp, buf = 0;
+    issue_halo(tp, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // weights + first halo (the in-loop wait only covers later halos)
+    for (;;) {
+        int n, oy0, ox0;
+        origin(tp, n, oy0, ox0);
+        const int tp_next = tp + PS;
+        // the halo of this tile (issued one tile ago) and, first time round, the weights have landed; the 8 epilogue
+        // stores of the previous tile are younger and may still be in flight
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (tp_next < tiles) issue_halo(tp_next, buf ^ 1);
+        else issue_halo(tp, buf ^ 1);  // keep the DMA count per tile constant (harmless re-load into the idle buffer)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
+        const unsigned char *hb = lds + buf * HBUF + ((2 * wave) * HS_X + tx) * 16;
+#pragma unroll
+        for (int ks = 0; ks < 13; ++ks) {
+            const bf16x8 w0 = *reinterpret_cast<const bf16x8 *>(wfrag + ks * 32);
+            const bf16x8 w1 = *reinterpret_cast<const bf16x8 *>(wfrag + 32 * WPITCH + ks * 32);
+            const bf16x8 p0 = *reinterpret_cast<const bf16x8 *>(hb + poff[ks]);
+            const bf16x8 p1 = *reinterpret_cast<const bf16x8 *>(hb + HS_X * 16 + poff[ks]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, p0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, p1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p1, acc[1][1], 0, 0, 0);
+        }
+        // epilogue: acc[j][i][r] = channel 64 tn + 32 j + 8 (r>>2) + 4 half + (r&3), pixel (oy0 + 2 wave + i, ox0 + tx)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t pix = ((size_t)n * a.H + (oy0 + 2 * wave + i)) * a.W + ox0 + tx;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cbase = tn * 64 + 32 * j;
+                uint2 pk[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (a.bias) b4 = *reinterpret_cast<const float4 *>(a.bias + cbase + 8 * g + 4 * half);
+                    float v[4] = {acc[j][i][4 * g] + b4.x, acc[j][i][4 * g + 1] + b4.y, acc[j][i][4 * g + 2] + b4.z,
+                                  acc[j][i][4 * g + 3] + b4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * a.slope;
+                    pk[g].x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                    pk[g].y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    auto sx = __builtin_amdgcn_permlane32_swap(pk[g].x, pk[g + 1].x, false, false);
+                    auto sy = __builtin_amdgcn_permlane32_swap(pk[g].y, pk[g + 1].y, false, false);
+                    uint4 o;
+                    o.x = sx[0]; o.y = sy[0]; o.z = sx[1]; o.w = sy[1];
+                    *reinterpret_cast<uint4 *>(a.y + pix * a.Cout + cbase + 8 * (g + half)) = o;
+                }
+            }
+        }
+        if (tp_next >= tiles) break;
+        tp = tp_next;
+        buf ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+bool conv_c8_eligible(const m355_conv_desc *d, int y_f32_nchw)
+{
+    return !y_f32_nchw && d->Cin == 8 && d->kh == 5 && d->kw == 5 && d->stride == 1 && d->upsample == 0 && d->pad_h == 2 &&
+           d->pad_w == 2 && d->Cout % 64 == 0 && d->W % 32 == 0 && d->H % 8 == 0 &&
+           (size_t)d->N * d->H * d->W * 16 < (1ull << 31);
+}
+
+int conv_c8_launch(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, float slope, int Kp,
+                   size_t wbytes, hipStream_t st)
+{
+    C8Args a = {};
+    a.x = (const unsigned short *)x;
+    a.w = (const unsigned short *)w_fwd;
+    a.bias = bias;
+    a.y = (unsigned short *)y;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cout = d->Cout; a.Kp = Kp;
+    a.slope = slope;
+    a.xbytes = (unsigned)((size_t)d->N * d->H * d->W * 16);
+    a.wbytes = (unsigned)wbytes;
+    const int tiles = d->N * (d->H / 8) * (d->W / 32), nN = d->Cout / 64;
+    int per = 768 / nN;  // 3 resident workgroups per CU (42 KB of LDS each)
+    if (per > tiles) per = tiles;
+    if (per < 1) per = 1;
+    const dim3 grid(per * nN);
+    if (d->pad_w_mode == 0) hipLaunchKernelGGL((k_conv_c8<0>), grid, dim3(256), 0, st, a);
+    else if (d->pad_w_mode == 1) hipLaunchKernelGGL((k_conv_c8<1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_conv_c8<2>), grid, dim3(256), 0, st, a);
+    return check_launch("conv2d_fwd (8 input channels)");
+}
+
 // host side: eligibility + launch (called from m355_conv2d_fwd)
 bool conv_small_eligible(const m355_conv_desc *d, int y_f32_nchw)
 {

@@ -11,7 +11,7 @@ LAYERS = [  # name, H, W (stored), Cin, Cout, k, stride, ph, pw, mode, ups
     ("G.blk6.conv1 128->64 3x3 up", 128, 64, 128, 64, 3, 1, 1, 1, 1, 1),
     ("G.blk6.conv2 64->64 3x3", 256, 128, 64, 64, 3, 1, 1, 1, 1, 0),
     ("G.conv_final 64->3 5x5", 256, 128, 64, 3, 5, 1, 2, 2, 1, 0),
-    ("D.conv1 8(32)->64 5x5", 256, 256, 32, 64, 5, 1, 2, 2, 2, 0),
+    ("D.conv1 8->64 5x5", 256, 256, 8, 64, 5, 1, 2, 2, 2, 0),
     ("D.conv2 64->128 4x4 s2", 256, 256, 64, 128, 4, 2, 1, 1, 2, 0),
     ("D.conv3 128->256 4x4 s2", 128, 128, 128, 256, 4, 2, 1, 1, 2, 0),
     ("D.conv4 256->512 4x4 s2", 64, 64, 256, 512, 4, 2, 1, 1, 2, 0),

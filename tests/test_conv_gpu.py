@@ -55,6 +55,9 @@ CASES = [
     (2, 32, 64, 128, 256, 4, 2, 1, 1, 2, 0),  # stride-2 dgrad: four 2x2 classes of dy on the halo kernel, circular
     (2, 32, 64, 64, 128, 4, 2, 1, 1, 0, 0),   # stride-2 dgrad with zero W pad, dx has 64 channels (4-wave variant)
     (1, 16, 32, 64, 64, 3, 1, 1, 1, 2, 0),    # 3x3 circular
+    # ---- 8-input-channel kernel (conv_small.hip k_conv_c8): D.conv1
+    (3, 24, 64, 8, 64, 5, 1, 2, 2, 2, 0),     # circular, several tiles per image
+    (2, 16, 32, 8, 128, 5, 1, 2, 2, 0, 0),    # zero W pad, two 64-channel output tiles
 ]
 
 
