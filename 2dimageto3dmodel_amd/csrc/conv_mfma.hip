@@ -532,6 +532,9 @@ int conv_small_launch(const m355_conv_desc *d, const void *x, const void *w_fwd,
 bool conv_c8_eligible(const m355_conv_desc *d, int y_f32_nchw);
 int conv_c8_launch(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, float slope, int Kp,
                    size_t wbytes, hipStream_t st);
+bool dgrad_small_eligible(const m355_conv_desc *d, int Cy);
+int dgrad_small_launch(const m355_conv_desc *d, const void *dy, int Cy, const void *w_dgrad, int Kp, size_t wbytes, void *dx,
+                       hipStream_t st);
 bool wgrad_small_eligible(const m355_conv_desc *d, int Cy);
 int wgrad_small_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, hipStream_t st);
 }  // namespace m355
@@ -698,6 +701,8 @@ extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const 
     a.mask_x = (const unsigned short *)mask_x;
     a.mask_slope = mask_slope;
     int rc = 0;
+    if (direct && !mask_x && m355::dgrad_small_eligible(d, cout32) && !getenv("M355_NO_C8"))
+        return m355::dgrad_small_launch(d, dy, cout32, w_dgrad, a.Kp, (size_t)cin64 * a.Kp * 2, dx, st);
     if (direct && d->stride == 1) {
         a.w = (const unsigned short *)w_dgrad;
         a.KH = d->kh; a.KW = d->kw;

@@ -19,13 +19,15 @@
 namespace m355 {
 
 constexpr int ST = 16;       // output tile side
-constexpr int SMAXCO = 4;    // output channels served (weights chunk <= 4 * 25 * 128 B = 12.5 KiB of LDS)
+constexpr int SMAXCO = 8;    // output channels served (weights chunk <= 8 * 25 * 128 B = 25 KiB of LDS)
 
 struct SmallArgs {
     const unsigned short *x;  // bf16 NHWC [N,H,W,Cin], Cin % 64 == 0
     const unsigned short *w;  // bf16 forward view [rows][Kp], row = output channel, K ordered (kh, kw, ci)
     const float *bias;        // [Cout] or null
-    float *y;                 // fp32 NCHW [N,Cout,H,W]
+    float *y;                 // fp32 NCHW [N,Cout,H,W]   (heads)            -- exactly one of y / yb
+    unsigned short *yb;       // bf16 NHWC [N,H,W,Cs]     (dgrad of an 8-channel-input conv: Cout = 8 here)
+    int Cs;
     int N, H, W, Cin, Cout, Kp;
     int tiles_x;
     float slope;
@@ -129,13 +131,22 @@ __global__ __launch_bounds__(256, 2) void k_conv_smallco(SmallArgs a)
     for (int g = 0; g < 4; ++g) {
         const int oy = ty * ST + 4 * wave + g;
         if (oy < a.H && ox < a.W) {
+            if (a.yb) {  // 4 consecutive channels of this lane's pixel = one 8-byte store
+                if (4 * kg < a.Cout) {
+                    uint2 o;
+                    o.x = (unsigned)f2bf(acc[g][0]) | ((unsigned)f2bf(acc[g][1]) << 16);
+                    o.y = (unsigned)f2bf(acc[g][2]) | ((unsigned)f2bf(acc[g][3]) << 16);
+                    *reinterpret_cast<uint2 *>(a.yb + (((size_t)n * a.H + oy) * a.W + ox) * a.Cs + 4 * kg) = o;
+                }
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = 4 * kg + r;
-                if (co < a.Cout) {
-                    float v = acc[g][r] + (a.bias ? a.bias[co] : 0.0f);
-                    v = v >= 0.0f ? v : v * a.slope;
-                    a.y[(((size_t)n * a.Cout + co) * a.H + oy) * a.W + ox] = v;
+                for (int r = 0; r < 4; ++r) {
+                    const int co = 4 * kg + r;
+                    if (co < a.Cout) {
+                        float v = acc[g][r] + (a.bias ? a.bias[co] : 0.0f);
+                        v = v >= 0.0f ? v : v * a.slope;
+                        a.y[(((size_t)n * a.Cout + co) * a.H + oy) * a.W + ox] = v;
+                    }
                 }
             }
         }
@@ -493,9 +504,45 @@ int conv_c8_launch(const m355_conv_desc *d, const void *x, const void *w_fwd, co
 // host side: eligibility + launch (called from m355_conv2d_fwd)
 bool conv_small_eligible(const m355_conv_desc *d, int y_f32_nchw)
 {
-    return y_f32_nchw && d->Cout <= SMAXCO && d->stride == 1 && d->upsample == 0 && d->kh == d->kw &&
+    return y_f32_nchw && d->Cout <= 4 && d->stride == 1 && d->upsample == 0 && d->kh == d->kw &&
            (d->kh == 5 || d->kh == 3) && d->pad_h == d->kh / 2 && d->pad_w == d->kw / 2 && d->Cin % 64 == 0 &&
            (size_t)d->N * d->H * d->W * d->Cin * 2 < (1ull << 31);
+}
+
+// dgrad of a stride-1, "same"-padded conv with <= 8 INPUT channels (TextureDiscriminator.conv1): a conv of dy (Cy % 64 == 0
+// channels) with the flipped, transposed weights onto 8 channels -- the same halo kernel with bf16 NHWC output
+bool dgrad_small_eligible(const m355_conv_desc *d, int Cy)
+{
+    return d->Cin == 8 && d->stride == 1 && d->upsample == 0 && d->pad_w_mode != 1 && d->kh == d->kw &&
+           (d->kh == 5 || d->kh == 3) && d->pad_h == d->kh / 2 && d->pad_w == d->kw / 2 && Cy % 64 == 0 &&
+           (size_t)d->N * d->H * d->W * Cy * 2 < (1ull << 31);
+}
+
+int dgrad_small_launch(const m355_conv_desc *d, const void *dy, int Cy, const void *w_dgrad, int Kp, size_t wbytes, void *dx,
+                       hipStream_t st)
+{
+    m355_conv_desc t = *d;
+    t.Cin = Cy;   // the "input" of this conv is dy
+    t.Cout = 8;
+    SmallArgs a = {};
+    a.x = (const unsigned short *)dy;
+    a.w = (const unsigned short *)w_dgrad;
+    a.yb = (unsigned short *)dx;
+    a.Cs = 8;
+    a.N = t.N; a.H = t.H; a.W = t.W; a.Cin = Cy; a.Cout = 8; a.Kp = Kp;
+    a.tiles_x = (t.W + ST - 1) / ST;
+    a.slope = 1.0f;
+    a.xbytes = (unsigned)((size_t)t.N * t.H * t.W * Cy * 2);
+    a.wbytes = (unsigned)wbytes;
+    const dim3 grid(a.tiles_x * ((t.H + ST - 1) / ST), t.N);
+    if (t.kh == 5) {
+        if (t.pad_w_mode == 0) hipLaunchKernelGGL((k_conv_smallco<5, 0>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_conv_smallco<5, 2>), grid, dim3(256), 0, st, a);
+    } else {
+        if (t.pad_w_mode == 0) hipLaunchKernelGGL((k_conv_smallco<3, 0>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_conv_smallco<3, 2>), grid, dim3(256), 0, st, a);
+    }
+    return check_launch("conv2d_dgrad (8 input channels)");
 }
 
 int conv_small_launch(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, float slope,
