@@ -92,9 +92,20 @@ class GanTrainer(torch.nn.Module):
         """one pass of the loop body main.py:691-723 on one loader batch; returns the scalar losses"""
         if self.total_it % (1 + self.d_steps_per_g) == 0:
             self.optimizer_g.zero_grad(set_to_none=True)
-            loss, _, _ = self('g', None, X_alpha, None, C, caption)
-            loss = loss.mean()
-            loss.backward()
+            # The G step only needs dL/d(input) from the discriminator: the reference lets autograd also compute D's
+            # weight gradients and then throws them away (optimizer_d.zero_grad(), code/main.py:716; SURVEY 8a G-bwd).
+            # Switching requires_grad off for the duration skips those wgrad kernels; the generator's gradients are
+            # bit-identical.
+            d_params = [p for p in self.discriminator.parameters() if p.requires_grad]
+            for p in d_params:
+                p.requires_grad_(False)
+            try:
+                loss, _, _ = self('g', None, X_alpha, None, C, caption)
+                loss = loss.mean()
+                loss.backward()
+            finally:
+                for p in d_params:
+                    p.requires_grad_(True)
             self.reduce_g()
             self.optimizer_g.step()
             self.update_generator_running_avg()
