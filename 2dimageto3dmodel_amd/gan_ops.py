@@ -308,9 +308,11 @@ class CbnActFn(torch.autograd.Function):
         part = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev)
         launch("bn_stats_partial", ptr(x), ptr(part), P, c, stream())
         if sync:
-            v = torch.cat((part.sum(0).reshape(-1), part.new_tensor([count])))
-            dist.all_reduce(v, op=dist.ReduceOp.SUM)
-            part, nblk, count = v[:-1].contiguous(), 1, float(v[-1])
+            # one all-reduce of [sum | sumsq]; every rank holds the same number of pixels (the loader shards the batch
+            # evenly), so the global count is known without communication -- no host round trip in the forward
+            part = part.sum(0)
+            dist.all_reduce(part, op=dist.ReduceOp.SUM)
+            nblk, count = 1, count * dist.get_world_size()
         coef = torch.empty((2 * n + 2, c), dtype=torch.float32, device=dev)   # a[N,C] | b[N,C] | mean | rstd
         a, b, mean, rstd = coef[:n], coef[n:2 * n], coef[2 * n], coef[2 * n + 1]
         launch("bn_finalize", ptr(part), nblk, count, ptr(gamma), ptr(beta), int(gamma.stride(0)), n, c, float(eps),
