@@ -27,6 +27,14 @@ __device__ __forceinline__ unsigned short f2bf(float f)
     return (unsigned short)(u >> 16);
 }
 
+// two fp32 -> packed bf16x2 (lo in bits 15:0), round-to-nearest-even: ONE v_cvt_pk_bf16_f32 instead of ~10 integer ops
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
+{
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
 
 // launch description shared by the implicit-GEMM kernels (csrc/conv_mfma.hip, csrc/conv_halo.hip)

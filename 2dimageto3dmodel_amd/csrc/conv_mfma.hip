@@ -347,8 +347,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void k_conv_glds(ConvArgs
                     v[2] = x2 > 0.0f ? v[2] : v[2] * a.mask_slope;
                     v[3] = x3 > 0.0f ? v[3] : v[3] * a.mask_slope;
                 }
-                pk[g].x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                pk[g].y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                pk[g].x = pack_bf16(v[0], v[1]);
+                pk[g].y = pack_bf16(v[2], v[3]);
             }
 #pragma unroll
             for (int g = 0; g < 4; g += 2) {

@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_smallco(SmallArgs a)
             if (a.yb) {  // 4 consecutive channels of this lane's pixel = one 8-byte store
                 if (4 * kg < a.Cout) {
                     uint2 o;
-                    o.x = (unsigned)f2bf(acc[g][0]) | ((unsigned)f2bf(acc[g][1]) << 16);
-                    o.y = (unsigned)f2bf(acc[g][2]) | ((unsigned)f2bf(acc[g][3]) << 16);
+                    o.x = pack_bf16(acc[g][0], acc[g][1]);
+                    o.y = pack_bf16(acc[g][2], acc[g][3]);
                     *reinterpret_cast<uint2 *>(a.yb + (((size_t)n * a.H + oy) * a.W + ox) * a.Cs + 4 * kg) = o;
                 }
             } else {
@@ -451,8 +451,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
                                   acc[j][i][4 * g + 3] + b4.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * a.slope;
-                    pk[g].x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                    pk[g].y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                    pk[g].x = pack_bf16(v[0], v[1]);
+                    pk[g].y = pack_bf16(v[2], v[3]);
                 }
 #pragma unroll
                 for (int g = 0; g < 4; g += 2) {

@@ -13,6 +13,18 @@ namespace m355 {
 typedef __attribute__((ext_vector_type(8))) short bf16x8e;
 
 __device__ __forceinline__ float bf2f_e(short h) { return __uint_as_float(((unsigned int)(unsigned short)h) << 16); }
+__device__ __forceinline__ unsigned pack2_e(float lo, float hi)  // v_cvt_pk_bf16_f32: RNE, one instruction
+{
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ bf16x8e pack8_e(const float (&z)[8])
+{
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    u4 w = {pack2_e(z[0], z[1]), pack2_e(z[2], z[3]), pack2_e(z[4], z[5]), pack2_e(z[6], z[7])};
+    return __builtin_bit_cast(bf16x8e, w);
+}
 __device__ __forceinline__ short f2bf_e(float f)
 {
     unsigned int u = __float_as_uint(f);
@@ -141,17 +153,20 @@ __global__ __launch_bounds__(256) void k_affine_act(const short *__restrict__ x,
         const bf16x8e v = *reinterpret_cast<const bf16x8e *>(xn + i * 8);
         bf16x8e r = {0, 0, 0, 0, 0, 0, 0, 0};
         if (rn) r = *reinterpret_cast<const bf16x8e *>(rn + i * 8);
-        bf16x8e o;
+        float zz[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float z = bf2f_e(v[j]) * av[j] + bv[j];
-            z = z >= 0.0f ? z : z * slope;
+            zz[j] = z >= 0.0f ? z : z * slope;
+        }
+        if (rn) {
             // residual branch of ResBlockUp (gan.py:312): the activation is rounded to bf16 first, as the
             // separate bf16 add it replaces did
-            if (rn) z = bf2f_e(f2bf_e(z)) + bf2f_e(r[j]);
-            o[j] = f2bf_e(z);
+            const bf16x8e q = pack8_e(zz);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) zz[j] = bf2f_e(q[j]) + bf2f_e(r[j]);
         }
-        *reinterpret_cast<bf16x8e *>(yn + i * 8) = o;
+        *reinterpret_cast<bf16x8e *>(yn + i * 8) = pack8_e(zz);
     }
 }
 
@@ -211,15 +226,15 @@ __global__ __launch_bounds__(256) void k_act_bwd_apply(const short *__restrict__
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const bf16x8e vx = *reinterpret_cast<const bf16x8e *>(x + off + i * 8);
         const bf16x8e vd = *reinterpret_cast<const bf16x8e *>(dy + off + i * 8);
-        bf16x8e o;
+        float oo[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float xf = bf2f_e(vx[j]);
             const float z = xf * av[j] + bv[j];
             const float dz = bf2f_e(vd[j]) * (z >= 0.0f ? 1.0f : slope);
-            o[j] = f2bf_e(dz * Av[j] + xf * Bv[j] + Cv[j]);
+            oo[j] = dz * Av[j] + xf * Bv[j] + Cv[j];
         }
-        *reinterpret_cast<bf16x8e *>(dx + off + i * 8) = o;
+        *reinterpret_cast<bf16x8e *>(dx + off + i * 8) = pack8_e(oo);
     }
 }
 
