@@ -259,6 +259,38 @@ __global__ __launch_bounds__(256) void k_lrelu_bwd(const short *__restrict__ dy,
     });
 }
 
+// NCHW fp32 image (C <= 8 planes) [+ P constant planes, e.g. the positional encoding of gan.py:9-20] -> NHWC bf16 with
+// exactly 8 channels (zero filled beyond C + P): what TextureDiscriminator.forward builds with cat + permute + cast
+// (gan.py:204-209) in one pass.  One thread per pixel: plane reads are coalesced along W, the store is 16 bytes.
+__global__ __launch_bounds__(256) void k_pack_nhwc8(const float *__restrict__ x, const float *__restrict__ pos, short *__restrict__ out,
+                                                    int C, int P, size_t HW, size_t total)
+{
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t n = i / HW, p = i - n * HW;
+        float z[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float v = 0.0f;
+            if (c < C) v = x[(n * C + c) * HW + p];
+            else if (c - C < P) v = pos[(size_t)(c - C) * HW + p];
+            z[c] = v;
+        }
+        *reinterpret_cast<bf16x8e *>(out + i * 8) = pack8_e(z);
+    }
+}
+
+// backward of the above w.r.t. the image: d out [.., 8] bf16 -> dx NCHW fp32 (first C channels)
+__global__ __launch_bounds__(256) void k_unpack_nhwc8(const short *__restrict__ g, float *__restrict__ dx, int C, size_t HW, size_t total)
+{
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t n = i / HW, p = i - n * HW;
+        const bf16x8e v = *reinterpret_cast<const bf16x8e *>(g + i * 8);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < C) dx[(n * C + c) * HW + p] = bf2f_e(v[c]);
+    }
+}
+
 static int check_c(int C, const char *who)
 {
     if (C < 8 || C % 8 != 0 || C > 2048 || 256 % (C / 8) != 0) {
@@ -387,4 +419,24 @@ extern "C" int m355_lrelu_bwd(const void *dy, const void *y, void *g, float *dbi
                        (float *)ws, P, C, slope, ppb);
     hipLaunchKernelGGL(k_sum_partials, dim3((C + 31) / 32, 1), dim3(256), 0, st, (const float *)ws, dbias, nblk, C);
     return check_launch("lrelu_bwd");
+}
+
+extern "C" int m355_pack_nhwc8(const float *x_nchw, const float *pos, void *out_nhwc8, int N, int C, int P, int H, int W,
+                               void *stream)
+{
+    M355_REQUIRE(x_nchw && out_nhwc8 && N > 0 && C >= 1 && C <= 8 && P >= 0 && C + P <= 8 && (P == 0 || pos) && H > 0 && W > 0,
+                 "pack_nhwc8: bad argument");
+    const size_t HW = (size_t)H * W, total = (size_t)N * HW;
+    const unsigned g = (unsigned)min((size_t)65535, (total + 255) / 256);
+    hipLaunchKernelGGL(k_pack_nhwc8, dim3(g), dim3(256), 0, (hipStream_t)stream, x_nchw, pos, (short *)out_nhwc8, C, P, HW, total);
+    return check_launch("pack_nhwc8");
+}
+
+extern "C" int m355_unpack_nhwc8(const void *g_nhwc8, float *dx_nchw, int N, int C, int H, int W, void *stream)
+{
+    M355_REQUIRE(g_nhwc8 && dx_nchw && N > 0 && C >= 1 && C <= 8 && H > 0 && W > 0, "unpack_nhwc8: bad argument");
+    const size_t HW = (size_t)H * W, total = (size_t)N * HW;
+    const unsigned g = (unsigned)min((size_t)65535, (total + 255) / 256);
+    hipLaunchKernelGGL(k_unpack_nhwc8, dim3(g), dim3(256), 0, (hipStream_t)stream, (const short *)g_nhwc8, dx_nchw, C, HW, total);
+    return check_launch("unpack_nhwc8");
 }

@@ -442,9 +442,8 @@ class TextureDiscriminator(_DiscBase):
         if self.args.mask_output:
             with torch.no_grad():
                 mask = F.avg_pool2d(x[:, 3:4], 16 if self.stride_first else 8)
-        if self.positional_embeddings:
-            x = torch.cat((x, self._pos(x)), dim=1)
-        h = G.to_nhwc_bf16(x, pad_to=8)
+        # cat((x, positional encoding)) -> NHWC bf16 (8 channels) in one pass
+        h = G.pack_nhwc8(x, self._pos(x)[0] if self.positional_embeddings else None)
         n2, n3, n4 = getattr(self, "bn2", None), getattr(self, "bn3", None), getattr(self, "bn4", None)
         h = self._act(self.conv1, None, h, False, n2 is None)
         h = self._act(self.conv2, n2, h, True, n3 is None)

@@ -28,6 +28,37 @@ def to_nhwc_bf16(x_nchw, pad_to=1):
     return x.contiguous().to(torch.bfloat16)
 
 
+class PackNHWC8(torch.autograd.Function):
+    """cat((x, pos)) -> NHWC bf16 with 8 channels in one pass (csrc/gan_elem.hip k_pack_nhwc8); x [N,C,H,W] fp32,
+    pos [P,H,W] fp32 or None, C + P <= 8"""
+
+    @staticmethod
+    def forward(ctx, x, pos):
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        p = 0 if pos is None else pos.shape[0]
+        out = torch.empty((n, h, w, 8), dtype=torch.bfloat16, device=x.device)
+        launch("pack_nhwc8", ptr(x), ptr(pos), ptr(out), n, c, p, h, w, stream())
+        ctx.shape = (n, c, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, c, h, w = ctx.shape
+        dx = torch.empty((n, c, h, w), dtype=torch.float32, device=g.device)
+        launch("unpack_nhwc8", ptr(g.contiguous()), ptr(dx), n, c, h, w, stream())
+        return dx, None
+
+
+def pack_nhwc8(x_nchw, pos=None):
+    """the discriminators' input assembly; falls back to torch ops off the GPU / for other dtypes"""
+    if x_nchw.is_cuda and x_nchw.dtype == torch.float32 and x_nchw.shape[1] + (0 if pos is None else pos.shape[0]) <= 8:
+        return PackNHWC8.apply(x_nchw, None if pos is None else pos.contiguous())
+    if pos is not None:
+        x_nchw = torch.cat((x_nchw, pos.unsqueeze(0).expand(x_nchw.shape[0], -1, -1, -1)), dim=1)
+    return to_nhwc_bf16(x_nchw, pad_to=8)
+
+
 def to_nchw_f32(x_nhwc):
     return x_nhwc.permute(0, 3, 1, 2).float()
 

@@ -199,6 +199,11 @@ int m355_bn_stats_partial(const void *x, float *part, size_t P, int C, void *str
 int m355_affine_act_bwd_partial(const void *dy, const void *x, const float *a, const float *b, float *part, int N, int HW,
                                 int C, float slope, void *stream);
 
+/* ---- G5  discriminator input: [N,C,H,W] fp32 image (C <= 8) ++ P constant planes pos[P][H][W] (positional encoding,
+ *      gan.py:9-20,204-209) -> NHWC bf16 with 8 channels (zero beyond C+P); and the backward w.r.t. the image. */
+int m355_pack_nhwc8(const float *x_nchw, const float *pos, void *out_nhwc8, int N, int C, int P, int H, int W, void *stream);
+int m355_unpack_nhwc8(const void *g_nhwc8, float *dx_nchw, int N, int C, int H, int W, void *stream);
+
 /* ---- G9  spectral normalisation (torch.nn.utils.spectral_norm, one power iteration per training forward:
  *      v = normalize(W^T u), u = normalize(W v), sigma = u.(W v); gan.py:57-65,163-177,294-302) for ALL layers of
  *      a network in three launches.  `table` is a device-resident array of L entries; norms[2L] must be zero on
