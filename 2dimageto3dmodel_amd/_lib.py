@@ -19,6 +19,7 @@ _lib = None
 _P = c_void_p
 SIGNATURES = {
     "m355_last_error": (ctypes.c_char_p, []),
+    "m355_last_kernel": (ctypes.c_char_p, []),
     "m355_abi_version": (c_int, []),
     "m355_proj_transform_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, _P]),
     "m355_proj_ntiles": (c_int, [c_int]),
@@ -136,6 +137,10 @@ def launch(name, *args, work=0.0, tag=None):
         e0.record()
         rc = fn(*args)
         e1.record()
+        if name.startswith("conv2d_") and name != "conv2d_weight_prep":
+            # label by the kernel family the C side dispatched to (what rocprofv3 lists), keeping the entry point
+            fam = lib().m355_last_kernel().decode()
+            name_t = fam + " [" + name_t + "]" if (TIMER_TAGS and tag) else fam
         _TIMER_EVENTS.append((name_t, e0, e1, float(work)))
     else:
         rc = fn(*args)

@@ -9,6 +9,7 @@
 namespace m355 {
 
 void set_error(const char *fmt, ...);
+void note_kernel(const char *name);  // records which kernel family an entry point dispatched to (m355_last_kernel)
 
 inline int check_launch(const char *what)
 {

@@ -297,9 +297,9 @@ bool conv_halo_eligible(const ConvArgs &a)
     if (a.ncls > 1)
         for (int c = 0; c < a.ncls; ++c)
             if (a.ups) return false;
-    // measured (profiles/r01_conv_halo_ab.txt): the 4-wave variant (Cout <= 64: one workgroup of 4 waves per CU, nothing
-    // to hide its prologue / epilogue behind) only pays when a tile carries enough work -- 3x3 with >= 2 channel chunks
-    if (rows_le64(a.Cout) && !(a.KH == 3 && a.Cin >= 128) && !getenv("M355_HALO_ALL")) return false;
+    // (measured, profiles/r01_conv_halo_ab.txt: with the single-instruction bf16 packing in the epilogue the 4-wave variant
+    // for Cout <= 64 wins too: G.blk6.conv2 605 -> 657 TF, D.conv2 dgrad 518 -> 616 TF)
+    if (getenv("M355_HALO_8W_ONLY") && rows_le64(a.Cout)) return false;
     return true;
 }
 
@@ -336,6 +336,7 @@ int conv_halo_launch(const ConvArgs &a, unsigned xb, unsigned wb, hipStream_t st
 #undef M355_HK
 #undef M355_HM
 #undef M355_HL
+    note_kernel("k_conv_halo");
     return check_launch("conv2d (halo)");
 }
 

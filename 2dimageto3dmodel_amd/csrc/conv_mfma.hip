@@ -510,6 +510,7 @@ static int launch_conv(ConvArgs a, hipStream_t st)
 #undef M355_TILE
 #undef M355_MODES
 #undef M355_GO
+        note_kernel("k_conv_glds");
         return check_launch("conv2d (dma)");
     }
     if (a.ncls != 1) {
@@ -518,6 +519,7 @@ static int launch_conv(ConvArgs a, hipStream_t st)
     }
     dim3 grid((M + BM - 1) / BM, a.CoutP / BN);
     hipLaunchKernelGGL(k_conv_mfma, grid, dim3(256), 0, st, a);
+    note_kernel("k_conv_mfma");
     return check_launch("conv2d");
 }
 
@@ -1148,6 +1150,7 @@ extern "C" int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const v
         if (TM == 128) M355_WG(128, 128);
         else M355_WG(64, 256);
 #undef M355_WG
+        m355::note_kernel("k_wgrad_dma");
         return m355::check_launch("conv2d_wgrad (dma)");
     }
     const int TM = d->Cout > 64 ? 128 : 64;
@@ -1161,5 +1164,6 @@ extern "C" int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const v
     splits = (P + a.chunk - 1) / a.chunk;
     if (TM == 128) hipLaunchKernelGGL(m355::k_wgrad_mfma<128>, dim3(gx, gy, splits), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(m355::k_wgrad_mfma<64>, dim3(gx, gy, splits), dim3(256), 0, st, a);
+    m355::note_kernel("k_wgrad_mfma");
     return m355::check_launch("conv2d_wgrad");
 }

@@ -314,6 +314,7 @@ int wgrad_small_launch(const m355_conv_desc *d, const void *x, const void *dy, i
     if (d->kh == 5) M355_SW(5);
     else M355_SW(3);
 #undef M355_SW
+    note_kernel("k_wgrad_smallco");
     return check_launch("conv2d_wgrad (small Cout)");
 }
 
@@ -498,6 +499,7 @@ int conv_c8_launch(const m355_conv_desc *d, const void *x, const void *w_fwd, co
     if (d->pad_w_mode == 0) hipLaunchKernelGGL((k_conv_c8<0>), grid, dim3(256), 0, st, a);
     else if (d->pad_w_mode == 1) hipLaunchKernelGGL((k_conv_c8<1>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_conv_c8<2>), grid, dim3(256), 0, st, a);
+    note_kernel("k_conv_c8");
     return check_launch("conv2d_fwd (8 input channels)");
 }
 
@@ -542,6 +544,7 @@ int dgrad_small_launch(const m355_conv_desc *d, const void *dy, int Cy, const vo
         if (t.pad_w_mode == 0) hipLaunchKernelGGL((k_conv_smallco<3, 0>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_conv_smallco<3, 2>), grid, dim3(256), 0, st, a);
     }
+    note_kernel("k_conv_smallco");
     return check_launch("conv2d_dgrad (8 input channels)");
 }
 
@@ -568,6 +571,7 @@ int conv_small_launch(const m355_conv_desc *d, const void *x, const void *w_fwd,
     if (d->kh == 5) M355_SM(5);
     else M355_SM(3);
 #undef M355_SM
+    note_kernel("k_conv_smallco");
     return check_launch("conv2d_fwd (small Cout)");
 }
 

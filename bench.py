@@ -33,9 +33,6 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (2:1-sparsity marketing figure excluded)
-# entry point -> kernel family (what rocprofv3 lists; csrc/conv_mfma.hip)
-FAMILY = {"conv2d_fwd": "k_conv_glds (conv2d_fwd + conv2d_dgrad)", "conv2d_dgrad": "k_conv_glds (conv2d_fwd + conv2d_dgrad)",
-          "conv2d_wgrad": "k_wgrad_dma (conv2d_wgrad)"}
 
 
 def make_clouds(B, N, S, seed, device):
@@ -171,23 +168,21 @@ def main():
     pkg._lib.enable_kernel_timers(False)
 
     if rank == 0:
-        # conv2d_fwd and conv2d_dgrad launch the same implicit-GEMM kernel (k_conv_glds): one roofline family
-        fam = {}
-        for k, v in kt.items():
-            f = FAMILY.get(k, k)
-            c0, t0, w0 = fam.get(f, (0, 0.0, 0.0))
-            fam[f] = (c0 + v[0], t0 + v[1], w0 + v[2])
+        # the conv entry points are timed per KERNEL FAMILY they dispatched to (m355_last_kernel: k_conv_glds, k_conv_halo,
+        # k_wgrad_dma, ...), i.e. under the names rocprofv3 lists
+        fam = kt
         dom = max(fam, key=lambda k: fam[k][1])
         cnt, tot_ms, work = fam[dom]
         is_conv = dom.startswith("k_conv") or dom.startswith("k_wgrad")
-        traffic = None
+        traffic = rocprof_us = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):  # measured by separate rocprofv3 --pmc passes (scripts/make_profile.sh)
-            traffic = json.load(open(tpath)).get(dom.split(" ")[0], {}).get("hbm_bytes_per_launch")
+        if os.path.exists(tpath):  # measured by separate rocprofv3 passes (scripts/make_profile.sh)
+            e = json.load(open(tpath)).get(dom, {})
+            traffic, rocprof_us = e.get("hbm_bytes_per_launch"), e.get("rocprof_avg_us")
         rate = work / (tot_ms * 1e-3) / (1e12 if is_conv else 1e9)
         peak = MFMA_BF16_PEAK_TF if is_conv else HBM_PEAK_GBS
-        conv_ms = sum(v[1] for k, v in kt.items() if k.startswith("conv2d_") and k != "conv2d_weight_prep")
-        conv_fl = sum(v[2] for k, v in kt.items() if k.startswith("conv2d_") and k != "conv2d_weight_prep")
+        conv_ms = sum(v[1] for k, v in kt.items() if k.startswith("k_conv") or k.startswith("k_wgrad"))
+        conv_fl = sum(v[2] for k, v in kt.items() if k.startswith("k_conv") or k.startswith("k_wgrad"))
         workload = []
         if do_p:
             workload.append(f"projection+silhouette-loss fwd/bwd on {B} clouds/GPU of {N} pts -> {S}x{S}")
@@ -206,7 +201,8 @@ def main():
             "gan_samples_per_s": (world * 3 * B * args.steps / dt_g) if do_g else None,
             "roofline": {"bound": "mfma" if is_conv else "hbm", "kernel": dom, "achieved": rate, "peak": peak,
                          "unit": "TFLOP/s" if is_conv else "GB/s", "frac": rate / peak, "traffic": traffic,
-                         "avg_kernel_us": tot_ms / cnt * 1e3, "launches_per_step": cnt / args.steps,
+                         "avg_kernel_us": tot_ms / cnt * 1e3, "rocprof_avg_kernel_us": rocprof_us,
+                         "launches_per_step": cnt / args.steps,
                          "share_of_kernel_time": tot_ms / sum(v[1] for v in kt.values()),
                          "all_conv_tflops": (conv_fl / (conv_ms * 1e-3) / 1e12) if conv_ms else None,
                          "work_per_launch": work / cnt,

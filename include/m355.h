@@ -32,6 +32,8 @@ typedef enum {
 } m355_status;
 
 const char *m355_last_error(void);
+/* name of the kernel family the calling thread's last m355_conv2d_* call dispatched to (profiling aid) */
+const char *m355_last_kernel(void);
 int m355_abi_version(void);
 
 /* flags for the projection entry points */
