@@ -36,6 +36,9 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s4v lds_s4v;
+
 template <int N>
 __device__ __forceinline__ void wait_vm()
 {
@@ -284,6 +287,155 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
         tp = tp_next;
     }
     wait_vm<0>();  // the trailing (unused) prefetches
+}
+
+// =====================================================================================================
+// k_wgrad_halo: weight gradient of a stride-1 3x3 conv with ALL NINE TAPS per workgroup.
+//   dw[co][kh][kw][ci] = sum over pixels p of dy[p][co] * xpad[p + (kh,kw)][ci]
+// k_wgrad_dma gives every (tap, ci) column tile its own workgroup, so the same input pixels are gathered nine times
+// and the dy tile once per column tile: 15 bytes into LDS per kFLOP, and the kernel waits on the DMA 58 % of its
+// time (SQ_WAIT_ANY).  Here a workgroup owns (64 output channels) x (64 input channels) x all 9 taps and walks 8 x 32
+// pixel tiles: per tile the dy tile (256 px x 64 co) and the x halo (10 x 34 px x 64 ci) are DMA'd ONCE (4 B / kFLOP),
+// double buffered one tile ahead; the nine 64 x 64 accumulators live in registers across all the tiles of the
+// workgroup (8 waves = 2 co halves x 2 ci halves x 2 tap groups, one 32 x 32 accumulator per tap), fragments by
+// ds_read_b64_tr_b16 (pixel axis = K for both operands); split-K over workgroups, fp32 atomics at the end.
+template <int UPS, int MODE>
+__global__ __launch_bounds__(512, 2) void k_wgrad_halo(WgradArgs a, unsigned xbytes, unsigned ybytes)
+{
+    constexpr int TH = 8, TW = 32, KS = 3, T = 9, NW = 8, NT = 5;   // NT: taps per tap group (5 + 4)
+    constexpr int HH = UPS ? TH / 2 + 2 : TH + KS - 1, HWD = UPS ? TW / 2 + 2 : TW + KS - 1, HR = HH * HWD;
+    constexpr int NAX = ((HR + 7) / 8 + NW - 1) / NW;   // x-halo DMA slots per wave
+    constexpr int NAY = 4;                               // dy tile: 32 instructions / 8 waves
+    constexpr int XBUF = NW * NAX * 1024, YBUF = 256 * 128, STAGE = XBUF + YBUF;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nci = a.Cin >> 6;
+    const int co0 = (blockIdx.y / nci) * 64, ci0 = (blockIdx.y % nci) * 64;
+    const int tpx = a.Wo / TW, tpy = a.Ho / TH, tiles = a.N * tpx * tpy;
+    if ((int)blockIdx.x >= tiles) return;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, ybytes, 0x00020000);
+
+    // DMA roles: 128-byte LDS rows (64 channels); row r of an instruction q: r = 8q + (lane>>3), slot lane&7 holds source
+    // chunk (lane&7) ^ 4*((r>>1)&1) = (lane&7) ^ 4*((lane>>4)&1)  (transpose-read bank spreading, as k_wgrad_dma)
+    const int csrc = (lane & 7) ^ (((lane >> 4) & 1) << 2);
+    auto issue = [&](int tile, int buf) {
+        const int n = tile / (tpx * tpy), rem = tile - n * (tpx * tpy);
+        const int oy0 = (rem / tpx) * TH, ox0 = (rem % tpx) * TW;
+        unsigned char *dX = lds + buf * STAGE, *dY = dX + XBUF;
+        const int Y0 = UPS ? (oy0 - a.pad_h) >> 1 : oy0 - a.pad_h, X0 = UPS ? (ox0 - a.pad_w) >> 1 : ox0 - a.pad_w;
+#pragma unroll
+        for (int k = 0; k < NAX; ++k) {
+            const int rho = 8 * (NW * k + wave) + (lane >> 3);
+            const int hy = rho / HWD, hx = rho - hy * HWD;
+            const int iy = Y0 + hy;
+            int ix = X0 + hx;
+            bool ok = rho < HR && (unsigned)iy < (unsigned)a.H;
+            if (MODE == 1) ix = min(max(ix, 0), a.W - 1);
+            else if (MODE == 2) ix = ix < 0 ? ix + a.W : (ix >= a.W ? ix - a.W : ix);
+            ok = ok && (unsigned)ix < (unsigned)a.W;
+            dma16(rx, dX + (NW * k + wave) * 1024, ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin + ci0) * 2 + csrc * 16) : OOB, 0u);
+        }
+#pragma unroll
+        for (int k = 0; k < NAY; ++k) {
+            const int p = 8 * (NW * k + wave) + (lane >> 3);  // tile pixel = (p >> 5, p & 31)
+            const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
+            dma16(ry, dY + (NW * k + wave) * 1024, (unsigned)((((n * a.Ho + oy) * a.Wo + ox) * a.Cy + co0) * 2 + csrc * 16), 0u);
+        }
+    };
+
+    // fragment roles
+    const int w_co = wave & 1, w_ci = (wave >> 1) & 1, w_tg = wave >> 2;
+    const int q = lane & 15, g16 = (lane >> 4) & 1, hh = lane >> 5;
+    const int ey = UPS ? ((0 - a.pad_h) & 1) : 0, ex = UPS ? ((0 - a.pad_w) & 1) : 0;
+    // dy^T (A operand): chunk of this lane's 4 output channels, swizzle 4*((p>>1)&1) = 4*((q>>3)&1)
+    const int ya = (((w_co * 4 + g16 * 2 + ((q & 3) >> 1)) ^ (((q >> 3) & 1) << 2)) << 4) + (q & 1) * 8 + (8 * hh + (q >> 2)) * 128;
+    const int xchunk = w_ci * 4 + g16 * 2 + ((q & 3) >> 1);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    int buf = 0;
+    issue(blockIdx.x, 0);
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this tile's DMAs (issued one tile ago)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (tile + (int)gridDim.x < tiles) issue(tile + gridDim.x, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char *bx = lds + buf * STAGE, *by = bx + XBUF;
+#pragma unroll 2
+        for (int kg = 0; kg < 16; ++kg) {  // K group = 16 pixels: tile row kg>>1, columns 16(kg&1) .. +15
+            const s4v y0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v *)(by + ya + kg * 2048));
+            const s4v y1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v *)(by + ya + kg * 2048 + 512));
+            const bf16x8 yf = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+            const int ty = kg >> 1, txb = (kg & 1) * 16 + 8 * hh + (q >> 2);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int tap = w_tg * NT + t;   // (the 10th slot, tap 9, does not exist)
+                if (tap < T) {
+                    const int kh = tap / KS, kw = tap - kh * KS;
+                    const int ly = ty + kh;
+                    s4v x01[2];
+#pragma unroll
+                    for (int rd = 0; rd < 2; ++rd) {
+                        const int lx = txb + 4 * rd + kw;
+                        const int rho = UPS ? ((ly + ey) >> 1) * HWD + ((lx + ex) >> 1) : ly * HWD + lx;
+                        x01[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (lds_s4v *)(bx + rho * 128 + ((xchunk ^ (((rho >> 1) & 1) << 2)) << 4) + (q & 1) * 8));
+                    }
+                    const bf16x8 xf = __builtin_shufflevector(x01[0], x01[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf, xf, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // acc[t][r]: co = co0 + 32 w_co + (r&3) + 8(r>>2) + 4(lane>>5), ci = ci0 + 32 w_ci + (lane&31), tap = w_tg*NT + t
+    const int K = T * a.Cin;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tap = w_tg * NT + t;
+        if (tap < T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + 32 * w_co + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < a.Cout) atomicAdd(a.dw + (size_t)co * K + tap * a.Cin + ci0 + 32 * w_ci + (lane & 31), acc[t][r]);
+            }
+        }
+    }
+}
+
+bool wgrad_halo_eligible(const WgradArgs &a)
+{
+    if (a.stride != 1 || a.KH != 3 || a.KW != 3 || a.pad_h != 1 || a.pad_w != 1) return false;
+    if (a.Cin % 64 || a.Cy % 64 || a.Wo % 32 || a.Ho % 8) return false;
+    return !getenv("M355_NO_WGRAD_HALO");
+}
+
+int wgrad_halo_launch(const WgradArgs &a, unsigned xb, unsigned yb, hipStream_t st)
+{
+    const int tiles = a.N * (a.Ho / 8) * (a.Wo / 32);
+    const int ny = ((a.Cout + 63) / 64) * (a.Cin / 64);
+    int per = 256 / ny;  // one 8-wave workgroup per CU; each walks a strided list of pixel tiles (split K)
+    if (per < 1) per = 1;
+    if (per > tiles) per = tiles;
+    const dim3 grid(per, ny);
+#define M355_WH(UPS_)                                                                                             \
+    do {                                                                                                          \
+        if (a.pad_w_mode == 0) hipLaunchKernelGGL((k_wgrad_halo<UPS_, 0>), grid, dim3(512), 0, st, a, xb, yb);     \
+        else if (a.pad_w_mode == 1) hipLaunchKernelGGL((k_wgrad_halo<UPS_, 1>), grid, dim3(512), 0, st, a, xb, yb); \
+        else hipLaunchKernelGGL((k_wgrad_halo<UPS_, 2>), grid, dim3(512), 0, st, a, xb, yb);                        \
+    } while (0)
+    if (a.ups) M355_WH(1);
+    else M355_WH(0);
+#undef M355_WH
+    note_kernel("k_wgrad_halo");
+    return check_launch("conv2d_wgrad (halo)");
 }
 
 // host side (called from launch_conv, conv_mfma.hip)

@@ -452,6 +452,9 @@ static inline int dy_channels(int cout) { return cout <= 8 ? 8 : (cout + 31) / 3
 bool conv_halo_eligible(const ConvArgs &a);  // csrc/conv_halo.hip
 int conv_halo_launch(const ConvArgs &a, unsigned xb, unsigned wb, hipStream_t st);
 
+bool wgrad_halo_eligible(const WgradArgs &a);  // csrc/conv_halo.hip
+int wgrad_halo_launch(const WgradArgs &a, unsigned xb, unsigned yb, hipStream_t st);
+
 static bool dma_eligible(const ConvArgs &a)
 {
     const size_t xbytes = (size_t)a.N * a.H * a.W * a.Cin * 2, wbytes = (size_t)rows_padded(a.Cout) * a.Kp * 2;
@@ -794,16 +797,6 @@ namespace m355 {
 constexpr int WN = 128, WK = 64;
 constexpr int WLD = WK + 8;  // LDS row pitch in bf16 (144 bytes)
 
-struct WgradArgs {
-    const unsigned short *x;   // bf16 NHWC [N,H,W,Cin]
-    const unsigned short *dy;  // bf16 NHWC [N,Ho,Wo,Cy]
-    float *dw;                 // fp32 [Cout][KH][KW][Cin], pre-zeroed
-    float *db;                 // k_wgrad_dma only, nullable: fp32 [Cout] += column sums of dy (bias gradient), pre-zeroed
-    int N, H, W, Cin, Hl, Wl, ups;
-    int Ho, Wo, Cout, Cy;
-    int KH, KW, stride, pad_h, pad_w, pad_w_mode;
-    int chunk;  // pixels per z-slice (multiple of WK)
-};
 
 // 4 granules (pixels q..q+3, channels c..c+7) -> 8 x 8 bytes: for channel j the 4 pixel values
 __device__ __forceinline__ void transpose_store(const bf16x8 (&g)[4], unsigned short *row0 /* &T[c][4*pq] */)
@@ -1129,6 +1122,8 @@ extern "C" int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const v
     if (m355::wgrad_small_eligible(d, a.Cy)) return m355::wgrad_small_launch(d, x, dy, a.Cy, dw, st);
     const size_t xbytes = (size_t)d->N * d->H * d->W * d->Cin * 2, ybytes = (size_t)P * a.Cy * 2;
     const int lgWo = m355::ilog2_exact(a.Wo), lgHo = m355::ilog2_exact(a.Ho);
+    if (wgrad_dma_ok(d) && !dbias && m355::wgrad_halo_eligible(a))
+        return m355::wgrad_halo_launch(a, (unsigned)xbytes, (unsigned)ybytes, st);
     if (wgrad_dma_ok(d)) {
         const int TM = d->Cout > 64 ? 128 : 64, TN = d->Cout > 64 ? 128 : 256;
         const int gx = (d->Cout + TM - 1) / TM, gy = (K + TN - 1) / TN;
