@@ -70,7 +70,7 @@ struct WgradArgs {
     const unsigned short *x;   // bf16 NHWC [N,H,W,Cin]
     const unsigned short *dy;  // bf16 NHWC [N,Ho,Wo,Cy]
     float *dw;                 // fp32 [Cout][KH][KW][Cin], pre-zeroed
-    float *db;                 // k_wgrad_dma only, nullable: fp32 [Cout] += column sums of dy (bias gradient), pre-zeroed
+    float *db;                 // k_wgrad_dma / k_wgrad_halo, nullable: fp32 [Cout] += column sums of dy (bias gradient), pre-zeroed
     int N, H, W, Cin, Hl, Wl, ups;
     int Ho, Wo, Cout, Cy;
     int KH, KW, stride, pad_h, pad_w, pad_w_mode;

@@ -299,20 +299,29 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
 // double buffered one tile ahead; the nine 64 x 64 accumulators live in registers across all the tiles of the
 // workgroup (8 waves = 2 co halves x 2 ci halves x 2 tap groups, one 32 x 32 accumulator per tap), fragments by
 // ds_read_b64_tr_b16 (pixel axis = K for both operands); split-K over workgroups, fp32 atomics at the end.
-template <int UPS, int MODE>
+// KS = 3: stride-1 3x3 (generator), tap groups split over the two wave quartets (5 + 4 taps, one accumulator each).
+// KS = 2: one PARITY CLASS (blockIdx.z = 2p+q) of a stride-2 4x4 conv (discriminators): with X_pq[i][j] = xpad[2i+p][2j+q]
+//         dw[co][2a+p][2b+q][ci] = sum_o dy[o][co] * X_pq[o + (a,b)][ci]   -- a stride-1 2x2 all-taps problem on a plane
+//         of x that the DMA addresses with pixel stride 2; each wave holds all 4 taps and the two wave quartets split
+//         the tile's pixels (both add their partial sums atomically).
+template <int KS, int UPS, int MODE>
 __global__ __launch_bounds__(512, 2) void k_wgrad_halo(WgradArgs a, unsigned xbytes, unsigned ybytes)
 {
-    constexpr int TH = 8, TW = 32, KS = 3, T = 9, NW = 8, NT = 5;   // NT: taps per tap group (5 + 4)
+    constexpr int TH = 8, TW = 32, T = KS * KS, NW = 8;
+    constexpr int NT = KS == 3 ? 5 : 4;                  // accumulators per wave
+    constexpr int SUB = KS == 2 ? 2 : 1;                 // input pixel stride of the plane
     constexpr int HH = UPS ? TH / 2 + 2 : TH + KS - 1, HWD = UPS ? TW / 2 + 2 : TW + KS - 1, HR = HH * HWD;
     constexpr int NAX = ((HR + 7) / 8 + NW - 1) / NW;   // x-halo DMA slots per wave
     constexpr int NAY = 4;                               // dy tile: 32 instructions / 8 waves
     constexpr int XBUF = NW * NAX * 1024, YBUF = 256 * 128, STAGE = XBUF + YBUF;
+    static_assert(!(UPS && KS == 2), "no upsample with classes");
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nci = a.Cin >> 6;
     const int co0 = (blockIdx.y / nci) * 64, ci0 = (blockIdx.y % nci) * 64;
+    const int cp = KS == 2 ? (int)blockIdx.z >> 1 : 0, cq = KS == 2 ? (int)blockIdx.z & 1 : 0;  // parity class
     const int tpx = a.Wo / TW, tpy = a.Ho / TH, tiles = a.N * tpx * tpy;
     if ((int)blockIdx.x >= tiles) return;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, xbytes, 0x00020000);
@@ -325,13 +334,15 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_halo(WgradArgs a, unsigned xby
         const int n = tile / (tpx * tpy), rem = tile - n * (tpx * tpy);
         const int oy0 = (rem / tpx) * TH, ox0 = (rem % tpx) * TW;
         unsigned char *dX = lds + buf * STAGE, *dY = dX + XBUF;
-        const int Y0 = UPS ? (oy0 - a.pad_h) >> 1 : oy0 - a.pad_h, X0 = UPS ? (ox0 - a.pad_w) >> 1 : ox0 - a.pad_w;
+        // plane coordinates of halo pixel (0,0); image pixel = SUB * plane + class offset - pad
+        const int Y0 = UPS ? (oy0 - a.pad_h) >> 1 : (SUB == 2 ? oy0 : oy0 - a.pad_h);
+        const int X0 = UPS ? (ox0 - a.pad_w) >> 1 : (SUB == 2 ? ox0 : ox0 - a.pad_w);
 #pragma unroll
         for (int k = 0; k < NAX; ++k) {
             const int rho = 8 * (NW * k + wave) + (lane >> 3);
             const int hy = rho / HWD, hx = rho - hy * HWD;
-            const int iy = Y0 + hy;
-            int ix = X0 + hx;
+            const int iy = SUB == 2 ? 2 * (Y0 + hy) + cp - a.pad_h : Y0 + hy;
+            int ix = SUB == 2 ? 2 * (X0 + hx) + cq - a.pad_w : X0 + hx;
             bool ok = rho < HR && (unsigned)iy < (unsigned)a.H;
             if (MODE == 1) ix = min(max(ix, 0), a.W - 1);
             else if (MODE == 2) ix = ix < 0 ? ix + a.W : (ix >= a.W ? ix - a.W : ix);
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_halo(WgradArgs a, unsigned xby
     };
 
     // fragment roles
-    const int w_co = wave & 1, w_ci = (wave >> 1) & 1, w_tg = wave >> 2;
+    const int w_co = wave & 1, w_ci = (wave >> 1) & 1, w_hi = wave >> 2;  // w_hi: tap group (KS 3) / pixel half (KS 2)
     const int q = lane & 15, g16 = (lane >> 4) & 1, hh = lane >> 5;
     const int ey = UPS ? ((0 - a.pad_h) & 1) : 0, ex = UPS ? ((0 - a.pad_w) & 1) : 0;
     // dy^T (A operand): chunk of this lane's 4 output channels, swizzle 4*((p>>1)&1) = 4*((q>>3)&1)
@@ -360,6 +371,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_halo(WgradArgs a, unsigned xby
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
+    // bias gradient (column sums of dy) by the workgroups of the first ci tile / class: thread -> channel tid % 64,
+    // pixels 32 (tid / 64) .. +31 of every tile
+    const bool do_db = a.db != nullptr && (blockIdx.y % nci) == 0 && blockIdx.z == 0;
+    const int dbc = tid & 63, dbq = tid >> 6;
+    float dbacc = 0.0f;
+
     int buf = 0;
     issue(blockIdx.x, 0);
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x, buf ^= 1) {
@@ -369,15 +386,23 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_halo(WgradArgs a, unsigned xby
         if (tile + (int)gridDim.x < tiles) issue(tile + gridDim.x, buf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char *bx = lds + buf * STAGE, *by = bx + XBUF;
+        if (do_db) {
+#pragma unroll 8
+            for (int pp = 0; pp < 32; ++pp) {
+                const int prow = dbq * 32 + pp;
+                dbacc += bf2f(*reinterpret_cast<const unsigned short *>(by + prow * 128 + (((dbc >> 3) ^ (((prow >> 1) & 1) << 2)) << 4) + (dbc & 7) * 2));
+            }
+        }
+        const int kg0 = KS == 2 ? 8 * w_hi : 0, kg1 = KS == 2 ? kg0 + 8 : 16;
 #pragma unroll 2
-        for (int kg = 0; kg < 16; ++kg) {  // K group = 16 pixels: tile row kg>>1, columns 16(kg&1) .. +15
+        for (int kg = kg0; kg < kg1; ++kg) {  // K group = 16 pixels: tile row kg>>1, columns 16(kg&1) .. +15
             const s4v y0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v *)(by + ya + kg * 2048));
             const s4v y1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v *)(by + ya + kg * 2048 + 512));
             const bf16x8 yf = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
             const int ty = kg >> 1, txb = (kg & 1) * 16 + 8 * hh + (q >> 2);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int tap = w_tg * NT + t;   // (the 10th slot, tap 9, does not exist)
+                const int tap = KS == 3 ? w_hi * NT + t : t;   // (KS 3: the 10th slot, tap 9, does not exist)
                 if (tap < T) {
                     const int kh = tap / KS, kw = tap - kh * KS;
                     const int ly = ty + kh;
@@ -395,16 +420,19 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_halo(WgradArgs a, unsigned xby
             }
         }
     }
-    // acc[t][r]: co = co0 + 32 w_co + (r&3) + 8(r>>2) + 4(lane>>5), ci = ci0 + 32 w_ci + (lane&31), tap = w_tg*NT + t
-    const int K = T * a.Cin;
+    if (do_db && co0 + dbc < a.Cout) atomicAdd(a.db + co0 + dbc, dbacc);
+    // acc[t][r]: co = co0 + 32 w_co + (r&3) + 8(r>>2) + 4(lane>>5), ci = ci0 + 32 w_ci + (lane&31)
+    const int K = a.KH * a.KW * a.Cin;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int tap = w_tg * NT + t;
+        const int tap = KS == 3 ? w_hi * NT + t : t;
         if (tap < T) {
+            const int kh = KS == 3 ? tap / 3 : 2 * (tap >> 1) + cp, kw = KS == 3 ? tap % 3 : 2 * (tap & 1) + cq;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + 32 * w_co + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < a.Cout) atomicAdd(a.dw + (size_t)co * K + tap * a.Cin + ci0 + 32 * w_ci + (lane & 31), acc[t][r]);
+                if (co < a.Cout)
+                    atomicAdd(a.dw + (size_t)co * K + (kh * a.KW + kw) * a.Cin + ci0 + 32 * w_ci + (lane & 31), acc[t][r]);
             }
         }
     }
@@ -412,27 +440,32 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_halo(WgradArgs a, unsigned xby
 
 bool wgrad_halo_eligible(const WgradArgs &a)
 {
-    if (a.stride != 1 || a.KH != 3 || a.KW != 3 || a.pad_h != 1 || a.pad_w != 1) return false;
+    if (getenv("M355_NO_WGRAD_HALO")) return false;
     if (a.Cin % 64 || a.Cy % 64 || a.Wo % 32 || a.Ho % 8) return false;
-    return !getenv("M355_NO_WGRAD_HALO");
+    if (a.stride == 1) return a.KH == 3 && a.KW == 3 && a.pad_h == 1 && a.pad_w == 1;
+    // parity classes of a 4x4 stride-2 conv: measured +45 % on D.conv2 (64 input channels), -5..-10 % on D.conv3 / conv4
+    // (their 128-wide k_wgrad_dma tiles already amortise the gathers): only for Cin <= 64
+    return a.stride == 2 && a.KH == 4 && a.KW == 4 && !a.ups && a.H == 2 * a.Ho && a.W == 2 * a.Wo &&
+           (a.Cin <= 64 || getenv("M355_WGRAD_HALO_ALL"));
 }
 
 int wgrad_halo_launch(const WgradArgs &a, unsigned xb, unsigned yb, hipStream_t st)
 {
     const int tiles = a.N * (a.Ho / 8) * (a.Wo / 32);
-    const int ny = ((a.Cout + 63) / 64) * (a.Cin / 64);
-    int per = 256 / ny;  // one 8-wave workgroup per CU; each walks a strided list of pixel tiles (split K)
+    const int ny = ((a.Cout + 63) / 64) * (a.Cin / 64), ncls = a.stride == 2 ? 4 : 1;
+    int per = 256 / (ny * ncls);  // one 8-wave workgroup per CU; each walks a strided list of pixel tiles (split K)
     if (per < 1) per = 1;
     if (per > tiles) per = tiles;
-    const dim3 grid(per, ny);
-#define M355_WH(UPS_)                                                                                             \
-    do {                                                                                                          \
-        if (a.pad_w_mode == 0) hipLaunchKernelGGL((k_wgrad_halo<UPS_, 0>), grid, dim3(512), 0, st, a, xb, yb);     \
-        else if (a.pad_w_mode == 1) hipLaunchKernelGGL((k_wgrad_halo<UPS_, 1>), grid, dim3(512), 0, st, a, xb, yb); \
-        else hipLaunchKernelGGL((k_wgrad_halo<UPS_, 2>), grid, dim3(512), 0, st, a, xb, yb);                        \
+    const dim3 grid(per, ny, ncls);
+#define M355_WH(KS_, UPS_)                                                                                              \
+    do {                                                                                                                \
+        if (a.pad_w_mode == 0) hipLaunchKernelGGL((k_wgrad_halo<KS_, UPS_, 0>), grid, dim3(512), 0, st, a, xb, yb);     \
+        else if (a.pad_w_mode == 1) hipLaunchKernelGGL((k_wgrad_halo<KS_, UPS_, 1>), grid, dim3(512), 0, st, a, xb, yb); \
+        else hipLaunchKernelGGL((k_wgrad_halo<KS_, UPS_, 2>), grid, dim3(512), 0, st, a, xb, yb);                        \
     } while (0)
-    if (a.ups) M355_WH(1);
-    else M355_WH(0);
+    if (a.stride == 2) M355_WH(2, 0);
+    else if (a.ups) M355_WH(3, 1);
+    else M355_WH(3, 0);
 #undef M355_WH
     note_kernel("k_wgrad_halo");
     return check_launch("conv2d_wgrad (halo)");

@@ -1122,7 +1122,7 @@ extern "C" int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const v
     if (m355::wgrad_small_eligible(d, a.Cy)) return m355::wgrad_small_launch(d, x, dy, a.Cy, dw, st);
     const size_t xbytes = (size_t)d->N * d->H * d->W * d->Cin * 2, ybytes = (size_t)P * a.Cy * 2;
     const int lgWo = m355::ilog2_exact(a.Wo), lgHo = m355::ilog2_exact(a.Ho);
-    if (wgrad_dma_ok(d) && !dbias && m355::wgrad_halo_eligible(a))
+    if (wgrad_dma_ok(d) && m355::wgrad_halo_eligible(a))
         return m355::wgrad_halo_launch(a, (unsigned)xbytes, (unsigned)ybytes, st);
     if (wgrad_dma_ok(d)) {
         const int TM = d->Cout > 64 ? 128 : 64, TN = d->Cout > 64 ? 128 : 256;
