@@ -45,9 +45,15 @@ __device__ __forceinline__ void wait_vm()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BN, int NW, int KS, int UPS, int MODE>
+// SUB = 2: FORWARD of a 4x4 stride-2 conv (discriminators) as the sum of four 2x2 stride-1 convs on the parity planes
+// X_pq[i][j] = xpad[2i+p][2j+q] of the input: out[o] = sum_{p,q} sum_{a,b} X_pq[o+(a,b)] . W[2a+p][2b+q].  The segment
+// stream of a tile is then (class, channel chunk) instead of (channel chunk): each segment has its own halo (the DMA
+// addresses the plane with pixel stride 2) and all of them accumulate into the same output tile.
+template <int BN, int NW, int KS, int UPS, int MODE, int SUB = 1>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs a, unsigned xbytes, unsigned wbytes)
 {
+    static_assert(SUB == 1 || (KS == 2 && !UPS), "stride-2 forward = 2x2 classes");
+    constexpr int NC = SUB == 2 ? 4 : 1;  // classes accumulated into one output tile
     constexpr int TH = 8, TW = 32;
     constexpr int T = KS * KS;
     constexpr int HH = UPS ? TH / 2 + 2 : TH + KS - 1;   // halo rows / columns (stored pixels)
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
         oy0 = (trem / tpx) * TH;
         ox0 = (trem % tpx) * TW;
     };
-    auto compute_aoff = [&](int tp) {
+    auto compute_aoff = [&](int tp, int cls) {
         int n, oy0, ox0;
         tile_origin(tp, n, oy0, ox0);
         const int Y0 = UPS ? (oy0 - pad_h) >> 1 : oy0 - pad_h, X0 = UPS ? (ox0 - pad_w) >> 1 : ox0 - pad_w;
@@ -103,8 +109,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
         for (int k = 0; k < NAW; ++k) {
             const int rho = 8 * (NW * k + wave) + (lane >> 3);
             const int hy = rho / HWD, hx = rho - hy * HWD;
-            const int iy = Y0 + hy;
-            int ix = X0 + hx;
+            // SUB 2: plane pixel (oy0 + hy, ox0 + hx) of class (cls>>1, cls&1) = image pixel 2*plane + class - pad
+            const int iy = SUB == 2 ? 2 * (oy0 + hy) + (cls >> 1) - pad_h : Y0 + hy;
+            int ix = SUB == 2 ? 2 * (ox0 + hx) + (cls & 1) - pad_w : X0 + hx;
             bool ok = rho < HR && (unsigned)iy < (unsigned)a.H;
             if (MODE == 1) ix = min(max(ix, 0), a.W - 1);
             else if (MODE == 2) ix = ix < 0 ? ix + a.W : (ix >= a.W ? ix - a.W : ix);
@@ -116,13 +123,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
 #pragma unroll
     for (int j = 0; j < NBW; ++j) wrow[j] = (unsigned)(n0 + 8 * (NW * j + wave) + (lane >> 3)) * (unsigned)(a.Kp * 2) + csrc * 16;
 
-    const int ncc = a.Cin >> 6, S = ncc * T;
+    const int ncc = a.Cin >> 6, NSEG = NC * ncc, S = NSEG * T;
 
-    // weights of step s of a tile (= chunk s / T, tap s % T) -> ring slot; steps >= S are the next tile's first ones
+    // weights of step s of a tile (= segment s / T, tap s % T) -> ring slot; steps >= S are the next tile's first ones
     auto issue_B = [&](int s, int slot) {
         if (s >= S) s -= S;
-        const int cc = s / T, tap = s - cc * T;
-        const unsigned so = (unsigned)((tap * a.Cin + cc * 64) * 2);
+        const int sg = s / T, tap = s - sg * T;
+        const int cls = sg / ncc, cc = sg - cls * ncc;
+        // SUB 2: tap (a,b) of class (p,q) is the conv's tap (2a+p, 2b+q); the weight view is ordered (kh, kw, ci)
+        const int ktap = SUB == 2 ? (2 * (tap >> 1) + (cls >> 1)) * 4 + 2 * (tap & 1) + (cls & 1) : tap;
+        const unsigned so = (unsigned)((ktap * a.Cin + cc * 64) * 2);
 #pragma unroll
         for (int j = 0; j < NBW; ++j) dma16(rw, ldsB + slot * BBUF + (NW * j + wave) * 1024, wrow[j], so);
     };
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
 
     // ---- prologue: the whole first halo of the first tile, then the two weight steps the loop expects in flight
     int tp = bp;
-    compute_aoff(tp);
+    compute_aoff(tp, 0);
 #pragma unroll
     for (int k = 0; k < NAW; ++k) dma16(rx, lds + (NW * k + wave) * 1024, aoff[k], 0u);
     issue_B(0, 0);
@@ -168,15 +178,21 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
         tile_origin(tp, n, oy0, ox0);
         const int tp_next = tp + PS;
         const bool has_next = tp_next < tiles_p;
-        for (int cc = 0; cc < ncc; ++cc) {
+        for (int sg = 0; sg < NSEG; ++sg) {
             const unsigned char *ha = lds + hb * ABUF;
-            // what the slices of this chunk prefetch: the tile's next chunk, else the next tile's chunk 0 (new offsets:
-            // this tile's own halo loads have all been issued by now), else (nothing left) the current chunk again
-            int chunk_next = cc + 1;
-            if (cc == ncc - 1) {
-                chunk_next = has_next ? 0 : cc;
-                if (has_next) compute_aoff(tp_next);
+            // what the slices of this segment prefetch: the tile's next segment (new offsets when the class changes),
+            // else the next tile's first segment (this tile's own halo loads have all been issued by now), else (nothing
+            // left) the current segment again
+            int chunk_next;
+            if (sg + 1 < NSEG) {
+                const int cls_n = (sg + 1) / ncc;
+                chunk_next = (sg + 1) - cls_n * ncc;
+                if (NC > 1 && chunk_next == 0) compute_aoff(tp, cls_n);
+            } else {
+                chunk_next = has_next ? 0 : (sg % ncc);
+                if (has_next) compute_aoff(tp_next, 0);
             }
+            const int cc = sg;  // (step index base below)
             static_for<0, T>([&](auto tapc) {
                 constexpr int tap = decltype(tapc)::value;
                 const int s = cc * T + tap;
@@ -476,6 +492,11 @@ static inline bool rows_le64(int cout) { return cout <= 64; }
 
 bool conv_halo_eligible(const ConvArgs &a)
 {
+    if (a.stride == 2) {  // forward of a 4x4 stride-2 conv = four accumulated 2x2 class convs on planes of the input
+        return !a.y_f32_nchw && a.KH == 4 && a.KW == 4 && a.pad_h == 1 && a.pad_w == 1 && !a.ups && a.ncls <= 1 &&
+               a.Cin % 64 == 0 && a.Wo % 32 == 0 && a.Ho % 8 == 0 && a.H == 2 * a.Ho && a.W == 2 * a.Wo && a.Cout % 8 == 0 &&
+               a.Cs % 8 == 0 && !getenv("M355_NO_HALO_S2");
+    }
     if (a.y_f32_nchw || a.stride != 1 || a.KH != a.KW || (a.KH != 2 && a.KH != 3)) return false;
     if (a.ups && (a.KH != 3 || a.pad_h != 1 || a.pad_w != 1)) return false;
     if (a.Cin % 64 || a.Wo % 32 || a.Ho % 8 || a.Cout % 8 || a.Cs % 8) return false;
@@ -509,9 +530,16 @@ int conv_halo_launch(const ConvArgs &a, unsigned xb, unsigned wb, hipStream_t st
         else if (a.pad_w_mode == 1) M355_HL(BN_, NW_, KS_, UPS_, 1);   \
         else M355_HL(BN_, NW_, KS_, UPS_, 2);                          \
     } while (0)
+#define M355_HS2(BN_, NW_)                                                                                       \
+    do {                                                                                                         \
+        if (a.pad_w_mode == 0) hipLaunchKernelGGL((k_conv_halo<BN_, NW_, 2, 0, 0, 2>), grid, dim3(NW_ * 64), 0, st, a, xb, wb);      \
+        else if (a.pad_w_mode == 1) hipLaunchKernelGGL((k_conv_halo<BN_, NW_, 2, 0, 1, 2>), grid, dim3(NW_ * 64), 0, st, a, xb, wb); \
+        else hipLaunchKernelGGL((k_conv_halo<BN_, NW_, 2, 0, 2, 2>), grid, dim3(NW_ * 64), 0, st, a, xb, wb);                        \
+    } while (0)
 #define M355_HK(BN_, NW_)                                              \
     do {                                                               \
-        if (a.KH == 2) M355_HM(BN_, NW_, 2, 0);                        \
+        if (a.stride == 2) M355_HS2(BN_, NW_);                         \
+        else if (a.KH == 2) M355_HM(BN_, NW_, 2, 0);                   \
         else if (a.ups) M355_HM(BN_, NW_, 3, 1);                       \
         else M355_HM(BN_, NW_, 3, 0);                                  \
     } while (0)
@@ -519,6 +547,7 @@ int conv_halo_launch(const ConvArgs &a, unsigned xb, unsigned wb, hipStream_t st
     if (a.CoutP == 64) M355_HK(64, 4);
     else M355_HK(128, 8);
 #undef M355_HK
+#undef M355_HS2
 #undef M355_HM
 #undef M355_HL
     note_kernel("k_conv_halo");
