@@ -40,6 +40,7 @@ SIGNATURES = {
     "m355_chamfer_nn_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "m355_conv2d_out_hw": (c_int, [_P, _P, _P]),
     "m355_conv2d_dy_channels": (c_int, [c_int]),
+    "m355_fold2x2": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "m355_conv2d_weight_elems": (c_size_t, [_P, c_int]),
     "m355_conv2d_weight_prep": (c_int, [_P, _P, c_int, _P, _P, _P, _P]),
     "m355_conv2d_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P]),
@@ -50,7 +51,7 @@ SIGNATURES = {
     "m355_chan_reduce_ws_bytes": (c_size_t, [c_size_t, c_int, c_int, c_int]),
     "m355_bn_stats": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
     "m355_chan_sum": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
-    "m355_affine_act_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
+    "m355_affine_act_fwd": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_float, _P]),
     "m355_affine_act_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "m355_affine_act_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "m355_lrelu_bwd": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_float, _P]),

@@ -572,6 +572,16 @@ extern "C" int m355_conv2d_out_hw(const m355_conv_desc *d, int *Ho, int *Wo)
     return conv_out_hw(d, Ho, Wo) == 0 ? M355_OK : M355_ERR_BAD_ARG;
 }
 
+/* adjoint of the nearest x2 upsample on NHWC bf16: dx[n,h,w,:] = sum of the 2x2 block of g[n,2h..2h+1,2w..2w+1,:] */
+extern "C" int m355_fold2x2(const void *g, void *dx, int N, int H, int W, int C, void *stream)
+{
+    M355_REQUIRE(g && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "fold2x2: bad argument");
+    const size_t total = (size_t)N * H * W * (C / 8);
+    hipLaunchKernelGGL(m355::k_fold_pad, dim3((unsigned)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const unsigned short *)g, (unsigned short *)dx, N, H, W, C, 1, 0, 0, 2 * H, 0);
+    return m355::check_launch("fold2x2");
+}
+
 extern "C" int m355_conv2d_dy_channels(int cout) { return m355::dy_channels(cout); }
 
 extern "C" size_t m355_conv2d_weight_elems(const m355_conv_desc *d, int which)

@@ -133,14 +133,16 @@ __global__ __launch_bounds__(256) void k_sum_partials(const float *__restrict__ 
 // streaming (the first version re-read a/b per element and ran at a third of the HBM rate).
 __global__ __launch_bounds__(256) void k_affine_act(const short *__restrict__ x, const float *__restrict__ a,
                                                     const float *__restrict__ b, const short *__restrict__ res,
-                                                    short *__restrict__ y, int HW, int C, float slope)
+                                                    short *__restrict__ y, int HW, int C, float slope, int res_w)
 {
+    // res_w > 0: the residual is stored at HALF resolution ([N][H/2][res_w/2][C]) and read through the nearest x2
+    // upsample (a 1x1 shortcut conv commutes with it, so the shortcut runs on 4x fewer pixels -- gan.py:306-312,319)
     const int n = blockIdx.y;
     const int vecs = C >> 3;
     const size_t total = (size_t)HW * vecs;
     const short *xn = x + (size_t)n * HW * C;
     short *yn = y + (size_t)n * HW * C;
-    const short *rn = res ? res + (size_t)n * HW * C : nullptr;
+    const short *rn = res ? res + (size_t)n * (res_w > 0 ? HW / 4 : HW) * C : nullptr;
     const int c0 = (int)(threadIdx.x % vecs) * 8;   // (blockIdx.x * 256 + k * gridDim.x * 256) % vecs == 0
     float av[8], bv[8];
 #pragma unroll
@@ -152,7 +154,15 @@ __global__ __launch_bounds__(256) void k_affine_act(const short *__restrict__ x,
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const bf16x8e v = *reinterpret_cast<const bf16x8e *>(xn + i * 8);
         bf16x8e r = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (rn) r = *reinterpret_cast<const bf16x8e *>(rn + i * 8);
+        if (rn) {
+            size_t ri = i;
+            if (res_w > 0) {
+                const size_t p = i / vecs, v = i - p * vecs;
+                const size_t h = p / res_w, w = p - h * res_w;
+                ri = ((h >> 1) * (res_w >> 1) + (w >> 1)) * vecs + v;
+            }
+            r = *reinterpret_cast<const bf16x8e *>(rn + ri * 8);
+        }
         float zz[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -365,16 +375,18 @@ extern "C" int m355_bn_stats(const void *x, float *sums /*[2][C]*/, void *ws, si
     return check_launch("bn_stats");
 }
 
-extern "C" int m355_affine_act_fwd(const void *x, const float *a, const float *b, const void *res, void *y, int N, int HW,
-                                   int C, float slope, void *stream)
+extern "C" int m355_affine_act_fwd(const void *x, const float *a, const float *b, const void *res, int res_w, void *y, int N,
+                                   int HW, int C, float slope, void *stream)
 {
     M355_REQUIRE(x && a && b && y && N > 0 && HW > 0, "affine_act_fwd: null pointer / empty");
+    M355_REQUIRE(res_w >= 0 && (res_w == 0 || (res_w % 2 == 0 && HW % res_w == 0 && (HW / res_w) % 2 == 0)),
+                 "affine_act_fwd: res_w=%d does not describe an even H x W = %d image", res_w, HW);
     if (int rc = check_c(C, "affine_act_fwd")) return rc;
     const size_t total = (size_t)HW * (C / 8);
     // ~8 vectors per thread (its coefficients are loaded once), still thousands of workgroups with N in grid.y
     const unsigned gx = (unsigned)min((size_t)4096, (total + 2047) / 2048);
     hipLaunchKernelGGL(k_affine_act, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, (const short *)x, a, b,
-                       (const short *)res, (short *)y, HW, C, slope);
+                       (const short *)res, (short *)y, HW, C, slope, res ? res_w : 0);
     return check_launch("affine_act_fwd");
 }
 

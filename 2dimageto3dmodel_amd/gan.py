@@ -145,10 +145,9 @@ class ResBlockUp(nn.Module):
         """x is the block input BEFORE the nearest x2 upsample that precedes the block in Generator.forward
         (gan.py:386-404) when upsample=1; the upsample is folded into conv1 and the shortcut.
         gb: {norm module: (gamma, beta)} from the generator's batched conditioning GEMM."""
-        if isinstance(self.shortcut, _Identity):
-            sc = G.upsample2x(x) if upsample else x
-        else:
-            sc = self.shortcut(x, upsample=upsample)
+        # the shortcut branch stays at the block's INPUT resolution: a 1x1 conv (or the identity) commutes with the
+        # nearest x2 upsample, and the fused norm2 kernel reads the residual through that upsample
+        sc = x if isinstance(self.shortcut, _Identity) else self.shortcut(x)
         g1 = gb.get(self.norm1) if gb is not None else None
         g2 = gb.get(self.norm2) if gb is not None else None
         h = self.norm1(self.conv1(x, upsample=upsample), z, LRELU, g1)

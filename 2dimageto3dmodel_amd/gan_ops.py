@@ -281,7 +281,7 @@ class AffineActFn(torch.autograd.Function):
         a = (rstd * scale.float()).contiguous()            # [N,C]
         b = (shift.float() - mean * a).contiguous()
         y = torch.empty_like(x)
-        launch("affine_act_fwd", ptr(x), ptr(a), ptr(b), None, ptr(y), n, h * w, c, float(slope), stream())
+        launch("affine_act_fwd", ptr(x), ptr(a), ptr(b), None, 0, ptr(y), n, h * w, c, float(slope), stream())
         ctx.save_for_backward(x, a, b, scale, mean, rstd)
         ctx.cfg = (slope, batch_stats, count, sync)
         return y
@@ -328,9 +328,13 @@ class CbnActFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope, res=None, sync=False):
         n, h, w, c = x.shape
         x = x.contiguous()
+        res_w = 0
         if res is not None:
             res = res.contiguous()
-            assert res.shape == x.shape and res.dtype == x.dtype
+            assert res.dtype == x.dtype
+            if res.shape != x.shape:   # half-resolution residual, read through the nearest x2 upsample
+                assert tuple(res.shape) == (n, h // 2, w // 2, c) and h % 2 == 0 and w % 2 == 0, (res.shape, x.shape)
+                res_w = w
         assert gamma.stride(1) == 1 and beta.stride(1) == 1 and gamma.stride(0) == beta.stride(0)
         dev = x.device
         P = n * h * w
@@ -349,9 +353,9 @@ class CbnActFn(torch.autograd.Function):
         launch("bn_finalize", ptr(part), nblk, count, ptr(gamma), ptr(beta), int(gamma.stride(0)), n, c, float(eps),
                float(momentum), ptr(running_mean), ptr(running_var), ptr(mean), ptr(rstd), ptr(a), ptr(b), stream())
         y = torch.empty_like(x)
-        launch("affine_act_fwd", ptr(x), ptr(a), ptr(b), ptr(res), ptr(y), n, h * w, c, float(slope), stream())
+        launch("affine_act_fwd", ptr(x), ptr(a), ptr(b), ptr(res), res_w, ptr(y), n, h * w, c, float(slope), stream())
         ctx.save_for_backward(x, coef, gamma)
-        ctx.cfg = (slope, count, res is not None, sync)
+        ctx.cfg = (slope, count, (0 if res is None else (2 if res_w else 1)), sync)
         return y
 
     @staticmethod
@@ -376,8 +380,18 @@ class CbnActFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         launch("affine_act_bwd_apply", ptr(dy), ptr(x), ptr(a), ptr(b), ptr(A), ptr(Bc), ptr(Cc), ptr(dx), n, h * w, c,
                float(slope), stream())
-        return (dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None, None, None, None, None,
-                (dy if has_res else None), None)
+        dres = None
+        if has_res == 1:
+            dres = dy
+        elif has_res == 2:   # adjoint of the nearest x2 upsample: sum of each 2x2 block
+            dres = torch.empty((n, h // 2, w // 2, c), dtype=dy.dtype, device=dy.device)
+            launch("fold2x2", ptr(dy), ptr(dres), n, h // 2, w // 2, c, stream())
+        return (dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None, None, None, None, None, dres, None)
+
+
+def _match_res(res, x):
+    """a half-resolution residual is the nearest x2 upsample of itself (torch fallback paths)"""
+    return res if res.shape == x.shape else upsample2x(res)
 
 
 def _fused_ok(x):
@@ -448,7 +462,7 @@ class BatchNorm2d(nn.Module):
                     self.num_batches_tracked += 1
                 return y
         if res is not None:
-            return self.forward(x, gamma, beta, slope) + res
+            return self.forward(x, gamma, beta, slope) + _match_res(res, x)
         if _fused_ok(x):
             sync = self._is_sync()
             scale = 1 + gamma
@@ -496,7 +510,7 @@ class InstanceNorm2d(nn.Module):
 
     def forward(self, x, gamma, beta, slope=1.0, res=None):
         if res is not None:
-            return self.forward(x, gamma, beta, slope) + res
+            return self.forward(x, gamma, beta, slope) + _match_res(res, x)
         xf = x.float()
         mean = xf.mean((1, 2), keepdim=True)
         var = xf.var((1, 2), unbiased=False, keepdim=True)
@@ -506,7 +520,7 @@ class InstanceNorm2d(nn.Module):
 class NoNorm(nn.Module):
     def forward(self, x, gamma, beta, slope=1.0, res=None):
         if res is not None:
-            return self.forward(x, gamma, beta, slope) + res
+            return self.forward(x, gamma, beta, slope) + _match_res(res, x)
         if _fused_ok(x):
             c = x.shape[-1]
             zero = torch.zeros(c, dtype=torch.float32, device=x.device)

@@ -143,6 +143,8 @@ typedef struct {
 } m355_conv_desc;
 
 int m355_conv2d_out_hw(const m355_conv_desc *d, int *Ho, int *Wo);
+/*      adjoint of the nearest x2 upsample (gan.py:319) on NHWC bf16: g[N,2H,2W,C] -> dx[N,H,W,C] (2x2 block sums) */
+int m355_fold2x2(const void *g, void *dx, int N, int H, int W, int C, void *stream);
 int m355_conv2d_dy_channels(int cout);
 /*      elements (bf16) of the weight views: which 0 forward [ceil64(Cout)][ceil32(kh*kw*Cin)], 1 dgrad */
 size_t m355_conv2d_weight_elems(const m355_conv_desc *d, int which);
@@ -179,9 +181,10 @@ int m355_bn_stats(const void *x, float *sums, void *ws, size_t P, int C, void *s
 /*      x[P][C] -> sums[C] (bias gradient) */
 int m355_chan_sum(const void *x, float *sums, void *ws, size_t P, int C, void *stream);
 /*      y = LeakyReLU_slope(x * a[n,c] + b[n,c]) [+ res];  x,y,res [N][HW][C];  a = rstd*(1+gamma), b = beta - mean*a;
- *      res (nullable): the residual branch of ResBlockUp (gan.py:312) added in the same pass */
-int m355_affine_act_fwd(const void *x, const float *a, const float *b, const void *res, void *y, int N, int HW, int C,
-                        float slope, void *stream);
+ *      res (nullable): the residual branch of ResBlockUp (gan.py:312) added in the same pass; res_w > 0: res is stored
+ *      at half resolution [N][H/2][res_w/2][C] and read through the nearest x2 upsample (res_w = full-res width) */
+int m355_affine_act_fwd(const void *x, const float *a, const float *b, const void *res, int res_w, void *y, int N, int HW,
+                        int C, float slope, void *stream);
 /*      dz = dy * LeakyReLU'(x*a+b);  sums[N][2][C] = (sum_hw dz, sum_hw dz*x) */
 int m355_affine_act_bwd_reduce(const void *dy, const void *x, const float *a, const float *b, float *sums, void *ws,
                                int N, int HW, int C, float slope, void *stream);
