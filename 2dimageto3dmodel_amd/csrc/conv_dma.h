@@ -59,6 +59,8 @@ struct ConvArgs {
     // pads and output offsets
     const unsigned short *mask_x;  // dgrad only (k_conv_glds): tensor of the output's shape; y *= (mask_x > 0 ? 1 : mask_slope)
     float mask_slope;              //   = the backward of the LeakyReLU that produced this conv's input, folded in
+    int fold2;           // k_conv_halo only: sum each 2x2 block of output pixels before the store (adjoint of the nearest
+                         //   x2 upsample folded into the dgrad of an upsample+conv layer); OH, OW are the LOW-res extents
     int lgWo, lgHo;      // log2 of the GEMM pixel grid sides when both are powers of two (else -1): shift/mask decode
     int ncls;
     int cpad_h[4], cpad_w[4], coy[4], cox[4];

@@ -245,10 +245,24 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
 
         // ---- epilogue of this tile (as k_conv_glds), while the next tile's halo and first weights are in flight:
         // acc[j][i][r] = channel n0 + 64wn + 32j + 8(r>>2) + 4half + (r&3), pixel (2wm+i, tx)
+        if (a.fold2) {
+            // adjoint of the nearest x2 upsample: the wave's two tile rows are one low-res row (registers i = 0, 1), and
+            // neighbouring lanes (tx, tx^1) one low-res column
+#pragma unroll
+            for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[j][0][r] + acc[j][1][r];
+                    acc[j][0][r] = v + __shfl_xor(v, 1);
+                }
+        }
 #pragma unroll
         for (int i = 0; i < PI; ++i) {
+            if (a.fold2 && i == 1) continue;
             const int ho = oy0 + 2 * wm + i, wo = ox0 + tx;
-            const size_t pix = ((size_t)n * a.OH + (ho * a.oy_mul + oy_off)) * a.OW + (wo * a.ox_mul + ox_off);
+            const bool st_ok = !a.fold2 || !(tx & 1);
+            const size_t pix = a.fold2 ? ((size_t)n * a.OH + (ho >> 1)) * a.OW + (wo >> 1)
+                                       : ((size_t)n * a.OH + (ho * a.oy_mul + oy_off)) * a.OW + (wo * a.ox_mul + ox_off);
 #pragma unroll
             for (int j = 0; j < CJ; ++j) {
                 const int cbase = n0 + wn * 64 + 32 * j;
@@ -289,16 +303,21 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                     auto sx = __builtin_amdgcn_permlane32_swap(pk[g].x, pk[g + 1].x, false, false);
                     auto sy = __builtin_amdgcn_permlane32_swap(pk[g].y, pk[g + 1].y, false, false);
                     const int co = cbase + 8 * (g + half);
-                    if (co < a.Cout) {
+                    if (co < a.Cout && st_ok) {
                         uint4 o;
                         o.x = sx[0]; o.y = sy[0]; o.z = sx[1]; o.w = sy[1];
                         *reinterpret_cast<uint4 *>(yb + pix * a.Cs + co) = o;
                     }
                 }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CJ; ++j)
+#pragma unroll
+            for (int i = 0; i < PI; ++i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
             }
-        }
         if (!has_next) break;
         tp = tp_next;
     }
@@ -410,7 +429,6 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_halo(WgradArgs a, unsigned xby
             }
         }
         const int kg0 = KS == 2 ? 8 * w_hi : 0, kg1 = KS == 2 ? kg0 + 8 : 16;
-#pragma unroll 2
         for (int kg = kg0; kg < kg1; ++kg) {  // K group = 16 pixels: tile row kg>>1, columns 16(kg&1) .. +15
             const s4v y0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v *)(by + ya + kg * 2048));
             const s4v y1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v *)(by + ya + kg * 2048 + 512));
@@ -487,9 +505,76 @@ int wgrad_halo_launch(const WgradArgs &a, unsigned xb, unsigned yb, hipStream_t 
     return check_launch("conv2d_wgrad (halo)");
 }
 
-// host side (called from launch_conv, conv_mfma.hip)
-static inline bool rows_le64(int cout) { return cout <= 64; }
+// =====================================================================================================
+// Replicate-pad adjoint for the DIRECT dgrad of the generator's 3x3 convs (F.pad(mode='replicate') on W, gan.py:329).
+//   xp = replicate_pad_W(up(x)),  y = conv3x3_valid_W(xp):   dL/d up(x) = conv_zero_same(dy, flipped w) + E,
+//   E is non-zero only in the first / last logical column (the pad columns' gradient lands on their source column):
+//     E[h][0]    = sum_{kh', co} dy[h-1+kh'][0]    * w'[ci][kh'][2][co]
+//     E[h][Wl-1] = sum_{kh', co} dy[h-1+kh'][Wl-1] * w'[ci][kh'][0][co]          (w' = the dgrad weight view)
+// The main term runs on k_conv_halo (zero pad, optionally folding the 2x2 upsample blocks); this kernel adds E
+// (folded over the two logical rows of a stored row when FOLD) into columns 0 and W-1 of dx.  One workgroup per
+// (image, 4 stored rows): thread = output channel ci (x 2 edges), weights read once per 4 rows; ~2/W of the layer's FLOPs.
+constexpr int kEdgeRows = 4;  // stored rows of dx per workgroup (H % 4 == 0 is part of the eligibility)
+__global__ __launch_bounds__(256) void k_dgrad_edge(const unsigned short *__restrict__ dy, const unsigned short *__restrict__ wd,
+                                                    unsigned short *__restrict__ dx, int N, int Hl, int Wl, int Cy, int Cin, int Kp,
+                                                    int fold)
+{
+    extern __shared__ float sdy[];  // [2 edges][logical rows: (kEdgeRows << fold) + 2][Cy]
+    const int H = Hl >> fold, W = Wl >> fold, hb = H / kEdgeRows;
+    const int n = blockIdx.x / hb, h0 = (blockIdx.x - n * hb) * kEdgeRows;
+    const int lrows = kEdgeRows << fold, nrows = lrows + 2, hl0 = (h0 << fold) - 1;  // dy rows hl0 .. hl0 + nrows - 1
+    for (int e = threadIdx.x; e < 2 * nrows * (Cy / 8); e += blockDim.x) {
+        const int c8 = e % (Cy / 8), r = (e / (Cy / 8)) % nrows, edge = e / ((Cy / 8) * nrows);
+        const int hl = hl0 + r;
+        bf16x8 v = {};
+        if (hl >= 0 && hl < Hl) v = *(const bf16x8 *)(dy + (((size_t)n * Hl + hl) * Wl + (edge ? Wl - 1 : 0)) * Cy + c8 * 8);
+        float *o = sdy + ((size_t)(edge * nrows + r) * Cy + c8 * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = bf2f((unsigned short)v[k]);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * Cin; t += blockDim.x) {
+        const int edge = t / Cin, ci = t - edge * Cin;
+        const unsigned short *wrow = wd + (size_t)ci * Kp + (edge ? 0 : 2) * Cy;  // [kh'][kw' = 2 | 0][Cy]
+        const float *sd = sdy + (size_t)edge * nrows * Cy;
+        float acc[kEdgeRows] = {};
+        for (int c = 0; c < Cy; c += 8) {
+            float wv[3][8];
+#pragma unroll
+            for (int khp = 0; khp < 3; ++khp) {
+                const bf16x8 v = *(const bf16x8 *)(wrow + khp * 3 * Cy + c);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) wv[khp][k] = bf2f((unsigned short)v[k]);
+            }
+            if (fold) {
+#pragma unroll
+                for (int lr = 0; lr < 2 * kEdgeRows; ++lr)
+#pragma unroll
+                    for (int khp = 0; khp < 3; ++khp) {
+                        const float *d = sd + (lr + khp) * Cy + c;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) acc[lr >> 1] += d[k] * wv[khp][k];
+                    }
+            } else {
+#pragma unroll
+                for (int lr = 0; lr < kEdgeRows; ++lr)
+#pragma unroll
+                    for (int khp = 0; khp < 3; ++khp) {
+                        const float *d = sd + (lr + khp) * Cy + c;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) acc[lr] += d[k] * wv[khp][k];
+                    }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kEdgeRows; ++r) {
+            unsigned short *o = dx + (((size_t)n * H + h0 + r) * W + (edge ? W - 1 : 0)) * Cin + ci;
+            *o = f2bf(bf2f(*o) + acc[r]);
+        }
+    }
+}
 
+// host side (called from launch_conv, conv_mfma.hip)
 bool conv_halo_eligible(const ConvArgs &a)
 {
     if (a.stride == 2) {  // forward of a 4x4 stride-2 conv = four accumulated 2x2 class convs on planes of the input
@@ -505,7 +590,7 @@ bool conv_halo_eligible(const ConvArgs &a)
             if (a.ups) return false;
     // (measured, profiles/r01_conv_halo_ab.txt: with the single-instruction bf16 packing in the epilogue the 4-wave variant
     // for Cout <= 64 wins too: G.blk6.conv2 605 -> 657 TF, D.conv2 dgrad 518 -> 616 TF)
-    if (getenv("M355_HALO_8W_ONLY") && rows_le64(a.Cout)) return false;
+    if (getenv("M355_HALO_8W_ONLY") && a.Cout <= 64) return false;  // A/B switch
     return true;
 }
 
@@ -552,6 +637,42 @@ int conv_halo_launch(const ConvArgs &a, unsigned xb, unsigned wb, hipStream_t st
 #undef M355_HL
     note_kernel("k_conv_halo");
     return check_launch("conv2d (halo)");
+}
+
+bool dgrad_direct_replicate_eligible(const m355_conv_desc *d, int Cy)
+{
+    const int Hl = d->H << d->upsample, Wl = d->W << d->upsample;
+    return d->stride == 1 && d->kh == 3 && d->kw == 3 && d->pad_h == 1 && d->pad_w == 1 && d->pad_w_mode == 1 && Cy % 64 == 0 &&
+           d->Cin % 8 == 0 && Wl % 32 == 0 && Hl % 8 == 0 && d->H % kEdgeRows == 0 &&
+           Cy * ((kEdgeRows << d->upsample) + 2) <= 8192 /* edge kernel's LDS */ &&
+           (size_t)d->N * Hl * Wl * Cy * 2 < (1ull << 31) && !getenv("M355_NO_DIRECT_REPLICATE");
+}
+
+// dy [N,Hl,Wl,Cy] -> dx [N,H,W,Cin]   (w_dgrad: [rows_padded(Cin)][Kp] bf16, K ordered (kh', kw', co))
+int dgrad_direct_replicate_launch(const m355_conv_desc *d, const void *dy, int Cy, const void *w_dgrad, int Kp, int rows_p,
+                                  void *dx, hipStream_t st)
+{
+    const int Hl = d->H << d->upsample, Wl = d->W << d->upsample;
+    ConvArgs a = {};
+    a.x = (const unsigned short *)dy;
+    a.w = (const unsigned short *)w_dgrad;
+    a.y = dx;
+    a.N = d->N; a.H = Hl; a.W = Wl; a.Cin = Cy; a.Hl = Hl; a.Wl = Wl; a.ups = 0;
+    a.Ho = Hl; a.Wo = Wl; a.Cout = d->Cin; a.CoutP = rows_p;
+    a.KH = 3; a.KW = 3; a.stride = 1; a.pad_h = 1; a.pad_w = 1; a.pad_w_mode = 0;   // zero pad: the interior term
+    a.OH = d->H; a.OW = d->W; a.oy_mul = a.ox_mul = 1;
+    a.Kp = Kp; a.Cs = d->Cin; a.slope = 1.0f; a.ncls = 1;
+    a.fold2 = d->upsample;
+    if (!conv_halo_eligible(a)) {
+        set_error("conv2d_dgrad: direct replicate form not eligible");
+        return M355_ERR_BAD_ARG;
+    }
+    const size_t xbytes = (size_t)d->N * Hl * Wl * Cy * 2, wbytes = (size_t)rows_p * Kp * 2;
+    if (int rc = conv_halo_launch(a, (unsigned)xbytes, (unsigned)wbytes, st)) return rc;
+    const int nrows = (kEdgeRows << d->upsample) + 2;
+    hipLaunchKernelGGL(k_dgrad_edge, dim3(d->N * (d->H / kEdgeRows)), dim3(256), sizeof(float) * 2 * nrows * Cy, st, (const unsigned short *)dy,
+                       (const unsigned short *)w_dgrad, (unsigned short *)dx, d->N, Hl, Wl, Cy, d->Cin, Kp, d->upsample);
+    return check_launch("conv2d_dgrad (direct replicate)");
 }
 
 }  // namespace m355

@@ -452,6 +452,9 @@ static inline int dy_channels(int cout) { return cout <= 8 ? 8 : (cout + 31) / 3
 bool conv_halo_eligible(const ConvArgs &a);  // csrc/conv_halo.hip
 int conv_halo_launch(const ConvArgs &a, unsigned xb, unsigned wb, hipStream_t st);
 
+bool dgrad_direct_replicate_eligible(const m355_conv_desc *d, int Cy);  // csrc/conv_halo.hip
+int dgrad_direct_replicate_launch(const m355_conv_desc *d, const void *dy, int Cy, const void *w_dgrad, int Kp, int rows_p,
+                                  void *dx, hipStream_t st);
 bool wgrad_halo_eligible(const WgradArgs &a);  // csrc/conv_halo.hip
 int wgrad_halo_launch(const WgradArgs &a, unsigned xb, unsigned yb, hipStream_t st);
 
@@ -679,6 +682,7 @@ static bool dgrad_direct(const m355_conv_desc *d)
     ConvArgs a = {};
     a.N = d->N; a.H = Ho; a.W = Wo; a.Cin = cy; a.Cout = d->Cin; a.Cs = d->Cin;
     a.Kp = m355::k_padded((d->stride == 1 ? d->kh * d->kw : (d->kh / 2) * (d->kw / 2)) * cy);
+    if (m355::dgrad_direct_replicate_eligible(d, cy) && m355::dma_eligible(a)) return true;  // 3x3 replicate (+upsample)
     return !d->upsample && d->pad_w_mode != 1 && m355::dma_eligible(a) &&
            (d->stride == 1 || (d->H % 2 == 0 && d->W % 2 == 0 && d->kh % 2 == 0 && d->kw % 2 == 0));
 }
@@ -716,6 +720,10 @@ extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const 
     a.mask_x = (const unsigned short *)mask_x;
     a.mask_slope = mask_slope;
     int rc = 0;
+    if (direct && d->pad_w_mode == 1) {  // generator 3x3: zero-pad conv of dy on the halo kernel + replicate edge terms
+        M355_REQUIRE(!mask_x, "conv2d_dgrad: no fused activation backward on the replicate form");
+        return m355::dgrad_direct_replicate_launch(d, dy, cout32, w_dgrad, a.Kp, cin64, dx, st);
+    }
     if (direct && !mask_x && m355::dgrad_small_eligible(d, cout32) && !getenv("M355_NO_C8"))
         return m355::dgrad_small_launch(d, dy, cout32, w_dgrad, a.Kp, (size_t)cin64 * a.Kp * 2, dx, st);
     if (direct && d->stride == 1) {
