@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libm355.so")
+LIB_PATH = os.path.join(_HERE, "lib", os.environ.get("M355_LIB", "libm355.so"))  # M355_LIB: A/B builds of the same ABI (build.py)
 
 c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 

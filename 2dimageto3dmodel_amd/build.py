@@ -12,12 +12,12 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "build")
+OBJ = os.path.join(HERE, "build" + ("_" + os.environ["M355_BUILD_LIB"] if os.environ.get("M355_BUILD_LIB") else ""))
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libm355.so")
+LIB = os.path.join(LIBDIR, os.environ.get("M355_BUILD_LIB", "libm355.so"))  # A/B builds: M355_BUILD_LIB + M355_BUILD_DEFS
 ARCH = "gfx950"
 
-COMMON = ["-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wall", "-Wno-unused-function"] + os.environ.get("M355_BUILD_DEFS", "").split()
 STRICT = ["-ffp-contract=off"]  # bit-exactness with torch-CPU elementwise arithmetic
 
 SOURCES = [

@@ -49,6 +49,35 @@ __device__ __forceinline__ void wait_vm()
 // X_pq[i][j] = xpad[2i+p][2j+q] of the input: out[o] = sum_{p,q} sum_{a,b} X_pq[o+(a,b)] . W[2a+p][2b+q].  The segment
 // stream of a tile is then (class, channel chunk) instead of (channel chunk): each segment has its own halo (the DMA
 // addresses the plane with pixel stride 2) and all of them accumulate into the same output tile.
+#ifndef M355_HALO_EARLY
+#define M355_HALO_EARLY 0
+#endif
+#ifndef M355_HALO_PIPE
+#define M355_HALO_PIPE 1
+#endif
+#ifndef M355_HALO_RB4
+#define M355_HALO_RB4 3
+#endif
+#ifndef M355_HALO_RB8
+#define M355_HALO_RB8 3
+#endif
+// halo DMAs one wave issues at tap t (slices of NAS on taps 0 .. T-3), and their sum over the D steps before tap t
+template <int T, int NAW, int NAS>
+constexpr int halo_dmas_at(int t)
+{
+    t = ((t % T) + T) % T;
+    if (t > T - 3) return 0;
+    const int lo = t * NAS, hi = lo + NAS > NAW ? NAW : lo + NAS;
+    return hi > lo ? hi - lo : 0;
+}
+template <int T, int NAW, int NAS, int D>
+constexpr int halo_dmas_behind(int tap)
+{
+    int n = 0;
+    for (int j = 1; j <= D; ++j) n += halo_dmas_at<T, NAW, NAS>(tap - j);
+    return n;
+}
+
 template <int BN, int NW, int KS, int UPS, int MODE, int SUB = 1>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs a, unsigned xbytes, unsigned wbytes)
 {
@@ -61,12 +90,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
     constexpr int HR = HH * HWD;                          // LDS rows of a halo buffer
     constexpr int NA = (HR + 7) / 8;                      // DMA instructions per halo
     constexpr int NAW = (NA + NW - 1) / NW;               //   ... per wave
-    constexpr int NAS = (NAW + T - 3) / (T - 2);          // halo-slice DMAs per step (taps 0 .. T-3 carry the slices)
+    // halo-slice DMAs per step (taps 0 .. T-3 carry the slices); EARLY: the whole next halo at tap 0
+    constexpr int NAS = M355_HALO_EARLY ? NAW : (NAW + T - 3) / (T - 2);
+    constexpr int RB = NW == 4 ? M355_HALO_RB4 : M355_HALO_RB8;  // weight ring slots
+    // software pipeline (one wave per SIMD has no partner wave to hide its LDS-read latency): fragments of step s+1 are
+    // read during step s.  The 8-wave variant (2 waves per SIMD, 256 registers each) reads them in the step itself.
+    constexpr int L = (NW == 4 && M355_HALO_PIPE) ? 1 : 0;
     constexpr int NBW = BN / (8 * NW);                    // weight DMAs per wave per step
     constexpr int ABUF = NW * NAW * 1024, BBUF = BN * 128;
     constexpr int WGN = BN / 64, PI = 2, CJ = 2;          // waves along N; each wave 2 tile rows x 64 channels
     static_assert(NW / WGN == 4 && NBW >= 1 && T >= 4, "tile shape");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * ABUF + 3 * BBUF];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * ABUF + RB * BBUF];
     unsigned char *const ldsB = lds + 2 * ABUF;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -127,14 +161,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
 
     // weights of step s of a tile (= segment s / T, tap s % T) -> ring slot; steps >= S are the next tile's first ones
     auto issue_B = [&](int s, int slot) {
-        if (s >= S) s -= S;
+        while (s >= S) s -= S;
         const int sg = s / T, tap = s - sg * T;
         const int cls = sg / ncc, cc = sg - cls * ncc;
         // SUB 2: tap (a,b) of class (p,q) is the conv's tap (2a+p, 2b+q); the weight view is ordered (kh, kw, ci)
         const int ktap = SUB == 2 ? (2 * (tap >> 1) + (cls >> 1)) * 4 + 2 * (tap & 1) + (cls & 1) : tap;
         const unsigned so = (unsigned)((ktap * a.Cin + cc * 64) * 2);
+#ifndef M355_DBG_NO_B
 #pragma unroll
         for (int j = 0; j < NBW; ++j) dma16(rw, ldsB + slot * BBUF + (NW * j + wave) * 1024, wrow[j], so);
+#endif
     };
     // halo slice `tap` (slots tap*NAS .. +NAS-1, as far as they exist) of the NEXT (tile, chunk) into halo buffer hbuf.
     // Every step issues a COMPILE-TIME-KNOWN number of DMAs (the counted wait depends on it): when there is no next
@@ -143,8 +179,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
         constexpr int tap = decltype(tapc)::value;
 #pragma unroll
         for (int k = 0; k < NAW; ++k)
-            if (k >= tap * NAS && k < (tap + 1) * NAS && tap <= T - 3)
+            if (k >= tap * NAS && k < (tap + 1) * NAS && tap <= T - 3) {
+#ifndef M355_DBG_NO_A
                 dma16(rx, lds + hbuf * ABUF + (NW * k + wave) * 1024, aoff[k], (unsigned)chunk * 128u);
+#endif
+            }
     };
 
     f32x16 acc[CJ][PI];
@@ -163,13 +202,44 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
     const int swzb = (lane >> 1) & 7;
     unsigned short *yb = reinterpret_cast<unsigned short *>(a.y);
 
-    // ---- prologue: the whole first halo of the first tile, then the two weight steps the loop expects in flight
+    // ---- fragments of one step (tap of the halo buffer `ha`, ring slot): 4 k-groups of 16 channels
+    struct Frags {
+        bf16x8 p[4][PI], w[4][CJ];
+    };
+    auto read_frags = [&](Frags &f, const unsigned char *ha, int slot_, auto tapc) {
+        constexpr int tap = decltype(tapc)::value;
+        constexpr int kh = tap / KS, kw = tap - kh * KS;
+        const unsigned char *bs = fb + slot_ * BBUF;
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            const int ly = 2 * wm + i + kh, lx = tx + kw;
+            const int rho = UPS ? ((ly + ey) >> 1) * HWD + ((lx + ex) >> 1) : ly * HWD + lx;
+            const int rowa = rho * 128, swa = (rho >> 1) & 7;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                f.p[kk][i] = *reinterpret_cast<const bf16x8 *>(ha + rowa + (((kk * 2 + half) ^ swa) << 4));
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int j = 0; j < CJ; ++j)
+                f.w[kk][j] = *reinterpret_cast<const bf16x8 *>(bs + j * 32 * 128 + (((kk * 2 + half) ^ swzb) << 4));
+    };
+
+    // ---- prologue: the whole first halo of the first tile and the first RB weight steps; the fragments of step 0
     int tp = bp;
     compute_aoff(tp, 0);
 #pragma unroll
     for (int k = 0; k < NAW; ++k) dma16(rx, lds + (NW * k + wave) * 1024, aoff[k], 0u);
-    issue_B(0, 0);
-    issue_B(1, 1);
+#pragma unroll
+    for (int q = 0; q < RB - 1 + L; ++q) issue_B(q, q);
+    int warm = RB;  // the first RB steps have fewer DMAs behind them than the counted wait assumes: drain instead
+    Frags cur;
+    if (L) {
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        read_frags(cur, lds, 0, std::integral_constant<int, 0>{});
+    }
 
     int slot = 0;  // ring slot of the current step
     int hb = 0;    // halo buffer of the current chunk
@@ -196,49 +266,54 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
             static_for<0, T>([&](auto tapc) {
                 constexpr int tap = decltype(tapc)::value;
                 const int s = cc * T + tap;
-                // DMAs younger than the weights of step s: the halo slices of the two previous steps and the weights
-                // of step s+1 -- their number is a compile-time function of the tap.  Everything older has landed in
-                // THIS wave's rows; and this wave's fragment reads of step s-1 have returned (their ring slot is
-                // refilled next).  (Epilogue loads / stores of the previous tile are younger still: they only make the
-                // wait stricter.)
-                constexpr int t1 = (tap + T - 1) % T, t2 = (tap + T - 2) % T;
-                constexpr int nA1 = t1 <= T - 3 ? (NAW - t1 * NAS < 0 ? 0 : (NAW - t1 * NAS > NAS ? NAS : NAW - t1 * NAS)) : 0;
-                constexpr int nA2 = t2 <= T - 3 ? (NAW - t2 * NAS < 0 ? 0 : (NAW - t2 * NAS > NAS ? NAS : NAW - t2 * NAS)) : 0;
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NBW + nA1 + nA2) : "memory");
+                // Step s issues the weights of step s+RB-1+L into the ring slot last read in step s-1+L, and its barrier
+                // publishes what step s+L reads: those weights (issued first thing in step s-RB+1) and, when s+L opens a
+                // chunk, that chunk's halo (last slice at tap TL of the chunk before).  L = 1: the fragments of step s+1
+                // are read from LDS while this step's MFMAs run.  DMAs younger than the awaited weights: the halo slice of
+                // their own step, then the weights and slices of steps s-RB+2 .. s-1 -- a compile-time function of the
+                // tap.  Everything older has landed in THIS wave's rows; this wave's earlier fragment reads have returned
+                // (lgkmcnt), so the slot is free to be refilled.  (Epilogue loads / stores of the previous tile are
+                // younger still: they only make the wait stricter.)
+                constexpr int cnt_b = (RB - 2) * NBW + halo_dmas_behind<T, NAW, NAS, RB - 1>(tap);
+                constexpr int TL = (NAW + NAS - 1) / NAS - 1;
+                static_assert(TL <= T - 3 && RB >= 2, "halo slices must be out by tap T-3");
+                constexpr int cnt_a = (T - 1 - L - TL) * NBW;
+                constexpr int cnt = (tap == (T - L) % T && cnt_a < cnt_b) ? cnt_a : cnt_b;
+                if (warm) {
+                    --warm;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(cnt) : "memory");
                 __builtin_amdgcn_s_barrier();      // ... the same holds for every wave
                 __builtin_amdgcn_sched_barrier(0);
-                {
-                    const int ns = slot == 0 ? 2 : slot - 1;  // (slot + 2) % 3: the slot read at step s-1
-                    issue_B(s + 2, ns);
-                    issue_A(hb ^ 1, chunk_next, tapc);  // taps T-2, T-1 issue none
-                }
+                const int slot_n = slot == RB - 1 ? 0 : slot + 1;
+                const int slot_p = slot == 0 ? RB - 1 : slot - 1;
+                issue_B(s + RB - 1 + L, L ? slot : slot_p);
+                issue_A(hb ^ 1, chunk_next, tapc);  // taps T-2, T-1 issue none
                 __builtin_amdgcn_sched_barrier(0);
-                constexpr int kh = tap / KS, kw = tap - kh * KS;
-                int rowa[PI], swa[PI];
+#ifndef M355_DBG_NO_MMA
+                Frags nxt;
+                if (L) read_frags(nxt, tap == T - 1 ? lds + (hb ^ 1) * ABUF : ha, slot_n, std::integral_constant<int, (tap + 1) % T>{});
+                else read_frags(cur, ha, slot, tapc);
 #pragma unroll
-                for (int i = 0; i < PI; ++i) {
-                    const int ly = 2 * wm + i + kh, lx = tx + kw;
-                    const int rho = UPS ? ((ly + ey) >> 1) * HWD + ((lx + ex) >> 1) : ly * HWD + lx;
-                    rowa[i] = rho * 128;
-                    swa[i] = (rho >> 1) & 7;
-                }
-                const unsigned char *bs = fb + slot * BBUF;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    bf16x8 pf[PI], wf[CJ];
-#pragma unroll
-                    for (int i = 0; i < PI; ++i)
-                        pf[i] = *reinterpret_cast<const bf16x8 *>(ha + rowa[i] + (((kk * 2 + half) ^ swa[i]) << 4));
-#pragma unroll
-                    for (int j = 0; j < CJ; ++j)
-                        wf[j] = *reinterpret_cast<const bf16x8 *>(bs + j * 32 * 128 + (((kk * 2 + half) ^ swzb) << 4));
+                for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                     for (int j = 0; j < CJ; ++j)
 #pragma unroll
                         for (int i = 0; i < PI; ++i)
-                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], pf[i], acc[j][i], 0, 0, 0);
+                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.w[kk][j], cur.p[kk][i], acc[j][i], 0, 0, 0);
+                if (L) {
+                    // the next step's 16 fragment reads ride in the issue gaps of the first MFMAs (two per gap), so the
+                    // last of them has returned well before the step's closing lgkmcnt(0)
+#pragma unroll
+                    for (int q = 0; q < 2 * (PI + CJ); ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+                    cur = nxt;
                 }
-                slot = slot == 2 ? 0 : slot + 1;
+#endif
+                slot = slot_n;
             });
             hb ^= 1;
         }
@@ -303,7 +378,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                     auto sx = __builtin_amdgcn_permlane32_swap(pk[g].x, pk[g + 1].x, false, false);
                     auto sy = __builtin_amdgcn_permlane32_swap(pk[g].y, pk[g + 1].y, false, false);
                     const int co = cbase + 8 * (g + half);
+#ifdef M355_DBG_NO_EPI
+                    if (co < a.Cout && st_ok && a.N < 0) {
+#else
                     if (co < a.Cout && st_ok) {
+#endif
                         uint4 o;
                         o.x = sx[0]; o.y = sy[0]; o.z = sx[1]; o.w = sy[1];
                         *reinterpret_cast<uint4 *>(yb + pix * a.Cs + co) = o;
@@ -512,64 +591,52 @@ int wgrad_halo_launch(const WgradArgs &a, unsigned xb, unsigned yb, hipStream_t 
 //     E[h][0]    = sum_{kh', co} dy[h-1+kh'][0]    * w'[ci][kh'][2][co]
 //     E[h][Wl-1] = sum_{kh', co} dy[h-1+kh'][Wl-1] * w'[ci][kh'][0][co]          (w' = the dgrad weight view)
 // The main term runs on k_conv_halo (zero pad, optionally folding the 2x2 upsample blocks); this kernel adds E
-// (folded over the two logical rows of a stored row when FOLD) into columns 0 and W-1 of dx.  One workgroup per
-// (image, 4 stored rows): thread = output channel ci (x 2 edges), weights read once per 4 rows; ~2/W of the layer's FLOPs.
-constexpr int kEdgeRows = 4;  // stored rows of dx per workgroup (H % 4 == 0 is part of the eligibility)
+// (folded over the two logical rows of a stored row when FOLD) into columns 0 and W-1 of dx.
+// As a GEMM per edge: D[ci][pixel (n, h)] = sum_{(lr, kh', c)} w'[ci][kh'][kw'][c] * dy[n][2h + lr - 1 + kh'][edge][c]  -- both
+// MFMA operands are 16-byte global loads in their natural layouts (no LDS: ~2/W of the layer's FLOPs, L1/L2-resident).
+// Workgroup = 32 edge pixels x all input channels (wave w takes the 32-channel tiles w, w+4, ...); blockIdx.y = edge.
 __global__ __launch_bounds__(256) void k_dgrad_edge(const unsigned short *__restrict__ dy, const unsigned short *__restrict__ wd,
                                                     unsigned short *__restrict__ dx, int N, int Hl, int Wl, int Cy, int Cin, int Kp,
                                                     int fold)
 {
-    extern __shared__ float sdy[];  // [2 edges][logical rows: (kEdgeRows << fold) + 2][Cy]
-    const int H = Hl >> fold, W = Wl >> fold, hb = H / kEdgeRows;
-    const int n = blockIdx.x / hb, h0 = (blockIdx.x - n * hb) * kEdgeRows;
-    const int lrows = kEdgeRows << fold, nrows = lrows + 2, hl0 = (h0 << fold) - 1;  // dy rows hl0 .. hl0 + nrows - 1
-    for (int e = threadIdx.x; e < 2 * nrows * (Cy / 8); e += blockDim.x) {
-        const int c8 = e % (Cy / 8), r = (e / (Cy / 8)) % nrows, edge = e / ((Cy / 8) * nrows);
-        const int hl = hl0 + r;
-        bf16x8 v = {};
-        if (hl >= 0 && hl < Hl) v = *(const bf16x8 *)(dy + (((size_t)n * Hl + hl) * Wl + (edge ? Wl - 1 : 0)) * Cy + c8 * 8);
-        float *o = sdy + ((size_t)(edge * nrows + r) * Cy + c8 * 8);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = bf2f((unsigned short)v[k]);
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < 2 * Cin; t += blockDim.x) {
-        const int edge = t / Cin, ci = t - edge * Cin;
-        const unsigned short *wrow = wd + (size_t)ci * Kp + (edge ? 0 : 2) * Cy;  // [kh'][kw' = 2 | 0][Cy]
-        const float *sd = sdy + (size_t)edge * nrows * Cy;
-        float acc[kEdgeRows] = {};
-        for (int c = 0; c < Cy; c += 8) {
-            float wv[3][8];
-#pragma unroll
+    const int H = Hl >> fold, W = Wl >> fold;
+    const int edge = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    const int m = blockIdx.x * 32 + (lane & 31);
+    const bool mok = m < N * H;
+    const int n = mok ? m / H : 0, h = mok ? m - n * H : 0;
+    const int col = edge ? Wl - 1 : 0, kwp = edge ? 0 : 2;
+    const bf16x8 zero = {};
+    for (int ct = wave; ct * 32 < Cin; ct += 4) {
+        const unsigned short *wrow = wd + (size_t)(ct * 32 + (lane & 31)) * Kp + kwp * Cy + 8 * half;  // rows padded to 64
+        f32x16 acc = {};
+        for (int lr = 0; lr <= fold; ++lr)
             for (int khp = 0; khp < 3; ++khp) {
-                const bf16x8 v = *(const bf16x8 *)(wrow + khp * 3 * Cy + c);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) wv[khp][k] = bf2f((unsigned short)v[k]);
+                const int hl = (h << fold) + lr - 1 + khp;
+                const bool ok = mok && (unsigned)hl < (unsigned)Hl;
+                const unsigned short *src = dy + (((size_t)n * Hl + (ok ? hl : 0)) * Wl + col) * Cy + 8 * half;
+                const unsigned short *wk = wrow + khp * 3 * Cy;
+#pragma unroll 4
+                for (int c = 0; c < Cy; c += 16) {
+                    const bf16x8 pf = ok ? *reinterpret_cast<const bf16x8 *>(src + c) : zero;
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(wk + c);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, pf, acc, 0, 0, 0);
+                }
             }
-            if (fold) {
+        // acc[r] = channel 32ct + 8(r>>2) + 4half + (r&3) of pixel lane&31
+        if (mok) {
+            unsigned short *o = dx + (((size_t)n * H + h) * W + (edge ? W - 1 : 0)) * Cin;
 #pragma unroll
-                for (int lr = 0; lr < 2 * kEdgeRows; ++lr)
-#pragma unroll
-                    for (int khp = 0; khp < 3; ++khp) {
-                        const float *d = sd + (lr + khp) * Cy + c;
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) acc[lr >> 1] += d[k] * wv[khp][k];
-                    }
-            } else {
-#pragma unroll
-                for (int lr = 0; lr < kEdgeRows; ++lr)
-#pragma unroll
-                    for (int khp = 0; khp < 3; ++khp) {
-                        const float *d = sd + (lr + khp) * Cy + c;
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) acc[lr] += d[k] * wv[khp][k];
-                    }
+            for (int g = 0; g < 4; ++g) {
+                const int ci = ct * 32 + 8 * g + 4 * half;
+                if (ci < Cin) {
+                    uint2 *p = reinterpret_cast<uint2 *>(o + ci);
+                    const uint2 old = *p;
+                    uint2 nw;
+                    nw.x = pack_bf16(__uint_as_float(old.x << 16) + acc[4 * g], __uint_as_float(old.x & 0xffff0000u) + acc[4 * g + 1]);
+                    nw.y = pack_bf16(__uint_as_float(old.y << 16) + acc[4 * g + 2], __uint_as_float(old.y & 0xffff0000u) + acc[4 * g + 3]);
+                    *p = nw;
+                }
             }
-        }
-#pragma unroll
-        for (int r = 0; r < kEdgeRows; ++r) {
-            unsigned short *o = dx + (((size_t)n * H + h0 + r) * W + (edge ? W - 1 : 0)) * Cin + ci;
-            *o = f2bf(bf2f(*o) + acc[r]);
         }
     }
 }
@@ -643,8 +710,7 @@ bool dgrad_direct_replicate_eligible(const m355_conv_desc *d, int Cy)
 {
     const int Hl = d->H << d->upsample, Wl = d->W << d->upsample;
     return d->stride == 1 && d->kh == 3 && d->kw == 3 && d->pad_h == 1 && d->pad_w == 1 && d->pad_w_mode == 1 && Cy % 64 == 0 &&
-           d->Cin % 8 == 0 && Wl % 32 == 0 && Hl % 8 == 0 && d->H % kEdgeRows == 0 &&
-           Cy * ((kEdgeRows << d->upsample) + 2) <= 8192 /* edge kernel's LDS */ &&
+           d->Cin % 8 == 0 && Wl % 32 == 0 && Hl % 8 == 0 &&
            (size_t)d->N * Hl * Wl * Cy * 2 < (1ull << 31) && !getenv("M355_NO_DIRECT_REPLICATE");
 }
 
@@ -669,8 +735,7 @@ int dgrad_direct_replicate_launch(const m355_conv_desc *d, const void *dy, int C
     }
     const size_t xbytes = (size_t)d->N * Hl * Wl * Cy * 2, wbytes = (size_t)rows_p * Kp * 2;
     if (int rc = conv_halo_launch(a, (unsigned)xbytes, (unsigned)wbytes, st)) return rc;
-    const int nrows = (kEdgeRows << d->upsample) + 2;
-    hipLaunchKernelGGL(k_dgrad_edge, dim3(d->N * (d->H / kEdgeRows)), dim3(256), sizeof(float) * 2 * nrows * Cy, st, (const unsigned short *)dy,
+    hipLaunchKernelGGL(k_dgrad_edge, dim3((d->N * d->H + 31) / 32, 2), dim3(256), 0, st, (const unsigned short *)dy,
                        (const unsigned short *)w_dgrad, (unsigned short *)dx, d->N, Hl, Wl, Cy, d->Cin, Kp, d->upsample);
     return check_launch("conv2d_dgrad (direct replicate)");
 }

@@ -25,7 +25,9 @@ def timeit(f, n=10):
     for _ in range(n): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e-3
+FILT = os.environ.get("M355_LAYERS")
 for name, H, W, Cin, Cout, k, s, ph, pw, mode, ups in LAYERS:
+    if FILT and not any(f in name for f in FILT.split(",")): continue
     d = conv.make_desc(B, H, W, Cin, Cout, k, k, s, ph, pw, mode, ups)
     ho, wo = conv.out_hw(d)
     x = torch.randn(B, H, W, Cin, device="cuda").bfloat16()
