@@ -288,23 +288,29 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                 __builtin_amdgcn_sched_barrier(0);
                 const int slot_n = slot == RB - 1 ? 0 : slot + 1;
                 const int slot_p = slot == 0 ? RB - 1 : slot - 1;
+                auto mma = [&](int kk) {
+#pragma unroll
+                    for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                        for (int i = 0; i < PI; ++i)
+                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.w[kk][j], cur.p[kk][i], acc[j][i], 0, 0, 0);
+                };
+#ifndef M355_DBG_NO_MMA
+                if (!L) read_frags(cur, ha, slot, tapc);
+                mma(0);  // the DMA issue below (scalar address work, M0 writes) runs in the shadow of these MFMAs
+#endif
+                __builtin_amdgcn_sched_barrier(0);
                 issue_B(s + RB - 1 + L, L ? slot : slot_p);
                 issue_A(hb ^ 1, chunk_next, tapc);  // taps T-2, T-1 issue none
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef M355_DBG_NO_MMA
                 Frags nxt;
                 if (L) read_frags(nxt, tap == T - 1 ? lds + (hb ^ 1) * ABUF : ha, slot_n, std::integral_constant<int, (tap + 1) % T>{});
-                else read_frags(cur, ha, slot, tapc);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int j = 0; j < CJ; ++j)
-#pragma unroll
-                        for (int i = 0; i < PI; ++i)
-                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.w[kk][j], cur.p[kk][i], acc[j][i], 0, 0, 0);
+                for (int kk = 1; kk < 4; ++kk) mma(kk);
                 if (L) {
-                    // the next step's 16 fragment reads ride in the issue gaps of the first MFMAs (two per gap), so the
-                    // last of them has returned well before the step's closing lgkmcnt(0)
+                    // the next step's 16 fragment reads ride in the issue gaps of the MFMAs (two per gap), so the last of
+                    // them has returned well before the step's closing lgkmcnt(0)
 #pragma unroll
                     for (int q = 0; q < 2 * (PI + CJ); ++q) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -331,64 +337,86 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                     acc[j][0][r] = v + __shfl_xor(v, 1);
                 }
         }
+        // Variants by what the epilogue has to do (65 values per lane: every VALU op here is exposed on a one-wave-per-SIMD
+        // workgroup): PLAIN = no bias, no activation; MASK = the fused activation backward; GUARD = partial channel
+        // tiles / the folded store.  The generic variant decides bias / mask at run time.
+        auto store_tile = [&](auto plainc, auto maskc, auto guardc) {
+            constexpr bool PLAIN = decltype(plainc)::value, MASK = decltype(maskc)::value, GUARD = decltype(guardc)::value;
 #pragma unroll
-        for (int i = 0; i < PI; ++i) {
-            if (a.fold2 && i == 1) continue;
-            const int ho = oy0 + 2 * wm + i, wo = ox0 + tx;
-            const bool st_ok = !a.fold2 || !(tx & 1);
-            const size_t pix = a.fold2 ? ((size_t)n * a.OH + (ho >> 1)) * a.OW + (wo >> 1)
-                                       : ((size_t)n * a.OH + (ho * a.oy_mul + oy_off)) * a.OW + (wo * a.ox_mul + ox_off);
+            for (int i = 0; i < PI; ++i) {
+                if (GUARD && a.fold2 && i == 1) continue;
+                const int ho = oy0 + 2 * wm + i, wo = ox0 + tx;
+                const bool st_ok = !GUARD || !a.fold2 || !(tx & 1);
+                const size_t pix = (GUARD && a.fold2) ? ((size_t)n * a.OH + (ho >> 1)) * a.OW + (wo >> 1)
+                                                      : ((size_t)n * a.OH + (ho * a.oy_mul + oy_off)) * a.OW + (wo * a.ox_mul + ox_off);
 #pragma unroll
-            for (int j = 0; j < CJ; ++j) {
-                const int cbase = n0 + wn * 64 + 32 * j;
-                float4 b4[4];
+                for (int j = 0; j < CJ; ++j) {
+                    const int cbase = n0 + wn * 64 + 32 * j;
+                    float4 b4[4];
+                    if (!PLAIN) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int co = cbase + 8 * g + 4 * half;
-                    b4[g] = (a.bias && co < a.Cout) ? *reinterpret_cast<const float4 *>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-                uint2 mk[4];
-                if (a.mask_x) {
+                        for (int g = 0; g < 4; ++g) {
+                            const int co = cbase + 8 * g + 4 * half;
+                            b4[g] = (a.bias && (!GUARD || co < a.Cout)) ? *reinterpret_cast<const float4 *>(a.bias + co)
+                                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                    }
+                    const bool masked = MASK && (!GUARD || a.mask_x);
+                    uint2 mk[4];
+                    if (masked) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int co = cbase + 8 * g + 4 * half;
+                            mk[g] = (!GUARD || co < a.Cout) ? *reinterpret_cast<const uint2 *>(a.mask_x + pix * a.Cs + co) : make_uint2(0u, 0u);
+                        }
+                    }
+                    uint2 pk[4];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const int co = cbase + 8 * g + 4 * half;
-                        mk[g] = co < a.Cout ? *reinterpret_cast<const uint2 *>(a.mask_x + pix * a.Cs + co) : make_uint2(0u, 0u);
+                        float v[4] = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+                        if (!PLAIN) {
+                            v[0] += b4[g].x; v[1] += b4[g].y; v[2] += b4[g].z; v[3] += b4[g].w;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * a.slope;
+                        }
+                        if (masked) {
+                            const float x0 = __uint_as_float(mk[g].x << 16), x1 = __uint_as_float(mk[g].x & 0xffff0000u);
+                            const float x2 = __uint_as_float(mk[g].y << 16), x3 = __uint_as_float(mk[g].y & 0xffff0000u);
+                            v[0] = x0 > 0.0f ? v[0] : v[0] * a.mask_slope;
+                            v[1] = x1 > 0.0f ? v[1] : v[1] * a.mask_slope;
+                            v[2] = x2 > 0.0f ? v[2] : v[2] * a.mask_slope;
+                            v[3] = x3 > 0.0f ? v[3] : v[3] * a.mask_slope;
+                        }
+                        pk[g].x = pack_bf16(v[0], v[1]);
+                        pk[g].y = pack_bf16(v[2], v[3]);
                     }
-                }
-                uint2 pk[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float v[4] = {acc[j][i][4 * g] + b4[g].x, acc[j][i][4 * g + 1] + b4[g].y, acc[j][i][4 * g + 2] + b4[g].z,
-                                  acc[j][i][4 * g + 3] + b4[g].w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * a.slope;
-                    if (a.mask_x) {
-                        const float x0 = __uint_as_float(mk[g].x << 16), x1 = __uint_as_float(mk[g].x & 0xffff0000u);
-                        const float x2 = __uint_as_float(mk[g].y << 16), x3 = __uint_as_float(mk[g].y & 0xffff0000u);
-                        v[0] = x0 > 0.0f ? v[0] : v[0] * a.mask_slope;
-                        v[1] = x1 > 0.0f ? v[1] : v[1] * a.mask_slope;
-                        v[2] = x2 > 0.0f ? v[2] : v[2] * a.mask_slope;
-                        v[3] = x3 > 0.0f ? v[3] : v[3] * a.mask_slope;
-                    }
-                    pk[g].x = pack_bf16(v[0], v[1]);
-                    pk[g].y = pack_bf16(v[2], v[3]);
-                }
-#pragma unroll
-                for (int g = 0; g < 4; g += 2) {
-                    auto sx = __builtin_amdgcn_permlane32_swap(pk[g].x, pk[g + 1].x, false, false);
-                    auto sy = __builtin_amdgcn_permlane32_swap(pk[g].y, pk[g + 1].y, false, false);
-                    const int co = cbase + 8 * (g + half);
+                    for (int g = 0; g < 4; g += 2) {
+                        auto sx = __builtin_amdgcn_permlane32_swap(pk[g].x, pk[g + 1].x, false, false);
+                        auto sy = __builtin_amdgcn_permlane32_swap(pk[g].y, pk[g + 1].y, false, false);
+                        const int co = cbase + 8 * (g + half);
 #ifdef M355_DBG_NO_EPI
-                    if (co < a.Cout && st_ok && a.N < 0) {
+                        if (a.N < 0) {
 #else
-                    if (co < a.Cout && st_ok) {
+                        if (!GUARD || (co < a.Cout && st_ok)) {
 #endif
-                        uint4 o;
-                        o.x = sx[0]; o.y = sy[0]; o.z = sx[1]; o.w = sy[1];
-                        *reinterpret_cast<uint4 *>(yb + pix * a.Cs + co) = o;
+                            uint4 o;
+                            o.x = sx[0]; o.y = sy[0]; o.z = sx[1]; o.w = sy[1];
+                            *reinterpret_cast<uint4 *>(yb + pix * a.Cs + co) = o;
+                        }
                     }
                 }
             }
+        };
+        {
+            using std::false_type;
+            using std::true_type;
+            const bool guard = a.fold2 || a.Cout != a.CoutP, plain = !a.bias && a.slope == 1.0f;
+            if (guard) store_tile(false_type{}, true_type{}, true_type{});
+            else if (plain && !a.mask_x) store_tile(true_type{}, false_type{}, false_type{});
+            else if (plain) store_tile(true_type{}, true_type{}, false_type{});
+            else if (!a.mask_x) store_tile(false_type{}, false_type{}, false_type{});
+            else store_tile(false_type{}, true_type{}, true_type{});
         }
 #pragma unroll
         for (int j = 0; j < CJ; ++j)
