@@ -128,49 +128,75 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
     // ---- halo DMA offsets of a tile.  Slot k of wave w is DMA instruction q = NW*k + w = halo rows 8q .. 8q+7;
     // lane l -> row 8q + (l>>3), LDS chunk slot l&7, source chunk (l&7) ^ ((row>>1)&7)  [(row>>1)&7 = 4(w&1) + (l>>4)&3]
     const int csrc = (lane & 7) ^ (((wave & 1) << 2) | ((lane >> 4) & 3));
-    unsigned aoff[NAW];
+    // hyx[k]: the slot's halo pixel (row << 16 | column, in image-pixel steps), tile-independent; slots past the halo get
+    // a row no image has.  Per prefetch target only the scalar origin changes (Tgt), and the per-slot work is ~a dozen
+    // VALU ops -- done in the MFMA shadow of the last two steps of the segment BEFORE the one whose slices use it.
+    unsigned aoff[NAW], hyx[NAW];
+#pragma unroll
+    for (int k = 0; k < NAW; ++k) {
+        const int rho = 8 * (NW * k + wave) + (lane >> 3);
+        const int hy = rho / HWD, hx = rho - hy * HWD;
+        hyx[k] = rho < HR ? (unsigned)((SUB * hy) << 16 | (SUB * hx)) : 0x7fff0000u;
+    }
+    const unsigned c16 = (unsigned)csrc * 16u, cin2 = (unsigned)a.Cin * 2u;
     auto tile_origin = [&](int tp, int &n, int &oy0, int &ox0) {
         n = tp / (tpx * tpy);
         const int trem = tp - n * (tpx * tpy);
         oy0 = (trem / tpx) * TH;
         ox0 = (trem % tpx) * TW;
     };
-    auto compute_aoff = [&](int tp, int cls) {
+    struct Tgt {
+        int Yb, Xb;      // image pixel of halo pixel (0, 0)
+        unsigned nbase;  // byte offset of the image
+    };
+    auto target = [&](int tp, int cls) {
         int n, oy0, ox0;
         tile_origin(tp, n, oy0, ox0);
-        const int Y0 = UPS ? (oy0 - pad_h) >> 1 : oy0 - pad_h, X0 = UPS ? (ox0 - pad_w) >> 1 : ox0 - pad_w;
+        Tgt t;
+        // SUB 2: plane pixel (oy0 + hy, ox0 + hx) of class (cls>>1, cls&1) = image pixel 2*plane + class - pad
+        t.Yb = SUB == 2 ? 2 * oy0 + (cls >> 1) - pad_h : (UPS ? (oy0 - pad_h) >> 1 : oy0 - pad_h);
+        t.Xb = SUB == 2 ? 2 * ox0 + (cls & 1) - pad_w : (UPS ? (ox0 - pad_w) >> 1 : ox0 - pad_w);
+        t.nbase = (unsigned)(n * a.H * a.W) * cin2;
+        return t;
+    };
+    auto compute_aoff = [&](const Tgt &t, auto k0c, auto k1c) {
 #pragma unroll
-        for (int k = 0; k < NAW; ++k) {
-            const int rho = 8 * (NW * k + wave) + (lane >> 3);
-            const int hy = rho / HWD, hx = rho - hy * HWD;
-            // SUB 2: plane pixel (oy0 + hy, ox0 + hx) of class (cls>>1, cls&1) = image pixel 2*plane + class - pad
-            const int iy = SUB == 2 ? 2 * (oy0 + hy) + (cls >> 1) - pad_h : Y0 + hy;
-            int ix = SUB == 2 ? 2 * (ox0 + hx) + (cls & 1) - pad_w : X0 + hx;
-            bool ok = rho < HR && (unsigned)iy < (unsigned)a.H;
+        for (int k = decltype(k0c)::value; k < decltype(k1c)::value; ++k) {
+            const int iy = t.Yb + (int)(hyx[k] >> 16);
+            int ix = t.Xb + (int)(hyx[k] & 0xffffu);
             if (MODE == 1) ix = min(max(ix, 0), a.W - 1);
             else if (MODE == 2) ix = ix < 0 ? ix + a.W : (ix >= a.W ? ix - a.W : ix);
-            ok = ok && (unsigned)ix < (unsigned)a.W;
-            aoff[k] = ok ? (unsigned)(((n * a.H + iy) * a.W + ix) * a.Cin * 2 + csrc * 16) : OOB;
+            const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const unsigned off = __umul24(__umul24(iy, a.W) + ix, cin2) + (t.nbase + c16);
+            aoff[k] = ok ? off : OOB;
         }
     };
+    using K0 = std::integral_constant<int, 0>;
+    using KH = std::integral_constant<int, NAW / 2>;
+    using KN = std::integral_constant<int, NAW>;
     unsigned wrow[NBW];
 #pragma unroll
     for (int j = 0; j < NBW; ++j) wrow[j] = (unsigned)(n0 + 8 * (NW * j + wave) + (lane >> 3)) * (unsigned)(a.Kp * 2) + csrc * 16;
 
-    const int ncc = a.Cin >> 6, NSEG = NC * ncc, S = NSEG * T;
+    const int ncc = a.Cin >> 6, NSEG = NC * ncc;
 
-    // weights of step s of a tile (= segment s / T, tap s % T) -> ring slot; steps >= S are the next tile's first ones
-    auto issue_B = [&](int s, int slot) {
-        while (s >= S) s -= S;
-        const int sg = s / T, tap = s - sg * T;
-        const int cls = sg / ncc, cc = sg - cls * ncc;
+    // weights of one step (class, channel chunk, tap) -> ring slot.  The weight stream runs RB-1+L steps ahead of the
+    // compute stream: its (class, chunk) is the current segment's advanced by a compile-time number of segments.
+    auto issue_B = [&](int cls, int cc, auto tapc, int slot) {
+        constexpr int tap = decltype(tapc)::value;
         // SUB 2: tap (a,b) of class (p,q) is the conv's tap (2a+p, 2b+q); the weight view is ordered (kh, kw, ci)
         const int ktap = SUB == 2 ? (2 * (tap >> 1) + (cls >> 1)) * 4 + 2 * (tap & 1) + (cls & 1) : tap;
-        const unsigned so = (unsigned)((ktap * a.Cin + cc * 64) * 2);
+        const unsigned so = (unsigned)(ktap * a.Cin + cc * 64) * 2u;
 #ifndef M355_DBG_NO_B
 #pragma unroll
         for (int j = 0; j < NBW; ++j) dma16(rw, ldsB + slot * BBUF + (NW * j + wave) * 1024, wrow[j], so);
 #endif
+    };
+    auto advance = [&](int &cls, int &cc) {  // next segment of the (cyclic) segment sequence of a tile
+        if (++cc == ncc) {
+            cc = 0;
+            if (NC > 1) cls = cls + 1 == NC ? 0 : cls + 1;
+        }
     };
     // halo slice `tap` (slots tap*NAS .. +NAS-1, as far as they exist) of the NEXT (tile, chunk) into halo buffer hbuf.
     // Every step issues a COMPILE-TIME-KNOWN number of DMAs (the counted wait depends on it): when there is no next
@@ -226,13 +252,36 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                 f.w[kk][j] = *reinterpret_cast<const bf16x8 *>(bs + j * 32 * 128 + (((kk * 2 + half) ^ swzb) << 4));
     };
 
-    // ---- prologue: the whole first halo of the first tile and the first RB weight steps; the fragments of step 0
+    // what the slices of segment `sgn` of tile `tpn` prefetch -- the tile's next segment (new offsets only when the class
+    // changes), else the next tile's first segment: does aoff[] have to be recomputed for it, and for which target?
+    auto plan = [&](int sgn, int tpn, Tgt &t) {
+        if (sgn + 1 < NSEG) {
+            if (NC == 1) return false;
+            const int cls_n = (sgn + 1) / ncc;
+            if ((sgn + 1) - cls_n * ncc != 0) return false;
+            t = target(tpn, cls_n);
+            return true;
+        }
+        if (tpn + PS >= tiles_p) return false;  // nothing left: the slices re-load what aoff[] already describes
+        t = target(tpn + PS, 0);
+        return true;
+    };
+
+    // ---- prologue: the whole first halo of the first tile and the first weight steps; the fragments of step 0
     int tp = bp;
-    compute_aoff(tp, 0);
+    Tgt tg = target(tp, 0);
+    compute_aoff(tg, K0{}, KN{});
 #pragma unroll
     for (int k = 0; k < NAW; ++k) dma16(rx, lds + (NW * k + wave) * 1024, aoff[k], 0u);
-#pragma unroll
-    for (int q = 0; q < RB - 1 + L; ++q) issue_B(q, q);
+    if (plan(0, tp, tg)) compute_aoff(tg, K0{}, KN{});
+    {
+        int cls = 0, cc = 0;
+        static_for<0, RB - 1 + L>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            issue_B(cls, cc, std::integral_constant<int, q % T>{}, q);
+            if (q % T == T - 1) advance(cls, cc);
+        });
+    }
     int warm = RB;  // the first RB steps have fewer DMAs behind them than the counted wait assumes: drain instead
     Frags cur;
     if (L) {
@@ -241,6 +290,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
         read_frags(cur, lds, 0, std::integral_constant<int, 0>{});
     }
 
+    int cls_cur = 0, cc_cur = 0;  // (class, chunk) of the current segment
     int slot = 0;  // ring slot of the current step
     int hb = 0;    // halo buffer of the current chunk
     for (;;) {
@@ -250,22 +300,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
         const bool has_next = tp_next < tiles_p;
         for (int sg = 0; sg < NSEG; ++sg) {
             const unsigned char *ha = lds + hb * ABUF;
-            // what the slices of this segment prefetch: the tile's next segment (new offsets when the class changes),
-            // else the next tile's first segment (this tile's own halo loads have all been issued by now), else (nothing
-            // left) the current segment again
-            int chunk_next;
-            if (sg + 1 < NSEG) {
-                const int cls_n = (sg + 1) / ncc;
-                chunk_next = (sg + 1) - cls_n * ncc;
-                if (NC > 1 && chunk_next == 0) compute_aoff(tp, cls_n);
-            } else {
-                chunk_next = has_next ? 0 : (sg % ncc);
-                if (has_next) compute_aoff(tp_next, 0);
-            }
-            const int cc = sg;  // (step index base below)
+            // the chunk this segment's slices prefetch (their offsets aoff[] were prepared during the previous segment)
+            const int chunk_next = sg + 1 < NSEG ? (cc_cur + 1 == ncc ? 0 : cc_cur + 1) : (has_next ? 0 : cc_cur);
+            // ... and what the NEXT segment's slices will need: prepared in this segment's last two steps
+            const int sgn = sg + 1 < NSEG ? sg + 1 : 0, tpn = sg + 1 < NSEG ? tp : tp_next;
+            const bool replan = (sg + 1 < NSEG || has_next) && plan(sgn, tpn, tg);
             static_for<0, T>([&](auto tapc) {
                 constexpr int tap = decltype(tapc)::value;
-                const int s = cc * T + tap;
                 // Step s issues the weights of step s+RB-1+L into the ring slot last read in step s-1+L, and its barrier
                 // publishes what step s+L reads: those weights (issued first thing in step s-RB+1) and, when s+L opens a
                 // chunk, that chunk's halo (last slice at tap TL of the chunk before).  L = 1: the fragments of step s+1
@@ -300,9 +341,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                 mma(0);  // the DMA issue below (scalar address work, M0 writes) runs in the shadow of these MFMAs
 #endif
                 __builtin_amdgcn_sched_barrier(0);
-                issue_B(s + RB - 1 + L, L ? slot : slot_p);
+                {
+                    constexpr int ahead = tap + RB - 1 + L;  // the weight stream's step, relative to this segment's tap 0
+                    int cls_b = cls_cur, cc_b = cc_cur;
+#pragma unroll
+                    for (int q = 0; q < ahead / T; ++q) advance(cls_b, cc_b);
+                    issue_B(cls_b, cc_b, std::integral_constant<int, ahead % T>{}, L ? slot : slot_p);
+                }
                 issue_A(hb ^ 1, chunk_next, tapc);  // taps T-2, T-1 issue none
                 __builtin_amdgcn_sched_barrier(0);
+                if (tap == T - 2 && replan) compute_aoff(tg, K0{}, KH{});  // (VALU work in the MFMA shadow below)
+                if (tap == T - 1 && replan) compute_aoff(tg, KH{}, KN{});
 #ifndef M355_DBG_NO_MMA
                 Frags nxt;
                 if (L) read_frags(nxt, tap == T - 1 ? lds + (hb ^ 1) * ABUF : ha, slot_n, std::integral_constant<int, (tap + 1) % T>{});
@@ -322,6 +371,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                 slot = slot_n;
             });
             hb ^= 1;
+            advance(cls_cur, cc_cur);
         }
 
         // ---- epilogue of this tile (as k_conv_glds), while the next tile's halo and first weights are in flight:
