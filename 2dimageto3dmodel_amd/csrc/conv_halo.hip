@@ -78,7 +78,7 @@ constexpr int halo_dmas_behind(int tap)
     return n;
 }
 
-template <int BN, int NW, int KS, int UPS, int MODE, int SUB = 1>
+template <int BN, int NW, int KS, int UPS, int MODE, int SUB = 1, int RES = 0>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs a, unsigned xbytes, unsigned wbytes)
 {
     static_assert(SUB == 1 || (KS == 2 && !UPS), "stride-2 forward = 2x2 classes");
@@ -92,7 +92,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
     constexpr int NAW = (NA + NW - 1) / NW;               //   ... per wave
     // halo-slice DMAs per step (taps 0 .. T-3 carry the slices); EARLY: the whole next halo at tap 0
     constexpr int NAS = M355_HALO_EARLY ? NAW : (NAW + T - 3) / (T - 2);
-    constexpr int RB = NW == 4 ? M355_HALO_RB4 : M355_HALO_RB8;  // weight ring slots
+    // RES: the WHOLE weight panel of the workgroup's output channels stays resident in LDS (64 channels x K <= 576: the
+    // class convs of a stride-2 dgrad with <= 128 dy channels, a 3x3 conv of 64 channels) -- those layers are bound by
+    // the bytes DMA'd into LDS per flop, and the weights were half of them or more.  No weight DMAs in the loop, and one
+    // barrier per channel chunk (the one that publishes the next halo) instead of one per tap.
+    static_assert(!RES || (BN == 64 && NW == 4 && SUB == 1 && !UPS), "resident weights: 4-wave variant only");
+    constexpr int RB = RES ? (KS == 2 ? 8 : 9) : (NW == 4 ? M355_HALO_RB4 : M355_HALO_RB8);  // weight slots (ring / panel)
     // software pipeline (one wave per SIMD has no partner wave to hide its LDS-read latency): fragments of step s+1 are
     // read during step s.  The 8-wave variant (2 waves per SIMD, 256 registers each) reads them in the step itself.
     constexpr int L = (NW == 4 && M355_HALO_PIPE) ? 1 : 0;
@@ -274,7 +279,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
 #pragma unroll
     for (int k = 0; k < NAW; ++k) dma16(rx, lds + (NW * k + wave) * 1024, aoff[k], 0u);
     if (plan(0, tp, tg)) compute_aoff(tg, K0{}, KN{});
-    {
+    if (RES) {
+        for (int cc = 0; cc < ncc; ++cc)
+            static_for<0, T>([&](auto tapc) { issue_B(0, cc, tapc, cc * T + decltype(tapc)::value); });
+    } else {
         int cls = 0, cc = 0;
         static_for<0, RB - 1 + L>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
@@ -282,6 +290,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
             if (q % T == T - 1) advance(cls, cc);
         });
     }
+    const int nslot = RES ? ncc * T : RB;  // slots in use (RES: one per step of a tile)
     int warm = RB;  // the first RB steps have fewer DMAs behind them than the counted wait assumes: drain instead
     Frags cur;
     if (L) {
@@ -320,15 +329,24 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                 static_assert(TL <= T - 3 && RB >= 2, "halo slices must be out by tap T-3");
                 constexpr int cnt_a = (T - 1 - L - TL) * NBW;
                 constexpr int cnt = (tap == (T - L) % T && cnt_a < cnt_b) ? cnt_a : cnt_b;
-                if (warm) {
-                    --warm;
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (RES) {
+                    // only the halo is in flight: the step that first touches the next chunk's halo drains this wave's
+                    // DMAs and meets the others (which also retires every read of the buffer refilled next)
+                    if (tap == (T - L) % T) {
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                    }
+                } else {
+                    if (warm) {
+                        --warm;
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(cnt) : "memory");
+                    __builtin_amdgcn_s_barrier();      // ... the same holds for every wave
                 }
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(cnt) : "memory");
-                __builtin_amdgcn_s_barrier();      // ... the same holds for every wave
                 __builtin_amdgcn_sched_barrier(0);
-                const int slot_n = slot == RB - 1 ? 0 : slot + 1;
-                const int slot_p = slot == 0 ? RB - 1 : slot - 1;
+                const int slot_n = slot == nslot - 1 ? 0 : slot + 1;
+                const int slot_p = slot == 0 ? nslot - 1 : slot - 1;
                 auto mma = [&](int kk) {
 #pragma unroll
                     for (int j = 0; j < CJ; ++j)
@@ -341,7 +359,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                 mma(0);  // the DMA issue below (scalar address work, M0 writes) runs in the shadow of these MFMAs
 #endif
                 __builtin_amdgcn_sched_barrier(0);
-                {
+                if (!RES) {
                     constexpr int ahead = tap + RB - 1 + L;  // the weight stream's step, relative to this segment's tap 0
                     int cls_b = cls_cur, cc_b = cc_cur;
 #pragma unroll
@@ -774,8 +792,23 @@ int conv_halo_launch(const ConvArgs &a, unsigned xb, unsigned wb, hipStream_t st
         else M355_HM(BN_, NW_, 3, 0);                                  \
     } while (0)
     const dim3 grid((unsigned)per * nN, a.ncls);
-    if (a.CoutP == 64) M355_HK(64, 4);
+    // resident weight panel (64 output channels x K <= 576)
+    const bool res = a.CoutP == 64 && a.stride == 1 && !a.ups && ((a.KH == 2 && a.Cin <= 128) || (a.KH == 3 && a.Cin == 64)) &&
+                     !getenv("M355_NO_HALO_RES");
+#define M355_HR(KS_, MD_) hipLaunchKernelGGL((k_conv_halo<64, 4, KS_, 0, MD_, 1, 1>), grid, dim3(256), 0, st, a, xb, wb)
+    if (res) {
+        if (a.KH == 2) {
+            if (a.pad_w_mode == 0) M355_HR(2, 0);
+            else if (a.pad_w_mode == 1) M355_HR(2, 1);
+            else M355_HR(2, 2);
+        } else {
+            if (a.pad_w_mode == 0) M355_HR(3, 0);
+            else if (a.pad_w_mode == 1) M355_HR(3, 1);
+            else M355_HR(3, 2);
+        }
+    } else if (a.CoutP == 64) M355_HK(64, 4);
     else M355_HK(128, 8);
+#undef M355_HR
 #undef M355_HK
 #undef M355_HS2
 #undef M355_HM
