@@ -575,6 +575,20 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_halo(WgradArgs a, unsigned xby
     const int ya = (((w_co * 4 + g16 * 2 + ((q & 3) >> 1)) ^ (((q >> 3) & 1) << 2)) << 4) + (q & 1) * 8 + (8 * hh + (q >> 2)) * 128;
     const int xchunk = w_ci * 4 + g16 * 2 + ((q & 3) >> 1);
 
+    constexpr int NKG = KS == 2 ? 8 : 16;  // K groups per wave and tile
+    const int lp = 8 * hh + (q >> 2);      // this lane's pixel within a 16-pixel K group
+    const int ybase = ya + (KS == 2 ? 8 * w_hi * 2048 : 0);
+    // x fragment bases: halo row = (lane part) + (static part c); the swizzle bit ((row>>1)&1) depends on the two low
+    // bits of both parts only -> one base per (c & 3) [and per parity of the static column when the upsample halves it]
+    int xbase[UPS ? 8 : 4];
+#pragma unroll
+    for (int m = 0; m < (UPS ? 8 : 4); ++m) {
+        const int lpm = UPS ? (lp + (m >> 2)) >> 1 : lp;
+        const int sbit = (((lpm & 3) + (m & 3)) >> 1) & 1;
+        xbase[m] = (lpm + (KS == 2 ? 4 * w_hi * HWD : 0)) * 128 + ((xchunk ^ (sbit << 2)) << 4) + (q & 1) * 8;
+    }
+    static_assert(KS != 2 || (4 * HWD) % 4 == 0, "the quartet's row offset must not disturb the swizzle bits");
+
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -603,31 +617,43 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_halo(WgradArgs a, unsigned xby
                 dbacc += bf2f(*reinterpret_cast<const unsigned short *>(by + prow * 128 + (((dbc >> 3) ^ (((prow >> 1) & 1) << 2)) << 4) + (dbc & 7) * 2));
             }
         }
-        const int kg0 = KS == 2 ? 8 * w_hi : 0, kg1 = KS == 2 ? kg0 + 8 : 16;
-        for (int kg = kg0; kg < kg1; ++kg) {  // K group = 16 pixels: tile row kg>>1, columns 16(kg&1) .. +15
-            const s4v y0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v *)(by + ya + kg * 2048));
-            const s4v y1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v *)(by + ya + kg * 2048 + 512));
-            const bf16x8 yf = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
-            const int ty = kg >> 1, txb = (kg & 1) * 16 + 8 * hh + (q >> 2);
+        // K groups of 16 pixels (tile row kg>>1, columns 16(kg&1) .. +15), fully unrolled: every fragment address is a
+        // lane-dependent base + an immediate.  KS 3: wave quartet w_hi owns taps 5 w_hi .. (two code copies); KS 2: it
+        // owns the K groups 8 w_hi .. +7 (folded into the bases).
+        auto tile_mma = [&](auto whc) {
+            constexpr int WH = decltype(whc)::value;  // tap group (KS 3 only)
+            static_for<0, NKG>([&](auto kgc) {
+                constexpr int kg = decltype(kgc)::value;
+                const s4v y0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v *)(by + ybase + kg * 2048));
+                const s4v y1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v *)(by + ybase + kg * 2048 + 512));
+                const bf16x8 yf = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+                constexpr int ty = kg >> 1;
+                static_for<0, NT>([&](auto tc) {
+                    constexpr int tap = KS == 3 ? WH * NT + decltype(tc)::value : decltype(tc)::value;
+                    if constexpr (tap < T) {
+                        constexpr int kh = tap / KS, kw = tap - kh * KS;
+                        s4v x01[2];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int tap = KS == 3 ? w_hi * NT + t : t;   // (KS 3: the 10th slot, tap 9, does not exist)
-                if (tap < T) {
-                    const int kh = tap / KS, kw = tap - kh * KS;
-                    const int ly = ty + kh;
-                    s4v x01[2];
-#pragma unroll
-                    for (int rd = 0; rd < 2; ++rd) {
-                        const int lx = txb + 4 * rd + kw;
-                        const int rho = UPS ? ((ly + ey) >> 1) * HWD + ((lx + ex) >> 1) : ly * HWD + lx;
-                        x01[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (lds_s4v *)(bx + rho * 128 + ((xchunk ^ (((rho >> 1) & 1) << 2)) << 4) + (q & 1) * 8));
+                        for (int rd = 0; rd < 2; ++rd) {
+                            if constexpr (UPS) {
+                                // (pad 1: ey = ex = 1)  stored halo row = C + LP(par): C static, LP(par) = (lp + par) >> 1
+                                const int cx = (kg & 1) * 16 + 4 * rd + kw + 1;  // (folds: rd is unrolled)
+                                const int C = ((ty + kh + 1) >> 1) * HWD + (cx >> 1);
+                                x01[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v *)(bx + xbase[(cx & 1) * 4 + (C & 3)] + C * 128));
+                            } else {
+                                // halo row rho = lp + c: the swizzle bit ((rho>>1)&1) depends on (lp & 3) and (c & 3) only
+                                const int c = (ty + kh) * HWD + (kg & 1) * 16 + 4 * rd + kw;
+                                x01[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v *)(bx + xbase[c & 3] + c * 128));
+                            }
+                        }
+                        const bf16x8 xf = __builtin_shufflevector(x01[0], x01[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc[decltype(tc)::value] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf, xf, acc[decltype(tc)::value], 0, 0, 0);
                     }
-                    const bf16x8 xf = __builtin_shufflevector(x01[0], x01[1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf, xf, acc[t], 0, 0, 0);
-                }
-            }
-        }
+                });
+            });
+        };
+        if (KS == 3 && w_hi) tile_mma(std::integral_constant<int, 1>{});
+        else tile_mma(std::integral_constant<int, 0>{});
     }
     if (do_db && co0 + dbc < a.Cout) atomicAdd(a.db + co0 + dbc, dbacc);
     // acc[t][r]: co = co0 + 32 w_co + (r&3) + 8(r>>2) + 4(lane>>5), ci = ci0 + 32 w_ci + (lane&31)
