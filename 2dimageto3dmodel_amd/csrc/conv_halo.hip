@@ -678,10 +678,10 @@ bool wgrad_halo_eligible(const WgradArgs &a)
     if (getenv("M355_NO_WGRAD_HALO")) return false;
     if (a.Cin % 64 || a.Cy % 64 || a.Wo % 32 || a.Ho % 8) return false;
     if (a.stride == 1) return a.KH == 3 && a.KW == 3 && a.pad_h == 1 && a.pad_w == 1;
-    // parity classes of a 4x4 stride-2 conv: measured +45 % on D.conv2 (64 input channels), -5..-10 % on D.conv3 / conv4
-    // (their 128-wide k_wgrad_dma tiles already amortise the gathers): only for Cin <= 64
+    // parity classes of a 4x4 stride-2 conv (measured against k_wgrad_dma: D.conv2 x1.6, D.conv3 / conv4 x1.13;
+    // M355_WGRAD_HALO_CIN64 restores the older split for A/B runs)
     return a.stride == 2 && a.KH == 4 && a.KW == 4 && !a.ups && a.H == 2 * a.Ho && a.W == 2 * a.Wo &&
-           (a.Cin <= 64 || getenv("M355_WGRAD_HALO_ALL"));
+           (a.Cin <= 64 || !getenv("M355_WGRAD_HALO_CIN64"));
 }
 
 int wgrad_halo_launch(const WgradArgs &a, unsigned xb, unsigned yb, hipStream_t st)

@@ -370,13 +370,26 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void k_conv_glds(ConvArgs
 //   transpose == 0:  out[o][a][b][i] = in[o][i][th0+ths*a][tw0+tws*b]        (forward)
 //   transpose == 1:  out[i][a][b][o] = in[o][i][th0+ths*a][tw0+tws*b]        (dgrad: flipped taps, swapped roles)
 // rows/channels beyond the real extents are zero filled.
-__global__ void k_weight_prep(const float *__restrict__ in, unsigned short *__restrict__ out, int O, int I, int KH,
-                              int KW, int transpose, int A, int B, int th0, int ths, int tw0, int tws, int Rp, int Cp,
-                              int Kp, const float *__restrict__ sigma)
+struct WeightPrepPart {
+    unsigned short *out;
+    int transpose, A, B, th0, ths, tw0, tws, Rp, Cp, Kp;
+};
+struct WeightPrepArgs {
+    const float *in;
+    const float *sigma;
+    int O, I, KH, KW, nparts;
+    WeightPrepPart part[5];  // forward view + the dgrad view (stride 1) or its four parity classes (stride 2)
+};
+// one launch for all views of a layer: blockIdx.y = view
+__global__ void k_weight_prep(WeightPrepArgs w)
 {
-    const float wscale = sigma ? 1.0f / sigma[0] : 1.0f;  // spectral norm: W_sn = W_orig / sigma (gan_glue.hip)
+    const WeightPrepPart &p = w.part[blockIdx.y];
+    const float *__restrict__ in = w.in;
+    unsigned short *__restrict__ out = p.out;
+    const int O = w.O, I = w.I, KH = w.KH, KW = w.KW, transpose = p.transpose, A = p.A, B = p.B, Cp = p.Cp, Kp = p.Kp;
+    const float wscale = w.sigma ? 1.0f / w.sigma[0] : 1.0f;  // spectral norm: W_sn = W_orig / sigma (gan_glue.hip)
     // out is [Rp][Kp], a row = (A x B taps) x Cp channels then zero fill; R = transpose ? I : O, C = transpose ? O : I
-    const size_t total = (size_t)Rp * Kp;
+    const size_t total = (size_t)p.Rp * Kp;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int k = idx % Kp;
         const int r = idx / Kp;
@@ -385,7 +398,7 @@ __global__ void k_weight_prep(const float *__restrict__ in, unsigned short *__re
             const int c = k % Cp, t = k / Cp;
             const int b = t % B, aa = t / B;
             const int o = transpose ? c : r, i = transpose ? r : c;
-            if (o < O && i < I) v = in[(((size_t)o * I + i) * KH + (th0 + ths * aa)) * KW + (tw0 + tws * b)];
+            if (o < O && i < I) v = in[(((size_t)o * I + i) * KH + (p.th0 + p.ths * aa)) * KW + (p.tw0 + p.tws * b)];
         }
         out[idx] = f2bf(v * wscale);
     }
@@ -607,20 +620,18 @@ extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_o
     M355_REQUIRE(cin_w >= 1 && cin_w <= d->Cin, "conv2d_weight_prep: cin_w=%d outside 1..Cin=%d", cin_w, d->Cin);
     hipStream_t st = (hipStream_t)stream;
     const int cout64 = m355::rows_padded(d->Cout), cin64 = m355::rows_padded(d->Cin), cout32 = m355::dy_channels(d->Cout);
-    if (w_fwd) {
-        const int Kp = m355::k_padded(d->kh * d->kw * d->Cin);
-        const size_t total = (size_t)cout64 * Kp;
-        hipLaunchKernelGGL(m355::k_weight_prep, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),
-                           dim3(256), 0, st, w_oihw, (unsigned short *)w_fwd, d->Cout, cin_w, d->kh, d->kw, 0, d->kh,
-                           d->kw, 0, 1, 0, 1, cout64, d->Cin, Kp, sigma);
-    }
+    m355::WeightPrepArgs w = {};
+    w.in = w_oihw; w.sigma = sigma; w.O = d->Cout; w.I = cin_w; w.KH = d->kh; w.KW = d->kw;
+    size_t most = 0;
+    auto add = [&](unsigned short *out, int transpose, int A, int B, int th0, int ths, int tw0, int tws, int Rp, int Cp, int Kp) {
+        w.part[w.nparts++] = m355::WeightPrepPart{out, transpose, A, B, th0, ths, tw0, tws, Rp, Cp, Kp};
+        if ((size_t)Rp * Kp > most) most = (size_t)Rp * Kp;
+    };
+    if (w_fwd) add((unsigned short *)w_fwd, 0, d->kh, d->kw, 0, 1, 0, 1, cout64, d->Cin, m355::k_padded(d->kh * d->kw * d->Cin));
     if (w_dgrad) {
         if (d->stride == 1) {
-            const int Kp = m355::k_padded(d->kh * d->kw * cout32);
-            const size_t total = (size_t)cin64 * Kp;
-            hipLaunchKernelGGL(m355::k_weight_prep, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),
-                               dim3(256), 0, st, w_oihw, (unsigned short *)w_dgrad, d->Cout, cin_w, d->kh, d->kw, 1,
-                               d->kh, d->kw, d->kh - 1, -1, d->kw - 1, -1, cin64, cout32, Kp, sigma);
+            add((unsigned short *)w_dgrad, 1, d->kh, d->kw, d->kh - 1, -1, d->kw - 1, -1, cin64, cout32,
+                m355::k_padded(d->kh * d->kw * cout32));
         } else {
             M355_REQUIRE(d->kh % 2 == 0 && d->kw % 2 == 0, "conv2d_weight_prep: stride-2 dgrad needs even kernels");
             const int A = d->kh / 2, B = d->kw / 2;
@@ -628,12 +639,12 @@ extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_o
             const size_t each = (size_t)cin64 * Kp;
             for (int py = 0; py < 2; ++py)
                 for (int px = 0; px < 2; ++px)
-                    hipLaunchKernelGGL(m355::k_weight_prep, dim3((unsigned)((each + 255) / 256 > 4096 ? 4096 : (each + 255) / 256)),
-                                       dim3(256), 0, st, w_oihw, (unsigned short *)w_dgrad + (size_t)(py * 2 + px) * each,
-                                       d->Cout, cin_w, d->kh, d->kw, 1, A, B, py + 2 * (A - 1), -2, px + 2 * (B - 1), -2,
-                                       cin64, cout32, Kp, sigma);
+                    add((unsigned short *)w_dgrad + (size_t)(py * 2 + px) * each, 1, A, B, py + 2 * (A - 1), -2, px + 2 * (B - 1), -2,
+                        cin64, cout32, Kp);
         }
     }
+    const unsigned bx = (unsigned)((most + 255) / 256 > 2048 ? 2048 : (most + 255) / 256);
+    hipLaunchKernelGGL(m355::k_weight_prep, dim3(bx, w.nparts), dim3(256), 0, st, w);
     return m355::check_launch("conv2d_weight_prep");
 }
 

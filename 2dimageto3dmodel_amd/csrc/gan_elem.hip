@@ -33,12 +33,14 @@ __device__ __forceinline__ short f2bf_e(float f)
     return (short)(u >> 16);
 }
 
-constexpr int kMinPixPerBlock = 1024;  // pixels a workgroup reduces (more when that keeps the partial count <= 1024)
+constexpr int kMinElemsPerBlock = 65536;  // elements a workgroup reduces (more when that keeps the partial count <= 1024)
 
-static inline int pix_per_block(size_t P)
+static inline int pix_per_block(size_t P, int C)
 {
     size_t ppb = (P + 1023) / 1024;
-    if (ppb < (size_t)kMinPixPerBlock) ppb = kMinPixPerBlock;
+    const size_t lo = (size_t)kMinElemsPerBlock / (size_t)(C > 0 ? C : 1);  // (C = 512: 128 pixels; C = 64: 1024)
+    if (ppb < lo) ppb = lo;
+    if (ppb < 64) ppb = 64;
     return (int)((ppb + 63) / 64 * 64);
 }
 
@@ -316,14 +318,14 @@ using namespace m355;
 
 extern "C" size_t m355_chan_reduce_ws_bytes(size_t pixels_per_group, int groups, int nvals, int C)
 {
-    const size_t ppb = pix_per_block(pixels_per_group);
+    const size_t ppb = pix_per_block(pixels_per_group, C);
     const size_t nblk = (pixels_per_group + ppb - 1) / ppb;
     return sizeof(float) * nblk * (size_t)groups * nvals * C;
 }
 
-extern "C" int m355_chan_reduce_nblk(size_t pixels_per_group)
+extern "C" int m355_chan_reduce_nblk(size_t pixels_per_group, int C)
 {
-    const size_t ppb = pix_per_block(pixels_per_group);
+    const size_t ppb = pix_per_block(pixels_per_group, C);
     return (int)((pixels_per_group + ppb - 1) / ppb);
 }
 
@@ -332,7 +334,7 @@ extern "C" int m355_bn_stats_partial(const void *x, float *part, size_t P, int C
 {
     M355_REQUIRE(x && part && P > 0, "bn_stats_partial: null pointer / empty");
     if (int rc = check_c(C, "bn_stats_partial")) return rc;
-    const int ppb = pix_per_block(P);
+    const int ppb = pix_per_block(P, C);
     const int nblk = (int)((P + ppb - 1) / ppb);
     hipLaunchKernelGGL(k_chan_stats, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const short *)x, part, P, C, ppb);
     return check_launch("bn_stats_partial");
@@ -344,7 +346,7 @@ extern "C" int m355_affine_act_bwd_partial(const void *dy, const void *x, const 
 {
     M355_REQUIRE(dy && x && a && b && part && N > 0 && HW > 0, "affine_act_bwd_partial: null pointer / empty");
     if (int rc = check_c(C, "affine_act_bwd_partial")) return rc;
-    const int ppb = pix_per_block((size_t)HW);
+    const int ppb = pix_per_block((size_t)HW, C);
     const int nblk = (HW + ppb - 1) / ppb;
     hipLaunchKernelGGL(k_act_bwd_reduce, dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, (const short *)dy, (const short *)x,
                        a, b, part, HW, C, slope, ppb);
@@ -355,7 +357,7 @@ extern "C" int m355_chan_sum(const void *x, float *sums /*[C]*/, void *ws, size_
 {
     M355_REQUIRE(x && sums && ws && P > 0, "chan_sum: null pointer / empty");
     if (int rc = check_c(C, "chan_sum")) return rc;
-    const int ppb = pix_per_block(P);
+    const int ppb = pix_per_block(P, C);
     const int nblk = (int)((P + ppb - 1) / ppb);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_chan_sum, dim3(nblk), dim3(256), 0, st, (const short *)x, (float *)ws, P, C, ppb);
@@ -367,7 +369,7 @@ extern "C" int m355_bn_stats(const void *x, float *sums /*[2][C]*/, void *ws, si
 {
     M355_REQUIRE(x && sums && ws && P > 0, "bn_stats: null pointer / empty");
     if (int rc = check_c(C, "bn_stats")) return rc;
-    const int ppb = pix_per_block(P);
+    const int ppb = pix_per_block(P, C);
     const int nblk = (int)((P + ppb - 1) / ppb);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_chan_stats, dim3(nblk), dim3(256), 0, st, (const short *)x, (float *)ws, P, C, ppb);
@@ -396,7 +398,7 @@ extern "C" int m355_affine_act_bwd_reduce(const void *dy, const void *x, const f
 {
     M355_REQUIRE(dy && x && a && b && sums && ws && N > 0 && HW > 0, "affine_act_bwd_reduce: null pointer / empty");
     if (int rc = check_c(C, "affine_act_bwd_reduce")) return rc;
-    const int ppb = pix_per_block((size_t)HW);
+    const int ppb = pix_per_block((size_t)HW, C);
     const int nblk = (HW + ppb - 1) / ppb;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_act_bwd_reduce, dim3(nblk, N), dim3(256), 0, st, (const short *)dy, (const short *)x, a, b,
@@ -424,7 +426,7 @@ extern "C" int m355_lrelu_bwd(const void *dy, const void *y, void *g, float *dbi
 {
     M355_REQUIRE(dy && y && g && dbias && ws && P > 0, "lrelu_bwd: null pointer / empty");
     if (int rc = check_c(C, "lrelu_bwd")) return rc;
-    const int ppb = pix_per_block(P);
+    const int ppb = pix_per_block(P, C);
     const int nblk = (int)((P + ppb - 1) / ppb);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_lrelu_bwd, dim3(nblk), dim3(256), 0, st, (const short *)dy, (const short *)y, (short *)g,

@@ -156,28 +156,40 @@ __global__ __launch_bounds__(256) void k_sn_bwd_apply(const float *__restrict__ 
 // Block = 32 channels x 8 helper lanes.  part[nblk][2][C] -> mean, rstd (biased variance, eps inside the sqrt =
 // F.batch_norm, code/sync_batchnorm/batchnorm.py:71-73), running stats (unbiased variance, momentum), and
 // a[n,c] = rstd * (1 + gamma[n,c]),  b[n,c] = beta[n,c] - mean * a[n,c].
-__global__ __launch_bounds__(256) void k_bn_finalize(const float *__restrict__ part, int nblk, float count, const float *__restrict__ gamma,
+__global__ __launch_bounds__(1024) void k_bn_finalize(const float *__restrict__ part, int nblk, float count, const float *__restrict__ gamma,
                                                      const float *__restrict__ beta, int gstride, int N, int C, float eps,
                                                      float momentum, float *__restrict__ rmean, float *__restrict__ rvar,
                                                      float *__restrict__ mean_o, float *__restrict__ rstd_o, float *__restrict__ a,
                                                      float *__restrict__ b)
 {
-    __shared__ float red[2][8][32];
+    // (up to 1024 partial rows: 32 row groups per channel and 4 independent loads in flight per thread -- the serial
+    // version spent ~12 us in dependent-latency loads)
+    __shared__ float red[2][32][32];
     __shared__ float stat[2][32];
     const int cl = threadIdx.x & 31, l = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
     float s0 = 0.0f, s1 = 0.0f;
-    if (c < C)
-        for (int k = l; k < nblk; k += 8) {
-            s0 += part[((size_t)k * 2) * C + c];
-            s1 += part[((size_t)k * 2 + 1) * C + c];
+    if (c < C) {
+        float p0[4] = {0.f, 0.f, 0.f, 0.f}, p1[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = l; k < nblk; k += 128) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = k + 32 * u;
+                if (kk < nblk) {
+                    p0[u] += part[((size_t)kk * 2) * C + c];
+                    p1[u] += part[((size_t)kk * 2 + 1) * C + c];
+                }
+            }
         }
+        s0 = (p0[0] + p0[1]) + (p0[2] + p0[3]);
+        s1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
+    }
     red[0][l][cl] = s0;
     red[1][l][cl] = s1;
     __syncthreads();
     if (l == 0 && c < C) {
         float t0 = 0.0f, t1 = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 32; ++k) {
             t0 += red[0][k][cl];
             t1 += red[1][k][cl];
         }
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float *__restrict__ p
     __syncthreads();
     if (c < C) {
         const float mean = stat[0][cl], rstd = stat[1][cl];
-        for (int n = l; n < N; n += 8) {
+        for (int n = l; n < N; n += 32) {
             const float av = rstd * (1.0f + gamma[(size_t)n * gstride + c]);
             a[(size_t)n * C + c] = av;
             b[(size_t)n * C + c] = beta[(size_t)n * gstride + c] - mean * av;
@@ -209,27 +221,32 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float *__restrict__ p
 //   dgamma[n,c] = rstd (s2 - mean s1),  dbeta[n,c] = s1,  A[n,c] = rstd (1+gamma),
 //   m1 = sum_n (1+gamma) s1 / count,  m2 = sum_n (1+gamma) dgamma / count,
 //   Bc = -rstd^2 m2,  Cc = -rstd m1 + rstd^2 mean m2            (zeros when the statistics are not batch statistics)
-__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float *__restrict__ part, int nblk, float count,
+__global__ __launch_bounds__(1024) void k_bn_bwd_finalize(const float *__restrict__ part, int nblk, float count,
                                                          const float *__restrict__ gamma, int gstride, int N, int C,
                                                          const float *__restrict__ mean_i, const float *__restrict__ rstd_i,
                                                          int batch_stats, float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                          float *__restrict__ A, float *__restrict__ Bc, float *__restrict__ Cc,
                                                          float *__restrict__ m_out)
 {
-    __shared__ float red[2][8][32];
+    __shared__ float red[2][32][32];
     const int cl = threadIdx.x & 31, l = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
     float m1 = 0.0f, m2 = 0.0f;
     float mean = 0.0f, rstd = 1.0f;
     if (c < C) {
         mean = mean_i[c];
         rstd = rstd_i[c];
-        for (int n = l; n < N; n += 8) {
-            float s1 = 0.0f, s2 = 0.0f;
+        for (int n = l; n < N; n += 32) {
+            float q1[4] = {0.f, 0.f, 0.f, 0.f}, q2[4] = {0.f, 0.f, 0.f, 0.f};
             const float *p = part + (size_t)n * nblk * 2 * C;
-            for (int k = 0; k < nblk; ++k) {
-                s1 += p[((size_t)k * 2) * C + c];
-                s2 += p[((size_t)k * 2 + 1) * C + c];
+            for (int k = 0; k < nblk; k += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (k + u < nblk) {
+                        q1[u] += p[((size_t)(k + u) * 2) * C + c];
+                        q2[u] += p[((size_t)(k + u) * 2 + 1) * C + c];
+                    }
             }
+            const float s1 = (q1[0] + q1[1]) + (q1[2] + q1[3]), s2 = (q2[0] + q2[1]) + (q2[2] + q2[3]);
             const float sc = 1.0f + gamma[(size_t)n * gstride + c];
             const float dg = rstd * (s2 - mean * s1);
             dgamma[(size_t)n * C + c] = dg;
@@ -245,7 +262,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float *__restrict
     if (l == 0 && c < C) {
         float t1 = 0.0f, t2 = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 32; ++k) {
             t1 += red[0][k][cl];
             t2 += red[1][k][cl];
         }
@@ -311,7 +328,7 @@ extern "C" int m355_bn_finalize(const float *part, int nblk, float count, const 
                                 float *mean, float *rstd, float *a, float *b, void *stream)
 {
     M355_REQUIRE(part && gamma && beta && mean && rstd && a && b && nblk > 0 && N > 0 && C > 0, "bn_finalize: bad argument");
-    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, part, nblk, count, gamma, beta,
+    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, nblk, count, gamma, beta,
                        gstride, N, C, eps, momentum, running_mean, running_var, mean, rstd, a, b);
     return check_launch("bn_finalize");
 }
@@ -322,7 +339,7 @@ extern "C" int m355_bn_bwd_finalize(const float *part, int nblk, float count, co
 {
     M355_REQUIRE(part && gamma && mean && rstd && dgamma && dbeta && A && Bc && Cc && nblk > 0 && N > 0 && C > 0,
                  "bn_bwd_finalize: bad argument");
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, part, nblk, count, gamma,
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, nblk, count, gamma,
                        gstride, N, C, mean, rstd, batch_stats, dgamma, dbeta, A, Bc, Cc, m_out);
     return check_launch("bn_bwd_finalize");
 }

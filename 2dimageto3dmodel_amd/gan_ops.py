@@ -339,7 +339,7 @@ class CbnActFn(torch.autograd.Function):
         dev = x.device
         P = n * h * w
         count = float(P)
-        nblk = lib().m355_chan_reduce_nblk(P)
+        nblk = lib().m355_chan_reduce_nblk(P, c)
         part = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev)
         launch("bn_stats_partial", ptr(x), ptr(part), P, c, stream())
         if sync:
@@ -366,7 +366,7 @@ class CbnActFn(torch.autograd.Function):
         a, b, mean, rstd = coef[:n], coef[n:2 * n], coef[2 * n], coef[2 * n + 1]
         dy = dy.contiguous()
         dev = x.device
-        nblk = lib().m355_chan_reduce_nblk(h * w)
+        nblk = lib().m355_chan_reduce_nblk(h * w, c)
         part = torch.empty((n, nblk, 2, c), dtype=torch.float32, device=dev)
         launch("affine_act_bwd_partial", ptr(dy), ptr(x), ptr(a), ptr(b), ptr(part), n, h * w, c, float(slope), stream())
         out = torch.empty((3 * n + 4, c), dtype=torch.float32, device=dev)   # dgamma | dbeta | A | Bc | Cc | m[2]

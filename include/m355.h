@@ -198,8 +198,8 @@ int m355_lrelu_bwd(const void *dy, const void *y, void *g, float *dbias, void *w
                    void *stream);
 
 /*      first stages only (the second stage is fused into m355_bn_finalize / m355_bn_bwd_finalize):
- *      part[m355_chan_reduce_nblk(P)][2][C] resp. part[N][m355_chan_reduce_nblk(HW)][2][C] */
-int m355_chan_reduce_nblk(size_t pixels_per_group);
+ *      part[m355_chan_reduce_nblk(P, C)][2][C] resp. part[N][m355_chan_reduce_nblk(HW, C)][2][C] */
+int m355_chan_reduce_nblk(size_t pixels_per_group, int C);
 int m355_bn_stats_partial(const void *x, float *part, size_t P, int C, void *stream);
 int m355_affine_act_bwd_partial(const void *dy, const void *x, const float *a, const float *b, float *part, int N, int HW,
                                 int C, float slope, void *stream);
