@@ -12,21 +12,28 @@
 namespace m355 {
 
 // ------------------------------------------------------------------------------------------- spectral norm, forward
-// t = W^T u   (train only).  Block = 64 columns x 4 row groups.
-__global__ __launch_bounds__(256) void k_sn_wtu(const m355_sn_layer *__restrict__ tab, float *__restrict__ norms)
+// t = W^T u   (train only).  Block = 64 columns x 16 row groups, 4 independent loads in flight per thread (the
+// 4-group version walked 128 rows of the 512-row layers one dependent load at a time).
+__global__ __launch_bounds__(1024) void k_sn_wtu(const m355_sn_layer *__restrict__ tab, float *__restrict__ norms)
 {
-    __shared__ float red[4][64];
+    __shared__ float red[16][64];
     const m355_sn_layer L = tab[blockIdx.y];
     const int c0 = blockIdx.x * 64;
     if (c0 >= L.cols) return;
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = c0 + cl;
-    float acc = 0.0f;
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < L.cols)
-        for (int i = rg; i < L.rows; i += 4) acc += L.w[(size_t)i * L.cols + c] * L.u[i];
-    red[rg][cl] = acc;
+        for (int i = rg; i < L.rows; i += 64) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + 16 * u < L.rows) a4[u] += L.w[(size_t)(i + 16 * u) * L.cols + c] * L.u[i + 16 * u];
+        }
+    red[rg][cl] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     __syncthreads();
     if (rg == 0) {
-        const float t = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
         if (c < L.cols) L.t[c] = t;
         float sq = c < L.cols ? t * t : 0.0f;
 #pragma unroll
@@ -53,7 +60,13 @@ __global__ __launch_bounds__(256) void k_sn_wv(const m355_sn_layer *__restrict__
     float acc = 0.0f;
     if (i < L.rows) {
         const float *wr = L.w + (size_t)i * L.cols;
-        for (int j = lane; j < L.cols; j += 64) acc += wr[j] * vv[j];
+        float a4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = lane; j < L.cols; j += 256) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j + 64 * u < L.cols) a4[u] += wr[j + 64 * u] * vv[j + 64 * u];
+        }
+        acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
@@ -301,7 +314,7 @@ extern "C" int m355_sn_power_iter(const m355_sn_layer *table_dev, int L, int max
 {
     M355_REQUIRE(table_dev && norms && sigma && L > 0 && max_rows > 0 && max_cols > 0, "sn_power_iter: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    if (training) hipLaunchKernelGGL(k_sn_wtu, dim3((max_cols + 63) / 64, L), dim3(256), 0, st, table_dev, norms);
+    if (training) hipLaunchKernelGGL(k_sn_wtu, dim3((max_cols + 63) / 64, L), dim3(1024), 0, st, table_dev, norms);
     hipLaunchKernelGGL(k_sn_wv, dim3((max_rows + 3) / 4, L), dim3(256), 0, st, table_dev, norms, training, eps);
     hipLaunchKernelGGL(k_sn_final, dim3(L), dim3(256), 0, st, table_dev, norms, sigma, training, eps);
     return check_launch("sn_power_iter");
