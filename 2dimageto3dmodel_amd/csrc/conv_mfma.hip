@@ -556,6 +556,8 @@ int conv_c8_launch(const m355_conv_desc *d, const void *x, const void *w_fwd, co
 bool dgrad_small_eligible(const m355_conv_desc *d, int Cy);
 int dgrad_small_launch(const m355_conv_desc *d, const void *dy, int Cy, const void *w_dgrad, int Kp, size_t wbytes, void *dx,
                        hipStream_t st);
+bool wgrad_c8_eligible(const m355_conv_desc *d, int Cy);  // csrc/conv_small.hip
+int wgrad_c8_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, float *db, hipStream_t st);
 bool wgrad_small_eligible(const m355_conv_desc *d, int Cy);
 int wgrad_small_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, hipStream_t st);
 }  // namespace m355
@@ -1119,14 +1121,18 @@ static bool wgrad_dma_ok(const m355_conv_desc *d)
 }
 
 /* 1 when m355_conv2d_wgrad can also produce the bias gradient (column sums of dy) for this layer */
-extern "C" int m355_conv2d_wgrad_fuses_dbias(const m355_conv_desc *d) { return d && wgrad_dma_ok(d) ? 1 : 0; }
+static bool wgrad_has_dbias(const m355_conv_desc *d)
+{
+    return wgrad_dma_ok(d) || m355::wgrad_c8_eligible(d, m355::dy_channels(d->Cout));
+}
+extern "C" int m355_conv2d_wgrad_fuses_dbias(const m355_conv_desc *d) { return d && wgrad_has_dbias(d) ? 1 : 0; }
 
 extern "C" int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias,
                                  void *stream)
 {
     if (int rc = check_desc(d, "conv2d_wgrad")) return rc;
     M355_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
-    M355_REQUIRE(!dbias || wgrad_dma_ok(d), "conv2d_wgrad: dbias is only fused on the DMA path (m355_conv2d_wgrad_fuses_dbias)");
+    M355_REQUIRE(!dbias || wgrad_has_dbias(d), "conv2d_wgrad: dbias is only fused on the DMA paths (m355_conv2d_wgrad_fuses_dbias)");
     hipStream_t st = (hipStream_t)stream;
     m355::WgradArgs a = {};
     a.x = (const unsigned short *)x;
@@ -1148,6 +1154,7 @@ extern "C" int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const v
         m355::set_error("conv2d_wgrad: memset failed");
         return M355_ERR_LAUNCH;
     }
+    if (m355::wgrad_c8_eligible(d, a.Cy)) return m355::wgrad_c8_launch(d, x, dy, a.Cy, dw, dbias, st);
     if (m355::wgrad_small_eligible(d, a.Cy)) return m355::wgrad_small_launch(d, x, dy, a.Cy, dw, st);
     const size_t xbytes = (size_t)d->N * d->H * d->W * d->Cin * 2, ybytes = (size_t)P * a.Cy * 2;
     const int lgWo = m355::ilog2_exact(a.Wo), lgHo = m355::ilog2_exact(a.Ho);

@@ -575,4 +575,174 @@ int conv_small_launch(const m355_conv_desc *d, const void *x, const void *w_fwd,
     return check_launch("conv2d_fwd (small Cout)");
 }
 
+// ---- weight (and bias) gradient of the 8-input-channel 5x5 layer (D.conv1): dw[co][kh][kw][ci] = sum_p dy[p][co] x[p + (kh,kw)][ci].
+// As a GEMM: M = 64 output channels, N = 200 (tap, ci) columns, K = all pixels -- 215 GFLOP per launch at N = 128 against
+// 1.07 GB of dy: HBM-side.  k_wgrad_dma gathers every pixel of x 25 times through L2 into its 256-column tile (19 KB of
+// LDS-DMA per MFLOP; 0.55 ms).  Here a workgroup walks 8 x 32-pixel tiles: the dy tile (32 KB) and the 12 x 36 x 16-byte
+// halo of x (6.9 KB) are DMA'd once, three stages deep; both MFMA operands come from transpose reads with the pixel axis
+// as K.  An x "row" for ds_read_b64_tr_b16 is 32 contiguous bytes = the 8 channels of halo pixels (px + kw), (px + kw + 1):
+// a 32-column MFMA block = 4 consecutive kw taps x 8 ci of one kh; 2 blocks per kh (kw 0..3 | 4..7, taps 5..7 are
+// discarded columns), 10 blocks in all.  8 waves = 2 pixel halves x 2 co blocks x 2 groups of 5 column blocks; the 5
+// accumulators of a wave stay in registers across all tiles; fp32 atomics at the end (split K over workgroups).
+struct C8WgArgs {
+    const unsigned short *x;   // bf16 NHWC [N,H,W,8]
+    const unsigned short *dy;  // bf16 NHWC [N,H,W,Cy], Cy = 64 * k
+    float *dw, *db;            // fp32 [Cout][5][5][8] (+=), [Cout] (+=) or null
+    int N, H, W, Cout, Cy;
+    unsigned xbytes, ybytes;
+};
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void sfor(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sfor<I + 1, N>(f);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void k_wgrad_c8(C8WgArgs a)
+{
+    constexpr int TH = 8, TW = 32, KS = 5, HS_X = TW + KS - 1, HS_Y = TH + KS - 1, HPIX = HS_X * HS_Y;
+    constexpr int XBUF = 8192, YBUF = 256 * 128, STAGE = XBUF + YBUF, NST = 3;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co0 = blockIdx.y * 64;
+    const int tpx = a.W / TW, tpy = a.H / TH, tiles = a.N * tpx * tpy, G = gridDim.x;
+    if ((int)blockIdx.x >= tiles) return;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, a.ybytes, 0x00020000);
+
+    // ---- DMA: every wave issues 4 dy instructions (rows 8q .. 8q+7 of the tile, q = 8k + wave, swizzled as k_wgrad_halo)
+    // and 1 x instruction (halo pixels 64 wave + lane; wave 7 fills the unused tail with zeros): 5 per tile and wave
+    const int csrc = (lane & 7) ^ (((lane >> 4) & 1) << 2);
+    auto issue = [&](int tile, int st) {
+        const int n = tile / (tpx * tpy), rem = tile - n * (tpx * tpy);
+        const int oy0 = (rem / tpx) * TH, ox0 = (rem % tpx) * TW;
+        unsigned char *dX = lds + st * STAGE, *dY = dX + XBUF;
+        {
+            const int P = 64 * wave + lane, hy = P / HS_X, hx = P - hy * HS_X;
+            const int gy = oy0 - KS / 2 + hy;
+            int gx = ox0 - KS / 2 + hx;
+            bool ok = P < HPIX && (unsigned)gy < (unsigned)a.H;
+            if (MODE == 1) gx = min(max(gx, 0), a.W - 1);
+            else if (MODE == 2) gx = gx < 0 ? gx + a.W : (gx >= a.W ? gx - a.W : gx);
+            ok = ok && (unsigned)gx < (unsigned)a.W;
+            dma16(rx, dX + wave * 1024, ok ? (unsigned)(((n * a.H + gy) * a.W + gx) * 16) : OOB, 0u);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = 8 * (8 * k + wave) + (lane >> 3);  // tile pixel = (p >> 5, p & 31)
+            const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
+            dma16(ry, dY + (8 * k + wave) * 1024, (unsigned)((((n * a.H + oy) * a.W + ox) * a.Cy + co0) * 2 + csrc * 16), 0u);
+        }
+    };
+
+    // ---- fragment roles
+    const int ph = wave >> 2, cb = wave & 1, cg = (wave >> 1) & 1;  // pixel half (tile rows 4ph..), co block, column group
+    const int q = lane & 15, g16 = (lane >> 4) & 1, hh = lane >> 5;
+    // dy^T (A operand, rows = 32 co of block cb): as k_wgrad_halo
+    const int ybase = (((cb * 4 + g16 * 2 + ((q & 3) >> 1)) ^ (((q >> 3) & 1) << 2)) << 4) + (q & 1) * 8 + (8 * hh + (q >> 2)) * 128 +
+                      ph * 8 * 2048;
+    // x (B operand, 32 columns = taps kw0 .. kw0+3 x 8 ci): lane part of the halo address; the rest is an immediate
+    const int xbase = ((4 * ph) * HS_X + 8 * hh + (q >> 2) + 2 * g16) * 16 + (q & 3) * 8;
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    const bool do_db = a.db != nullptr;
+    const int dbc = tid & 63, dbq = tid >> 6;  // channel, 32-pixel group
+    float dbacc = 0.0f;
+
+    auto tile_mma = [&](const unsigned char *bx, const unsigned char *by, auto cgc) {
+        constexpr int CG = decltype(cgc)::value;
+        sfor<0, 8>([&](auto kgc) {
+            constexpr int kg = decltype(kgc)::value;  // 16 pixels: tile row 4ph + (kg>>1), columns 16(kg&1) ..
+            const s4w y0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4w *)(by + ybase + kg * 2048));
+            const s4w y1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4w *)(by + ybase + kg * 2048 + 512));
+            const bf16x8 yf = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+            sfor<0, 5>([&](auto tc) {
+                constexpr int blk = CG * 5 + decltype(tc)::value, kh = blk >> 1, kw0 = 4 * (blk & 1);
+                constexpr int c = ((kg >> 1) + kh) * HS_X + 16 * (kg & 1) + kw0;
+                const s4w x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4w *)(bx + xbase + c * 16));
+                const s4w x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4w *)(bx + xbase + (c + 4) * 16));
+                const bf16x8 xf = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+                acc[decltype(tc)::value] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf, xf, acc[decltype(tc)::value], 0, 0, 0);
+            });
+        });
+    };
+
+    // ---- tiles blockIdx.x, +G, +2G, ...: three stages, two tiles in flight behind the one being consumed
+    int tile = blockIdx.x, st = 0;
+    issue(tile, 0);
+    if (tile + G < tiles) issue(tile + G, 1);
+    for (; tile < tiles; tile += G) {
+        // this tile's 5 DMAs per wave were issued two tiles ago; only the next tile's 5 may still be in flight
+        if (tile + G < tiles) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const int st2 = st == 0 ? 2 : st - 1;  // the stage consumed one tile ago
+        if (tile + 2 * G < tiles) issue(tile + 2 * G, st2);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char *bx = lds + st * STAGE, *by = bx + XBUF;
+        if (do_db) {
+#pragma unroll 8
+            for (int pp = 0; pp < 32; ++pp) {
+                const int prow = dbq * 32 + pp;
+                dbacc += bf2f(*reinterpret_cast<const unsigned short *>(by + prow * 128 + (((dbc >> 3) ^ (((prow >> 1) & 1) << 2)) << 4) + (dbc & 7) * 2));
+            }
+        }
+        if (cg) tile_mma(bx, by, std::integral_constant<int, 1>{});
+        else tile_mma(bx, by, std::integral_constant<int, 0>{});
+        st = st == 2 ? 0 : st + 1;
+    }
+    if (do_db && co0 + dbc < a.Cout) atomicAdd(a.db + co0 + dbc, dbacc);
+    // acc[t][r]: co = co0 + 32 cb + (r&3) + 8(r>>2) + 4(lane>>5); column lane&31 of block 5cg + t = (kh, kw0 + (n>>3), n&7)
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int blk = cg * 5 + t, kh = blk >> 1, kw = 4 * (blk & 1) + ((lane & 31) >> 3), ci = lane & 7;
+        if (kw < KS) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + 32 * cb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < a.Cout) atomicAdd(a.dw + ((size_t)co * 25 + kh * 5 + kw) * 8 + ci, acc[t][r]);
+            }
+        }
+    }
+}
+
+bool wgrad_c8_eligible(const m355_conv_desc *d, int Cy)
+{
+    return d->Cin == 8 && d->kh == 5 && d->kw == 5 && d->stride == 1 && d->upsample == 0 && d->pad_h == 2 && d->pad_w == 2 &&
+           Cy % 64 == 0 && d->W % 32 == 0 && d->H % 8 == 0 && (size_t)d->N * d->H * d->W * Cy * 2 < (1ull << 31) &&
+           !getenv("M355_NO_C8");
+}
+
+int wgrad_c8_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, float *db, hipStream_t st)
+{
+    C8WgArgs a = {};
+    a.x = (const unsigned short *)x;
+    a.dy = (const unsigned short *)dy;
+    a.dw = dw; a.db = db;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cout = d->Cout; a.Cy = Cy;
+    a.xbytes = (unsigned)((size_t)d->N * d->H * d->W * 16);
+    a.ybytes = (unsigned)((size_t)d->N * d->H * d->W * Cy * 2);
+    const int tiles = d->N * (d->H / 8) * (d->W / 32), ny = Cy / 64;
+    int gx = 256 / ny;  // one 8-wave workgroup per CU (120 KB of LDS)
+    if (gx < 1) gx = 1;
+    if (gx > tiles) gx = tiles;
+    const dim3 grid(gx, ny);
+    if (d->pad_w_mode == 0) hipLaunchKernelGGL((k_wgrad_c8<0>), grid, dim3(512), 0, st, a);
+    else if (d->pad_w_mode == 1) hipLaunchKernelGGL((k_wgrad_c8<1>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_wgrad_c8<2>), grid, dim3(512), 0, st, a);
+    note_kernel("k_wgrad_c8");
+    return check_launch("conv2d_wgrad (8 input channels)");
+}
+
 }  // namespace m355
