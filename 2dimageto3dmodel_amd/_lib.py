@@ -46,6 +46,9 @@ SIGNATURES = {
     "m355_conv2d_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P]),
     "m355_conv2d_dgrad_ws_bytes": (c_size_t, [_P]),
     "m355_conv2d_dgrad": (c_int, [_P, _P, _P, _P, _P, _P, c_float, _P]),
+    "m355_conv2d_maskbits_ok": (c_int, [_P, c_int]),
+    "m355_conv2d_fwd_bits": (c_int, [_P, _P, _P, _P, _P, c_float, _P, _P]),
+    "m355_conv2d_dgrad_bits": (c_int, [_P, _P, _P, _P, _P, _P, c_float, _P]),
     "m355_conv2d_wgrad_fuses_dbias": (c_int, [_P]),
     "m355_conv2d_wgrad": (c_int, [_P, _P, _P, _P, _P, _P]),
     "m355_chan_reduce_ws_bytes": (c_size_t, [c_size_t, c_int, c_int, c_int]),

@@ -62,7 +62,14 @@ def weight_prep(d, w_oihw, want_dgrad=True, sigma=None):
     return wf, wd
 
 
-def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0, cin_real=None):
+def maskbits_ok(d, role):
+    """role 0: the forward of this layer can write bit-packed activation masks; role 1: its dgrad can read them"""
+    return bool(lib().m355_conv2d_maskbits_ok(ctypes.byref(d), int(role)))
+
+
+def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0, cin_real=None, emit_bits=False):
+    """emit_bits: also return the sign bits of the pre-activation ([N,Ho,Wo,Cout/64,2] int32, opaque layout) for
+    the consumer's conv_dgrad(mask_bits=...); requires maskbits_ok(d, 0)"""
     x = _req(x, torch.bfloat16, "x")
     assert tuple(x.shape) == (d.N, d.H, d.W, d.Cin), (tuple(x.shape), (d.N, d.H, d.W, d.Cin))
     ho, wo = out_hw(d)
@@ -71,20 +78,32 @@ def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0, cin_real=Non
     else:
         y = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.bfloat16, device=x.device)
     b = None if bias is None else _req(bias.detach(), torch.float32, "bias")
+    if emit_bits:
+        assert not out_f32_nchw
+        bits = torch.empty((d.N, ho, wo, d.Cout // 64, 2), dtype=torch.int32, device=x.device)
+        launch("conv2d_fwd_bits", ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(b), ptr(y), float(slope), ptr(bits), stream(),
+               work=flops(d, cin_real), tag=tag(d))
+        return y, bits
     launch("conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(b), ptr(y), int(out_f32_nchw), float(slope), stream(),
            work=flops(d, cin_real), tag=tag(d))
     return y
 
 
-def conv_dgrad(d, dy, w_dgrad, cin_real=None, mask_x=None, mask_slope=1.0):
+def conv_dgrad(d, dy, w_dgrad, cin_real=None, mask_x=None, mask_slope=1.0, mask_bits=None):
     """mask_x: this conv's input x when it is the output of a fused conv+LeakyReLU(mask_slope): the returned gradient
-    is then already multiplied by that activation's derivative"""
+    is then already multiplied by that activation's derivative; mask_bits: the same from the producer's bit masks
+    (conv_fwd(emit_bits=True)), 1/16 of the bytes"""
     dy = _req(dy, torch.bfloat16, "dy")
     ho, wo = out_hw(d)
     assert tuple(dy.shape) == (d.N, ho, wo, dy_channels(d.Cout)), tuple(dy.shape)
     dx = torch.empty((d.N, d.H, d.W, d.Cin), dtype=torch.bfloat16, device=dy.device)
     nws = lib().m355_conv2d_dgrad_ws_bytes(ctypes.byref(d))
     ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device)
+    if mask_bits is not None:
+        assert tuple(mask_bits.shape) == (d.N, d.H, d.W, d.Cin // 64, 2), (tuple(mask_bits.shape), d.Cin)
+        launch("conv2d_dgrad_bits", ctypes.byref(d), ptr(dy), ptr(w_dgrad), ptr(dx), ptr(ws), ptr(mask_bits), float(mask_slope),
+               stream(), work=flops(d, cin_real), tag=tag(d))
+        return dx
     launch("conv2d_dgrad", ctypes.byref(d), ptr(dy), ptr(w_dgrad), ptr(dx), ptr(ws), ptr(mask_x), float(mask_slope), stream(),
            work=flops(d, cin_real), tag=tag(d))
     return dx

@@ -59,7 +59,12 @@ struct ConvArgs {
     // pads and output offsets
     const unsigned short *mask_x;  // dgrad only (k_conv_glds): tensor of the output's shape; y *= (mask_x > 0 ? 1 : mask_slope)
     float mask_slope;              //   = the backward of the LeakyReLU that produced this conv's input, folded in
-    int fold2;           // k_conv_halo only: sum each 2x2 block of output pixels before the store (adjoint of the nearest
+    int fold2;
+    // bit-packed LeakyReLU masks (1 bit per activation, [pixel][C/64][2] uint32; word = lane half, bit = 16 j + 4 g + e of the
+    // epilogue's register layout -- producer and consumer are the same kernel family): written by a forward with an
+    // activation epilogue, read by the consumer's dgrad instead of 2 bytes per element of the activation itself
+    unsigned *bits_out;
+    const unsigned *bits_in;           // k_conv_halo only: sum each 2x2 block of output pixels before the store (adjoint of the nearest
                          //   x2 upsample folded into the dgrad of an upsample+conv layer); OH, OW are the LOW-res extents
     int lgWo, lgHo;      // log2 of the GEMM pixel grid sides when both are powers of two (else -1): shift/mask decode
     int ncls;

@@ -417,6 +417,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                 const bool st_ok = !GUARD || !a.fold2 || !(tx & 1);
                 const size_t pix = (GUARD && a.fold2) ? ((size_t)n * a.OH + (ho >> 1)) * a.OW + (wo >> 1)
                                                       : ((size_t)n * a.OH + (ho * a.oy_mul + oy_off)) * a.OW + (wo * a.ox_mul + ox_off);
+                // bit masks (unguarded variants only): this lane's 32 channels of pixel `pix` are one word
+                const size_t bword = (pix * (size_t)(a.Cs >> 6) + (size_t)((n0 >> 6) + wn)) * 2 + half;
+                unsigned wbits = 0, rbits = 0;
+                const bool use_bits = !GUARD && MASK && a.bits_in != nullptr, emit_bits = !GUARD && !PLAIN && a.bits_out != nullptr;
+                if (use_bits) rbits = a.bits_in[bword];
 #pragma unroll
                 for (int j = 0; j < CJ; ++j) {
                     const int cbase = n0 + wn * 64 + 32 * j;
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
                         }
                     }
-                    const bool masked = MASK && (!GUARD || a.mask_x);
+                    const bool masked = MASK && (!GUARD || a.mask_x) && !use_bits;
                     uint2 mk[4];
                     if (masked) {
 #pragma unroll
@@ -444,8 +449,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                         float v[4] = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
                         if (!PLAIN) {
                             v[0] += b4[g].x; v[1] += b4[g].y; v[2] += b4[g].z; v[3] += b4[g].w;
+                            if (emit_bits) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) wbits |= (v[e] > 0.0f ? 1u : 0u) << (16 * j + 4 * g + e);
+                            }
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * a.slope;
+                        }
+                        if (use_bits) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = ((rbits >> (16 * j + 4 * g + e)) & 1u) ? v[e] : v[e] * a.mask_slope;
                         }
                         if (masked) {
                             const float x0 = __uint_as_float(mk[g].x << 16), x1 = __uint_as_float(mk[g].x & 0xffff0000u);
@@ -474,6 +487,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                         }
                     }
                 }
+                if (emit_bits) a.bits_out[bword] = wbits;
             }
         };
         {
@@ -481,9 +495,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
             using std::true_type;
             const bool guard = a.fold2 || a.Cout != a.CoutP, plain = !a.bias && a.slope == 1.0f;
             if (guard) store_tile(false_type{}, true_type{}, true_type{});
-            else if (plain && !a.mask_x) store_tile(true_type{}, false_type{}, false_type{});
+            else if (plain && !a.mask_x && !a.bits_in) store_tile(true_type{}, false_type{}, false_type{});
             else if (plain) store_tile(true_type{}, true_type{}, false_type{});
-            else if (!a.mask_x) store_tile(false_type{}, false_type{}, false_type{});
+            else if (!a.mask_x && !a.bits_in) store_tile(false_type{}, false_type{}, false_type{});
             else store_tile(false_type{}, true_type{}, true_type{});
         }
 #pragma unroll

@@ -478,6 +478,16 @@ static bool dma_eligible(const ConvArgs &a)
            xbytes < (1ull << 31) && wbytes < (1ull << 31);
 }
 
+// can this problem read / write bit masks?  (the kernel that will run it must be k_conv_halo with the unguarded epilogue)
+static bool halo_takes_bits(ConvArgs a)
+{
+    a.CoutP = rows_padded(a.Cout);
+    if (a.ncls < 1) a.ncls = 1;
+    const char *h = getenv("M355_CONV_HALO");
+    return dma_eligible(a) && !(h && h[0] == '0') && conv_halo_eligible(a) && a.Cout == a.CoutP && !a.fold2 && a.Cs % 64 == 0 &&
+           !a.y_f32_nchw && !getenv("M355_NO_MASKBITS");
+}
+
 static int launch_conv(ConvArgs a, hipStream_t st)
 {
     const int M = a.N * a.Ho * a.Wo;
@@ -488,6 +498,13 @@ static int launch_conv(ConvArgs a, hipStream_t st)
     if (a.lgWo < 0 || a.lgHo < 0) a.lgWo = a.lgHo = -1;
     const size_t xbytes = (size_t)a.N * a.H * a.W * a.Cin * 2, wbytes = (size_t)a.CoutP * a.Kp * 2;
     const bool dma_ok = dma_eligible(a);
+    if (a.bits_out || a.bits_in) {
+        const bool ok = halo_takes_bits(a);
+        if (!ok) {
+            set_error("conv2d: bit masks are only handled by the unguarded halo epilogue (ask m355_conv2d_maskbits_ok first)");
+            return M355_ERR_BAD_ARG;
+        }
+    }
     if (dma_ok) {
         const bool fast = a.Cin % 64 == 0;
         const unsigned xb = (unsigned)xbytes, wb = (unsigned)wbytes;
@@ -552,7 +569,7 @@ int conv_small_launch(const m355_conv_desc *d, const void *x, const void *w_fwd,
                       int Kp, size_t wbytes, hipStream_t st);
 bool conv_c8_eligible(const m355_conv_desc *d, int y_f32_nchw);
 int conv_c8_launch(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, float slope, int Kp,
-                   size_t wbytes, hipStream_t st);
+                   size_t wbytes, unsigned *bits, hipStream_t st);
 bool dgrad_small_eligible(const m355_conv_desc *d, int Cy);
 int dgrad_small_launch(const m355_conv_desc *d, const void *dy, int Cy, const void *w_dgrad, int Kp, size_t wbytes, void *dx,
                        hipStream_t st);
@@ -650,19 +667,23 @@ extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_o
     return m355::check_launch("conv2d_weight_prep");
 }
 
-extern "C" int m355_conv2d_fwd(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
-                               int y_f32_nchw, float lrelu_slope, void *stream)
+// probe != 0: do not launch, return 1 / 0 = this forward can / cannot write the activation bit masks
+static int conv_fwd_impl(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, int y_f32_nchw,
+                         float lrelu_slope, unsigned *bits_out, void *stream, int probe)
 {
-    if (int rc = check_desc(d, "conv2d_fwd")) return rc;
-    M355_REQUIRE(x && w_fwd && y, "conv2d_fwd: null pointer");
+    if (int rc = check_desc(d, "conv2d_fwd")) return probe ? 0 : rc;
+    if (!probe) M355_REQUIRE(x && w_fwd && y, "conv2d_fwd: null pointer");
     if (m355::conv_small_eligible(d, y_f32_nchw)) {  // heads: 1..4 output channels, HBM-bound halo kernel
+        if (probe) return 0;
+        M355_REQUIRE(!bits_out, "conv2d_fwd: no bit masks on the small-Cout kernel");
         const int Kp = m355::k_padded(d->kh * d->kw * d->Cin);
         return m355::conv_small_launch(d, x, w_fwd, bias, y, lrelu_slope, Kp, (size_t)m355::rows_padded(d->Cout) * Kp * 2,
                                        (hipStream_t)stream);
     }
     if (m355::conv_c8_eligible(d, y_f32_nchw) && !getenv("M355_NO_C8")) {  // TextureDiscriminator.conv1: 8 input channels
+        if (probe) return getenv("M355_NO_MASKBITS") ? 0 : 1;
         const int Kp = m355::k_padded(d->kh * d->kw * d->Cin);
-        return m355::conv_c8_launch(d, x, w_fwd, bias, y, lrelu_slope, Kp, (size_t)m355::rows_padded(d->Cout) * Kp * 2,
+        return m355::conv_c8_launch(d, x, w_fwd, bias, y, lrelu_slope, Kp, (size_t)m355::rows_padded(d->Cout) * Kp * 2, bits_out,
                                     (hipStream_t)stream);
     }
     ConvArgs a = {};
@@ -681,7 +702,24 @@ extern "C" int m355_conv2d_fwd(const m355_conv_desc *d, const void *x, const voi
     a.y_f32_nchw = y_f32_nchw; a.Cs = d->Cout;
     a.Kp = m355::k_padded(d->kh * d->kw * d->Cin);
     a.slope = lrelu_slope;
+    a.bits_out = bits_out;
+    if (probe) return m355::halo_takes_bits(a) ? 1 : 0;
     return m355::launch_conv(a, (hipStream_t)stream);
+}
+
+extern "C" int m355_conv2d_fwd(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
+                               int y_f32_nchw, float lrelu_slope, void *stream)
+{
+    return conv_fwd_impl(d, x, w_fwd, bias, y, y_f32_nchw, lrelu_slope, nullptr, stream, 0);
+}
+
+/* forward with a LeakyReLU epilogue that also writes the activation's sign bits (1 bit per element,
+ * [N,Ho,Wo,Cout/64,2] uint32) for the consumer's m355_conv2d_dgrad_bits; only where m355_conv2d_maskbits_ok(d, 0) */
+extern "C" int m355_conv2d_fwd_bits(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
+                                    float lrelu_slope, void *mask_bits_out, void *stream)
+{
+    M355_REQUIRE(mask_bits_out, "conv2d_fwd_bits: null pointer");
+    return conv_fwd_impl(d, x, w_fwd, bias, y, 0, lrelu_slope, (unsigned *)mask_bits_out, stream, 0);
 }
 
 // dy[N,Ho,Wo,Cout_p32] bf16 (channel stride = ceil32(Cout), padding channels zero) -> dx[N,H,W,Cin] bf16.
@@ -708,11 +746,11 @@ extern "C" size_t m355_conv2d_dgrad_ws_bytes(const m355_conv_desc *d)
     return (size_t)d->N * (Hl + 2 * d->pad_h) * (Wl + 2 * d->pad_w) * d->Cin * 2;
 }
 
-extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, void *ws,
-                                 const void *mask_x, float mask_slope, void *stream)
+static int conv_dgrad_impl(const m355_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, void *ws, const void *mask_x,
+                           const unsigned *mask_bits, float mask_slope, void *stream, int probe)
 {
-    if (int rc = check_desc(d, "conv2d_dgrad")) return rc;
-    M355_REQUIRE(dy && w_dgrad && dx, "conv2d_dgrad: null pointer");
+    if (int rc = check_desc(d, "conv2d_dgrad")) return probe ? 0 : rc;
+    if (!probe) M355_REQUIRE(dy && w_dgrad && dx, "conv2d_dgrad: null pointer");
     hipStream_t st = (hipStream_t)stream;
     int Ho, Wo;
     conv_out_hw(d, &Ho, &Wo);
@@ -728,16 +766,18 @@ extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const 
     // the padding is an index map on dy -- a circularly padded conv's dgrad is a circular conv of dy.
     a.Kp = m355::k_padded((d->stride == 1 ? d->kh * d->kw : (d->kh / 2) * (d->kw / 2)) * cout32);
     const bool direct = dgrad_direct(d);
-    M355_REQUIRE(!mask_x || direct, "conv2d_dgrad: the fused activation backward needs the direct form (no upsample, "
-                                    "no replicate pad, tensors < 2 GiB)");
+    if (probe && (!direct || d->pad_w_mode == 1)) return 0;
+    M355_REQUIRE((!mask_x && !mask_bits) || direct, "conv2d_dgrad: the fused activation backward needs the direct form (no "
+                                                    "upsample, no replicate pad, tensors < 2 GiB)");
     a.mask_x = (const unsigned short *)mask_x;
+    a.bits_in = mask_bits;
     a.mask_slope = mask_slope;
     int rc = 0;
     if (direct && d->pad_w_mode == 1) {  // generator 3x3: zero-pad conv of dy on the halo kernel + replicate edge terms
-        M355_REQUIRE(!mask_x, "conv2d_dgrad: no fused activation backward on the replicate form");
+        M355_REQUIRE(!mask_x && !mask_bits, "conv2d_dgrad: no fused activation backward on the replicate form");
         return m355::dgrad_direct_replicate_launch(d, dy, cout32, w_dgrad, a.Kp, cin64, dx, st);
     }
-    if (direct && !mask_x && m355::dgrad_small_eligible(d, cout32) && !getenv("M355_NO_C8"))
+    if (!probe && direct && !mask_x && !mask_bits && m355::dgrad_small_eligible(d, cout32) && !getenv("M355_NO_C8"))
         return m355::dgrad_small_launch(d, dy, cout32, w_dgrad, a.Kp, (size_t)cin64 * a.Kp * 2, dx, st);
     if (direct && d->stride == 1) {
         a.w = (const unsigned short *)w_dgrad;
@@ -746,6 +786,7 @@ extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const 
         a.pad_w_mode = d->pad_w_mode;
         a.Ho = d->H; a.Wo = d->W; a.OH = a.Ho; a.OW = a.Wo; a.oy_mul = a.ox_mul = 1;
         a.y = dx;
+        if (probe) return m355::halo_takes_bits(a) ? 1 : 0;
         return m355::launch_conv(a, st);
     }
     if (direct) {
@@ -763,8 +804,10 @@ extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const 
                 a.coy[c] = 2 * ioff + py - d->pad_h; a.cox[c] = 2 * joff + px - d->pad_w;
             }
         a.y = dx;
+        if (probe) return m355::halo_takes_bits(a) ? 1 : 0;
         return m355::launch_conv(a, st);
     }
+    if (probe) return 0;
     const bool need_fold = d->upsample || (d->pad_w_mode != 0 && d->pad_w > 0) || d->stride == 2;
     M355_REQUIRE(!need_fold || ws, "conv2d_dgrad: workspace required");
     if (d->stride == 1) {
@@ -810,6 +853,30 @@ extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const 
                        0, st, (const unsigned short *)ws, (unsigned short *)dx, d->N, d->H, d->W, d->Cin, d->upsample,
                        d->pad_w, d->pad_w_mode, Hp, d->pad_h);
     return m355::check_launch("conv2d_dgrad fold");
+}
+
+extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, void *ws,
+                                 const void *mask_x, float mask_slope, void *stream)
+{
+    return conv_dgrad_impl(d, dy, w_dgrad, dx, ws, mask_x, nullptr, mask_slope, stream, 0);
+}
+
+/* dgrad whose epilogue applies the producer's LeakyReLU backward from the bit masks m355_conv2d_fwd_bits wrote
+ * ([N,H,W,Cin/64,2] uint32, this conv's input frame); only where m355_conv2d_maskbits_ok(d, 1) */
+extern "C" int m355_conv2d_dgrad_bits(const m355_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, void *ws,
+                                      const void *mask_bits, float mask_slope, void *stream)
+{
+    M355_REQUIRE(mask_bits, "conv2d_dgrad_bits: null pointer");
+    return conv_dgrad_impl(d, dy, w_dgrad, dx, ws, nullptr, (const unsigned *)mask_bits, mask_slope, stream, 0);
+}
+
+/* role 0: can the forward of this layer (bf16 NHWC output, activation epilogue) write bit masks?
+ * role 1: can the dgrad of this layer read the bit masks of its input's producer? */
+extern "C" int m355_conv2d_maskbits_ok(const m355_conv_desc *d, int role)
+{
+    if (!d) return 0;
+    if (role == 0) return conv_fwd_impl(d, nullptr, nullptr, nullptr, nullptr, 0, 0.2f, nullptr, nullptr, 1);
+    return conv_dgrad_impl(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.2f, nullptr, 1);
 }
 
 // =====================================================================================================

@@ -332,6 +332,7 @@ struct C8Args {
     const unsigned short *w;  // bf16 forward view [rows][Kp], K ordered (kh, kw, ci): 200 real columns
     const float *bias;
     unsigned short *y;        // bf16 NHWC [N,H,W,Cout]
+    unsigned *bits;           // optional activation-sign bits [pixel][Cout/64][2] (conv_dma.h: ConvArgs::bits_out)
     int N, H, W, Cout, Kp;
     float slope;
     unsigned xbytes, wbytes;
@@ -440,6 +441,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const size_t pix = ((size_t)n * a.H + (oy0 + 2 * wave + i)) * a.W + ox0 + tx;
+            unsigned wbits = 0;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int cbase = tn * 64 + 32 * j;
@@ -450,6 +452,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
                     if (a.bias) b4 = *reinterpret_cast<const float4 *>(a.bias + cbase + 8 * g + 4 * half);
                     float v[4] = {acc[j][i][4 * g] + b4.x, acc[j][i][4 * g + 1] + b4.y, acc[j][i][4 * g + 2] + b4.z,
                                   acc[j][i][4 * g + 3] + b4.w};
+                    if (a.bits) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) wbits |= (v[e] > 0.0f ? 1u : 0u) << (16 * j + 4 * g + e);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * a.slope;
                     pk[g].x = pack_bf16(v[0], v[1]);
@@ -464,6 +470,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
                     *reinterpret_cast<uint4 *>(a.y + pix * a.Cout + cbase + 8 * (g + half)) = o;
                 }
             }
+            if (a.bits) a.bits[(pix * (size_t)(a.Cout >> 6) + tn) * 2 + half] = wbits;
         }
         if (tp_next >= tiles) break;
         tp = tp_next;
@@ -480,13 +487,14 @@ bool conv_c8_eligible(const m355_conv_desc *d, int y_f32_nchw)
 }
 
 int conv_c8_launch(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, float slope, int Kp,
-                   size_t wbytes, hipStream_t st)
+                   size_t wbytes, unsigned *bits, hipStream_t st)
 {
     C8Args a = {};
     a.x = (const unsigned short *)x;
     a.w = (const unsigned short *)w_fwd;
     a.bias = bias;
     a.y = (unsigned short *)y;
+    a.bits = bits;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cout = d->Cout; a.Kp = Kp;
     a.slope = slope;
     a.xbytes = (unsigned)((size_t)d->N * d->H * d->W * 16);

@@ -81,7 +81,7 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad_h, pad_w, mode, ups, slope, out_f32_nchw, sn, in_slope=1.0,
-                premasked=False):
+                premasked=False, in_bits=None):
         n, h, w, cx = x.shape
         cout, cw, kh, kw = weight.shape
         if cx % 8 or cx < cw:
@@ -90,17 +90,26 @@ class Conv2dFn(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         sigma = None if sn is None else sn.sigma
         wf, wd = C.weight_prep(d, weight, want_dgrad=need_dx, sigma=sigma)
-        y = C.conv_fwd(d, x.detach(), wf, None if bias is None else bias.detach(), out_f32_nchw, slope, cin_real=cw)
+        # premasked = the only consumer's dgrad applies this activation's backward: hand it 1 bit per element instead of
+        # making it re-read the bf16 activation (csrc/conv_dma.h: ConvArgs::bits_out)
+        bits = None
+        if premasked and slope != 1.0 and not out_f32_nchw and any(ctx.needs_input_grad[:3]) and C.maskbits_ok(d, 0):
+            y, bits = C.conv_fwd(d, x.detach(), wf, None if bias is None else bias.detach(), False, slope, cin_real=cw,
+                                 emit_bits=True)
+            ctx.mark_non_differentiable(bits)
+        else:
+            y = C.conv_fwd(d, x.detach(), wf, None if bias is None else bias.detach(), out_f32_nchw, slope, cin_real=cw)
         ctx.d, ctx.cw, ctx.slope, ctx.f32, ctx.sn = d, cw, slope, out_f32_nchw, sn
         ctx.in_slope, ctx.premasked = in_slope, premasked
         ctx.has_bias = bias is not None
+        use_bits = in_bits is not None and in_slope != 1.0 and C.maskbits_ok(d, 1)
         ctx.save_for_backward(x.detach(), wd, y if (slope != 1.0 and not premasked) else None,
-                              weight.detach() if sn is not None else None)
-        return y
+                              weight.detach() if sn is not None else None, in_bits if use_bits else None)
+        return y, bits
 
     @staticmethod
-    def backward(ctx, dy):
-        x, wd, y, w_orig = ctx.saved_tensors
+    def backward(ctx, dy, _dbits=None):
+        x, wd, y, w_orig, in_bits = ctx.saved_tensors
         d = ctx.d
         c32 = C.dy_channels(d.Cout)
         if ctx.premasked:
@@ -129,7 +138,9 @@ class Conv2dFn(torch.autograd.Function):
             g = g.contiguous().to(torch.bfloat16)
         dx = None
         if ctx.needs_input_grad[0]:
-            if ctx.in_slope != 1.0:   # fold the LeakyReLU backward of the layer that produced x into the epilogue
+            if ctx.in_slope != 1.0 and in_bits is not None:
+                dx = C.conv_dgrad(d, g, wd, cin_real=ctx.cw, mask_bits=in_bits, mask_slope=ctx.in_slope)
+            elif ctx.in_slope != 1.0:   # fold the LeakyReLU backward of the layer that produced x into the epilogue
                 dx = C.conv_dgrad(d, g, wd, cin_real=ctx.cw, mask_x=x, mask_slope=ctx.in_slope)
             else:
                 dx = C.conv_dgrad(d, g, wd, cin_real=ctx.cw)
@@ -143,7 +154,7 @@ class Conv2dFn(torch.autograd.Function):
             else:
                 sn.check()
                 dw = C.wgrad_finish(d, graw, ctx.cw, w_orig, sn.u, sn.v, sn.sigma)
-        return dx, dw, db, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias, stride, pad_h, pad_w, mode, upsample=0, slope=1.0, out_f32_nchw=False, sn=None, in_slope=1.0,
@@ -151,8 +162,11 @@ def conv2d(x, weight, bias, stride, pad_h, pad_w, mode, upsample=0, slope=1.0, o
     """in_slope != 1: x is the output of a fused conv+LeakyReLU(in_slope) whose ONLY consumer is this conv: the
     returned grad_x is pre-multiplied by that activation's derivative, and that producer must be called with
     premasked=True (it then skips its own activation backward).  Both flags are set by the discriminators."""
-    return Conv2dFn.apply(x, weight, bias, stride, pad_h, pad_w, mode, int(upsample), float(slope), bool(out_f32_nchw), sn,
-                          float(in_slope), bool(premasked))
+    y, bits = Conv2dFn.apply(x, weight, bias, stride, pad_h, pad_w, mode, int(upsample), float(slope), bool(out_f32_nchw), sn,
+                             float(in_slope), bool(premasked), getattr(x, "_m355_bits", None) if in_slope != 1.0 else None)
+    if bits is not None:
+        y._m355_bits = bits  # picked up by the consumer conv (same Python tensor object, see the discriminators' _act)
+    return y
 
 
 # ------------------------------------------------------------------------------------------------ spectral norm

@@ -165,6 +165,17 @@ size_t m355_conv2d_dgrad_ws_bytes(const m355_conv_desc *d);
  *      gradient arrives already masked.  Only with the direct form (no upsample, zero/circular W pad). */
 int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, void *ws,
                       const void *mask_x, float mask_slope, void *stream);
+
+/* Bit-packed activation masks between a conv+LeakyReLU forward and its (only) consumer's dgrad: 1 bit per element
+ * instead of re-reading the 2-byte activation (D.conv2's dgrad read 1 GB just to test signs).  Layout
+ * [N,H,W,C/64,2] uint32 in the register order of the epilogues (opaque: produce with _fwd_bits, consume with
+ * _dgrad_bits).  m355_conv2d_maskbits_ok(d, 0): this layer's forward can write them; (d, 1): this layer's dgrad can
+ * read them for its input.  Mirrors the autograd pair F.conv2d -> F.leaky_relu of models/gan.py:92-94,210-213. */
+int m355_conv2d_maskbits_ok(const m355_conv_desc *d, int role);
+int m355_conv2d_fwd_bits(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
+                         float lrelu_slope, void *mask_bits_out, void *stream);
+int m355_conv2d_dgrad_bits(const m355_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, void *ws,
+                           const void *mask_bits, float mask_slope, void *stream);
 /*      x[N,H,W,Cin], dy[N,Ho,Wo,dy_channels(Cout)] -> dw fp32 [Cout][kh][kw][Cin] (overwritten; split-K partial tiles are
  *      combined with fp32 atomics, so the last bits depend on arrival order). */
 /*      dbias (nullable, [Cout] fp32): column sums of dy = the bias gradient, accumulated by the workgroups that stage

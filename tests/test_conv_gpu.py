@@ -173,3 +173,40 @@ def test_conv_halo_persistent_tiles(pkg, case, wgs, monkeypatch):
     for _ in range(3):
         dx = conv.conv_dgrad(d, dy_nhwc.bfloat16().to(DEV), wd).float().cpu().permute(0, 3, 1, 2)
         assert (dx - xr.grad).abs().max().item() / xr.grad.abs().max().item() < 1.2e-2
+
+
+@pytest.mark.parametrize("chain", [
+    # producer (N,H,W,Cin,Cout,k,s,ph,pw,mode) -> consumer Cout', both of the discriminators' shapes
+    ((2, 16, 64, 8, 64, 5, 1, 2, 2, 2), 128),     # D.conv1 (k_conv_c8 writes the bits) -> D.conv2 dgrad (resident-weight halo)
+    ((2, 32, 128, 64, 128, 4, 2, 1, 1, 2), 256),  # D.conv2 forward (stride-2 halo, bias + LeakyReLU) -> D.conv3 dgrad
+    ((2, 32, 128, 128, 256, 4, 2, 1, 1, 0), 128), # zero pad, 256 channels: two 128-channel tiles of mask words
+])
+def test_activation_bit_masks(pkg, chain):
+    """conv+LeakyReLU forward writing 1 bit per activation, the consumer's dgrad reading them: identical to the dgrad
+    that re-reads the bf16 activation as its mask"""
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    (N, H, W, Cin, Cout, k, stride, ph, pw, mode), Cout2 = chain
+    g = torch.Generator().manual_seed(Cin + Cout)
+    d1 = conv.make_desc(N, H, W, Cin, Cout, k, k, stride, ph, pw, mode, 0)
+    assert conv.maskbits_ok(d1, 0)
+    x = torch.randn(N, H, W, Cin, generator=g).bfloat16().to(DEV)
+    w1 = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(DEV)
+    b1 = torch.randn(Cout, generator=g).to(DEV)
+    wf1, _ = conv.weight_prep(d1, w1, want_dgrad=False)
+    y_plain = conv.conv_fwd(d1, x, wf1, b1, slope=0.2)
+    y, bits = conv.conv_fwd(d1, x, wf1, b1, slope=0.2, emit_bits=True)
+    assert torch.equal(y, y_plain)
+    ho, wo = conv.out_hw(d1)
+    # the bits are the sign of the pre-activation: as many set bits as positive activations
+    popc = sum(((bits >> b) & 1).sum().item() for b in range(32))
+    assert popc == (y.float() > 0).sum().item()
+    # consumer: 4x4 stride-2 conv on y (the discriminators' next layer)
+    d2 = conv.make_desc(N, ho, wo, Cout, Cout2, 4, 4, 2, 1, 1, mode, 0)
+    assert conv.maskbits_ok(d2, 1)
+    w2 = (torch.randn(Cout2, Cout, 4, 4, generator=g) / (Cout * 16) ** 0.5).to(DEV)
+    _, wd2 = conv.weight_prep(d2, w2)
+    ho2, wo2 = conv.out_hw(d2)
+    dy2 = torch.randn(N, ho2, wo2, conv.dy_channels(Cout2), generator=g).bfloat16().to(DEV)
+    want = conv.conv_dgrad(d2, dy2, wd2, mask_x=y, mask_slope=0.2)
+    got = conv.conv_dgrad(d2, dy2, wd2, mask_bits=bits, mask_slope=0.2)
+    assert torch.equal(got, want)
