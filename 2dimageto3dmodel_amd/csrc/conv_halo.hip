@@ -217,17 +217,28 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
             }
     };
 
-    f32x16 acc[CJ][PI];
-#pragma unroll
-    for (int j = 0; j < CJ; ++j)
-#pragma unroll
-        for (int i = 0; i < PI; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
-
     // ---- fragment roles: wave (wm, wn): tile rows 2wm, 2wm+1 x channels 64wn..; lane -> pixel column tx = lane&31
     const int wm = wave / WGN, wn = wave % WGN;
     const int tx = lane & 31, half = lane >> 5;
+
+    // The accumulators START at the bias (acc[j][i][4g + e] = channel n0 + 64wn + 32j + 8g + 4half + e): a global load in
+    // the epilogue would wait (in order) behind the next tile's prefetches with nothing to overlap it; issued here, the
+    // loads have the whole first step to land.
+    f32x16 acc[CJ][PI];
+    auto init_acc = [&]() {
+#pragma unroll
+        for (int j = 0; j < CJ; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = n0 + wn * 64 + 32 * j + 8 * g + 4 * half;
+                const float4 b = (a.bias && co < a.Cout) ? *reinterpret_cast<const float4 *>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < PI; ++i) {
+                    acc[j][i][4 * g] = b.x; acc[j][i][4 * g + 1] = b.y; acc[j][i][4 * g + 2] = b.z; acc[j][i][4 * g + 3] = b.w;
+                }
+            }
+    };
+    init_acc();
     const int ey = UPS ? ((0 - pad_h) & 1) : 0, ex = UPS ? ((0 - pad_w) & 1) : 0;  // tile origins are even
     const unsigned char *fb = ldsB + (wn * 64 + (lane & 31)) * 128;
     const int swzb = (lane >> 1) & 7;
@@ -307,6 +318,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
         tile_origin(tp, n, oy0, ox0);
         const int tp_next = tp + PS;
         const bool has_next = tp_next < tiles_p;
+        // the tile's mask words (one per pixel row of the wave) are fetched NOW, not in the epilogue (see init_acc)
+        unsigned rbits_pf[PI] = {};
+        if (a.bits_in && !a.fold2) {
+#pragma unroll
+            for (int i = 0; i < PI; ++i) {
+                const size_t pix = ((size_t)n * a.OH + ((oy0 + 2 * wm + i) * a.oy_mul + oy_off)) * a.OW + ((ox0 + tx) * a.ox_mul + ox_off);
+                rbits_pf[i] = a.bits_in[(pix * (size_t)(a.Cs >> 6) + (size_t)((n0 >> 6) + wn)) * 2 + half];
+            }
+        }
         for (int sg = 0; sg < NSEG; ++sg) {
             const unsigned char *ha = lds + hb * ABUF;
             // the chunk this segment's slices prefetch (their offsets aoff[] were prepared during the previous segment)
@@ -406,8 +426,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                 }
         }
         // Variants by what the epilogue has to do (65 values per lane: every VALU op here is exposed on a one-wave-per-SIMD
-        // workgroup): PLAIN = no bias, no activation; MASK = the fused activation backward; GUARD = partial channel
-        // tiles / the folded store.  The generic variant decides bias / mask at run time.
+        // workgroup): PLAIN = no activation (the bias is in the accumulators' initial value); MASK = the fused activation
+        // backward; GUARD = partial channel tiles / the folded store.  The generic variant decides the mask at run time.
         auto store_tile = [&](auto plainc, auto maskc, auto guardc) {
             constexpr bool PLAIN = decltype(plainc)::value, MASK = decltype(maskc)::value, GUARD = decltype(guardc)::value;
 #pragma unroll
@@ -421,19 +441,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                 const size_t bword = (pix * (size_t)(a.Cs >> 6) + (size_t)((n0 >> 6) + wn)) * 2 + half;
                 unsigned wbits = 0, rbits = 0;
                 const bool use_bits = !GUARD && MASK && a.bits_in != nullptr, emit_bits = !GUARD && !PLAIN && a.bits_out != nullptr;
-                if (use_bits) rbits = a.bits_in[bword];
+                if (use_bits) rbits = rbits_pf[i];
 #pragma unroll
                 for (int j = 0; j < CJ; ++j) {
                     const int cbase = n0 + wn * 64 + 32 * j;
-                    float4 b4[4];
-                    if (!PLAIN) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int co = cbase + 8 * g + 4 * half;
-                            b4[g] = (a.bias && (!GUARD || co < a.Cout)) ? *reinterpret_cast<const float4 *>(a.bias + co)
-                                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
-                        }
-                    }
                     const bool masked = MASK && (!GUARD || a.mask_x) && !use_bits;
                     uint2 mk[4];
                     if (masked) {
@@ -448,7 +459,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                     for (int g = 0; g < 4; ++g) {
                         float v[4] = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
                         if (!PLAIN) {
-                            v[0] += b4[g].x; v[1] += b4[g].y; v[2] += b4[g].z; v[3] += b4[g].w;
                             if (emit_bits) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) wbits |= (v[e] > 0.0f ? 1u : 0u) << (16 * j + 4 * g + e);
@@ -493,21 +503,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
         {
             using std::false_type;
             using std::true_type;
-            const bool guard = a.fold2 || a.Cout != a.CoutP, plain = !a.bias && a.slope == 1.0f;
+            const bool guard = a.fold2 || a.Cout != a.CoutP, plain = a.slope == 1.0f;
             if (guard) store_tile(false_type{}, true_type{}, true_type{});
             else if (plain && !a.mask_x && !a.bits_in) store_tile(true_type{}, false_type{}, false_type{});
             else if (plain) store_tile(true_type{}, true_type{}, false_type{});
             else if (!a.mask_x && !a.bits_in) store_tile(false_type{}, false_type{}, false_type{});
             else store_tile(false_type{}, true_type{}, true_type{});
         }
-#pragma unroll
-        for (int j = 0; j < CJ; ++j)
-#pragma unroll
-            for (int i = 0; i < PI; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
-            }
         if (!has_next) break;
+        init_acc();
         tp = tp_next;
     }
     wait_vm<0>();  // the trailing (unused) prefetches

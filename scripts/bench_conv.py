@@ -38,4 +38,10 @@ for name, H, W, Cin, Cout, k, s, ph, pw, mode, ups in LAYERS:
     tf = timeit(lambda: conv.conv_fwd(d, x, wf, out_f32_nchw=Cout <= 4))
     td = timeit(lambda: conv.conv_dgrad(d, dy, wd))
     tw = timeit(lambda: conv.conv_wgrad(d, x, dy))
-    print(f"{name:32s} {fl/1e9:7.1f} GF  fwd {tf*1e6:8.1f} us {fl/tf/1e12:6.1f} TF | dgrad {td*1e6:8.1f} us {fl/td/1e12:6.1f} TF | wgrad {tw*1e6:8.1f} us {fl/tw/1e12:6.1f} TF", flush=True)
+    extra = ""
+    if os.environ.get("M355_BENCH_MASK") and conv.maskbits_ok(d, 1):
+        bits = torch.randint(-2**31, 2**31 - 1, (B, H, W, Cin // 64, 2), device="cuda", dtype=torch.int32)
+        tdm = timeit(lambda: conv.conv_dgrad(d, dy, wd, mask_x=x, mask_slope=0.2))
+        tdb = timeit(lambda: conv.conv_dgrad(d, dy, wd, mask_bits=bits, mask_slope=0.2))
+        extra = f" | dgrad mask_x {tdm*1e6:8.1f} us  mask_bits {tdb*1e6:8.1f} us" 
+    print(f"{name:32s} {fl/1e9:7.1f} GF  fwd {tf*1e6:8.1f} us {fl/tf/1e12:6.1f} TF | dgrad {td*1e6:8.1f} us {fl/td/1e12:6.1f} TF | wgrad {tw*1e6:8.1f} us {fl/tw/1e12:6.1f} TF" + extra, flush=True)
