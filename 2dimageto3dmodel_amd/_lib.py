@@ -46,6 +46,12 @@ SIGNATURES = {
     "m355_conv2d_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P]),
     "m355_conv2d_dgrad_ws_bytes": (c_size_t, [_P]),
     "m355_conv2d_dgrad": (c_int, [_P, _P, _P, _P, _P, _P, c_float, _P]),
+    "m355_mesh_vertices_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "m355_mesh_vertices_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "m355_mesh_normals_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "m355_mesh_normals_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "m355_mesh_flat_fwd": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "m355_mesh_flat_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     "m355_conv2d_maskbits_ok": (c_int, [_P, c_int]),
     "m355_conv2d_fwd_bits": (c_int, [_P, _P, _P, _P, _P, c_float, _P, _P]),
     "m355_conv2d_dgrad_bits": (c_int, [_P, _P, _P, _P, _P, _P, c_float, _P]),

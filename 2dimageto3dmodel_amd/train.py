@@ -1,8 +1,8 @@
 """The GAN training iteration of code/main.py (ModelWrapper.forward :476-526 and the loop :691-723) on the drop-in
 modules: schedule 1 generator step : d_steps_per_g discriminator steps, Adam(betas=(0,0.9)), EMA generator.
 
-Not reproduced: the mesh smoothness regulariser of the G step (`loss_flat`, needs the Kaolin mesh template,
-SURVEY.md 8f row 1) and the text encoder."""
+The mesh smoothness regulariser of the G step (main.py:697-705) is applied when the trainer is given a
+`mesh_template` (2dimageto3dmodel_amd.mesh.MeshTemplate).  Not reproduced: the text encoder."""
 import copy
 
 import torch
@@ -20,8 +20,11 @@ def divide_pred(pred):
 
 class GanTrainer(torch.nn.Module):
     def __init__(self, args, latent_dim=64, lr_g=1e-4, lr_d=4e-4, d_steps_per_g=2, loss="hinge", device="cuda",
-                 symmetric_g=True, use_mesh=True, ema_alpha=0.999, capturable=False):
+                 symmetric_g=True, use_mesh=True, ema_alpha=0.999, capturable=False, mesh_template=None,
+                 mesh_regularization=0.0001):
         super().__init__()
+        # main.py:152,697-705: flat_loss = loss_flat(mesh, compute_normals(get_vertex_positions(pred_mesh))) joins the G loss
+        self.mesh_template, self.mesh_regularization = (mesh_template if use_mesh else None), mesh_regularization
         self.args, self.latent_dim, self.d_steps_per_g, self.ema_alpha = args, latent_dim, d_steps_per_g, ema_alpha
         self.generator = G.Generator(args, latent_dim, symmetric=symmetric_g, mesh_head=use_mesh)
         self.generator_running_avg = copy.deepcopy(self.generator)          # main.py:453-457
@@ -100,9 +103,16 @@ class GanTrainer(torch.nn.Module):
             for p in d_params:
                 p.requires_grad_(False)
             try:
-                loss, _, _ = self('g', None, X_alpha, None, C, caption)
+                loss, _, pred_mesh = self('g', None, X_alpha, None, C, caption)
                 loss = loss.mean()
-                loss.backward()
+                flat = None
+                if self.mesh_template is not None and pred_mesh is not None:
+                    from . import mesh as M
+                    vtx = self.mesh_template.get_vertex_positions(pred_mesh)
+                    flat = M.loss_flat(self.mesh_template.mesh, self.mesh_template.compute_normals(vtx))
+                    (loss + self.mesh_regularization * flat).backward()
+                else:
+                    loss.backward()
             finally:
                 for p in d_params:
                     p.requires_grad_(True)
@@ -110,6 +120,8 @@ class GanTrainer(torch.nn.Module):
             self.optimizer_g.step()
             self.update_generator_running_avg()
             out = {"g": loss.detach()}
+            if flat is not None:
+                out["flat"] = flat.detach()
         else:
             self.optimizer_d.zero_grad(set_to_none=True)
             loss_fake, loss_real, _, _ = self('d', X_tex, X_alpha, X_mesh, C, caption)

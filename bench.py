@@ -114,7 +114,14 @@ def main():
                                    conditional_text=False, n_classes=[200], texture_resolution=R, mask_output=True,
                                    num_discriminators=2, texture_only=False, text_embedding_dim=256)
         torch.manual_seed(1234 + 3)
-        trainer = train.GanTrainer(gargs, device=dev)
+        # the G step's mesh smoothness regulariser (code/main.py:697-705) on a procedural 32 x 16 UV sphere (same topology
+        # as the reference's template asset, which is not redistributed)
+        import tempfile
+        mesh_mod = importlib.import_module("2dimageto3dmodel_amd.mesh")
+        with tempfile.TemporaryDirectory() as tmp:
+            template = mesh_mod.MeshTemplate(mesh_mod.write_uv_sphere_obj(os.path.join(tmp, "uvsphere_16rings.obj")),
+                                             is_symmetric=True, device=dev)
+        trainer = train.GanTrainer(gargs, device=dev, mesh_template=template)
         trainer.train()
         batches = [make_textures(B, R, 1234 + 3 + 17 * rank + i, dev) for i in range(3)]
 
@@ -188,7 +195,7 @@ def main():
             workload.append(f"projection+silhouette-loss fwd/bwd on {B} clouds/GPU of {N} pts -> {S}x{S}")
         if do_g:
             workload.append(f"GAN cycle (1 G + 2 D steps, Adam) at batch {B}/GPU, {R}x{R}, nd=2, class-conditional, "
-                            f"syncbatch")
+                            f"syncbatch, mesh flat-loss regulariser in the G step")
         out = {
             "metric": "train-step samples/sec (proj+loss+GAN fwd/bwd), batch 64", "value": world * B * args.steps / dt,
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -259,6 +259,28 @@ int m355_bn_bwd_finalize(const float *part, int nblk, float count, const float *
 int m355_bn_bwd_coeffs(const float *m, float count, const float *mean, const float *rstd, int C, float *Bc, float *Cc,
                        void *stream);
 
+/* ---- mesh-template deformation, face normals, flat (smoothness) loss -- code/main.py:697-699 ----
+ * Replaces MeshTemplate.get_vertex_positions / deform / compute_normals (code/rendering/mesh_template.py:106-149) and
+ * loss_flat (code/utils/losses.py:5-17); the reference-side binding is in INTEGRATION.md.  All fp32, row-major.
+ *   dmap  [B,3,H,W]  displacement map (the generator's mesh head, NCHW)
+ *   uv    [S,2]      grid_sample coordinates of the S source vertices in the W-padded map (host: mesh.py, per W)
+ *   tgm   [S,3,3]    tangent frames (normal, tangent, bitangent) of the source vertices
+ *   base  [V,3]      template vertices;  src [V] int32 source index of vertex v;  xsign [V] x-factor (-1 mirrored, 0 on
+ *                    the symmetry plane, +1 otherwise)
+ *   symmetric: 1 = circular pad by one column each side (mesh_template.py:166), 0 = one wrapped column (:169)
+ *   faces [F,3] int32, ff [F,3] int32 face-face adjacency (kaolin `mesh.ff`)
+ * _bwd entry points overwrite their gradient outputs. */
+int m355_mesh_vertices_fwd(const float *dmap, const float *uv, const float *tgm, const float *base, const int *src,
+                           const float *xsign, float *pos /*[B,V,3]*/, int B, int V, int H, int W, int symmetric, void *stream);
+int m355_mesh_vertices_bwd(const float *dpos, const float *uv, const float *tgm, const int *src, const float *xsign,
+                           float *ddmap /*[B,3,H,W]*/, int B, int V, int H, int W, int symmetric, void *stream);
+int m355_mesh_normals_fwd(const float *pos, const int *faces, float *normals /*[B,F,3]*/, int B, int V, int F, void *stream);
+int m355_mesh_normals_bwd(const float *pos, const int *faces, const float *dnormals, float *dpos, int B, int V, int F,
+                          void *stream);
+int m355_mesh_flat_fwd(const float *normals, const int *ff, float *loss /*[1]*/, int B, int F, void *stream);
+int m355_mesh_flat_bwd(const float *normals, const int *ff, const float *gloss /*[1]*/, float *dnormals, int B, int F,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif
