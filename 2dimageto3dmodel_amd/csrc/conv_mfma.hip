@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <cstring>
 #include "conv_dma.h"
 
 namespace m355 {
@@ -381,7 +382,15 @@ struct WeightPrepArgs {
     WeightPrepPart part[5];  // forward view + the dgrad view (stride 1) or its four parity classes (stride 2)
 };
 // one launch for all views of a layer: blockIdx.y = view
-__global__ void k_weight_prep(WeightPrepArgs w)
+__device__ __forceinline__ void weight_prep_body(const WeightPrepArgs &w);
+__global__ void k_weight_prep(WeightPrepArgs w) { weight_prep_body(w); }
+// ... and for all layers of a network: blockIdx.z = layer of a device-resident table (m355_weight_prep_batched)
+__global__ void k_weight_prep_batched(const WeightPrepArgs *__restrict__ tab)
+{
+    const WeightPrepArgs &w = tab[blockIdx.z];
+    if ((int)blockIdx.y < w.nparts) weight_prep_body(w);
+}
+__device__ __forceinline__ void weight_prep_body(const WeightPrepArgs &w)
 {
     const WeightPrepPart &p = w.part[blockIdx.y];
     const float *__restrict__ in = w.in;
@@ -631,17 +640,14 @@ extern "C" size_t m355_conv2d_weight_elems(const m355_conv_desc *d, int which)
     return 4 * rows_d * (size_t)m355::k_padded((d->kh / 2) * (d->kw / 2) * (int)cout32);  // four parity-class views
 }
 
-extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_oihw, int cin_w, const float *sigma,
-                                       void *w_fwd, void *w_dgrad, void *stream)
+// the views of one layer: forward [rows_padded(Cout)][Kp] + the dgrad view (stride 1) or its four parity classes (stride 2)
+static int fill_weight_prep(const m355_conv_desc *d, const float *w_oihw, int cin_w, const float *sigma, void *w_fwd, void *w_dgrad,
+                            m355::WeightPrepArgs &w, size_t &most)
 {
-    if (int rc = check_desc(d, "conv2d_weight_prep")) return rc;
-    M355_REQUIRE(w_oihw && (w_fwd || w_dgrad), "conv2d_weight_prep: null pointer");
-    M355_REQUIRE(cin_w >= 1 && cin_w <= d->Cin, "conv2d_weight_prep: cin_w=%d outside 1..Cin=%d", cin_w, d->Cin);
-    hipStream_t st = (hipStream_t)stream;
     const int cout64 = m355::rows_padded(d->Cout), cin64 = m355::rows_padded(d->Cin), cout32 = m355::dy_channels(d->Cout);
-    m355::WeightPrepArgs w = {};
+    w = m355::WeightPrepArgs{};
     w.in = w_oihw; w.sigma = sigma; w.O = d->Cout; w.I = cin_w; w.KH = d->kh; w.KW = d->kw;
-    size_t most = 0;
+    most = 0;
     auto add = [&](unsigned short *out, int transpose, int A, int B, int th0, int ths, int tw0, int tws, int Rp, int Cp, int Kp) {
         w.part[w.nparts++] = m355::WeightPrepPart{out, transpose, A, B, th0, ths, tw0, tws, Rp, Cp, Kp};
         if ((size_t)Rp * Kp > most) most = (size_t)Rp * Kp;
@@ -662,9 +668,50 @@ extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_o
                         cin64, cout32, Kp);
         }
     }
+    return M355_OK;
+}
+
+extern "C" int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_oihw, int cin_w, const float *sigma,
+                                       void *w_fwd, void *w_dgrad, void *stream)
+{
+    if (int rc = check_desc(d, "conv2d_weight_prep")) return rc;
+    M355_REQUIRE(w_oihw && (w_fwd || w_dgrad), "conv2d_weight_prep: null pointer");
+    M355_REQUIRE(cin_w >= 1 && cin_w <= d->Cin, "conv2d_weight_prep: cin_w=%d outside 1..Cin=%d", cin_w, d->Cin);
+    m355::WeightPrepArgs w;
+    size_t most = 0;
+    if (int rc = fill_weight_prep(d, w_oihw, cin_w, sigma, w_fwd, w_dgrad, w, most)) return rc;
     const unsigned bx = (unsigned)((most + 255) / 256 > 2048 ? 2048 : (most + 255) / 256);
-    hipLaunchKernelGGL(m355::k_weight_prep, dim3(bx, w.nparts), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(m355::k_weight_prep, dim3(bx, w.nparts), dim3(256), 0, (hipStream_t)stream, w);
     return m355::check_launch("conv2d_weight_prep");
+}
+
+/* All weight views of a network in ONE launch.  m355_weight_prep_entry_bytes() bytes per layer, filled on the host by
+ * m355_weight_prep_fill_entry (arguments of m355_conv2d_weight_prep, device pointers; returns the layer's largest view
+ * in elements, -1 on error) into a buffer the caller copies to the device once; m355_weight_prep_batched runs the
+ * table (max_elems = the largest value the fill calls returned). */
+extern "C" size_t m355_weight_prep_entry_bytes(void) { return sizeof(m355::WeightPrepArgs); }
+
+extern "C" long long m355_weight_prep_fill_entry(const m355_conv_desc *d, const float *w_oihw, int cin_w, const float *sigma,
+                                                 void *w_fwd, void *w_dgrad, void *entry_host)
+{
+    if (check_desc(d, "weight_prep_fill_entry") || !w_oihw || !(w_fwd || w_dgrad) || !entry_host || cin_w < 1 || cin_w > d->Cin) {
+        m355::set_error("weight_prep_fill_entry: bad argument");
+        return -1;
+    }
+    m355::WeightPrepArgs w;
+    size_t most = 0;
+    if (fill_weight_prep(d, w_oihw, cin_w, sigma, w_fwd, w_dgrad, w, most)) return -1;
+    memcpy(entry_host, &w, sizeof(w));
+    return (long long)most;
+}
+
+extern "C" int m355_weight_prep_batched(const void *table_dev, int L, long long max_elems, void *stream)
+{
+    M355_REQUIRE(table_dev && L > 0 && L <= 65535 && max_elems > 0, "weight_prep_batched: bad argument");
+    const unsigned bx = (unsigned)((max_elems + 255) / 256 > 256 ? 256 : (max_elems + 255) / 256);
+    hipLaunchKernelGGL(m355::k_weight_prep_batched, dim3(bx, 5, L), dim3(256), 0, (hipStream_t)stream,
+                       (const m355::WeightPrepArgs *)table_dev);
+    return m355::check_launch("weight_prep_batched");
 }
 
 // probe != 0: do not launch, return 1 / 0 = this forward can / cannot write the activation bit masks

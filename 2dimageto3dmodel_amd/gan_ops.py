@@ -89,7 +89,10 @@ class Conv2dFn(torch.autograd.Function):
         d = C.make_desc(n, h, w, cx, cout, kh, kw, stride, pad_h, pad_w, mode, ups)
         need_dx = ctx.needs_input_grad[0]
         sigma = None if sn is None else sn.sigma
-        wf, wd = C.weight_prep(d, weight, want_dgrad=need_dx, sigma=sigma)
+        if sn is not None and sn.wkey == (cx, cout, kh, kw, stride) and (sn.wd is not None or not need_dx):
+            wf, wd = sn.wf, (sn.wd if need_dx else None)   # prepared with the whole network's views (SpectralNormGroup.step)
+        else:
+            wf, wd = C.weight_prep(d, weight, want_dgrad=need_dx, sigma=sigma)
         # premasked = the only consumer's dgrad applies this activation's backward: hand it 1 bit per element instead of
         # making it re-read the bf16 activation (csrc/conv_dma.h: ConvArgs::bits_out)
         bits = None
@@ -172,10 +175,12 @@ def conv2d(x, weight, bias, stride, pad_h, pad_w, mode, upsample=0, slope=1.0, o
 # ------------------------------------------------------------------------------------------------ spectral norm
 class _SnState:
     """what one conv needs from one SpectralNormGroup.step(): views of that step's sigma / u / v"""
-    __slots__ = ("sigma", "u", "v", "_slot", "_version")
+    __slots__ = ("sigma", "u", "v", "_slot", "_version", "wf", "wd", "wkey")
 
-    def __init__(self, sigma, u, v, slot, version):
+    def __init__(self, sigma, u, v, slot, version, wf=None, wd=None, wkey=None):
         self.sigma, self.u, self.v, self._slot, self._version = sigma, u, v, slot, version
+        # bf16 GEMM views of weight_orig / sigma prepared by the group's batched launch, valid for descs with `wkey`
+        self.wf, self.wd, self.wkey = wf, wd, wkey
 
     def check(self):
         if self._slot["version"] != self._version:
@@ -222,7 +227,35 @@ class SpectralNormGroup:
                 ro += rows[i]
                 co += cols[i]
             table = torch.frombuffer(raw, dtype=torch.uint8).to(dev)
-            self._slots.append({"table": table, "snap": snap, "sigma": sigma, "views": views, "version": 0})
+            slot = {"table": table, "snap": snap, "sigma": sigma, "views": views, "version": 0}
+            self._build_weight_views(slot, dev)
+            self._slots.append(slot)
+
+    def _build_weight_views(self, slot, dev):
+        """per slot: the bf16 forward / dgrad views of every conv (m355_conv2d_weight_prep's outputs) and the device
+        table that produces all of them in one launch (m355_weight_prep_batched)"""
+        import ctypes
+        L = lib()
+        esz = L.m355_weight_prep_entry_bytes()
+        raw = (ctypes.c_char * (esz * len(self.convs)))()
+        weights, most = [], 0
+        for i, c in enumerate(self.convs):
+            cout, cw, kh, kw = c.weight_orig.shape
+            stride, pad_h, pad_w, mode = c.m355
+            cx = (cw + 7) // 8 * 8
+            d = C.make_desc(1, 64, 64, cx, cout, kh, kw, stride, pad_h, pad_w, mode, 0)
+            wf = torch.empty((L.m355_conv2d_weight_elems(ctypes.byref(d), 0),), dtype=torch.bfloat16, device=dev)
+            wd = None
+            if stride == 1 or (kh % 2 == 0 and kw % 2 == 0):
+                wd = torch.empty((L.m355_conv2d_weight_elems(ctypes.byref(d), 1),), dtype=torch.bfloat16, device=dev)
+            n = L.m355_weight_prep_fill_entry(ctypes.byref(d), ptr(c.weight_orig), int(cw), ptr(slot["sigma"][i:i + 1]), ptr(wf),
+                                              ptr(wd), ctypes.byref(raw, esz * i))
+            if n < 0:
+                _lib.check(1, "weight_prep_fill_entry")
+            most = max(most, n)
+            weights.append((wf, wd, (cx, cout, kh, kw, stride)))
+        slot["wtable"] = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).to(dev)
+        slot["weights"], slot["wmost"] = weights, most
 
     def step(self, training):
         """advance (training) / evaluate sigma for every conv of the group and hand each conv its state"""
@@ -237,8 +270,9 @@ class SpectralNormGroup:
         slot["version"] += 1
         launch("sn_power_iter", ptr(slot["table"]), len(self.convs), self._max[0], self._max[1], ptr(self._norms),
                ptr(slot["sigma"]), int(bool(training)), float(self.eps), stream())
-        for c, (sg, u, v) in zip(self.convs, slot["views"]):
-            c._sn_state = _SnState(sg, u, v, slot, slot["version"])
+        launch("weight_prep_batched", ptr(slot["wtable"]), len(self.convs), int(slot["wmost"]), stream())
+        for c, (sg, u, v), (wf, wd, wkey) in zip(self.convs, slot["views"], slot["weights"]):
+            c._sn_state = _SnState(sg, u, v, slot, slot["version"], wf, wd, wkey)
 
 
 def strip_sn_hook(conv):

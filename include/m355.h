@@ -153,6 +153,14 @@ size_t m355_conv2d_weight_elems(const m355_conv_desc *d, int which);
  *      (torch.nn.utils.spectral_norm: weight = weight_orig / sigma) folded into the bf16 conversion. */
 int m355_conv2d_weight_prep(const m355_conv_desc *d, const float *w_oihw, int cin_w, const float *sigma, void *w_fwd,
                             void *w_dgrad, void *stream);
+
+/* ... and the views of ALL layers of a network in one launch (the per-layer calls were 87 launches per GAN cycle):
+ * fill one host entry per layer (m355_weight_prep_entry_bytes() bytes each; same arguments as above, DEVICE pointers;
+ * returns the layer's largest view in elements or -1), copy the table to the device once, run it every step. */
+size_t m355_weight_prep_entry_bytes(void);
+long long m355_weight_prep_fill_entry(const m355_conv_desc *d, const float *w_oihw, int cin_w, const float *sigma,
+                                      void *w_fwd, void *w_dgrad, void *entry_host);
+int m355_weight_prep_batched(const void *table_dev, int n_layers, long long max_elems, void *stream);
 /*      y: bf16 NHWC [N,Ho,Wo,Cout] or (y_f32_nchw) fp32 [N,Cout,Ho,Wo]; epilogue: + bias[Cout] (nullable),
  *      LeakyReLU(lrelu_slope) (1.0 = identity). */
 int m355_conv2d_fwd(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
