@@ -55,6 +55,9 @@ __device__ __forceinline__ void wait_vm()
 #ifndef M355_HALO_PIPE
 #define M355_HALO_PIPE 1
 #endif
+#ifndef M355_HALO_PIPE8
+#define M355_HALO_PIPE8 0
+#endif
 #ifndef M355_HALO_RB4
 #define M355_HALO_RB4 3
 #endif
@@ -99,8 +102,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
     static_assert(!RES || (BN == 64 && NW == 4 && SUB == 1 && !UPS), "resident weights: 4-wave variant only");
     constexpr int RB = RES ? (KS == 2 ? 8 : 9) : (NW == 4 ? M355_HALO_RB4 : M355_HALO_RB8);  // weight slots (ring / panel)
     // software pipeline (one wave per SIMD has no partner wave to hide its LDS-read latency): fragments of step s+1 are
-    // read during step s.  The 8-wave variant (2 waves per SIMD, 256 registers each) reads them in the step itself.
-    constexpr int L = (NW == 4 && M355_HALO_PIPE) ? 1 : 0;
+    // read during step s.  The 8-wave variant (2 waves per SIMD, 256 registers each) does the same for the 2x2 class
+    // convs (+3-5 %); with 9 taps unrolled it would spill ~30 registers (-5 %), so 3x3 reads them in the step itself.
+    constexpr int L = ((NW == 4 || KS == 2 || M355_HALO_PIPE8) && M355_HALO_PIPE) ? 1 : 0;
     constexpr int NBW = BN / (8 * NW);                    // weight DMAs per wave per step
     constexpr int ABUF = NW * NAW * 1024, BBUF = BN * 128;
     constexpr int WGN = BN / 64, PI = 2, CJ = 2;          // waves along N; each wave 2 tile rows x 64 channels
