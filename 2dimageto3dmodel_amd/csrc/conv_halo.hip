@@ -22,6 +22,7 @@
 
 #include <type_traits>
 
+#include <cstring>
 #include "conv_dma.h"
 
 namespace m355 {
@@ -536,23 +537,27 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
 //         dw[co][2a+p][2b+q][ci] = sum_o dy[o][co] * X_pq[o + (a,b)][ci]   -- a stride-1 2x2 all-taps problem on a plane
 //         of x that the DMA addresses with pixel stride 2; each wave holds all 4 taps and the two wave quartets split
 //         the tile's pixels (both add their partial sums atomically).
-template <int KS, int UPS, int MODE>
-__global__ __launch_bounds__(512, 2) void k_wgrad_halo(WgradArgs a, unsigned xbytes, unsigned ybytes)
+// TH x 32-pixel tiles; NCO = 64-channel dy blocks per workgroup sharing one x halo.  The stride-2 classes run TH 4, NCO 1
+// with two workgroups per CU (see wgrad_halo_launch).
+template <int KS, int UPS, int MODE, int TH = 8, int NCO = 1>
+__global__ __launch_bounds__(512, (TH == 4 && NCO == 1) ? 4 : 2) void k_wgrad_halo(WgradArgs a, unsigned xbytes, unsigned ybytes)
 {
-    constexpr int TH = 8, TW = 32, T = KS * KS, NW = 8;
+    constexpr int TW = 32, T = KS * KS, NW = 8;
+    static_assert(TH == 8 || (TH == 4 && KS == 2), "4-row tiles: class kernels only");
     constexpr int NT = KS == 3 ? 5 : 4;                  // accumulators per wave
     constexpr int SUB = KS == 2 ? 2 : 1;                 // input pixel stride of the plane
     constexpr int HH = UPS ? TH / 2 + 2 : TH + KS - 1, HWD = UPS ? TW / 2 + 2 : TW + KS - 1, HR = HH * HWD;
     constexpr int NAX = ((HR + 7) / 8 + NW - 1) / NW;   // x-halo DMA slots per wave
-    constexpr int NAY = 4;                               // dy tile: 32 instructions / 8 waves
-    constexpr int XBUF = NW * NAX * 1024, YBUF = 256 * 128, STAGE = XBUF + YBUF;
+    constexpr int NAY = TH / 2;                          // dy block: TH*4 instructions / 8 waves
+    constexpr int YB1 = TH * TW * 128;                   // one [pixels][64 co] dy block
+    constexpr int XBUF = NW * NAX * 1024, YBUF = NCO * YB1, STAGE = XBUF + YBUF;
     static_assert(!(UPS && KS == 2), "no upsample with classes");
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nci = a.Cin >> 6;
-    const int co0 = (blockIdx.y / nci) * 64, ci0 = (blockIdx.y % nci) * 64;
+    const int co0 = (blockIdx.y / nci) * 64 * NCO, ci0 = (blockIdx.y % nci) * 64;
     const int cp = KS == 2 ? (int)blockIdx.z >> 1 : 0, cq = KS == 2 ? (int)blockIdx.z & 1 : 0;  // parity class
     const int tpx = a.Wo / TW, tpy = a.Ho / TH, tiles = a.N * tpx * tpy;
     if ((int)blockIdx.x >= tiles) return;
@@ -582,11 +587,14 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_halo(WgradArgs a, unsigned xby
             dma16(rx, dX + (NW * k + wave) * 1024, ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin + ci0) * 2 + csrc * 16) : OOB, 0u);
         }
 #pragma unroll
-        for (int k = 0; k < NAY; ++k) {
-            const int p = 8 * (NW * k + wave) + (lane >> 3);  // tile pixel = (p >> 5, p & 31)
-            const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
-            dma16(ry, dY + (NW * k + wave) * 1024, (unsigned)((((n * a.Ho + oy) * a.Wo + ox) * a.Cy + co0) * 2 + csrc * 16), 0u);
-        }
+        for (int c = 0; c < NCO; ++c)
+#pragma unroll
+            for (int k = 0; k < NAY; ++k) {
+                const int p = 8 * (NW * k + wave) + (lane >> 3);  // tile pixel = (p >> 5, p & 31)
+                const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
+                dma16(ry, dY + c * YB1 + (NW * k + wave) * 1024,
+                      (unsigned)((((n * a.Ho + oy) * a.Wo + ox) * a.Cy + co0 + 64 * c) * 2 + csrc * 16), 0u);
+            }
     };
 
     // fragment roles
@@ -597,31 +605,32 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_halo(WgradArgs a, unsigned xby
     const int ya = (((w_co * 4 + g16 * 2 + ((q & 3) >> 1)) ^ (((q >> 3) & 1) << 2)) << 4) + (q & 1) * 8 + (8 * hh + (q >> 2)) * 128;
     const int xchunk = w_ci * 4 + g16 * 2 + ((q & 3) >> 1);
 
-    constexpr int NKG = KS == 2 ? 8 : 16;  // K groups per wave and tile
+    constexpr int NKG = KS == 2 ? TH : 16;  // K groups per wave and tile (KS 2: the quartets split the tile's rows)
     const int lp = 8 * hh + (q >> 2);      // this lane's pixel within a 16-pixel K group
-    const int ybase = ya + (KS == 2 ? 8 * w_hi * 2048 : 0);
+    const int ybase = ya + (KS == 2 ? NKG * w_hi * 2048 : 0);
     // x fragment bases: halo row = (lane part) + (static part c); the swizzle bit ((row>>1)&1) depends on the two low
     // bits of both parts only -> one base per (c & 3) [and per parity of the static column when the upsample halves it]
     int xbase[UPS ? 8 : 4];
 #pragma unroll
     for (int m = 0; m < (UPS ? 8 : 4); ++m) {
-        const int lpm = UPS ? (lp + (m >> 2)) >> 1 : lp;
+        const int lpm = (UPS ? (lp + (m >> 2)) >> 1 : lp) + (KS == 2 ? (TH / 2) * w_hi * HWD : 0);  // + the quartet's rows
         const int sbit = (((lpm & 3) + (m & 3)) >> 1) & 1;
-        xbase[m] = (lpm + (KS == 2 ? 4 * w_hi * HWD : 0)) * 128 + ((xchunk ^ (sbit << 2)) << 4) + (q & 1) * 8;
+        xbase[m] = lpm * 128 + ((xchunk ^ (sbit << 2)) << 4) + (q & 1) * 8;
     }
-    static_assert(KS != 2 || (4 * HWD) % 4 == 0, "the quartet's row offset must not disturb the swizzle bits");
 
-    f32x16 acc[NT];
+    f32x16 acc[NCO][NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int c = 0; c < NCO; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.0f;
 
-    // bias gradient (column sums of dy) by the workgroups of the first ci tile / class: thread -> channel tid % 64,
-    // pixels 32 (tid / 64) .. +31 of every tile
+    // bias gradient (column sums of dy) by the workgroups of the first ci tile / class: thread -> channel tid % 64 (of
+    // every co block), pixels (TH*4) (tid / 64) .. of every tile
     const bool do_db = a.db != nullptr && (blockIdx.y % nci) == 0 && blockIdx.z == 0;
     const int dbc = tid & 63, dbq = tid >> 6;
-    float dbacc = 0.0f;
+    float dbacc[NCO] = {};
 
     int buf = 0;
     issue(blockIdx.x, 0);
@@ -633,11 +642,14 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_halo(WgradArgs a, unsigned xby
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char *bx = lds + buf * STAGE, *by = bx + XBUF;
         if (do_db) {
+#pragma unroll
+            for (int c = 0; c < NCO; ++c)
 #pragma unroll 8
-            for (int pp = 0; pp < 32; ++pp) {
-                const int prow = dbq * 32 + pp;
-                dbacc += bf2f(*reinterpret_cast<const unsigned short *>(by + prow * 128 + (((dbc >> 3) ^ (((prow >> 1) & 1) << 2)) << 4) + (dbc & 7) * 2));
-            }
+                for (int pp = 0; pp < TH * 4; ++pp) {
+                    const int prow = dbq * (TH * 4) + pp;
+                    dbacc[c] += bf2f(*reinterpret_cast<const unsigned short *>(by + c * YB1 + prow * 128 +
+                                                                               (((dbc >> 3) ^ (((prow >> 1) & 1) << 2)) << 4) + (dbc & 7) * 2));
+                }
         }
         // K groups of 16 pixels (tile row kg>>1, columns 16(kg&1) .. +15), fully unrolled: every fragment address is a
         // lane-dependent base + an immediate.  KS 3: wave quartet w_hi owns taps 5 w_hi .. (two code copies); KS 2: it
@@ -646,9 +658,13 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_halo(WgradArgs a, unsigned xby
             constexpr int WH = decltype(whc)::value;  // tap group (KS 3 only)
             static_for<0, NKG>([&](auto kgc) {
                 constexpr int kg = decltype(kgc)::value;
-                const s4v y0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v *)(by + ybase + kg * 2048));
-                const s4v y1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v *)(by + ybase + kg * 2048 + 512));
-                const bf16x8 yf = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+                bf16x8 yf[NCO];
+#pragma unroll
+                for (int c = 0; c < NCO; ++c) {
+                    const s4v y0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v *)(by + c * YB1 + ybase + kg * 2048));
+                    const s4v y1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v *)(by + c * YB1 + ybase + kg * 2048 + 512));
+                    yf[c] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
                 constexpr int ty = kg >> 1;
                 static_for<0, NT>([&](auto tc) {
                     constexpr int tap = KS == 3 ? WH * NT + decltype(tc)::value : decltype(tc)::value;
@@ -669,7 +685,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_halo(WgradArgs a, unsigned xby
                             }
                         }
                         const bf16x8 xf = __builtin_shufflevector(x01[0], x01[1], 0, 1, 2, 3, 4, 5, 6, 7);
-                        acc[decltype(tc)::value] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf, xf, acc[decltype(tc)::value], 0, 0, 0);
+#pragma unroll
+                        for (int c = 0; c < NCO; ++c)
+                            acc[c][decltype(tc)::value] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[c], xf, acc[c][decltype(tc)::value], 0, 0, 0);
                     }
                 });
             });
@@ -677,22 +695,28 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_halo(WgradArgs a, unsigned xby
         if (KS == 3 && w_hi) tile_mma(std::integral_constant<int, 1>{});
         else tile_mma(std::integral_constant<int, 0>{});
     }
-    if (do_db && co0 + dbc < a.Cout) atomicAdd(a.db + co0 + dbc, dbacc);
+    if (do_db) {
+#pragma unroll
+        for (int c = 0; c < NCO; ++c)
+            if (co0 + 64 * c + dbc < a.Cout) atomicAdd(a.db + co0 + 64 * c + dbc, dbacc[c]);
+    }
     // acc[t][r]: co = co0 + 32 w_co + (r&3) + 8(r>>2) + 4(lane>>5), ci = ci0 + 32 w_ci + (lane&31)
     const int K = a.KH * a.KW * a.Cin;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int tap = KS == 3 ? w_hi * NT + t : t;
-        if (tap < T) {
-            const int kh = KS == 3 ? tap / 3 : 2 * (tap >> 1) + cp, kw = KS == 3 ? tap % 3 : 2 * (tap & 1) + cq;
+    for (int c = 0; c < NCO; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + 32 * w_co + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < a.Cout)
-                    atomicAdd(a.dw + (size_t)co * K + (kh * a.KW + kw) * a.Cin + ci0 + 32 * w_ci + (lane & 31), acc[t][r]);
+        for (int t = 0; t < NT; ++t) {
+            const int tap = KS == 3 ? w_hi * NT + t : t;
+            if (tap < T) {
+                const int kh = KS == 3 ? tap / 3 : 2 * (tap >> 1) + cp, kw = KS == 3 ? tap % 3 : 2 * (tap & 1) + cq;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + 64 * c + 32 * w_co + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (co < a.Cout)
+                        atomicAdd(a.dw + (size_t)co * K + (kh * a.KW + kw) * a.Cin + ci0 + 32 * w_ci + (lane & 31), acc[c][t][r]);
+                }
             }
         }
-    }
 }
 
 bool wgrad_halo_eligible(const WgradArgs &a)
@@ -708,22 +732,33 @@ bool wgrad_halo_eligible(const WgradArgs &a)
 
 int wgrad_halo_launch(const WgradArgs &a, unsigned xb, unsigned yb, hipStream_t st)
 {
-    const int tiles = a.N * (a.Ho / 8) * (a.Wo / 32);
-    const int ny = ((a.Cout + 63) / 64) * (a.Cin / 64), ncls = a.stride == 2 ? 4 : 1;
-    int per = 256 / (ny * ncls);  // one 8-wave workgroup per CU; each walks a strided list of pixel tiles (split K)
+    // stride-2 classes with >= 128 output channels: 4 x 32 tiles, two 64-channel dy blocks per workgroup on one x halo
+    // stride-2 classes: 4 x 32-pixel tiles, TWO workgroups per CU (80 KB of LDS, 128 registers each).  The class kernels
+    // wait on their tile DMAs 46 % of the time (SQ_WAIT_ANY; L2 hit rate and HBM traffic are fine): with one tile of
+    // prefetch a workgroup cannot cover an HBM round trip, two independent pipelines per CU can (+12-17 % over one
+    // 8 x 32 workgroup, +10-14 % over 4 x 32 with two dy blocks on one x halo).  M355_WGRAD_HALO_VARIANT=narrow|wide: A/B.
+    const char *var = getenv("M355_WGRAD_HALO_VARIANT");
+    const bool wide = a.stride == 2 && a.Cout % 128 == 0 && var && !strcmp(var, "wide");
+    const bool twin = a.stride == 2 && !wide && !(var && !strcmp(var, "narrow"));
+    const int th = (wide || twin) ? 4 : 8, nco = wide ? 2 : 1;
+    const int tiles = a.N * (a.Ho / th) * (a.Wo / 32);
+    const int ny = ((a.Cout + 64 * nco - 1) / (64 * nco)) * (a.Cin / 64), ncls = a.stride == 2 ? 4 : 1;
+    int per = (twin ? 512 : 256) / (ny * ncls);  // one 8-wave workgroup per CU; each walks a strided list of pixel tiles (split K)
     if (per < 1) per = 1;
     if (per > tiles) per = tiles;
     const dim3 grid(per, ny, ncls);
-#define M355_WH(KS_, UPS_)                                                                                              \
-    do {                                                                                                                \
-        if (a.pad_w_mode == 0) hipLaunchKernelGGL((k_wgrad_halo<KS_, UPS_, 0>), grid, dim3(512), 0, st, a, xb, yb);     \
-        else if (a.pad_w_mode == 1) hipLaunchKernelGGL((k_wgrad_halo<KS_, UPS_, 1>), grid, dim3(512), 0, st, a, xb, yb); \
-        else hipLaunchKernelGGL((k_wgrad_halo<KS_, UPS_, 2>), grid, dim3(512), 0, st, a, xb, yb);                        \
+#define M355_WM(KS_, UPS_, TH_, NCO_)                                                                                         \
+    do {                                                                                                                      \
+        if (a.pad_w_mode == 0) hipLaunchKernelGGL((k_wgrad_halo<KS_, UPS_, 0, TH_, NCO_>), grid, dim3(512), 0, st, a, xb, yb);      \
+        else if (a.pad_w_mode == 1) hipLaunchKernelGGL((k_wgrad_halo<KS_, UPS_, 1, TH_, NCO_>), grid, dim3(512), 0, st, a, xb, yb); \
+        else hipLaunchKernelGGL((k_wgrad_halo<KS_, UPS_, 2, TH_, NCO_>), grid, dim3(512), 0, st, a, xb, yb);                        \
     } while (0)
-    if (a.stride == 2) M355_WH(2, 0);
-    else if (a.ups) M355_WH(3, 1);
-    else M355_WH(3, 0);
-#undef M355_WH
+    if (twin) M355_WM(2, 0, 4, 1);
+    else if (a.stride == 2 && wide) M355_WM(2, 0, 4, 2);
+    else if (a.stride == 2) M355_WM(2, 0, 8, 1);
+    else if (a.ups) M355_WM(3, 1, 8, 1);
+    else M355_WM(3, 0, 8, 1);
+#undef M355_WM
     note_kernel("k_wgrad_halo");
     return check_launch("conv2d_wgrad (halo)");
 }
