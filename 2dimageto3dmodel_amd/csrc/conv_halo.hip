@@ -226,22 +226,43 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
     const int wm = wave / WGN, wn = wave % WGN;
     const int tx = lane & 31, half = lane >> 5;
 
-    // The accumulators START at the bias (acc[j][i][4g + e] = channel n0 + 64wn + 32j + 8g + 4half + e): a global load in
-    // the epilogue would wait (in order) behind the next tile's prefetches with nothing to overlap it; issued here, the
-    // loads have the whole first step to land.
+    // The accumulators START at the bias (acc[j][i][4g + e] = channel n0 + 64wn + 32j + 8g + 4half + e).  A global load
+    // per tile -- in the epilogue or here -- makes the compiler wait (vmcnt is in order) behind the next tile's prefetch
+    // DMAs: with one wave per SIMD nothing overlaps that, so the 4-wave variants keep their 32 bias values in registers
+    // for the whole kernel (the budget is 512); the 8-wave variants reload them per tile (the partner wave covers it).
     f32x16 acc[CJ][PI];
-    auto init_acc = [&]() {
+    float4 bias_r[NW == 4 ? CJ : 1][4];
+    if (NW == 4) {
 #pragma unroll
         for (int j = 0; j < CJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int co = n0 + wn * 64 + 32 * j + 8 * g + 4 * half;
-                const float4 b = (a.bias && co < a.Cout) ? *reinterpret_cast<const float4 *>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int i = 0; i < PI; ++i) {
-                    acc[j][i][4 * g] = b.x; acc[j][i][4 * g + 1] = b.y; acc[j][i][4 * g + 2] = b.z; acc[j][i][4 * g + 3] = b.w;
-                }
+                bias_r[NW == 4 ? j : 0][g] = (a.bias && co < a.Cout) ? *reinterpret_cast<const float4 *>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+    }
+    auto init_acc = [&]() {
+        if (a.bias) {
+#pragma unroll
+            for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = n0 + wn * 64 + 32 * j + 8 * g + 4 * half;
+                    const float4 b = NW == 4 ? bias_r[NW == 4 ? j : 0][g]
+                                             : (co < a.Cout ? *reinterpret_cast<const float4 *>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f));
+#pragma unroll
+                    for (int i = 0; i < PI; ++i) {
+                        acc[j][i][4 * g] = b.x; acc[j][i][4 * g + 1] = b.y; acc[j][i][4 * g + 2] = b.z; acc[j][i][4 * g + 3] = b.w;
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                for (int i = 0; i < PI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
+        }
     };
     init_acc();
     const int ey = UPS ? ((0 - pad_h) & 1) : 0, ex = UPS ? ((0 - pad_w) & 1) : 0;  // tile origins are even
