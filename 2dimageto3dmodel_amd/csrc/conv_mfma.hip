@@ -407,7 +407,8 @@ __device__ __forceinline__ void weight_prep_body(const WeightPrepArgs &w)
             const int c = k % Cp, t = k / Cp;
             const int b = t % B, aa = t / B;
             const int o = transpose ? c : r, i = transpose ? r : c;
-            if (o < O && i < I) v = in[(((size_t)o * I + i) * KH + (p.th0 + p.ths * aa)) * KW + (p.tw0 + p.tws * b)];
+            const int th = p.th0 + p.ths * aa, tw = p.tw0 + p.tws * b;
+            if (o < O && i < I && th < KH && tw < KW) v = in[(((size_t)o * I + i) * KH + th) * KW + tw];
         }
         out[idx] = f2bf(v * wscale);
     }
@@ -637,7 +638,7 @@ extern "C" size_t m355_conv2d_weight_elems(const m355_conv_desc *d, int which)
     const size_t cout32 = (size_t)m355::dy_channels(d->Cout);
     if (which == 0) return rows_f * (size_t)m355::k_padded(d->kh * d->kw * d->Cin);
     if (d->stride == 1) return rows_d * (size_t)m355::k_padded(d->kh * d->kw * (int)cout32);
-    return 4 * rows_d * (size_t)m355::k_padded((d->kh / 2) * (d->kw / 2) * (int)cout32);  // four parity-class views
+    return 4 * rows_d * (size_t)m355::k_padded(((d->kh + 1) / 2) * ((d->kw + 1) / 2) * (int)cout32);  // four parity-class views
 }
 
 // the views of one layer: forward [rows_padded(Cout)][Kp] + the dgrad view (stride 1) or its four parity classes (stride 2)
@@ -658,8 +659,9 @@ static int fill_weight_prep(const m355_conv_desc *d, const float *w_oihw, int ci
             add((unsigned short *)w_dgrad, 1, d->kh, d->kw, d->kh - 1, -1, d->kw - 1, -1, cin64, cout32,
                 m355::k_padded(d->kh * d->kw * cout32));
         } else {
-            M355_REQUIRE(d->kh % 2 == 0 && d->kw % 2 == 0, "conv2d_weight_prep: stride-2 dgrad needs even kernels");
-            const int A = d->kh / 2, B = d->kw / 2;
+            // odd kernels (3x3 / 5x5 stride 2 of models/reconstruction.py:53-63) are handled as the next even size with a
+            // zero last row / column: same output size for an even padded frame, taps beyond the kernel read as zero
+            const int A = (d->kh + 1) / 2, B = (d->kw + 1) / 2;
             const int Kp = m355::k_padded(A * B * cout32);
             const size_t each = (size_t)cin64 * Kp;
             for (int py = 0; py < 2; ++py)
@@ -779,7 +781,7 @@ static bool dgrad_direct(const m355_conv_desc *d)
     const int cy = m355::dy_channels(d->Cout);
     ConvArgs a = {};
     a.N = d->N; a.H = Ho; a.W = Wo; a.Cin = cy; a.Cout = d->Cin; a.Cs = d->Cin;
-    a.Kp = m355::k_padded((d->stride == 1 ? d->kh * d->kw : (d->kh / 2) * (d->kw / 2)) * cy);
+    a.Kp = m355::k_padded((d->stride == 1 ? d->kh * d->kw : ((d->kh + 1) / 2) * ((d->kw + 1) / 2)) * cy);
     if (m355::dgrad_direct_replicate_eligible(d, cy) && m355::dma_eligible(a)) return true;  // 3x3 replicate (+upsample)
     return !d->upsample && d->pad_w_mode != 1 && m355::dma_eligible(a) &&
            (d->stride == 1 || (d->H % 2 == 0 && d->W % 2 == 0 && d->kh % 2 == 0 && d->kw % 2 == 0));
@@ -811,7 +813,7 @@ static int conv_dgrad_impl(const m355_conv_desc *d, const void *dy, const void *
     a.y_f32_nchw = 0; a.Cs = d->Cin; a.slope = 1.0f;
     // DIRECT form (no padded frame, no fold): without upsample and with a zero or circular W pad the adjoint of
     // the padding is an index map on dy -- a circularly padded conv's dgrad is a circular conv of dy.
-    a.Kp = m355::k_padded((d->stride == 1 ? d->kh * d->kw : (d->kh / 2) * (d->kw / 2)) * cout32);
+    a.Kp = m355::k_padded((d->stride == 1 ? d->kh * d->kw : ((d->kh + 1) / 2) * ((d->kw + 1) / 2)) * cout32);
     const bool direct = dgrad_direct(d);
     if (probe && (!direct || d->pad_w_mode == 1)) return 0;
     M355_REQUIRE((!mask_x && !mask_bits) || direct, "conv2d_dgrad: the fused activation backward needs the direct form (no "
@@ -881,7 +883,7 @@ static int conv_dgrad_impl(const m355_conv_desc *d, const void *dy, const void *
     // stride 2: four parity classes of the padded frame, each a (kh/2 x kw/2) conv of dy written with stride 2
     const int Hp = Hl + 2 * d->pad_h, Wp = Wl + 2 * d->pad_w;
     M355_REQUIRE(Hp % 2 == 0 && Wp % 2 == 0, "conv2d_dgrad: stride-2 frame %dx%d must be even", Hp, Wp);
-    const int A = d->kh / 2, B = d->kw / 2;
+    const int A = (d->kh + 1) / 2, B = (d->kw + 1) / 2;  // (odd kernels: the next even size, see fill_weight_prep)
     const size_t each = (size_t)cin64 * m355::k_padded(A * B * cout32);
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {

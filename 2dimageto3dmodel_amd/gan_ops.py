@@ -245,9 +245,7 @@ class SpectralNormGroup:
             cx = (cw + 7) // 8 * 8
             d = C.make_desc(1, 64, 64, cx, cout, kh, kw, stride, pad_h, pad_w, mode, 0)
             wf = torch.empty((L.m355_conv2d_weight_elems(ctypes.byref(d), 0),), dtype=torch.bfloat16, device=dev)
-            wd = None
-            if stride == 1 or (kh % 2 == 0 and kw % 2 == 0):
-                wd = torch.empty((L.m355_conv2d_weight_elems(ctypes.byref(d), 1),), dtype=torch.bfloat16, device=dev)
+            wd = torch.empty((L.m355_conv2d_weight_elems(ctypes.byref(d), 1),), dtype=torch.bfloat16, device=dev)
             n = L.m355_weight_prep_fill_entry(ctypes.byref(d), ptr(c.weight_orig), int(cw), ptr(slot["sigma"][i:i + 1]), ptr(wf),
                                               ptr(wd), ctypes.byref(raw, esz * i))
             if n < 0:
