@@ -508,7 +508,7 @@ class BatchNorm2d(nn.Module):
                     self.num_batches_tracked += 1
                 return y
         if res is not None:
-            return self.forward(x, gamma, beta, slope) + _match_res(res, x)
+            return BatchNorm2d.forward(self, x, gamma, beta, slope) + _match_res(res, x)  # (subclasses change the signature)
         if _fused_ok(x):
             sync = self._is_sync()
             scale = 1 + gamma
