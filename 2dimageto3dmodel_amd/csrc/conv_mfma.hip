@@ -544,12 +544,18 @@ static int launch_conv(ConvArgs a, hipStream_t st)
         const long tiles128 = (long)((M + 127) / 128) * (a.CoutP / 128) * a.ncls;
         const char *force = getenv("M355_CONV_TILE");  // tests / tuning: "128x128", "256x128", "256x256"
         int pick = a.CoutP == 64 ? 0 : (a.CoutP % 256 == 0 && tiles128 >= 4 * 1024) ? 3 : 1;
+        // small problems (the generator's 8x4 .. 32x16 stages, the mesh discriminator): fewer 128-wide tiles than CUs
+        // leave most of the chip idle for the whole K loop -- 64x64 tiles give 4x the workgroups (32 KB of LDS each)
+        const long tiles_now = pick == 0 ? (long)((M + 255) / 256) * a.ncls : tiles128;
+        if (tiles_now < 192 && !getenv("M355_NO_SMALL_TILE")) pick = 4;
         if (force && a.CoutP != 64) {
             if (!strcmp(force, "128x128")) pick = 1;
             else if (!strcmp(force, "256x128")) pick = 2;
             else if (!strcmp(force, "256x256") && a.CoutP % 256 == 0) pick = 3;
         }
-        if (pick == 0) M355_TILE(256, 64, 4, 1);
+        if (force && !strcmp(force, "64x64")) pick = 4;
+        if (pick == 4) M355_TILE(64, 64, 4, 2);
+        else if (pick == 0) M355_TILE(256, 64, 4, 1);
         else if (pick == 3) M355_TILE(256, 256, 8, 4);
         else if (pick == 2) M355_TILE(256, 128, 8, 2);
         else M355_TILE(128, 128, 4, 2);

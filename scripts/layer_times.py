@@ -16,6 +16,6 @@ cyc(); torch.cuda.synchronize()
 pkg._lib.enable_kernel_timers(True); cyc(); cyc(); torch.cuda.synchronize()
 kt = pkg._lib.collect_kernel_timers()
 tot = sum(v[1] for v in kt.values())
-for k, v in sorted(kt.items(), key=lambda kv: -kv[1][1])[:45]:
+for k, v in sorted(kt.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("M355_TOP", "45"))]:
     print(f"{v[1]/2:8.3f} ms {100*v[1]/tot:5.1f}%  x{v[0]//2:3d}  {(v[2]/(v[1]*1e-3)/1e12 if v[2] else 0):7.1f} TF  {k}")
 print("total m355 kernels per cycle: %.1f ms" % (tot / 2))

@@ -122,7 +122,7 @@ def test_conv_fwd_and_dgrad(pkg, case):
         assert (dxm.permute(0, 3, 1, 2) - want).abs().max().item() / want.abs().max().item() < 1.2e-2
 
 
-@pytest.mark.parametrize("tile", ["128x128", "256x128", "256x256"])
+@pytest.mark.parametrize("tile", ["64x64", "128x128", "256x128", "256x256"])
 @pytest.mark.parametrize("case", [(3, 20, 12, 128, 256, 3, 1, 1, 1, 1, 1), (2, 32, 32, 128, 256, 4, 2, 1, 1, 2, 0),
                                   (2, 16, 16, 64, 128, 4, 2, 1, 1, 2, 0), (3, 12, 6, 96, 96, 3, 1, 1, 1, 0, 0)])
 def test_conv_tile_variants(pkg, case, tile, monkeypatch):
