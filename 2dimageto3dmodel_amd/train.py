@@ -82,17 +82,28 @@ class GanTrainer(torch.nn.Module):
         with torch.no_grad():
             return self.generator_running_avg(noise, C, caption, return_attention=True)
 
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_ema_lists", None)   # .to() / .cuda() replace the buffer tensors
+        return super()._apply(fn, *args, **kwargs)
+
     @torch.no_grad()
     def update_generator_running_avg(self):
-        """main.py:431-447 (constant alpha; the reference ramps it over the first epochs)"""
-        src = self.generator.state_dict()
-        fl_dst, fl_src = [], []
-        for k, v in self.generator_running_avg.state_dict().items():
-            if torch.is_floating_point(v):
-                fl_dst.append(v)
-                fl_src.append(src[k])
-            else:
-                v.copy_(src[k])
+        """main.py:431-447 (constant alpha; the reference ramps it over the first epochs).  The (dst, src) tensor lists
+        are collected once: state_dict() on two 300-entry modules per step is pure host overhead."""
+        ema = self.__dict__.get("_ema_lists")
+        if ema is None:
+            src = self.generator.state_dict(keep_vars=True)
+            fl_dst, fl_src, other = [], [], []
+            for k, v in self.generator_running_avg.state_dict(keep_vars=True).items():
+                if torch.is_floating_point(v):
+                    fl_dst.append(v)
+                    fl_src.append(src[k])
+                else:
+                    other.append((v, src[k]))
+            ema = self.__dict__["_ema_lists"] = (fl_dst, fl_src, other)
+        fl_dst, fl_src, other = ema
+        for v, sv in other:
+            v.copy_(sv)
         torch._foreach_mul_(fl_dst, self.ema_alpha)
         torch._foreach_add_(fl_dst, fl_src, alpha=1 - self.ema_alpha)
 
