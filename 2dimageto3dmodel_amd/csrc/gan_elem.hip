@@ -312,6 +312,65 @@ static int check_c(int C, const char *who)
     return 0;
 }
 
+// ---- projection discriminator (gan.py:104-116, 216-228): o[n,p] = sum_c feat[n,p,c] * emb[n,c] on the bf16 NHWC feature
+// map (the torch path converted it to fp32 -- 67 M elements at batch 128 -- for an einsum).  One wave per pixel.
+__global__ __launch_bounds__(256) void k_cproj_fwd(const short *__restrict__ feat, const float *__restrict__ emb, float *__restrict__ o,
+                                                   int HW, int C)
+{
+    const int n = blockIdx.y, p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= HW) return;
+    const short *f = feat + ((size_t)n * HW + p) * C;
+    const float *e = emb + (size_t)n * C;
+    float acc = 0.0f;
+    for (int v = lane; v < (C >> 3); v += 64) {
+        const bf16x8e x = *reinterpret_cast<const bf16x8e *>(f + v * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += bf2f_e(x[j]) * e[v * 8 + j];
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
+    if (lane == 0) o[(size_t)n * HW + p] = acc;
+}
+
+// backward: dfeat[n,p,c] = g[n,p] * emb[n,c] (bf16), demb[n,c] += sum_p g[n,p] * feat[n,p,c]   (demb zeroed by the caller)
+__global__ __launch_bounds__(256) void k_cproj_bwd(const short *__restrict__ feat, const float *__restrict__ emb,
+                                                   const float *__restrict__ g, short *__restrict__ dfeat, float *__restrict__ demb,
+                                                   int HW, int C, int ppb)
+{
+    __shared__ float red[256 * 8];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int vecs = C >> 3, lanes = 256 / vecs, v = tid % vecs, pl = tid / vecs;
+    const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
+    float ev[8], acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ev[j] = emb[(size_t)n * C + v * 8 + j];
+        acc[j] = 0.0f;
+    }
+    if (pl < lanes)
+        for (int p = p0 + pl; p < p1; p += lanes) {
+            const float gp = g[(size_t)n * HW + p];
+            const size_t off = ((size_t)n * HW + p) * C + v * 8;
+            const bf16x8e x = *reinterpret_cast<const bf16x8e *>(feat + off);
+            float d[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                d[j] = gp * ev[j];
+                acc[j] += gp * bf2f_e(x[j]);
+            }
+            *reinterpret_cast<bf16x8e *>(dfeat + off) = pack8_e(d);
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = acc[j];
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int vv = c >> 3, jj = c & 7;
+        float sum = 0.0f;
+        for (int l = 0; l < lanes; ++l) sum += red[(l * vecs + vv) * 8 + jj];
+        atomicAdd(demb + (size_t)n * C + c, sum);
+    }
+}
+
 }  // namespace m355
 
 using namespace m355;
@@ -453,4 +512,28 @@ extern "C" int m355_unpack_nhwc8(const void *g_nhwc8, float *dx_nchw, int N, int
     const unsigned g = (unsigned)min((size_t)65535, (total + 255) / 256);
     hipLaunchKernelGGL(k_unpack_nhwc8, dim3(g), dim3(256), 0, (hipStream_t)stream, (const short *)g_nhwc8, dx_nchw, C, HW, total);
     return check_launch("unpack_nhwc8");
+}
+
+extern "C" int m355_cproj_fwd(const void *feat, const float *emb, float *out /*[N,HW]*/, int N, int HW, int C, void *stream)
+{
+    M355_REQUIRE(feat && emb && out && N > 0 && HW > 0 && N <= 65535, "cproj_fwd: bad argument");
+    if (int rc = check_c(C, "cproj_fwd")) return rc;
+    hipLaunchKernelGGL(k_cproj_fwd, dim3((HW + 3) / 4, N), dim3(256), 0, (hipStream_t)stream, (const short *)feat, emb, out, HW, C);
+    return check_launch("cproj_fwd");
+}
+
+extern "C" int m355_cproj_bwd(const void *feat, const float *emb, const float *g /*[N,HW]*/, void *dfeat, float *demb /*[N,C]*/,
+                              int N, int HW, int C, void *stream)
+{
+    M355_REQUIRE(feat && emb && g && dfeat && demb && N > 0 && HW > 0 && N <= 65535, "cproj_bwd: bad argument");
+    if (int rc = check_c(C, "cproj_bwd")) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(demb, 0, sizeof(float) * (size_t)N * C, st) != hipSuccess) {
+        set_error("cproj_bwd: memset failed");
+        return M355_ERR_LAUNCH;
+    }
+    const int ppb = pix_per_block((size_t)HW, C);
+    hipLaunchKernelGGL(k_cproj_bwd, dim3((HW + ppb - 1) / ppb, N), dim3(256), 0, st, (const short *)feat, emb, g, (short *)dfeat, demb,
+                       HW, C, ppb);
+    return check_launch("cproj_bwd");
 }

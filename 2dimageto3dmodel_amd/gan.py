@@ -334,7 +334,7 @@ class _DiscBase(nn.Module):
             c_emb = self.projector(c[:, 0])
             if a.conditional_color:
                 c_emb = c_emb + self.projector_col1(c[:, 1])
-            y = y + torch.einsum("nhwc,nc->nhw", feat.float(), c_emb).unsqueeze(1)
+            y = y + G.class_projection(feat, c_emb).unsqueeze(1)
         elif a.conditional_text:
             att_out, _ = self.att(G.to_nchw_f32(feat), *caption)
             y = y + torch.sum(G.to_nchw_f32(feat) * att_out, dim=1, keepdim=True)

@@ -445,6 +445,36 @@ def _fused_ok(x):
     return x.is_cuda and x.dtype == torch.bfloat16 and c % 8 == 0 and c <= 2048 and 256 % (c // 8) == 0
 
 
+class ClassProjection(torch.autograd.Function):
+    """projection discriminator term (gan.py:104-116, 216-228): feat [N,H,W,C] bf16, emb [N,C] fp32 -> [N,H,W] fp32
+    = sum_c feat * emb, on the bf16 feature map (csrc/gan_elem.hip k_cproj_*)"""
+
+    @staticmethod
+    def forward(ctx, feat, emb):
+        feat, emb = feat.detach().contiguous(), emb.detach().float().contiguous()
+        n, h, w, c = feat.shape
+        out = torch.empty((n, h, w), dtype=torch.float32, device=feat.device)
+        launch("cproj_fwd", ptr(feat), ptr(emb), ptr(out), n, h * w, c, stream())
+        ctx.save_for_backward(feat, emb)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        feat, emb = ctx.saved_tensors
+        n, h, w, c = feat.shape
+        dfeat = torch.empty_like(feat)
+        demb = torch.empty((n, c), dtype=torch.float32, device=feat.device)
+        launch("cproj_bwd", ptr(feat), ptr(emb), ptr(g.contiguous().float()), ptr(dfeat), ptr(demb), n, h * w, c, stream())
+        return dfeat, demb
+
+
+def class_projection(feat, emb):
+    """sum_c feat[n,h,w,c] * emb[n,c] -> [N,H,W] fp32"""
+    if _fused_ok(feat) and emb.dtype == torch.float32:
+        return ClassProjection.apply(feat, emb)
+    return torch.einsum("nhwc,nc->nhw", feat.float(), emb)
+
+
 # ------------------------------------------------------------------------------------------------ normalisation
 def _affine_act(xhat, scale, shift, slope):
     """(torch path, CPU tests / odd channel counts) xhat fp32 [N,H,W,C]; scale/shift [N,C]"""

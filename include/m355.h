@@ -267,6 +267,12 @@ int m355_bn_bwd_finalize(const float *part, int nblk, float count, const float *
 int m355_bn_bwd_coeffs(const float *m, float count, const float *mean, const float *rstd, int C, float *Bc, float *Cc,
                        void *stream);
 
+/* Projection discriminator (code/models/gan.py:104-116, 216-228): out[n,p] = sum_c feat[n,p,c] * emb[n,c] on the NHWC bf16
+ * feature map (C a power of two in 8..2048); backward: dfeat = g * emb (bf16, overwritten), demb[n,c] = sum_p g * feat. */
+int m355_cproj_fwd(const void *feat, const float *emb, float *out /*[N,HW]*/, int N, int HW, int C, void *stream);
+int m355_cproj_bwd(const void *feat, const float *emb, const float *g /*[N,HW]*/, void *dfeat, float *demb /*[N,C]*/,
+                   int N, int HW, int C, void *stream);
+
 /* ---- mesh-template deformation, face normals, flat (smoothness) loss -- code/main.py:697-699 ----
  * Replaces MeshTemplate.get_vertex_positions / deform / compute_normals (code/rendering/mesh_template.py:106-149) and
  * loss_flat (code/utils/losses.py:5-17); the reference-side binding is in INTEGRATION.md.  All fp32, row-major.
