@@ -216,3 +216,27 @@ def test_activation_bit_masks(pkg, chain):
     want = conv.conv_dgrad(d2, dy2, wd2, mask_x=y, mask_slope=0.2)
     got = conv.conv_dgrad(d2, dy2, wd2, mask_bits=bits, mask_slope=0.2)
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("variant", ["narrow", "wide", "twin"])
+@pytest.mark.parametrize("case", [(2, 32, 64, 128, 256, 4, 2, 1, 1, 2, 0), (3, 16, 64, 64, 128, 4, 2, 1, 1, 0, 0)])
+def test_wgrad_halo_class_variants(pkg, case, variant, monkeypatch):
+    """the three tilings of the stride-2 class wgrad (8x32 tiles; 4x32 with two dy blocks on one x halo; 4x32 with two
+    workgroups per CU = the default) give the same weight and bias gradients"""
+    monkeypatch.setenv("M355_WGRAD_HALO_VARIANT", variant)
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    N, H, W, Cin, Cout, k, stride, ph, pw, mode, ups = case
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(N, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).bfloat16().float().requires_grad_()
+    y_ref = ref_conv(x, w, None, stride, ph, pw, mode, ups)
+    dy = torch.randn(y_ref.shape, generator=g).bfloat16().float()
+    y_ref.backward(dy)
+    d = conv.make_desc(N, H, W, Cin, Cout, k, k, stride, ph, pw, mode, ups)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    dy_nhwc = dy.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    db = torch.empty(Cout, device=DEV)
+    dw = conv.conv_wgrad(d, x_nhwc, dy_nhwc, dbias=db).cpu()
+    assert (dw - w.grad).abs().max().item() < 2e-4 * w.grad.abs().max().item()
+    want = dy.sum((0, 2, 3))
+    assert (db.cpu() - want).abs().max().item() < 1e-3 * max(1.0, want.abs().max().item())
