@@ -3,6 +3,10 @@
 The directory name starts with a digit, so import it with
     importlib.import_module("2dimageto3dmodel_amd")
 or put `2dimageto3dmodel_amd/dropin` on sys.path and use the reference's own module paths.
+
+Modules: projection / ops (point-cloud projection + silhouette loss), gan / gan_ops / conv / train (GAN stacks and
+their training iteration), parallel (RCCL reducers), and the SURVEY 8f widenings mesh (template deformation + flat
+loss), reconstruction (ReconstructionNetwork), formats (on-disk caches and checkpoints).
 """
 from . import _lib, ops  # noqa: F401
 from .projection import (CameraUtilities, EffectiveLossFunction, SupervisedLoss,  # noqa: F401
