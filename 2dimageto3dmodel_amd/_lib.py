@@ -22,6 +22,8 @@ SIGNATURES = {
     "m355_last_kernel": (ctypes.c_char_p, []),
     "m355_abi_version": (c_int, []),
     "m355_proj_transform_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, _P]),
+    "m355_quat_rotate_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "m355_quat_rotate_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "m355_proj_ntiles": (c_int, [c_int]),
     "m355_proj_bin_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P]),
     "m355_proj_transform_bwd": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, c_int, _P, c_int, c_int, c_float,
@@ -76,11 +78,11 @@ SIGNATURES = {
     "m355_affine_act_bwd_partial": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "m355_sn_power_iter": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_float, _P]),
     "m355_sn_wgrad_finish": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-    "m355_bn_finalize": (c_int, [_P, c_int, c_float, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P,
-                                 _P]),
+    "m355_bn_finalize": (c_int, [_P, c_int, c_float, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P,
+                                 _P, _P]),
     "m355_bn_bwd_finalize": (c_int, [_P, c_int, c_float, _P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P,
                                      _P]),
-    "m355_bn_bwd_coeffs": (c_int, [_P, c_float, _P, _P, c_int, _P, _P, _P]),
+    "m355_bn_bwd_coeffs": (c_int, [_P, c_float, _P, _P, _P, c_int, _P, _P, _P]),
 }
 
 

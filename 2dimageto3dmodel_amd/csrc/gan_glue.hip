@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256) void k_sn_bwd_apply(const float *__restrict__ 
 // Block = 32 channels x 8 helper lanes.  part[nblk][2][C] -> mean, rstd (biased variance, eps inside the sqrt =
 // F.batch_norm, code/sync_batchnorm/batchnorm.py:71-73), running stats (unbiased variance, momentum), and
 // a[n,c] = rstd * (1 + gamma[n,c]),  b[n,c] = beta[n,c] - mean * a[n,c].
-__global__ __launch_bounds__(1024) void k_bn_finalize(const float *__restrict__ part, int nblk, float count, const float *__restrict__ gamma,
+__global__ __launch_bounds__(1024) void k_bn_finalize(const float *__restrict__ part, int nblk, float count_h,
+                                                     const float *__restrict__ count_dev, const float *__restrict__ gamma,
                                                      const float *__restrict__ beta, int gstride, int N, int C, float eps,
                                                      float momentum, float *__restrict__ rmean, float *__restrict__ rvar,
                                                      float *__restrict__ mean_o, float *__restrict__ rstd_o, float *__restrict__ a,
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float *__restrict__ 
     __shared__ float red[2][32][32];
     __shared__ float stat[2][32];
     const int cl = threadIdx.x & 31, l = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    const float count = count_dev ? *count_dev : count_h;   // SyncBN: the all-reduced pixel count, no host round trip
     float s0 = 0.0f, s1 = 0.0f;
     if (c < C) {
         float p0[4] = {0.f, 0.f, 0.f, 0.f}, p1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -295,11 +297,13 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_finalize(const float *__restric
 }
 
 // Bc, Cc from the (all-reduced) moment sums m[2][C] and the global pixel count
-__global__ void k_bn_bwd_coeffs(const float *__restrict__ m, float count, const float *__restrict__ mean_i,
-                                const float *__restrict__ rstd_i, int C, float *__restrict__ Bc, float *__restrict__ Cc)
+__global__ void k_bn_bwd_coeffs(const float *__restrict__ m, float count_h, const float *__restrict__ count_dev,
+                                const float *__restrict__ mean_i, const float *__restrict__ rstd_i, int C, float *__restrict__ Bc,
+                                float *__restrict__ Cc)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    const float count = count_dev ? *count_dev : count_h;
     const float t1 = m[c] / count, t2 = m[C + c] / count, rstd = rstd_i[c], mean = mean_i[c];
     Bc[c] = -rstd * rstd * t2;
     Cc[c] = -rstd * t1 + rstd * rstd * mean * t2;
@@ -336,13 +340,13 @@ extern "C" int m355_sn_wgrad_finish(const float *g_khwc, const float *w_orig, co
     return check_launch("sn_wgrad_finish");
 }
 
-extern "C" int m355_bn_finalize(const float *part, int nblk, float count, const float *gamma, const float *beta, int gstride,
+extern "C" int m355_bn_finalize(const float *part, int nblk, float count, const float *count_dev, const float *gamma, const float *beta, int gstride,
                                 int N, int C, float eps, float momentum, float *running_mean, float *running_var,
                                 float *mean, float *rstd, float *a, float *b, void *stream)
 {
     M355_REQUIRE(part && gamma && beta && mean && rstd && a && b && nblk > 0 && N > 0 && C > 0, "bn_finalize: bad argument");
-    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, nblk, count, gamma, beta,
-                       gstride, N, C, eps, momentum, running_mean, running_var, mean, rstd, a, b);
+    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, nblk, count, count_dev,
+                       gamma, beta, gstride, N, C, eps, momentum, running_mean, running_var, mean, rstd, a, b);
     return check_launch("bn_finalize");
 }
 
@@ -357,10 +361,11 @@ extern "C" int m355_bn_bwd_finalize(const float *part, int nblk, float count, co
     return check_launch("bn_bwd_finalize");
 }
 
-extern "C" int m355_bn_bwd_coeffs(const float *m, float count, const float *mean, const float *rstd, int C, float *Bc,
-                                  float *Cc, void *stream)
+extern "C" int m355_bn_bwd_coeffs(const float *m, float count, const float *count_dev, const float *mean, const float *rstd,
+                                  int C, float *Bc, float *Cc, void *stream)
 {
     M355_REQUIRE(m && mean && rstd && Bc && Cc && C > 0, "bn_bwd_coeffs: bad argument");
-    hipLaunchKernelGGL(k_bn_bwd_coeffs, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, m, count, mean, rstd, C, Bc, Cc);
+    hipLaunchKernelGGL(k_bn_bwd_coeffs, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, m, count, count_dev, mean, rstd, C,
+                       Bc, Cc);
     return check_launch("bn_bwd_coeffs");
 }

@@ -196,6 +196,30 @@ __global__ __launch_bounds__(256) void k_transform_fwd(const float *__restrict__
     cam[o + 2] = xo;
 }
 
+// P1 alone: PointsQuaternionsRotator.rotate_points (quaternions/points_quaternions.py:41-81), both directions:
+// inverse = 0: q (x) p (x) q*   (points_quaternions.py:72-75),   inverse = 1: q* (x) p (x) q   (:67-70); same rounding
+// contract as transform_point.
+__global__ __launch_bounds__(256) void k_rotate_fwd(const float *__restrict__ pc, const float *__restrict__ q,
+                                                     float *__restrict__ out, int N, int inverse)
+{
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float nrm;
+    const Quat qn = normalize_quat(q + 4 * b, &nrm);
+    const Quat qs = conj_quat(qn);
+    const size_t o = ((size_t)b * N + n) * 3;
+    Quat p4;
+    p4.w = 0.0f;
+    p4.x = pc[o];
+    p4.y = pc[o + 1];
+    p4.z = pc[o + 2];
+    const Quat r = inverse ? hamilton(hamilton(qs, p4), qn) : hamilton(hamilton(qn, p4), qs);
+    out[o] = r.x;  // points_quaternions.py:81: new_point[:, :, 1:4]
+    out[o + 1] = r.y;
+    out[o + 2] = r.z;
+}
+
 // r = a (x) b ; dr -> da, db (accumulating)
 __device__ __forceinline__ void hamilton_bwd(const Quat a, const Quat b, const Quat dr, Quat &da, Quat &db)
 {
@@ -215,8 +239,9 @@ __global__ __launch_bounds__(256) void k_transform_bwd(const float *__restrict__
                                                         const float *__restrict__ dcam, int nslots, int mask_oob,
                                                         float *__restrict__ dpc, float *__restrict__ dq,
                                                         const float *__restrict__ dscale_part, int nparts,
-                                                        float *__restrict__ dscale, int N, float fov, float dist)
+                                                        float *__restrict__ dscale, int N, float fov, float dist, int mode)
 {
+    // mode 0: camera transform (rotation + perspective); 1 / 2: rotate_points alone, forward / inverse direction
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     float nrm;
@@ -230,6 +255,26 @@ __global__ __launch_bounds__(256) void k_transform_bwd(const float *__restrict__
     for (int n = tid; n < N; n += 256) {
         const size_t o = ((size_t)b * N + n) * 3;
         Quat p4 = {0.0f, pc[o], pc[o + 1], pc[o + 2]};
+        if (mode != 0) {
+            const float *g = dcam + o;
+            const Quat dr = {0.f, g[0], g[1], g[2]};
+            Quat dt = {0.f, 0.f, 0.f, 0.f}, dqs = {0.f, 0.f, 0.f, 0.f}, dp4 = {0.f, 0.f, 0.f, 0.f};
+            if (mode == 1) {   // r = (qn p4) qs
+                hamilton_bwd(hamilton(qn, p4), qs, dr, dt, dqs);
+                hamilton_bwd(qn, p4, dt, dqn, dp4);
+            } else {           // r = (qs p4) qn
+                hamilton_bwd(hamilton(qs, p4), qn, dr, dt, dqn);
+                hamilton_bwd(qs, p4, dt, dqs, dp4);
+            }
+            dqn.w += dqs.w;
+            dqn.x -= dqs.x;
+            dqn.y -= dqs.y;
+            dqn.z -= dqs.z;
+            dpc[o] = dp4.x;
+            dpc[o + 1] = dp4.y;
+            dpc[o + 2] = dp4.z;
+            continue;
+        }
         const Quat t = hamilton(qn, p4);
         const Quat r = hamilton(t, qs);
         const float z = r.x, y = r.y, x = r.z;
@@ -354,6 +399,28 @@ extern "C" int m355_proj_transform_bwd(const float *pc, const float *q, const fl
     M355_REQUIRE((dscale_part == nullptr) == (dscale == nullptr), "proj_transform_bwd: dscale_part/dscale mismatch");
     if (B == 0) return M355_OK;
     hipLaunchKernelGGL(m355::k_transform_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, pc, q, dcam, nslots,
-                       mask_oob, dpc, dq, dscale_part, nparts, dscale, N, fov, dist);
+                       mask_oob, dpc, dq, dscale_part, nparts, dscale, N, fov, dist, 0);
     return m355::check_launch("proj_transform_bwd");
+}
+
+extern "C" int m355_quat_rotate_fwd(const float *pc, const float *q, float *out, int B, int N, int inverse, void *stream)
+{
+    M355_REQUIRE(B >= 0 && N >= 0, "quat_rotate_fwd: negative size B=%d N=%d", B, N);
+    if (B == 0 || N == 0) return M355_OK;
+    M355_REQUIRE(pc && q && out, "quat_rotate_fwd: null pointer");
+    M355_REQUIRE(B <= 65535, "quat_rotate_fwd: B=%d exceeds grid.y", B);
+    hipLaunchKernelGGL(m355::k_rotate_fwd, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, pc, q, out, N,
+                       inverse ? 1 : 0);
+    return m355::check_launch("quat_rotate_fwd");
+}
+
+extern "C" int m355_quat_rotate_bwd(const float *pc, const float *q, const float *dout, float *dpc, float *dq, int B, int N,
+                                    int inverse, void *stream)
+{
+    M355_REQUIRE(B >= 0 && N >= 0, "quat_rotate_bwd: negative size B=%d N=%d", B, N);
+    M355_REQUIRE(q && dq && (N == 0 || (pc && dout && dpc)), "quat_rotate_bwd: null pointer");
+    if (B == 0) return M355_OK;
+    hipLaunchKernelGGL(m355::k_transform_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, pc, q, dout, 1, 0, dpc, dq,
+                       (const float *)nullptr, 0, (float *)nullptr, N, 1.0f, 1.0f, inverse ? 2 : 1);
+    return m355::check_launch("quat_rotate_bwd");
 }

@@ -262,6 +262,13 @@ class Generator(nn.Module):
         parts = out.split([w.shape[0] for w in ws], dim=1)
         return {m: (parts[2 * i], parts[2 * i + 1]) for i, m in enumerate(layers)}
 
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .half() replace parameter and buffer tensors: the batching caches (device tables of the
+        # spectral-norm group, the layer list and the num_batches_tracked references) must be rebuilt from the new ones
+        for k in ("_sn", "_cbn", "_nbt"):
+            self.__dict__.pop(k, None)
+        return super()._apply(fn, *args, **kwargs)
+
     def __deepcopy__(self, memo):
         # the batching caches hold device pointers / module references of THIS instance: rebuild them in the copy
         import copy

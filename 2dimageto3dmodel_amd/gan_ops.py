@@ -11,7 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import conv as C
-from ._lib import launch, lib, ptr, stream
+from ._lib import check, launch, lib, ptr, stream
 
 
 def _ceil(a, b):
@@ -114,6 +114,10 @@ class Conv2dFn(torch.autograd.Function):
     def backward(ctx, dy, _dbits=None):
         x, wd, y, w_orig, in_bits = ctx.saved_tensors
         d = ctx.d
+        if ctx.sn is not None:
+            # wd / sigma / u / v are slots of the group, overwritten in place by later forwards (invisible to autograd's
+            # version counters): both the dgrad and the wgrad branch must see this forward's snapshot
+            ctx.sn.check()
         c32 = C.dy_channels(d.Cout)
         if ctx.premasked:
             # the consumer's dgrad already applied this layer's LeakyReLU derivative (mask_x below): dy IS g
@@ -155,7 +159,6 @@ class Conv2dFn(torch.autograd.Function):
             if sn is None:
                 dw = C.wgrad_finish(d, graw, ctx.cw)
             else:
-                sn.check()
                 dw = C.wgrad_finish(d, graw, ctx.cw, w_orig, sn.u, sn.v, sn.sigma)
         return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
 
@@ -249,7 +252,7 @@ class SpectralNormGroup:
             n = L.m355_weight_prep_fill_entry(ctypes.byref(d), ptr(c.weight_orig), int(cw), ptr(slot["sigma"][i:i + 1]), ptr(wf),
                                               ptr(wd), ctypes.byref(raw, esz * i))
             if n < 0:
-                _lib.check(1, "weight_prep_fill_entry")
+                check(1, "weight_prep_fill_entry")
             most = max(most, n)
             weights.append((wf, wd, (cx, cout, kh, kw, stride)))
         slot["wtable"] = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).to(dev)
@@ -388,25 +391,29 @@ class CbnActFn(torch.autograd.Function):
         nblk = lib().m355_chan_reduce_nblk(P, c)
         part = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev)
         launch("bn_stats_partial", ptr(x), ptr(part), P, c, stream())
+        cnt_dev = None
         if sync:
-            # one all-reduce of [sum | sumsq]; every rank holds the same number of pixels (the loader shards the batch
-            # evenly), so the global count is known without communication -- no host round trip in the forward
-            part = part.sum(0)
-            dist.all_reduce(part, op=dist.ReduceOp.SUM)
-            nblk, count = 1, count * dist.get_world_size()
+            # one all-reduce of [sum | sumsq | count]: the global pixel count comes back with the sums and stays on the
+            # device (ragged shards are handled like the reference's _data_parallel_master, no host round trip)
+            vec = torch.empty(2 * c + 1, dtype=torch.float32, device=dev)
+            torch.sum(part.view(nblk, 2 * c), dim=0, out=vec[:2 * c])
+            vec[2 * c:].fill_(count)
+            dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+            _count_syncbn()
+            part, nblk, cnt_dev = vec, 1, vec[2 * c:]
         coef = torch.empty((2 * n + 2, c), dtype=torch.float32, device=dev)   # a[N,C] | b[N,C] | mean | rstd
         a, b, mean, rstd = coef[:n], coef[n:2 * n], coef[2 * n], coef[2 * n + 1]
-        launch("bn_finalize", ptr(part), nblk, count, ptr(gamma), ptr(beta), int(gamma.stride(0)), n, c, float(eps),
+        launch("bn_finalize", ptr(part), nblk, count, ptr(cnt_dev), ptr(gamma), ptr(beta), int(gamma.stride(0)), n, c, float(eps),
                float(momentum), ptr(running_mean), ptr(running_var), ptr(mean), ptr(rstd), ptr(a), ptr(b), stream())
         y = torch.empty_like(x)
         launch("affine_act_fwd", ptr(x), ptr(a), ptr(b), ptr(res), res_w, ptr(y), n, h * w, c, float(slope), stream())
-        ctx.save_for_backward(x, coef, gamma)
+        ctx.save_for_backward(x, coef, gamma, cnt_dev)
         ctx.cfg = (slope, count, (0 if res is None else (2 if res_w else 1)), sync)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, coef, gamma = ctx.saved_tensors
+        x, coef, gamma, cnt_dev = ctx.saved_tensors
         slope, count, has_res, sync = ctx.cfg
         n, h, w, c = x.shape
         a, b, mean, rstd = coef[:n], coef[n:2 * n], coef[2 * n], coef[2 * n + 1]
@@ -422,7 +429,8 @@ class CbnActFn(torch.autograd.Function):
                ptr(dgamma), ptr(dbeta), ptr(A), ptr(Bc), ptr(Cc), ptr(m), stream())
         if sync:
             dist.all_reduce(m, op=dist.ReduceOp.SUM)
-            launch("bn_bwd_coeffs", ptr(m), count, ptr(mean), ptr(rstd), c, ptr(Bc), ptr(Cc), stream())
+            _count_syncbn()
+            launch("bn_bwd_coeffs", ptr(m), count, ptr(cnt_dev), ptr(mean), ptr(rstd), c, ptr(Bc), ptr(Cc), stream())
         dx = torch.empty_like(x)
         launch("affine_act_bwd_apply", ptr(dy), ptr(x), ptr(a), ptr(b), ptr(A), ptr(Bc), ptr(Cc), ptr(dx), n, h * w, c,
                float(slope), stream())
@@ -433,6 +441,11 @@ class CbnActFn(torch.autograd.Function):
             dres = torch.empty((n, h // 2, w // 2, c), dtype=dy.dtype, device=dy.device)
             launch("fold2x2", ptr(dy), ptr(dres), n, h // 2, w // 2, c, stream())
         return (dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None, None, None, None, None, dres, None)
+
+
+def _count_syncbn():
+    from . import parallel
+    parallel.stats["syncbn_collectives"] += 1
 
 
 def _match_res(res, x):
@@ -516,7 +529,8 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
     def _is_sync(self):
-        return self.sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        from . import parallel
+        return self.sync and parallel.collectives_on()
 
     def _update_running(self, mean, var, cnt):
         with torch.no_grad():

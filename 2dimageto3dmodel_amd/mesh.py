@@ -189,6 +189,35 @@ class _Flat(torch.autograd.Function):
         return dn, None
 
 
+def grid_sample_bilinear(input, grid):
+    """rendering/utils.py:6-13: F.grid_sample(mode='bilinear', align_corners=True) (the torch >= 1.3 branch)"""
+    return torch.nn.functional.grid_sample(input, grid, mode='bilinear', align_corners=True)
+
+
+def qrot(q, v):
+    """rendering/utils.py:36-47: rotate vectors v [B,V,3] by (un-normalised-as-given) quaternions q [B,4]:
+    v + 2 (w (u x v) + u x (u x v)), u = q[:, 1:].  B x <=962 vertices per call (main.py:285,880): plain tensor ops."""
+    if q.shape[-1] != 4 or v.shape[-1] != 3:
+        raise ValueError(f"qrot: expected q [...,4] and v [...,3], got {tuple(q.shape)} / {tuple(v.shape)}")
+    u = q[:, 1:].unsqueeze(1).expand(-1, v.shape[1], -1)
+    uv = torch.cross(u, v, dim=2)
+    uuv = torch.cross(u, uv, dim=2)
+    return v + 2 * (q[:, :1].unsqueeze(1) * uv + uuv)
+
+
+def qmul(q, r):
+    """rendering/utils.py:49-64: Hamilton product q * r of [..., 4] quaternions (run_reconstruction.py:196-202)"""
+    if q.shape[-1] != 4 or r.shape[-1] != 4:
+        raise ValueError("qmul: the last dimension must be 4")
+    shape = q.shape
+    t = torch.bmm(r.reshape(-1, 4, 1), q.reshape(-1, 1, 4))      # t[i, j] = r_i q_j
+    w = t[:, 0, 0] - t[:, 1, 1] - t[:, 2, 2] - t[:, 3, 3]
+    x = t[:, 0, 1] + t[:, 1, 0] - t[:, 2, 3] + t[:, 3, 2]
+    y = t[:, 0, 2] + t[:, 1, 3] + t[:, 2, 0] - t[:, 3, 1]
+    z = t[:, 0, 3] - t[:, 1, 2] + t[:, 2, 1] + t[:, 3, 0]
+    return torch.stack((w, x, y, z), dim=1).view(shape)
+
+
 def loss_flat(mesh, norms):
     """utils/losses.py:5-17 -- smoothness regulariser: neighbouring faces should have similar normals.
     `mesh` is `MeshTemplate.mesh` (needs `.ff` [F,3]); norms [B,F,3]."""

@@ -56,6 +56,28 @@ class CameraTransform(torch.autograd.Function):
         return dpc, dq, None, None
 
 
+class QuatRotate(torch.autograd.Function):
+    """PointsQuaternionsRotator.rotate_points (quaternions/points_quaternions.py:41-81), either direction."""
+
+    @staticmethod
+    def forward(ctx, pc, q, inverse):
+        pc, q = _f32c(pc.detach(), "xyz_triplet"), _f32c(q.detach(), "q")
+        B, N, _ = pc.shape
+        out = torch.empty_like(pc)
+        _launch("quat_rotate_fwd", ptr(pc), ptr(q), ptr(out), B, N, int(inverse), stream())
+        ctx.save_for_backward(pc, q)
+        ctx.inverse = int(inverse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        pc, q = ctx.saved_tensors
+        B, N, _ = pc.shape
+        dpc, dq = torch.empty_like(pc), torch.empty_like(q)
+        _launch("quat_rotate_bwd", ptr(pc), ptr(q), ptr(_f32c(dout, "grad")), ptr(dpc), ptr(dq), B, N, ctx.inverse, stream())
+        return dpc, dq, None
+
+
 class ProjectSilhouette(torch.autograd.Function):
     """EffectiveLossFunction.forward (utils/effective_loss_function.py:58-81), fused:
     camera transform -> splat -> depth smoothing -> scale/clamp -> termination -> depth sum -> flip."""
@@ -154,6 +176,13 @@ class SilhouetteSSE(torch.autograd.Function):
 
 def camera_transform(pc, q, fov=FOV, dist=CAM_DIST):
     return CameraTransform.apply(pc, q, float(fov), float(dist))
+
+
+def rotate_points(pc, q, inverse=False):
+    """[B,N,3] points rotated by F.normalize(q [B,4]); bit-exact with the reference's Hamilton products"""
+    if pc.dim() != 3 or pc.shape[-1] != 3 or q.dim() != 2 or q.shape != (pc.shape[0], 4):
+        raise ValueError(f"rotate_points: expected xyz [B,N,3] and q [B,4], got {tuple(pc.shape)} / {tuple(q.shape)}")
+    return QuatRotate.apply(pc, q, bool(inverse))
 
 
 def project_silhouette(pc, q, scale, taps_or_sigma, ntaps, S, flags):

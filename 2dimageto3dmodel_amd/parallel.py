@@ -13,17 +13,39 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(device_type="cuda"):
-    """torch.distributed.run contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT"""
+# collective bookkeeping (bench.py reports it): how many collectives the GAN path issued and, when `time_allreduce` is
+# on, device/host time of the gradient all-reduces
+stats = {"grad_allreduces": 0, "grad_allreduce_bytes": 0, "syncbn_collectives": 0, "time_allreduce": False, "events": []}
+
+
+def reset_stats(time_allreduce=False):
+    stats.update(grad_allreduces=0, grad_allreduce_bytes=0, syncbn_collectives=0, time_allreduce=bool(time_allreduce))
+    stats["events"] = []
+
+
+def allreduce_ms():
+    """total time of the gradient all-reduces recorded since reset_stats(time_allreduce=True); sync the device first"""
+    return sum(e if isinstance(e, float) else e[0].elapsed_time(e[1]) for e in stats["events"])
+
+
+def init_from_env(device_type="cuda", force=False):
+    """torch.distributed.run contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.
+    device_type "cuda" -> backend "nccl" (RCCL over xGMI on ROCm), bound to cuda:LOCAL_RANK; "cpu" -> gloo (tests).
+    force: initialise the process group even for a single rank (exercises the RCCL code path on a 1-GPU box)."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if device_type == "cuda":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            if local_rank >= torch.cuda.device_count():
+                raise RuntimeError(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible "
+                                   "(one process per GPU)")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     return rank, local_rank, world
 
 
@@ -31,10 +53,18 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def collectives_on():
+    """True when the data-parallel collectives must run: more than one rank, or M355_FORCE_COLLECTIVES=1 with an
+    initialised group (single-rank RCCL smoke test: same calls, trivially correct result)"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or bool(os.environ.get("M355_FORCE_COLLECTIVES"))
+
+
 def broadcast_parameters(module, src=0):
     """make every rank start from rank `src`'s parameters and buffers (the reference's replicate() does this
     on every forward; here once)"""
-    if world_size() == 1:
+    if not collectives_on():
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src)
@@ -48,9 +78,9 @@ class FlatGradReducer:
         self.flat = None
 
     def __call__(self):
-        ws = world_size()
-        if ws == 1:
+        if not collectives_on():
             return
+        ws = world_size()
         ps = [p for p in self.params if p.grad is not None]
         n = sum(p.numel() for p in ps)
         if self.flat is None or self.flat.numel() != n or self.flat.device != ps[0].device:
@@ -60,6 +90,20 @@ class FlatGradReducer:
             views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         torch._foreach_copy_(views, [p.grad for p in ps])
+        timed = stats["time_allreduce"]
+        if timed and self.flat.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        elif timed:
+            import time
+            t0 = time.perf_counter()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if timed and self.flat.is_cuda:
+            e1.record()   # the collective runs on RCCL's stream; the current stream waits for it, so e1 lands after it
+            stats["events"].append((e0, e1))
+        elif timed:
+            stats["events"].append((time.perf_counter() - t0) * 1e3)
+        stats["grad_allreduces"] += 1
+        stats["grad_allreduce_bytes"] += 4 * n
         self.flat.mul_(1.0 / ws)
         torch._foreach_copy_([p.grad for p in ps], views)

@@ -4,6 +4,7 @@ modules: schedule 1 generator step : d_steps_per_g discriminator steps, Adam(bet
 The mesh smoothness regulariser of the G step (main.py:697-705) is applied when the trainer is given a
 `mesh_template` (2dimageto3dmodel_amd.mesh.MeshTemplate).  Not reproduced: the text encoder."""
 import copy
+import math
 
 import torch
 
@@ -12,10 +13,24 @@ from . import parallel as P
 
 
 def divide_pred(pred):
-    """code/main.py:414-422: split the [fake; real] batch of every discriminator output"""
-    fake = [t[:t.size(0) // 2] for t in pred]
-    real = [t[t.size(0) // 2:] for t in pred]
-    return fake, real
+    """code/main.py:414-422: split the [fake; real] batch of every discriminator output; a missing list (None) and
+    missing entries (the masks when args.mask_output is off) pass through as None"""
+    if pred is None:
+        return None, None
+    if isinstance(pred, list):
+        fake = [t[:t.shape[0] // 2] if t is not None else None for t in pred]
+        real = [t[t.shape[0] // 2:] if t is not None else None for t in pred]
+        return fake, real
+    return pred[:pred.shape[0] // 2], pred[pred.shape[0] // 2:]
+
+
+def ema_alpha(alpha, epoch):
+    """code/main.py:433-438: the running-average generator follows faster during the first epochs"""
+    if epoch < 10:
+        return math.pow(alpha, 100)
+    if epoch < 100:
+        return math.pow(alpha, 10)
+    return alpha
 
 
 class GanTrainer(torch.nn.Module):
@@ -47,6 +62,7 @@ class GanTrainer(torch.nn.Module):
         self.reduce_g = P.FlatGradReducer(self.generator.parameters())
         self.reduce_d = P.FlatGradReducer(self.discriminator.parameters())
         self.total_it = 0
+        self.epoch = 0    # the caller's epoch counter (main.py:668); only the running-average ramp reads it
 
     def _d_weight(self):
         a = self.args
@@ -73,7 +89,8 @@ class GanTrainer(torch.nn.Module):
                 X_comb = torch.cat((X_fake, X_real), dim=0)
                 C_comb = torch.cat((C, C), dim=0) if C is not None else None
                 M_comb = torch.cat((pred_mesh, X_mesh), dim=0) if pred_mesh is not None else None
-            disc, mask = self.discriminator(X_comb, M_comb, C_comb, caption)
+            cap_comb = [torch.cat((t, t), dim=0) for t in caption] if caption is not None else None
+            disc, mask = self.discriminator(X_comb, M_comb, C_comb, cap_comb)
             d_fake, d_real = divide_pred(disc)
             m_fake, m_real = divide_pred(mask)
             loss_fake = self.criterion_gan(d_fake, False, for_discriminator=True, mask=m_fake, weight=w)
@@ -87,9 +104,10 @@ class GanTrainer(torch.nn.Module):
         return super()._apply(fn, *args, **kwargs)
 
     @torch.no_grad()
-    def update_generator_running_avg(self):
-        """main.py:431-447 (constant alpha; the reference ramps it over the first epochs).  The (dst, src) tensor lists
-        are collected once: state_dict() on two 300-entry modules per step is pure host overhead."""
+    def update_generator_running_avg(self, epoch=None):
+        """main.py:431-447, including the alpha ramp over the first 100 epochs.  The (dst, src) tensor lists are
+        collected once: state_dict() on two 300-entry modules per step is pure host overhead."""
+        alpha = ema_alpha(self.ema_alpha, self.epoch if epoch is None else epoch)
         ema = self.__dict__.get("_ema_lists")
         if ema is None:
             src = self.generator.state_dict(keep_vars=True)
@@ -104,11 +122,12 @@ class GanTrainer(torch.nn.Module):
         fl_dst, fl_src, other = ema
         for v, sv in other:
             v.copy_(sv)
-        torch._foreach_mul_(fl_dst, self.ema_alpha)
-        torch._foreach_add_(fl_dst, fl_src, alpha=1 - self.ema_alpha)
+        torch._foreach_mul_(fl_dst, alpha)
+        torch._foreach_add_(fl_dst, fl_src, alpha=1 - alpha)
 
-    def iteration(self, X_tex, X_alpha, X_mesh, C, caption=None):
-        """one pass of the loop body main.py:691-723 on one loader batch; returns the scalar losses"""
+    def iteration(self, X_tex, X_alpha, X_mesh, C, caption=None, noise=None, epoch=None):
+        """one pass of the loop body main.py:691-723 on one loader batch; returns the scalar losses.  `noise` fixes the
+        latent batch (ModelWrapper.forward's own argument); `epoch` overrides self.epoch for the running-average ramp."""
         if self.total_it % (1 + self.d_steps_per_g) == 0:
             self.optimizer_g.zero_grad(set_to_none=True)
             # The G step only needs dL/d(input) from the discriminator: the reference lets autograd also compute D's
@@ -119,7 +138,7 @@ class GanTrainer(torch.nn.Module):
             for p in d_params:
                 p.requires_grad_(False)
             try:
-                loss, _, pred_mesh = self('g', None, X_alpha, None, C, caption)
+                loss, _, pred_mesh = self('g', None, X_alpha, None, C, caption, noise)
                 loss = loss.mean()
                 flat = None
                 if self.mesh_template is not None and pred_mesh is not None:
@@ -134,13 +153,13 @@ class GanTrainer(torch.nn.Module):
                     p.requires_grad_(True)
             self.reduce_g()
             self.optimizer_g.step()
-            self.update_generator_running_avg()
+            self.update_generator_running_avg(epoch)
             out = {"g": loss.detach()}
             if flat is not None:
                 out["flat"] = flat.detach()
         else:
             self.optimizer_d.zero_grad(set_to_none=True)
-            loss_fake, loss_real, _, _ = self('d', X_tex, X_alpha, X_mesh, C, caption)
+            loss_fake, loss_real, _, _ = self('d', X_tex, X_alpha, X_mesh, C, caption, noise)
             loss_fake, loss_real = loss_fake.mean(), loss_real.mean()
             (loss_fake + loss_real).backward()
             self.reduce_d()

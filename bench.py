@@ -1,6 +1,11 @@
 """Headline benchmark: train-step samples/sec (proj + loss + GAN fwd/bwd), batch 64 per GPU, N MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU over RCCL.  Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`
+(RANK / LOCAL_RANK / WORLD_SIZE in the environment) each process is one rank; started plainly, `bench.py --gpus N`
+re-executes itself under torch.distributed.run with N ranks (the reference's one-command `--gpu_ids 0,..,N-1`,
+code/main.py:77,133,530-548) and fails loudly when fewer than N GPUs are visible -- it never silently measures 1 GPU.
 
 One "step" = one pass of BOTH hot paths over one batch of 64 synthetic samples resident in HBM:
   (P) EffectiveLossFunction.forward -> SupervisedLoss.forward -> backward to (point_cloud, rotation, scale) on
@@ -14,8 +19,9 @@ One "step" = one pass of BOTH hot paths over one batch of 64 synthetic samples r
 Weak scaling: every rank runs the same per-GPU batch; (P) has no collective, (G) all-reduces gradients (one flat
 RCCL all-reduce per optimiser step) and SyncBN statistics.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed over the same K steps) and
-`cpu_baseline` (the CPU oracle of the projection path, a scalar C port, on a bounded sample).
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed over the same K steps), `roofline_proj`
+(the projection kernels under SURVEY 8d's volume accounting AND their compulsory I/O), `cpu_baseline` (projection half:
+oracle/p_oracle.c on 1 core and on all cores) and `cpu_baseline_gan` (GAN half: oracle/gan_cpu.py, fp32 torch-CPU).
 """
 import argparse
 import importlib
@@ -53,16 +59,28 @@ def make_textures(B, R, seed, device):
     return [x.to(device) for x in (x_tex, x_alpha, x_mesh, c)]
 
 
-def cpu_baseline(N, S, seconds_budget=15.0):
-    """oracle/p_oracle.c (scalar C port of the reference's literal projection arithmetic) on 1 host core, fwd+bwd,
-    on a bounded sample of the same workload (clouds of N points into an S^3 grid).  The GAN half has no CPU leg
-    here: the reference's torch-CPU cycle at B=16 takes 12.75 s on 8 cores = 3.8 samples/s."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(N, S, seconds_budget=8.0):
+    """oracle/p_oracle.c (scalar C port of the reference's literal projection arithmetic), fwd+bwd, on a bounded sample of
+    the same workload (clouds of N points into an S^3 grid): first on 1 host core (`value`), then one cloud per core on all
+    cores (`all_cores`; ctypes releases the GIL, clouds are independent)."""
+    from concurrent.futures import ThreadPoolExecutor
+
     from oracle import p_oracle as po
 
-    rs = np.random.RandomState(0)
     taps = po.taps(3.0, 21, True)
-    done, t0 = 0, time.perf_counter()
-    while True:
+
+    def one(seed):
+        rs = np.random.RandomState(seed)
         pc = ((rs.rand(1, N, 3) - 0.5) * 0.7).astype(np.float32)
         q = rs.randn(1, 4).astype(np.float32)
         sc = (1 / (1 + np.exp(-rs.randn(1, 1)))).astype(np.float32)
@@ -70,13 +88,105 @@ def cpu_baseline(N, S, seconds_budget=15.0):
         proj = po.forward(pc, q, sc, S, taps)
         po.sup_loss(proj, mask)
         po.backward(pc, q, sc, po.sup_loss_bwd(proj, mask), S, taps)
+
+    done, t0 = 0, time.perf_counter()
+    while True:
+        one(done)
         done += 1
         el = time.perf_counter() - t0
         if el > seconds_budget or done >= 64:
             break
-    return {"value": done / el, "unit": "samples/s", "cores": 1, "kind": "port",
-            "sample": f"projection half only: {done} clouds of {N} points -> {S}^3 grid, fwd+bwd, oracle/p_oracle.c, "
-                      f"{el:.1f} s"}
+    cores = os.cpu_count() or 1
+    n_par = max(cores, min(4 * cores, int(cores * seconds_budget / max(el / done, 1e-3))))
+    t1 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(one, range(1000, 1000 + n_par)))
+    el_par = time.perf_counter() - t1
+    return {"value": done / el, "unit": "samples/s", "cores": 1, "kind": "port", "cpu_model": _cpu_model(),
+            "sample": f"projection half: {done} clouds of {N} points -> {S}^3 grid, fwd+bwd, oracle/p_oracle.c, {el:.1f} s",
+            "all_cores": {"value": n_par / el_par, "unit": "samples/s", "cores": cores,
+                          "sample": f"{n_par} clouds, one per thread on {cores} threads, {el_par:.1f} s"}}
+
+
+def cpu_baseline_gan(trainer, R, seconds_budget=10.0):
+    """The GAN half beside the HIP path: oracle/gan_cpu.py (fp32 torch-CPU restatement of models/gan.py + utils/losses.py +
+    Adam, pinned to the reference's goldens by tests/test_oracle_golden.py) running the SAME cycle (1 G step + 2 D steps incl.
+    the Adam updates) from the drop-in's own weights, batch 2 per step (6 textures per cycle), on all cores and on 1 thread
+    (the reference's scripts force OMP_NUM_THREADS=1, code/main.py:3)."""
+    from oracle import gan_cpu as gc
+
+    args = trainer.args
+    wg, wd = gc.Weights(trainer.generator.state_dict()), gc.Weights(trainer.discriminator.state_dict())
+    B = 2
+    g = torch.Generator().manual_seed(7)
+    z = torch.randn(B, trainer.latent_dim, generator=g)
+    c = torch.randint(0, args.n_classes[0], (B, 1), generator=g)
+    x_tex = torch.rand(B, 3, R, R, generator=g) * 2 - 1
+    x_alpha = (torch.rand(B, 1, R, R, generator=g) > 0.4).float()
+    x_mesh = 0.05 * torch.randn(B, 3, 32, 32, generator=g)
+    pg = {k: v for k, v in wg.store.items() if v.requires_grad}
+    pd = {k: v for k, v in wd.store.items() if v.requires_grad}
+    sg, sd, step = {}, {}, [0, 0]
+
+    def cycle():
+        wg.zero_grad()
+        wd.zero_grad()
+        loss = gc.g_step(wg, wd, args, z, c, x_alpha)[0].mean()
+        loss.backward()
+        step[0] += 1
+        gc.adam_step(pg, wg.grads(), sg, 1e-4, step[0])
+        for _ in range(2):
+            wd.zero_grad()
+            lf, lr, _ = gc.d_step(wg, wd, args, z, c, x_tex, x_alpha, x_mesh)
+            (lf + lr).mean().backward()
+            step[1] += 1
+            gc.adam_step(pd, wd.grads(), sd, 4e-4, step[1])
+
+    out = {}
+    nthr = torch.get_num_threads()
+    cores = os.cpu_count() or 1
+    try:
+        for key, thr in (("all", cores), ("one", 1)):
+            torch.set_num_threads(thr)
+            if key == "all":
+                cycle()   # warm-up (allocator, oneDNN primitives)
+            n, t0 = 0, time.perf_counter()
+            while True:
+                cycle()
+                n += 1
+                el = time.perf_counter() - t0
+                if el > seconds_budget / 2 or n >= 8:
+                    break
+            out[key] = (3 * B * n / el, n, el)
+    finally:
+        torch.set_num_threads(nthr)
+    return {"value": out["all"][0], "unit": "samples/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
+            "sample": f"GAN half: {out['all'][1]} cycles (1 G + 2 D steps, Adam) at batch {B}, {R}x{R}, fp32 torch-CPU "
+                      f"(oracle/gan_cpu.py), {out['all'][2]:.1f} s on {cores} threads",
+            "one_thread": {"value": out["one"][0], "unit": "samples/s", "cores": 1,
+                           "sample": f"{out['one'][1]} cycle(s), {out['one'][2]:.1f} s"}}
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def respawn_under_torchrun(args):
+    """`bench.py --gpus N` started as ONE process: become N ranks (one per GPU) under torch.distributed.run"""
+    if args.backend == "nccl":
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible; refusing to run a "
+                     f"{args.gpus}-GPU benchmark on fewer devices (one process per GPU)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL needs it on this driver)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    os.execve(sys.executable, cmd, env)
 
 
 def main():
@@ -88,17 +198,35 @@ def main():
     ap.add_argument("--points", type=int, default=2048)
     ap.add_argument("--grid", type=int, default=128)
     ap.add_argument("--res", type=int, default=256, help="texture resolution of the GAN half")
-    ap.add_argument("--workload", choices=["both", "proj", "gan"], default="both")
+    ap.add_argument("--workload", choices=["both", "proj", "gan", "collectives"], default="both",
+                    help="collectives: only the gradient all-reduce of the GAN half on a 61 MB flat buffer (launch-path test; "
+                         "the one workload that also runs with --backend gloo on CPU)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI (the product path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        respawn_under_torchrun(args)   # does not return
+    if env_world is not None and int(env_world) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch with --nproc-per-node {args.gpus}")
+    if args.backend == "gloo" and args.workload != "collectives":
+        sys.exit("bench.py: the projection and GAN workloads are HIP-only (no CPU path); --backend gloo serves "
+                 "--workload collectives")
 
-    pkg = importlib.import_module("2dimageto3dmodel_amd")
     par = importlib.import_module("2dimageto3dmodel_amd.parallel")
-    train = importlib.import_module("2dimageto3dmodel_amd.train")
-    rank, local_rank, world = par.init_from_env("cuda")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
+    on_gpu = args.backend == "nccl"
+    rank, local_rank, world = par.init_from_env("cuda" if on_gpu else "cpu")
+    assert world == args.gpus
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+    if args.workload == "collectives":
+        return bench_collectives(args, par, dist, rank, world, dev)
+    pkg = importlib.import_module("2dimageto3dmodel_amd")
+    train = importlib.import_module("2dimageto3dmodel_amd.train")
 
     B, N, S, R = args.batch, args.points, args.grid, args.res
     do_p, do_g = args.workload in ("both", "proj"), args.workload in ("both", "gan")
@@ -124,6 +252,9 @@ def main():
         trainer = train.GanTrainer(gargs, device=dev, mesh_template=template)
         trainer.train()
         batches = [make_textures(B, R, 1234 + 3 + 17 * rank + i, dev) for i in range(3)]
+        # the weights above are identical on every rank (same seed + broadcast); the latent noise must NOT be:
+        # GanTrainer draws it from the default generators, re-seeded here per rank
+        torch.manual_seed(1234 + 3 + 17 * rank)
 
     last = {}
 
@@ -161,17 +292,22 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    par.reset_stats()
     dt = timed(step, args.steps)
+    coll = dict(par.stats)
 
     # ---- the two halves separately, and per-kernel HIP-event timing of the same K steps (events on the launch
     #      stream = torch's current stream); separate passes so that no marker sits inside the timed region above
     dt_p = timed(step_p, args.steps) if do_p else None
     dt_g = timed(step_g, args.steps) if do_g else None
     pkg._lib.enable_kernel_timers(True)
+    par.reset_stats(time_allreduce=True)
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     kt = pkg._lib.collect_kernel_timers()  # name -> (launches, total_ms, total algorithmic work)
+    allreduce_ms = par.allreduce_ms() / args.steps
+    par.reset_stats()
     pkg._lib.enable_kernel_timers(False)
 
     if rank == 0:
@@ -204,6 +340,10 @@ def main():
             "config": {"workload": " + ".join(workload), "global_batch": world * B, "points": N, "grid": S,
                        "texture_resolution": R, "parallelism": f"dp{world}",
                        "losses": {k: float(v) for k, v in last.items()}},
+            "allreduce_ms_per_step": allreduce_ms,
+            "grad_allreduces_per_step": coll["grad_allreduces"] / args.steps,
+            "grad_allreduce_mb_per_step": coll["grad_allreduce_bytes"] / args.steps / 1e6,
+            "syncbn_collectives_per_step": coll["syncbn_collectives"] / args.steps,
             "proj_samples_per_s": (world * B * args.steps / dt_p) if do_p else None,
             "gan_samples_per_s": (world * 3 * B * args.steps / dt_g) if do_g else None,
             "roofline": {"bound": "mfma" if is_conv else "hbm", "kernel": dom, "achieved": rate, "peak": peak,
@@ -221,12 +361,65 @@ def main():
                                  "(2*FETCH+WRITE)*1024, gfx950 fetch correction), null if not collected"},
             "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(kt.items(), key=lambda kv: -kv[1][1])},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(N, S)
+            if do_g:
+                out["cpu_baseline_gan"] = cpu_baseline_gan(trainer, R)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_collectives(args, par, dist, rank, world, dev):
+    """launch-path workload: the two flat gradient all-reduces of one GAN cycle (G 47 MB + D 14 MB fp32) through
+    parallel.FlatGradReducer, nothing else.  Runs on RCCL (cuda) or gloo (cpu, tests/test_distributed_cpu.py)."""
+    sizes = (11_750_000, 3_500_000)
+    params = [torch.nn.Parameter(torch.zeros(n, device=dev)) for n in sizes]
+    for p in params:
+        p.grad = torch.full_like(p, float(rank + 1))
+    reducers = [par.FlatGradReducer([p]) for p in params]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+
+    def step():
+        for p, r in zip(params, reducers):
+            p.grad.fill_(float(rank + 1))
+            r()
+
+    for _ in range(args.warmup):
+        step()
+    par.reset_stats(time_allreduce=True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    want = sum(range(1, world + 1)) / world
+    ok = all(abs(float(p.grad[0]) - want) < 1e-6 and abs(float(p.grad[-1]) - want) < 1e-6 for p in params) or world == 1
+    nbytes = par.stats["grad_allreduce_bytes"] / max(args.steps, 1)
+    ar_ms = par.allreduce_ms() / args.steps
+    if rank == 0:
+        print(json.dumps({
+            "metric": "gradient all-reduce GB/s (algorithmic bytes of the flat fp32 buffers)", "unit": "GB/s",
+            "value": (nbytes / 1e9) / (ar_ms * 1e-3) if ar_ms > 0 else None, "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": t.item() / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "backend": args.backend,
+            "config": {"workload": "collectives: flat all-reduce of 47 MB + 14 MB fp32 gradient buffers", "parallelism": f"dp{world}"},
+            "allreduce_ms_per_step": ar_ms, "grad_allreduces_per_step": par.stats["grad_allreduces"] / max(args.steps, 1),
+            "grad_allreduce_mb_per_step": nbytes / 1e6, "averaged_correctly": bool(ok)}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit("bench.py: the all-reduced gradients are not the rank average")
 
 
 if __name__ == "__main__":

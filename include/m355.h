@@ -48,6 +48,15 @@ int m355_abi_version(void);
 int m355_proj_transform_fwd(const float *pc, const float *q, float *cam, int B, int N, float fov, float dist,
                             void *stream);
 
+/* ---- P1 alone  PointsQuaternionsRotator.rotate_points, quaternions/points_quaternions.py:41-81 (with
+ *      QuaternionOperations.quaternion_multiplication / quaternion_conjugate, quaternions/operations.py:68-97,120-136):
+ *      out[b,n,:] = vector part of q (x) (0,p) (x) q*  (inverse = 0, :72-75)  or  q* (x) (0,p) (x) q  (inverse = 1, :67-70)
+ *      with q = F.normalize(rotation); pc/out [B,N,3], q [B,4]; BIT-EXACT with the torch-CPU reference.
+ *      _bwd: dout [B,N,3] -> dpc [B,N,3], dq [B,4] (through the normalisation). */
+int m355_quat_rotate_fwd(const float *pc, const float *q, float *out, int B, int N, int inverse, void *stream);
+int m355_quat_rotate_bwd(const float *pc, const float *q, const float *dout, float *dpc, float *dq, int B, int N, int inverse,
+                         void *stream);
+
 /*      The same transform fused with the per-tile binning the fused renderer consumes (one launch).
  *      A tile is a TH x TW block of rays (silhouette pixels); m355_proj_ntiles(S) tiles cover the S x S image.
  *      pc/q both NULL: cam is an INPUT and only the binning runs.
@@ -254,18 +263,21 @@ int m355_sn_wgrad_finish(const float *g_khwc, const float *w_orig, const float *
  *      a[n,c] = rstd (1 + gamma[n,c]), b[n,c] = beta[n,c] - mean a[n,c];  gamma/beta rows are gstride floats apart.
  *      backward: part[N][nblk][2][C] (sum dz, sum dz x) -> dgamma, dbeta [N][C], A[N][C], Bc[C], Cc[C] with
  *      dx = dz A + x Bc + Cc. */
-int m355_bn_finalize(const float *part, int nblk, float count, const float *gamma, const float *beta, int gstride, int N,
-                     int C, float eps, float momentum, float *running_mean, float *running_var, float *mean, float *rstd,
-                     float *a, float *b, void *stream);
+int m355_bn_finalize(const float *part, int nblk, float count, const float *count_dev, const float *gamma, const float *beta,
+                     int gstride, int N, int C, float eps, float momentum, float *running_mean, float *running_var, float *mean,
+                     float *rstd, float *a, float *b, void *stream);
 int m355_bn_bwd_finalize(const float *part, int nblk, float count, const float *gamma, int gstride, int N, int C,
                          const float *mean, const float *rstd, int batch_stats, float *dgamma, float *dbeta, float *A,
                          float *Bc, float *Cc, float *m_out, void *stream);
 /*      SyncBN (one process per GPU): m_out != NULL makes m355_bn_bwd_finalize emit the local moment sums
  *      m[2][C] = (sum_n (1+gamma) s1, sum_n (1+gamma) dgamma) instead of Bc / Cc; after their all-reduce (RCCL)
  *      this turns them into Bc, Cc with the global pixel count.  The forward side needs no extra entry point:
- *      all-reduce the summed partials and call m355_bn_finalize with nblk = 1. */
-int m355_bn_bwd_coeffs(const float *m, float count, const float *mean, const float *rstd, int C, float *Bc, float *Cc,
-                       void *stream);
+ *      all-reduce the summed partials and call m355_bn_finalize with nblk = 1.
+ *      count_dev (both entry points): when non-NULL the pixel count is read from this DEVICE scalar instead of `count`
+ *      -- the all-reduced [sum | sumsq | count] vector's last element, so ranks with ragged shards need no host sync
+ *      (code/sync_batchnorm/batchnorm.py:110-131 sums the real sizes the same way). */
+int m355_bn_bwd_coeffs(const float *m, float count, const float *count_dev, const float *mean, const float *rstd, int C,
+                       float *Bc, float *Cc, void *stream);
 
 /* Projection discriminator (code/models/gan.py:104-116, 216-228): out[n,p] = sum_c feat[n,p,c] * emb[n,c] on the NHWC bf16
  * feature map (C a power of two in 8..2048); backward: dfeat = g * emb (bf16, overwritten), demb[n,c] = sum_p g * feat. */

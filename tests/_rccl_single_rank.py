@@ -1,0 +1,62 @@
+"""Helper of tests/test_distributed_gpu.py::test_rccl_single_rank (own process: it creates a process group).
+
+backend="nccl" (= RCCL) with ONE rank on cuda:0 and M355_FORCE_COLLECTIVES=1: every collective of the data-parallel GAN
+path -- parameter broadcast, the fused SyncBN [sum|sumsq|count] / moment all-reduces, the flat gradient all-reduce --
+goes through RCCL exactly as it does with N ranks (same tensors, same streams), with a trivially known result."""
+import argparse
+import importlib
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", M355_FORCE_COLLECTIVES="1")
+os.environ.setdefault("MASTER_PORT", "29611")
+par = importlib.import_module("2dimageto3dmodel_amd.parallel")
+train = importlib.import_module("2dimageto3dmodel_amd.train")
+rank, local_rank, world = par.init_from_env("cuda", force=True)
+import torch.distributed as dist
+
+assert dist.get_backend() == "nccl" and par.collectives_on()
+dev = "cuda:0"
+gargs = argparse.Namespace(norm_g="syncbatch", norm_d="none", conditional_class=True, conditional_color=False,
+                           conditional_text=False, n_classes=[200], texture_resolution=128, mask_output=True,
+                           num_discriminators=2, texture_only=False, text_embedding_dim=256)
+
+
+def run(force):
+    if force:
+        os.environ["M355_FORCE_COLLECTIVES"] = "1"
+    else:
+        os.environ.pop("M355_FORCE_COLLECTIVES", None)
+    torch.manual_seed(11)
+    tr = train.GanTrainer(gargs, device=dev)
+    tr.train()
+    g = torch.Generator().manual_seed(50)
+    par.reset_stats(time_allreduce=True)
+    losses = []
+    for it in range(3):
+        B, R = 2, 128
+        x_tex = (torch.rand(B, 3, R, R, generator=g) * 2 - 1).to(dev)
+        x_alpha = (torch.rand(B, 1, R, R, generator=g) > 0.4).float().to(dev)
+        x_mesh = (0.05 * torch.randn(B, 3, 32, 32, generator=g)).to(dev)
+        c = torch.randint(0, 200, (B, 1), generator=g).to(dev)
+        z = torch.randn(B, 64, generator=g).to(dev)
+        out = tr.iteration(x_tex, x_alpha, x_mesh, c, noise=z)
+        losses += [float(v) for v in out.values()]
+    torch.cuda.synchronize()
+    w = tr.generator.blk6.conv2.weight_orig.detach().clone()
+    st = dict(par.stats)
+    st["n_cbn"] = sum(1 for m in tr.generator.modules() if m.__class__.__name__ == "ConditionalBatchNorm2d")
+    return losses, w, st, par.allreduce_ms()
+
+
+l1, w1, st, ms = run(True)
+l0, w0, st0, _ = run(False)
+dist.destroy_process_group()
+print(json.dumps({"losses_rccl": l1, "losses_plain": l0, "max_w_diff": float((w1 - w0).abs().max()),
+                  "grad_allreduces": st["grad_allreduces"], "n_cbn": st["n_cbn"], "syncbn_collectives": st["syncbn_collectives"],
+                  "allreduce_ms": ms, "plain_collectives": st0["grad_allreduces"] + st0["syncbn_collectives"]}))

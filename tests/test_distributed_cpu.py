@@ -93,3 +93,43 @@ def test_two_ranks_gloo():
     assert sorted(r for r, _ in res) == [0, 1]
     for r, msg in res:
         assert msg == "ok", f"rank {r}:\n{msg}"
+
+
+# ---- bench.py's own launch path: `python bench.py --gpus N` started as ONE process becomes N ranks
+def _run_bench(*argv, timeout=300):
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=timeout,
+                          env=env, cwd=ROOT)
+
+
+@pytest.mark.timeout(400)
+def test_bench_gpus2_spawns_two_ranks_gloo():
+    """the same spawn path the driver's `python bench.py --gpus N` takes (re-exec under torch.distributed.run, rank/device
+    binding, barriers, MAX-over-ranks timing, one JSON line from rank 0), on gloo with the collectives-only workload"""
+    import json
+    r = _run_bench("--gpus", "2", "--backend", "gloo", "--workload", "collectives", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["averaged_correctly"] is True
+    assert out["grad_allreduces_per_step"] == 2 and out["allreduce_ms_per_step"] > 0
+    assert abs(out["grad_allreduce_mb_per_step"] - 61.0) < 1e-6
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`bench.py --gpus 9` on a box with fewer GPUs must fail loudly, never fall back to a 1-GPU measurement"""
+    r = _run_bench("--gpus", "9", "--steps", "1", "--warmup", "0", timeout=200)
+    assert r.returncode != 0
+    assert "only" in r.stderr and "GPU(s) are visible" in r.stderr and not any(ln.startswith("{") for ln in r.stdout.splitlines())
+
+
+def test_bench_rejects_world_size_mismatch():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True, timeout=200,
+                       env=env, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

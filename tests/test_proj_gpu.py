@@ -196,6 +196,50 @@ def test_unsupervised_loss_matches_torch_restatement(pkg):
     assert abs(ev["projection_loss"].item() / (((proj - mr) ** 2).sum() / rows).item() - 1) < 1e-5
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_unsupervised_loss_matches_reference(pkg, tag):
+    """P8 pinned: the reference's UnsupervisedLoss.forward executed on CPU (oracle/gen_golden_p8.py; eval branch unmodified,
+    training branch with the D8 attribute shim) -- losses, argmin indices, gradients to the projections and student poses"""
+    g = load_golden("p8_unsup")
+    B, K = int(g[f"{tag}:B"]), int(g[f"{tag}:K"])
+    proj = t(g[f"{tag}:proj"]).requires_grad_()
+    masks = t(g[f"{tag}:masks"].astype(np.float32))
+    ens, stu = t(g[f"{tag}:ens"]), t(g[f"{tag}:stu"]).requires_grad_()
+    lossm = pkg.UnsupervisedLoss(number_of_pose_predictor_candidates=K)
+    ev = lossm((proj[:B].detach(), ens[:B]), masks, training=False)
+    assert set(ev) == {"projection_loss"}
+    assert abs(ev["projection_loss"].item() / float(g[f"{tag}:eval_loss"]) - 1) < 1e-5
+    out = lossm((proj, ens, stu), masks, training=True)
+    for k in ("projection_loss", "student_loss", "total_loss"):
+        assert abs(out[k].item() / float(g[f"{tag}:{k}"]) - 1) < 1e-5, k
+    assert np.array_equal(lossm.minimum_indexes.cpu().numpy(), g[f"{tag}:min_idx"])
+    out["total_loss"].backward()
+    assert np.abs(proj.grad.cpu().numpy() - g[f"{tag}:dproj"]).max() < 1e-6 * max(1.0, np.abs(g[f"{tag}:dproj"]).max())
+    assert rel(stu.grad.cpu().numpy(), g[f"{tag}:dstu"]) < 1e-5
+
+
+@pytest.mark.timeout(900)
+def test_config5_s512_vs_oracle(pkg):
+    """BASELINE configs[4] geometry (N = 16384 points -> 512^3 grid, 512 x 512 silhouette; m355_proj_ntiles(512) = 16384 tiles,
+    a different tile shape from S <= 256) against the pinned CPU oracle on one cloud: silhouette, loss, all three gradients"""
+    B, N, S = 1, 16384, 512
+    pc, q, sc, mask = synth(5120, B, N, S)
+    taps = po.taps(3.0, 21, True)
+    proj_o = po.forward(pc, q, sc, S, taps)
+    dp_o, dq_o, ds_o, _ = po.backward(pc, q, sc, po.sup_loss_bwd(proj_o, mask), S, taps)
+    tpc, tq, tsc = t(pc).requires_grad_(), t(q).requires_grad_(), t(sc).requires_grad_()
+    elf = pkg.EffectiveLossFunction(voxel_size=S).to(DEV)
+    proj = elf(tpc, tq, tsc)
+    assert tuple(proj.shape) == (B, S, S)
+    assert np.abs(proj.detach().cpu().numpy() / proj_o - 1).max() < 2e-5
+    loss = pkg.SupervisedLoss()(proj, t(mask))["full_loss"]
+    assert abs(loss.item() / po.sup_loss(proj_o, mask) - 1) < 1e-5
+    loss.backward()
+    assert rel(tpc.grad.cpu().numpy(), dp_o) < 1e-3
+    assert rel(tq.grad.cpu().numpy(), dq_o) < 1e-3
+    assert rel(tsc.grad.cpu().numpy(), ds_o) < 1e-3
+
+
 def test_size_independent_properties_full_size(pkg):
     """BASELINE configs[1] size (B=32, N=2048, S=128): properties that need no oracle run."""
     B, N, S = 32, 2048, 128
