@@ -67,7 +67,17 @@ SIGNATURES = {
     "m355_chan_reduce_ws_bytes": (c_size_t, [c_size_t, c_int, c_int, c_int]),
     "m355_bn_stats": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
     "m355_chan_sum": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
-    "m355_affine_act_fwd": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_float, _P]),
+    "m355_affine_act_fwd": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_float, c_float, _P]),
+    "m355_mask_cat_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "m355_mask_cat_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "m355_pool_pack_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "m355_pool_pack_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, _P]),
+    "m355_pool_unpack_bwd": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "m355_unpack_range": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "m355_head_tail_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "m355_head_tail_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "m355_hinge_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "m355_hinge_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     "m355_affine_act_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "m355_affine_act_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "m355_lrelu_bwd": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_float, _P]),

@@ -33,6 +33,7 @@ SOURCES = [
     ("conv_halo.hip", []),
     ("gan_elem.hip", []),
     ("gan_glue.hip", []),
+    ("gan_io.hip", []),
     ("mesh_deform.hip", STRICT),
 ]
 

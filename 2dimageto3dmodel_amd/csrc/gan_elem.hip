@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256) void k_sum_partials(const float *__restrict__ 
 // streaming (the first version re-read a/b per element and ran at a third of the HBM rate).
 __global__ __launch_bounds__(256) void k_affine_act(const short *__restrict__ x, const float *__restrict__ a,
                                                     const float *__restrict__ b, const short *__restrict__ res,
-                                                    short *__restrict__ y, int HW, int C, float slope, int res_w)
+                                                    short *__restrict__ y, int HW, int C, float slope, int res_w,
+                                                    float out_slope)
 {
     // res_w > 0: the residual is stored at HALF resolution ([N][H/2][res_w/2][C]) and read through the nearest x2
     // upsample (a 1x1 shortcut conv commutes with it, so the shortcut runs on 4x fewer pixels -- gan.py:306-312,319)
@@ -177,6 +178,16 @@ __global__ __launch_bounds__(256) void k_affine_act(const short *__restrict__ x,
             const bf16x8e q = pack8_e(zz);
 #pragma unroll
             for (int j = 0; j < 8; ++j) zz[j] = bf2f_e(q[j]) + bf2f_e(r[j]);
+        }
+        if (out_slope != 1.0f) {
+            // the LeakyReLU the generator applies to a block's output in front of a head (gan.py:406,410), folded in:
+            // the sum is rounded to bf16 first, as the separate activation pass it replaces saw it
+            const bf16x8e q = pack8_e(zz);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float t = bf2f_e(q[j]);
+                zz[j] = t >= 0.0f ? t : t * out_slope;
+            }
         }
         *reinterpret_cast<bf16x8e *>(yn + i * 8) = pack8_e(zz);
     }
@@ -437,7 +448,7 @@ extern "C" int m355_bn_stats(const void *x, float *sums /*[2][C]*/, void *ws, si
 }
 
 extern "C" int m355_affine_act_fwd(const void *x, const float *a, const float *b, const void *res, int res_w, void *y, int N,
-                                   int HW, int C, float slope, void *stream)
+                                   int HW, int C, float slope, float out_slope, void *stream)
 {
     M355_REQUIRE(x && a && b && y && N > 0 && HW > 0, "affine_act_fwd: null pointer / empty");
     M355_REQUIRE(res_w >= 0 && (res_w == 0 || (res_w % 2 == 0 && HW % res_w == 0 && (HW / res_w) % 2 == 0)),
@@ -447,7 +458,7 @@ extern "C" int m355_affine_act_fwd(const void *x, const float *a, const float *b
     // ~8 vectors per thread (its coefficients are loaded once), still thousands of workgroups with N in grid.y
     const unsigned gx = (unsigned)min((size_t)4096, (total + 2047) / 2048);
     hipLaunchKernelGGL(k_affine_act, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, (const short *)x, a, b,
-                       (const short *)res, (short *)y, HW, C, slope, res ? res_w : 0);
+                       (const short *)res, (short *)y, HW, C, slope, res ? res_w : 0, out_slope);
     return check_launch("affine_act_fwd");
 }
 

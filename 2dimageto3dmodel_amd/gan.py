@@ -115,11 +115,12 @@ class ConditionalBatchNorm2d(nn.Module):
         self.fc_gamma = nn.Linear(emb_dim, ch)
         self.fc_beta = nn.Linear(emb_dim, ch)
 
-    def forward(self, x, z, slope=1.0, gb=None, res=None):
+    def forward(self, x, z, slope=1.0, gb=None, res=None, out_slope=1.0):
         """gb: (gamma, beta) of this layer when the owner evaluated all fc_gamma / fc_beta in one GEMM;
-        res: tensor added after the activation (the block's shortcut branch), fused into the same pass"""
+        res: tensor added after the activation (the block's shortcut branch), fused into the same pass;
+        out_slope: a LeakyReLU on top of everything whose backward the (single) consumer applies (gan_ops.head_conv)"""
         gamma, beta = gb if gb is not None else (self.fc_gamma(z), self.fc_beta(z))
-        return self.norm(x, gamma, beta, slope, res)
+        return self.norm(x, gamma, beta, slope, res, out_slope)
 
 
 class ResBlockUp(nn.Module):
@@ -141,7 +142,7 @@ class ResBlockUp(nn.Module):
         else:
             self.shortcut = _Identity()
 
-    def forward(self, x, z, upsample=0, gb=None):
+    def forward(self, x, z, upsample=0, gb=None, out_slope=1.0):
         """x is the block input BEFORE the nearest x2 upsample that precedes the block in Generator.forward
         (gan.py:386-404) when upsample=1; the upsample is folded into conv1 and the shortcut.
         gb: {norm module: (gamma, beta)} from the generator's batched conditioning GEMM."""
@@ -151,7 +152,7 @@ class ResBlockUp(nn.Module):
         g1 = gb.get(self.norm1) if gb is not None else None
         g2 = gb.get(self.norm2) if gb is not None else None
         h = self.norm1(self.conv1(x, upsample=upsample), z, LRELU, g1)
-        return self.norm2(self.conv2(h), z, LRELU, g2, sc)
+        return self.norm2(self.conv2(h), z, LRELU, g2, sc, out_slope)
 
 
 class Generator(nn.Module):
@@ -219,19 +220,17 @@ class Generator(nn.Module):
                 t = getattr(self, name)(t, z, upsample=1, gb=gb)
         t = self.blk4(t, z, upsample=1, gb=gb)
         t = self.blk5(t, z, upsample=1, gb=gb)
-        t = self.blk6(t, z, upsample=1, gb=gb)
-        t = G.leaky_relu(t, LRELU)
-        x_tex = torch.tanh(self.conv_final(t, out_f32_nchw=True))
+        # heads (gan.py:406-419): relu -> conv -> tanh_ | adjust_poles -> symmetrize.  The LeakyReLU is applied by the
+        # block's last fused pass (out_slope) and differentiated by the head; the tail is one elementwise kernel.
+        sym = G.HT_SYMM if self.symmetric else 0
+        t = self.blk6(t, z, upsample=1, gb=gb, out_slope=LRELU)
+        x_tex = G.head_conv(t, self.conv_final, G.HT_TANH | sym, in_slope=LRELU)
         x_mesh = None
         if self.mesh_head:
-            m = G.leaky_relu(self.blk3_mesh(x, z, upsample=1, gb=gb), LRELU)
-            x_mesh = adjust_poles(self.conv_mesh(m, out_f32_nchw=True))
-        if self.symmetric:
-            x_tex = symmetrize_texture(x_tex)
-            if x_mesh is not None:
-                x_mesh = symmetrize_texture(x_mesh)
-            if attention_map is not None:
-                attention_map = symmetrize_texture(attention_map)
+            m = self.blk3_mesh(x, z, upsample=1, gb=gb, out_slope=LRELU)
+            x_mesh = G.head_conv(m, self.conv_mesh, G.HT_POLES | sym, in_slope=LRELU)
+        if self.symmetric and attention_map is not None:
+            attention_map = symmetrize_texture(attention_map)
         if self.training and self._nbt:
             torch._foreach_add_(self._nbt, 1)  # num_batches_tracked of all the batch norms in one launch
         return (x_tex, x_mesh, attention_map) if return_attention else (x_tex, x_mesh)
@@ -322,6 +321,15 @@ class _DiscBase(nn.Module):
             dev = self.__dict__["_pos_dev"] = self.pos_emb.to(x.device)
         return dev.expand(x.shape[0], -1, -1, -1)
 
+    def _pos_hw(self, h, w, device):
+        """[4,h,w] positional encoding on `device` (same lazy cache as _pos: fixed by the first call's shape)"""
+        if self.pos_emb is None:
+            self.pos_emb = torch.FloatTensor(positional_encoding(h, w)).unsqueeze(0)
+        dev = self.__dict__.get("_pos_dev")
+        if dev is None or dev.device != device:
+            dev = self.__dict__["_pos_dev"] = self.pos_emb.to(device)
+        return dev[0]
+
     def _act(self, conv, norm, x, in_act=False, sole_consumer_masks=False):
         """conv -> [InstanceNorm] -> LeakyReLU on NHWC bf16.  With the activation in the conv epilogue (no norm):
         in_act = x is the previous layer's fused conv+LeakyReLU output and this conv is its only consumer -> this
@@ -378,8 +386,19 @@ class MeshDiscriminator(_DiscBase):
             if args.conditional_color:
                 self.projector_col1 = nn.Embedding(args.n_classes[1], 256)
 
+    def input_spec(self, texture, mesh_map):
+        """(pool factor, takes the mesh map, positional planes, packed channels, mask pool) for gan_ops.disc_inputs"""
+        f = texture.shape[2] // mesh_map.shape[2]
+        pos = self._pos_hw(texture.shape[2] // f, texture.shape[3] // f, texture.device) if self.positional_embeddings else None
+        nch = texture.shape[1] + mesh_map.shape[1] + (4 if self.positional_embeddings else 0)
+        return (f, True, pos, (nch + 7) // 8 * 8, 4 if self.args.mask_output else 0)
+
     def forward(self, texture, mesh_map, c=None, caption=None):
         self._sn_step()
+        spec = self.input_spec(texture, mesh_map)
+        if G.disc_inputs_ok(texture, mesh_map, [spec]):
+            (h,), (mask,) = G.disc_inputs(texture, mesh_map, [spec])
+            return self.trunk(h, mask, c, caption)
         x = F.avg_pool2d(texture, texture.shape[2] // mesh_map.shape[2])
         parts = [x, mesh_map]
         if self.positional_embeddings:
@@ -389,7 +408,10 @@ class MeshDiscriminator(_DiscBase):
         if self.args.mask_output:
             with torch.no_grad():
                 mask = F.avg_pool2d(x[:, 3:4], 4)
-        h = G.to_nhwc_bf16(x, pad_to=8)
+        return self.trunk(G.to_nhwc_bf16(x, pad_to=8), mask, c, caption)
+
+    def trunk(self, h, mask, c=None, caption=None):
+        """conv1 .. conv4 + projection on the packed NHWC bf16 input (gan.py:100-121)"""
         # conv1 -> conv2 -> conv3 are single-consumer chains when norm_d == 'none': each dgrad carries the LeakyReLU
         # backward of the layer below (conv3's output also feeds the projection term, so it keeps its own)
         n2, n3 = getattr(self, "bn2", None), getattr(self, "bn3", None)
@@ -440,8 +462,18 @@ class TextureDiscriminator(_DiscBase):
             if args.conditional_color:
                 self.projector_col1 = nn.Embedding(args.n_classes[1], 512)
 
+    def input_spec(self, x):
+        """(pool factor, takes the mesh map, positional planes, packed channels, mask pool) for gan_ops.disc_inputs"""
+        f = self.downsample
+        pos = self._pos_hw(x.shape[2] // f, x.shape[3] // f, x.device) if self.positional_embeddings else None
+        return (f, False, pos, 8, (16 if self.stride_first else 8) if self.args.mask_output else 0)
+
     def forward(self, x, c=None, caption=None):
         self._sn_step()
+        spec = self.input_spec(x)
+        if G.disc_inputs_ok(x, None, [spec]):
+            (h,), (mask,) = G.disc_inputs(x, None, [spec])
+            return self.trunk(h, mask, c, caption)
         if self.downsample > 1:
             x = F.avg_pool2d(x, self.downsample)
         mask = None
@@ -450,6 +482,10 @@ class TextureDiscriminator(_DiscBase):
                 mask = F.avg_pool2d(x[:, 3:4], 16 if self.stride_first else 8)
         # cat((x, positional encoding)) -> NHWC bf16 (8 channels) in one pass
         h = G.pack_nhwc8(x, self._pos(x)[0] if self.positional_embeddings else None)
+        return self.trunk(h, mask, c, caption)
+
+    def trunk(self, h, mask, c=None, caption=None):
+        """conv1 .. conv5 + projection on the packed NHWC bf16 input (gan.py:212-233)"""
         n2, n3, n4 = getattr(self, "bn2", None), getattr(self, "bn3", None), getattr(self, "bn4", None)
         h = self._act(self.conv1, None, h, False, n2 is None)
         h = self._act(self.conv2, n2, h, True, n3 is None)
@@ -492,6 +528,16 @@ class MultiScaleDiscriminator(nn.Module):
                 if isinstance(m, _DiscBase):
                     m.__dict__["_sn_external"] = True
         g.step(self.training)
+        members = [self.d1, self.d2] + ([self.d3] if self.args.num_discriminators == 3 else [])
+        # every member's input assembly (pooling, mesh / positional planes, masks, NHWC bf16 packing) from ONE read
+        # interface: one launch per member, one backward launch for all of them (gan_ops.DiscInputsFn)
+        if torch.is_tensor(x) and x.is_cuda and (self.args.texture_only or mesh_map is not None):
+            specs = [m.input_spec(x, mesh_map) if isinstance(m, MeshDiscriminator) else m.input_spec(x) for m in members]
+            extra = None if self.args.texture_only else mesh_map
+            if G.disc_inputs_ok(x, extra, specs):
+                hs, masks = G.disc_inputs(x, extra, specs)
+                outs = [m.trunk(h, mk, c, caption) for m, h, mk in zip(members, hs, masks)]
+                return [o[0] for o in outs], [o[1] for o in outs]
         d1, m1 = self.d1(x, c, caption)
         if self.args.texture_only:
             d2, m2 = self.d2(x, c, caption)
@@ -527,7 +573,8 @@ class SpatialAttention(nn.Module):
 # ------------------------------------------------------------------------------------------------ loss
 class GANLoss(nn.Module):
     """utils/losses.py:21-120 (hinge / ls / original / w, masked per-sample mean, per-discriminator weights).
-    Logits are [B,1,h,w] with h<=32: a few KB per call, evaluated with torch ops."""
+    The hinge loss over a list of CUDA logits (the training configuration) is one fused kernel each way
+    (csrc/gan_io.hip k_hinge_*); the other modes -- a few KB of logits per call -- use torch ops."""
 
     def __init__(self, gan_mode, target_real_label=1.0, target_fake_label=0.0, tensor=torch.FloatTensor, opt=None):
         super().__init__()
@@ -560,11 +607,29 @@ class GANLoss(nn.Module):
             return -self.mean(input, mask, weight)
         return -input.mean() if target_is_real else input.mean()
 
+    def d_losses(self, input, mask=None, weight=None):
+        """(loss vs target False on the first half of the batch, loss vs target True on the second half) of discriminator
+        outputs computed on a [fake; real] batch: divide_pred (main.py:414-422) + the two criterion calls of
+        main.py:518-519 in one pass"""
+        if self.gan_mode == 'hinge' and G.hinge_ok(input, mask) and input[0].shape[0] % 2 == 0:
+            return G.hinge_losses(input, mask, weight, 1, input[0].shape[0] // 2)
+        half = lambda ts: (None, None) if ts is None else ([None if t is None else t[:t.shape[0] // 2] for t in ts],
+                                                           [None if t is None else t[t.shape[0] // 2:] for t in ts])
+        (f, r), (mf, mr) = half(input), half(mask)
+        return self(f, False, True, mf, weight), self(r, True, True, mr, weight)
+
     def __call__(self, input, target_is_real, for_discriminator=True, mask=None, weight=None):
         if not isinstance(input, list):
             return self.loss(input, target_is_real, for_discriminator, mask)
         if mask is not None:
             assert isinstance(mask, list) and len(input) == len(mask)
+        if self.gan_mode == 'hinge' and G.hinge_ok(input, mask):
+            B = input[0].shape[0]
+            if for_discriminator:
+                lf, lr = G.hinge_losses(input, mask, weight, 1, 0 if target_is_real else B)
+                return lr if target_is_real else lf
+            assert target_is_real, "The generator's hinge loss must be aiming for real"
+            return G.hinge_losses(input, mask, weight, 0, B)[0]
         total = 0
         for i, pred in enumerate(input):
             if isinstance(pred, list):

@@ -63,6 +63,231 @@ def to_nchw_f32(x_nhwc):
     return x_nhwc.permute(0, 3, 1, 2).float()
 
 
+# ------------------------------------------------------------------------------------------------ input / output glue
+def _plain_f32(*ts):
+    return all(t is None or (t.is_cuda and t.dtype == torch.float32) for t in ts)
+
+
+class MaskCatFn(torch.autograd.Function):
+    """X = cat(fake * alpha, alpha) [and cat((that, cat(real, alpha)), dim=0)] in one pass (main.py:493,503-507)"""
+
+    @staticmethod
+    def forward(ctx, fake, alpha, real):
+        fake, alpha = fake.contiguous(), alpha.contiguous()
+        n, _, h, w = fake.shape
+        real = None if real is None else real.contiguous()
+        X = torch.empty(((1 if real is None else 2) * n, 4, h, w), dtype=torch.float32, device=fake.device)
+        launch("mask_cat_fwd", ptr(fake), ptr(real), ptr(alpha), ptr(X), n, h, w, stream())
+        ctx.save_for_backward(alpha)
+        return X
+
+    @staticmethod
+    def backward(ctx, dX):
+        (alpha,) = ctx.saved_tensors
+        n, _, h, w = alpha.shape
+        dfake = torch.empty((n, 3, h, w), dtype=torch.float32, device=dX.device)
+        launch("mask_cat_bwd", ptr(dX.contiguous()), ptr(alpha), ptr(dfake), n, h, w, stream())
+        return dfake, None, None
+
+
+def mask_cat(fake, alpha, real=None):
+    """discriminator input of main.py:493 (real=None) / :503-507 (fake and real halves stacked on the batch axis)"""
+    ok = _plain_f32(fake, alpha, real) and fake.dim() == 4 and fake.shape[1] == 3 and alpha.shape[1] == 1 and \
+        (fake.shape[2] * fake.shape[3]) % 4 == 0 and (real is None or real.shape == fake.shape)
+    if ok:
+        return MaskCatFn.apply(fake, alpha, real)
+    x = torch.cat((fake * alpha, alpha), dim=1)
+    return x if real is None else torch.cat((x, torch.cat((real, alpha), dim=1)), dim=0)
+
+
+class DiscInputsFn(torch.autograd.Function):
+    """What the member discriminators do to their input before conv1 (gan.py:79-99, 192-211), for all members at once:
+    per member k: h_k = NHWC bf16 of cat(avg_pool2d(x, f_k), extra_k, pos_k) (channels padded to 8 / 16) and, with
+    g_k > 0, mask_k = avg_pool2d(avg_pool2d(x, f_k)[:, 3:4], g_k).  One launch per member forward, ONE backward launch
+    (+ one for the mesh map).  specs: tuples (f, has_extra, pos [P,h,w] | None, CP, g)."""
+
+    @staticmethod
+    def forward(ctx, x, extra, specs):
+        x = x.contiguous()
+        m, c, h, w = x.shape
+        outs, masks = [], []
+        for f, has_extra, pos, cp, g in specs:
+            ho, wo = h // f, w // f
+            e = extra.contiguous() if has_extra else None
+            out = torch.empty((m, ho, wo, cp), dtype=torch.bfloat16, device=x.device)
+            mask = torch.empty((m, 1, ho // g, wo // g), dtype=torch.float32, device=x.device) if g else None
+            launch("pool_pack_fwd", ptr(x), m, c, h, w, f, ptr(e), 0 if e is None else e.shape[1], ptr(pos),
+                   0 if pos is None else pos.shape[0], ptr(out), cp, ptr(mask), 3, g, stream())
+            outs.append(out)
+            masks.append(mask)
+        ctx.shape, ctx.specs = (m, c, h, w), specs
+        ctx.eshape = None if extra is None else tuple(extra.shape)
+        res = tuple(outs) + tuple(mk for mk in masks if mk is not None)
+        ctx.mark_non_differentiable(*[mk for mk in masks if mk is not None])
+        ctx.nout = len(outs)
+        return res
+
+    @staticmethod
+    def backward(ctx, *grads):
+        m, c, h, w = ctx.shape
+        dhs = grads[:ctx.nout]
+        live = [(g.contiguous(), sp[0], sp[3]) for g, sp in zip(dhs, ctx.specs) if g is not None]
+        dx = dextra = None
+        if ctx.needs_input_grad[0] and live:
+            dx = torch.empty((m, c, h, w), dtype=torch.float32, device=live[0][0].device)
+            a = []
+            for k in range(3):
+                a += [ptr(live[k][0]), live[k][1], live[k][2]] if k < len(live) else [None, 1, 8]
+            launch("pool_unpack_bwd", *a, ptr(dx), m, c, h, w, stream())
+        if ctx.eshape is not None and ctx.needs_input_grad[1]:
+            for g, sp in zip(dhs, ctx.specs):
+                if sp[1] and g is not None:
+                    _, e, eh, ew = ctx.eshape
+                    dextra = torch.empty(ctx.eshape, dtype=torch.float32, device=g.device)
+                    launch("unpack_range", ptr(g.contiguous()), ptr(dextra), m, eh * ew, sp[3], c, e, stream())
+        return dx, dextra, None
+
+
+def disc_inputs_ok(x, extra, specs):
+    if not _plain_f32(x, extra) or x.dim() != 4 or x.shape[1] != 4:
+        return False
+    _, c, h, w = x.shape
+    for f, has_extra, pos, cp, g in specs:
+        e = extra.shape[1] if has_extra else 0
+        p = 0 if pos is None else pos.shape[0]
+        if not lib().m355_pool_pack_ok(c, h, w, f, e, p, g) or c + e + p > cp:
+            return False
+        if has_extra and tuple(extra.shape[2:]) != (h // f, w // f):
+            return False
+    return True
+
+
+def disc_inputs(x, extra, specs):
+    """-> ([h_k NHWC bf16], [mask_k or None]) for the member discriminators described by `specs`"""
+    res = DiscInputsFn.apply(x, extra, tuple(specs))
+    n = len(specs)
+    hs, rest, masks = list(res[:n]), list(res[n:]), []
+    for sp in specs:
+        masks.append(rest.pop(0) if sp[4] else None)
+    return hs, masks
+
+
+HT_TANH, HT_POLES, HT_SYMM = 1, 2, 4
+
+
+class HeadConvFn(torch.autograd.Function):
+    """A generator head (gan.py:407-419): conv_final / conv_mesh (5x5, 64 -> 3, plain conv) followed by tanh_ /
+    adjust_poles / symmetrize_texture, on NHWC bf16 input, NCHW fp32 output.  The tail is one elementwise kernel each
+    way; its backward writes the conv's incoming gradient straight in the 8-channel NHWC bf16 layout the dgrad / wgrad
+    kernels read, together with the bias gradient.  in_slope != 1: x is the output of a LeakyReLU(in_slope) fused into
+    its producer (CbnActFn out_slope) whose backward is applied HERE to the returned grad_x."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pad_h, pad_w, mode, flags, in_slope):
+        n, h, w, cx = x.shape
+        cout, cw, kh, kw = weight.shape
+        d = C.make_desc(n, h, w, cx, cout, kh, kw, 1, pad_h, pad_w, mode, 0)
+        need_dx = ctx.needs_input_grad[0]
+        wf, wd = C.weight_prep(d, weight, want_dgrad=need_dx)
+        y = C.conv_fwd(d, x.detach(), wf, bias.detach(), True, 1.0, cin_real=cw)
+        out = torch.empty((n, cout, h, 2 * w if flags & HT_SYMM else w), dtype=torch.float32, device=x.device)
+        launch("head_tail_fwd", ptr(y), ptr(out), n, cout, h, w, flags, stream())
+        ctx.d, ctx.cw, ctx.flags, ctx.in_slope = d, cw, flags, in_slope
+        ctx.save_for_backward(x.detach(), wd, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wd, out = ctx.saved_tensors
+        d = ctx.d
+        g = torch.empty((d.N, d.H, d.W, 8), dtype=torch.bfloat16, device=x.device)
+        db = torch.empty((d.Cout,), dtype=torch.float32, device=x.device)
+        launch("head_tail_bwd", ptr(dout.contiguous()), ptr(out), ptr(g), ptr(db), d.N, d.Cout, d.H, d.W, ctx.flags, stream())
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if ctx.in_slope != 1.0 and d.pad_w_mode != C.PAD_REPLICATE:
+                dx = C.conv_dgrad(d, g, wd, cin_real=ctx.cw, mask_x=x, mask_slope=ctx.in_slope)
+            else:
+                dx = C.conv_dgrad(d, g, wd, cin_real=ctx.cw)
+                if ctx.in_slope != 1.0:   # (the replicate-pad dgrad has no fused activation backward)
+                    dx = lrelu_bwd(dx, x, ctx.in_slope)[0]
+        if ctx.needs_input_grad[1]:
+            dw = C.wgrad_finish(d, C.conv_wgrad(d, x, g, cin_real=ctx.cw, raw=True), ctx.cw)
+        return dx, dw, (db if ctx.needs_input_grad[2] else None), None, None, None, None, None
+
+
+def head_conv(x, conv, flags, in_slope=1.0):
+    """x NHWC bf16 -> head output NCHW fp32 (see HeadConvFn); `conv` is a gan.Conv2d without spectral norm"""
+    stride, pad_h, pad_w, mode = conv.m355
+    assert stride == 1 and conv.bias is not None and "weight_orig" not in conv._parameters
+    return HeadConvFn.apply(x, conv.weight, conv.bias, pad_h, pad_w, mode, int(flags), float(in_slope))
+
+
+class HingeLossFn(torch.autograd.Function):
+    """GANLoss('hinge') over a list of discriminator outputs (utils/losses.py:49-120) in one launch each way.
+    mode 1: returns (loss on samples [0, split) against target False, loss on [split, B) against target True);
+    mode 0 (generator): returns (-masked mean, unused)."""
+
+    @staticmethod
+    def forward(ctx, mode, split, weights, K, *ts):
+        import ctypes
+        preds = [t.contiguous() for t in ts[:K]]
+        masks = [None if t is None else t.contiguous() for t in ts[K:]]
+        B = preds[0].shape[0]
+        dev = preds[0].device
+        hw = [p[0].numel() for p in preds]
+        PA = ctypes.c_void_p * 3
+        pa = PA(*[ptr(p) for p in preds] + [None] * (3 - K))
+        ma = PA(*[ptr(m) for m in masks] + [None] * (3 - K))
+        ha = (ctypes.c_int * 3)(*hw + [0] * (3 - K))
+        wa = None if weights is None else (ctypes.c_float * 3)(*[float(v) for v in weights] + [0.0] * (3 - K))
+        loss2 = torch.empty(2, dtype=torch.float32, device=dev)
+        msum = torch.empty((K, B), dtype=torch.float32, device=dev)
+        launch("hinge_fwd", K, pa, ma, ha, wa, B, split, mode, ptr(loss2), ptr(msum), stream())
+        ctx.cfg = (mode, split, weights, K, B, hw)
+        ctx.save_for_backward(msum, *preds, *[m for m in masks if m is not None])
+        ctx.mask_present = [m is not None for m in masks]
+        return loss2[0:1], loss2[1:2]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        import ctypes
+        mode, split, weights, K, B, hw = ctx.cfg
+        msum, *rest = ctx.saved_tensors
+        preds, mlist = rest[:K], list(rest[K:])
+        masks = [mlist.pop(0) if present else None for present in ctx.mask_present]
+        dev = preds[0].device
+        gl = torch.cat((g0 if g0 is not None else torch.zeros(1, device=dev), g1 if g1 is not None else torch.zeros(1, device=dev)))
+        dps = [torch.empty_like(p) for p in preds]
+        PA = ctypes.c_void_p * 3
+        pa = PA(*[ptr(p) for p in preds] + [None] * (3 - K))
+        ma = PA(*[ptr(m) for m in masks] + [None] * (3 - K))
+        da = PA(*[ptr(t) for t in dps] + [None] * (3 - K))
+        ha = (ctypes.c_int * 3)(*hw + [0] * (3 - K))
+        wa = None if weights is None else (ctypes.c_float * 3)(*[float(v) for v in weights] + [0.0] * (3 - K))
+        launch("hinge_bwd", K, pa, ma, ha, wa, B, split, mode, ptr(gl.contiguous()), ptr(msum), da, stream())
+        return (None, None, None, None) + tuple(dps) + (None,) * K
+
+
+def hinge_ok(preds, masks):
+    if not isinstance(preds, (list, tuple)) or not 1 <= len(preds) <= 3:
+        return False
+    if not all(torch.is_tensor(p) and p.is_cuda and p.dtype == torch.float32 and p.dim() == 4 and p.shape[1] == 1 for p in preds):
+        return False
+    if len({p.shape[0] for p in preds}) != 1:
+        return False
+    if masks is not None:
+        for p, m in zip(preds, masks):
+            if m is not None and not (m.is_cuda and m.dtype == torch.float32 and m.shape == p.shape):
+                return False
+    return True
+
+
+def hinge_losses(preds, masks, weights, mode, split):
+    ms = [None] * len(preds) if masks is None else list(masks)
+    return HingeLossFn.apply(int(mode), int(split), None if weights is None else tuple(weights), len(preds), *preds, *ms)
+
+
 def upsample2x(x):
     """nearest x2 of an NHWC tensor (F.interpolate(scale_factor=2, mode='nearest'), gan.py:319)"""
     n, h, w, c = x.shape
@@ -330,7 +555,7 @@ class AffineActFn(torch.autograd.Function):
         a = (rstd * scale.float()).contiguous()            # [N,C]
         b = (shift.float() - mean * a).contiguous()
         y = torch.empty_like(x)
-        launch("affine_act_fwd", ptr(x), ptr(a), ptr(b), None, 0, ptr(y), n, h * w, c, float(slope), stream())
+        launch("affine_act_fwd", ptr(x), ptr(a), ptr(b), None, 0, ptr(y), n, h * w, c, float(slope), 1.0, stream())
         ctx.save_for_backward(x, a, b, scale, mean, rstd)
         ctx.cfg = (slope, batch_stats, count, sync)
         return y
@@ -374,7 +599,9 @@ class CbnActFn(torch.autograd.Function):
     one of the two moment sums backward (RCCL), replacing code/sync_batchnorm/batchnorm.py:110-131's pipes."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope, res=None, sync=False):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope, res=None, sync=False, out_slope=1.0):
+        """out_slope != 1: y = LeakyReLU_out_slope(...) on top (the activation in front of a generator head); its backward is
+        NOT applied here -- the consuming head applies it to the gradient it returns (HeadConvFn in_slope)"""
         n, h, w, c = x.shape
         x = x.contiguous()
         res_w = 0
@@ -406,7 +633,8 @@ class CbnActFn(torch.autograd.Function):
         launch("bn_finalize", ptr(part), nblk, count, ptr(cnt_dev), ptr(gamma), ptr(beta), int(gamma.stride(0)), n, c, float(eps),
                float(momentum), ptr(running_mean), ptr(running_var), ptr(mean), ptr(rstd), ptr(a), ptr(b), stream())
         y = torch.empty_like(x)
-        launch("affine_act_fwd", ptr(x), ptr(a), ptr(b), ptr(res), res_w, ptr(y), n, h * w, c, float(slope), stream())
+        launch("affine_act_fwd", ptr(x), ptr(a), ptr(b), ptr(res), res_w, ptr(y), n, h * w, c, float(slope), float(out_slope),
+               stream())
         ctx.save_for_backward(x, coef, gamma, cnt_dev)
         ctx.cfg = (slope, count, (0 if res is None else (2 if res_w else 1)), sync)
         return y
@@ -440,7 +668,7 @@ class CbnActFn(torch.autograd.Function):
         elif has_res == 2:   # adjoint of the nearest x2 upsample: sum of each 2x2 block
             dres = torch.empty((n, h // 2, w // 2, c), dtype=dy.dtype, device=dy.device)
             launch("fold2x2", ptr(dy), ptr(dres), n, h // 2, w // 2, c, stream())
-        return (dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None, None, None, None, None, dres, None)
+        return (dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None, None, None, None, None, dres, None, None)
 
 
 def _count_syncbn():
@@ -539,18 +767,22 @@ class BatchNorm2d(nn.Module):
             self.running_var.mul_(1 - self.momentum).add_(unbiased.detach(), alpha=self.momentum)
             self.num_batches_tracked += 1
 
-    def forward(self, x, gamma, beta, slope=1.0, res=None):
-        """LeakyReLU(BN(x) * (1 + gamma) + beta) [+ res]; gamma / beta [N,C]; res: residual branch, same shape as x"""
+    def forward(self, x, gamma, beta, slope=1.0, res=None, out_slope=1.0):
+        """LeakyReLU(BN(x) * (1 + gamma) + beta) [+ res]; gamma / beta [N,C]; res: residual branch, same shape as x.
+        out_slope != 1: a second LeakyReLU on the result whose BACKWARD IS LEFT TO THE CONSUMER (a generator head,
+        gan_ops.head_conv(in_slope=...)): the returned tensor must have no other consumer."""
         if _fused_ok(x):
             sync = self._is_sync()
             if self.training and gamma.dtype == torch.float32:
                 # single-launch coefficient algebra (csrc/gan_glue.hip); num_batches_tracked is bumped by the owner
                 # (Generator.forward batches it over all layers) or here when used stand-alone
                 y = CbnActFn.apply(x, gamma, beta, self.running_mean, self.running_var, self.momentum, self.eps, slope, res,
-                                   sync)
+                                   sync, out_slope)
                 if not getattr(self, "_defer_count", False):
                     self.num_batches_tracked += 1
                 return y
+        if out_slope != 1.0:
+            return _OutAct.apply(BatchNorm2d.forward(self, x, gamma, beta, slope, res), out_slope)
         if res is not None:
             return BatchNorm2d.forward(self, x, gamma, beta, slope) + _match_res(res, x)  # (subclasses change the signature)
         if _fused_ok(x):
@@ -593,12 +825,27 @@ class SynchronizedBatchNorm2d(BatchNorm2d):
     sync = True
 
 
+class _OutAct(torch.autograd.Function):
+    """(torch paths) LeakyReLU forward with an IDENTITY backward: the consumer of the result applies the activation's
+    derivative itself (same contract as CbnActFn's out_slope)."""
+
+    @staticmethod
+    def forward(ctx, x, slope):
+        return F.leaky_relu(x, slope)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
 class InstanceNorm2d(nn.Module):
     def __init__(self, ch, eps=1e-5):
         super().__init__()
         self.eps = eps
 
-    def forward(self, x, gamma, beta, slope=1.0, res=None):
+    def forward(self, x, gamma, beta, slope=1.0, res=None, out_slope=1.0):
+        if out_slope != 1.0:
+            return _OutAct.apply(self.forward(x, gamma, beta, slope, res), out_slope)
         if res is not None:
             return self.forward(x, gamma, beta, slope) + _match_res(res, x)
         xf = x.float()
@@ -608,7 +855,9 @@ class InstanceNorm2d(nn.Module):
 
 
 class NoNorm(nn.Module):
-    def forward(self, x, gamma, beta, slope=1.0, res=None):
+    def forward(self, x, gamma, beta, slope=1.0, res=None, out_slope=1.0):
+        if out_slope != 1.0:
+            return _OutAct.apply(self.forward(x, gamma, beta, slope, res), out_slope)
         if res is not None:
             return self.forward(x, gamma, beta, slope) + _match_res(res, x)
         if _fused_ok(x):

@@ -9,6 +9,7 @@ import math
 import torch
 
 from . import gan as G
+from . import gan_ops as O
 from . import parallel as P
 
 
@@ -76,25 +77,22 @@ class GanTrainer(torch.nn.Module):
         w = self._d_weight()
         if mode == 'g':
             pred_tex, pred_mesh = self.generator(noise, C, caption)
-            X_fake = torch.cat((pred_tex * X_alpha, X_alpha), dim=1)
+            X_fake = O.mask_cat(pred_tex, X_alpha)                     # cat((pred_tex * X_alpha, X_alpha), dim=1)
             disc, mask = self.discriminator(X_fake, pred_mesh, C, caption)
             loss = self.criterion_gan(disc, True, for_discriminator=False, mask=mask, weight=w)
             return loss, pred_tex, pred_mesh
         if mode == 'd':
             with torch.no_grad():
                 pred_tex, pred_mesh = self.generator(noise, C, caption)
-                X_fake = torch.cat((pred_tex * X_alpha, X_alpha), dim=1)
-                X_real = torch.cat((X_tex, X_alpha), dim=1)
                 assert (X_mesh is None) == (pred_mesh is None)
-                X_comb = torch.cat((X_fake, X_real), dim=0)
+                # cat((cat((pred_tex * X_alpha, X_alpha), 1), cat((X_tex, X_alpha), 1)), 0) in one pass
+                X_comb = O.mask_cat(pred_tex, X_alpha, X_tex)
                 C_comb = torch.cat((C, C), dim=0) if C is not None else None
                 M_comb = torch.cat((pred_mesh, X_mesh), dim=0) if pred_mesh is not None else None
             cap_comb = [torch.cat((t, t), dim=0) for t in caption] if caption is not None else None
             disc, mask = self.discriminator(X_comb, M_comb, C_comb, cap_comb)
-            d_fake, d_real = divide_pred(disc)
-            m_fake, m_real = divide_pred(mask)
-            loss_fake = self.criterion_gan(d_fake, False, for_discriminator=True, mask=m_fake, weight=w)
-            loss_real = self.criterion_gan(d_real, True, for_discriminator=True, mask=m_real, weight=w)
+            # divide_pred + the two criterion calls of main.py:516-519
+            loss_fake, loss_real = self.criterion_gan.d_losses(disc, mask, w)
             return loss_fake, loss_real, pred_tex, pred_mesh
         with torch.no_grad():
             return self.generator_running_avg(noise, C, caption, return_attention=True)

@@ -39,6 +39,39 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (2:1-sparsity marketing figure excluded)
+VALU_FP32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: peak FP32 (vector)
+
+
+def roofline_proj(kt, B, N, S, ntaps=21):
+    """The projection kernels (k_render21 forward / backward) three ways, per launch, from the same HIP-event times:
+      volume : SURVEY 8d's operator-granular bytes (the S^3 occupancy volume written once and read once per producer /
+               consumer pair) -- what an HBM-streaming implementation would move; the north star's ">= 50 %" figure;
+      io     : the bytes the fused kernels really have to move (records in, silhouette / gradient slots out) -- the
+               volume lives in LDS, so this is what HBM sees (rocprofv3 FETCH/WRITE: profiles/pmc_traffic.json);
+      valu   : the fp32 vector work that cannot be fused away: the 21-tap depth convolution, 2*ntaps FLOP per voxel
+               forward, twice that backward (forward recompute + transposed convolution).  The kernels are bound HERE
+               (plus the fp64 prefix product and the DPP scans), not by HBM: `frac` of the 157.3 TF vector peak."""
+    out = {"bound": "valu", "peak_hbm_GBps": HBM_PEAK_GBS, "peak_valu_fp32_TFLOPs": VALU_FP32_PEAK_TF}
+    vox = float(B) * S ** 3
+    legs = {"fwd": ("proj_render_fwd", B * (16.0 * 4 * N + 4 * S * S + 24), 2.0 * ntaps * vox),
+            "bwd": ("proj_render_bwd", B * (16.0 * 4 * N + 4 * S * S + 48.0 * N + 24), 4.0 * ntaps * vox)}
+    for leg, (name, io_bytes, flops) in legs.items():
+        if name not in kt:
+            continue
+        cnt, ms, work = kt[name]
+        sec = ms * 1e-3 / cnt
+        out[leg] = {"avg_us": sec * 1e6, "volume_bytes": work / cnt, "volume_GBps": work / cnt / sec / 1e9,
+                    "volume_frac_of_hbm_peak": work / cnt / sec / 1e9 / HBM_PEAK_GBS,
+                    "io_bytes": io_bytes, "io_GBps": io_bytes / sec / 1e9, "io_frac_of_hbm_peak": io_bytes / sec / 1e9 / HBM_PEAK_GBS,
+                    "valu_floor_flops": flops, "valu_TFLOPs": flops / sec / 1e12,
+                    "valu_frac_of_fp32_peak": flops / sec / 1e12 / VALU_FP32_PEAK_TF}
+    if "fwd" in out and "bwd" in out:
+        sec = (out["fwd"]["avg_us"] + out["bwd"]["avg_us"]) * 1e-6
+        vol = out["fwd"]["volume_bytes"] + out["bwd"]["volume_bytes"]
+        out["volume_GBps"] = vol / sec / 1e9
+        out["frac"] = vol / sec / 1e9 / HBM_PEAK_GBS      # the SURVEY 8d / north-star figure (fwd + bwd)
+        out["bwd_over_fwd"] = out["bwd"]["avg_us"] / out["fwd"]["avg_us"]
+    return out
 
 
 def make_clouds(B, N, S, seed, device):
@@ -97,7 +130,7 @@ def cpu_baseline(N, S, seconds_budget=8.0):
         if el > seconds_budget or done >= 64:
             break
     cores = os.cpu_count() or 1
-    n_par = max(cores, min(4 * cores, int(cores * seconds_budget / max(el / done, 1e-3))))
+    n_par = max(cores, min(2 * cores, int(cores * seconds_budget / max(el / done, 1e-3))))
     t1 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
         list(ex.map(one, range(1000, 1000 + n_par)))
@@ -111,8 +144,8 @@ def cpu_baseline(N, S, seconds_budget=8.0):
 def cpu_baseline_gan(trainer, R, seconds_budget=10.0):
     """The GAN half beside the HIP path: oracle/gan_cpu.py (fp32 torch-CPU restatement of models/gan.py + utils/losses.py +
     Adam, pinned to the reference's goldens by tests/test_oracle_golden.py) running the SAME cycle (1 G step + 2 D steps incl.
-    the Adam updates) from the drop-in's own weights, batch 2 per step (6 textures per cycle), on all cores and on 1 thread
-    (the reference's scripts force OMP_NUM_THREADS=1, code/main.py:3)."""
+    the Adam updates) from the drop-in's own weights, batch 2 per step (6 textures per cycle), multi-threaded (`cores` =
+    threads used) and on 1 thread (the reference's scripts force OMP_NUM_THREADS=1, code/main.py:3)."""
     from oracle import gan_cpu as gc
 
     args = trainer.args
@@ -144,7 +177,9 @@ def cpu_baseline_gan(trainer, R, seconds_budget=10.0):
 
     out = {}
     nthr = torch.get_num_threads()
-    cores = os.cpu_count() or 1
+    # oneDNN on every hardware thread of a 2 x 64-core host is far slower than on a few (measured: 256 threads 0.02
+    # samples/s, 1 thread 1.7): the multi-thread leg uses one thread per 8 hardware threads, at most 32
+    cores = max(1, min(32, (os.cpu_count() or 1) // 8))
     try:
         for key, thr in (("all", cores), ("one", 1)):
             torch.set_num_threads(thr)
@@ -358,7 +393,9 @@ def main():
                                  "SURVEY 8d volume-based bytes for the projection kernels, which keep the volume in "
                                  "LDS) / HIP-event time on the launch stream; traffic = HBM bytes per launch from "
                                  "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/pmc_traffic.json, "
-                                 "(2*FETCH+WRITE)*1024, gfx950 fetch correction), null if not collected"},
+                                 "(2*FETCH+WRITE)*1024, gfx950 fetch correction), null if not collected",
+                         "traffic_source": "profiles/pmc_traffic.json" if traffic is not None else None},
+            "roofline_proj": roofline_proj(kt, B, N, S) if do_p else None,
             "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(kt.items(), key=lambda kv: -kv[1][1])},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -210,9 +210,11 @@ int m355_bn_stats(const void *x, float *sums, void *ws, size_t P, int C, void *s
 int m355_chan_sum(const void *x, float *sums, void *ws, size_t P, int C, void *stream);
 /*      y = LeakyReLU_slope(x * a[n,c] + b[n,c]) [+ res];  x,y,res [N][HW][C];  a = rstd*(1+gamma), b = beta - mean*a;
  *      res (nullable): the residual branch of ResBlockUp (gan.py:312) added in the same pass; res_w > 0: res is stored
- *      at half resolution [N][H/2][res_w/2][C] and read through the nearest x2 upsample (res_w = full-res width) */
+ *      at half resolution [N][H/2][res_w/2][C] and read through the nearest x2 upsample (res_w = full-res width);
+ *      out_slope != 1: y = LeakyReLU_out_slope(that) -- the activation Generator.forward applies to a block's output in
+ *      front of conv_final / conv_mesh (gan.py:406,410), whose backward the consuming conv's dgrad applies (mask_x) */
 int m355_affine_act_fwd(const void *x, const float *a, const float *b, const void *res, int res_w, void *y, int N, int HW,
-                        int C, float slope, void *stream);
+                        int C, float slope, float out_slope, void *stream);
 /*      dz = dy * LeakyReLU'(x*a+b);  sums[N][2][C] = (sum_hw dz, sum_hw dz*x) */
 int m355_affine_act_bwd_reduce(const void *dy, const void *x, const float *a, const float *b, float *sums, void *ws,
                                int N, int HW, int C, float slope, void *stream);
@@ -278,6 +280,45 @@ int m355_bn_bwd_finalize(const float *part, int nblk, float count, const float *
  *      (code/sync_batchnorm/batchnorm.py:110-131 sums the real sizes the same way). */
 int m355_bn_bwd_coeffs(const float *m, float count, const float *count_dev, const float *mean, const float *rstd, int C,
                        float *Bc, float *Cc, void *stream);
+
+/* ---- input / output glue of the GAN stacks (csrc/gan_io.hip); all tensors fp32 NCHW unless stated
+ *      ModelWrapper.forward, code/main.py:493,503-507: X = cat(fake * alpha, alpha) [N,4,H,W]; with `real` non-NULL the
+ *      batch concatenation with cat(real, alpha) in the same pass: X [2N,4,H,W].  _bwd: dfake = dX[:N,:3] * alpha. */
+int m355_mask_cat_fwd(const float *fake, const float *real, const float *alpha, float *X, int N, int H, int W, void *stream);
+int m355_mask_cat_bwd(const float *dX, const float *alpha, float *dfake, int N, int H, int W, void *stream);
+/*      TextureDiscriminator / MeshDiscriminator.forward up to conv1, code/models/gan.py:79-99,192-211:
+ *      out[m,y,x,:] (NHWC bf16, CP = 8 | 16 channels, zero filled) = avg_pool2d(x, f)[m,:,y,x] ++ extra[m,:,y,x] ++ pos[:,y,x];
+ *      mask (nullable) [M,H/(f g),W/(f g)] = avg_pool2d(avg_pool2d(x, f)[:, mask_chan], g).  m355_pool_pack_ok: shapes
+ *      the kernel takes (C <= 4, f in 1,2,4,8,16, pooled H and W multiples of 16, g in 4,8,16). */
+int m355_pool_pack_ok(int C, int H, int W, int f, int E, int P, int g);
+int m355_pool_pack_fwd(const float *x, int M, int C, int H, int W, int f, const float *extra, int E, const float *pos, int P,
+                       void *out, int CP, float *mask, int mask_chan, int g, void *stream);
+/*      adjoint with respect to x for up to three packed tensors of the same x (dh_k [M,H/f_k,W/f_k,cp_k] bf16, NULL ends
+ *      the list): dx[m,c,y,x] = sum_k dh_k[m,y/f_k,x/f_k,c] / f_k^2;  m355_unpack_range: channels c0..c0+E-1 of an NHWC
+ *      bf16 tensor -> [M,E,HW] fp32 (the gradient of `extra`) */
+int m355_pool_unpack_bwd(const void *dh0, int f0, int cp0, const void *dh1, int f1, int cp1, const void *dh2, int f2, int cp2,
+                         float *dx, int M, int C, int H, int W, void *stream);
+int m355_unpack_range(const void *g, float *out, int M, int HW, int CP, int c0, int E, void *stream);
+/*      Generator.forward after conv_final / conv_mesh, code/models/gan.py:407-419: flags M355_HT_TANH (tanh_),
+ *      M355_HT_POLES (adjust_poles, rendering/utils.py:21-26), M355_HT_SYMM (symmetrize_texture, rendering/utils.py:15-18:
+ *      out width 2W).  y [N,C<=3,H,W] -> out.  _bwd: dout, out -> g [N,H,W,8] bf16 (the layout m355_conv2d_dgrad / _wgrad
+ *      expect of a 3-channel head's dy) and dbias[C]. */
+#define M355_HT_TANH 1
+#define M355_HT_POLES 2
+#define M355_HT_SYMM 4
+int m355_head_tail_fwd(const float *y, float *out, int N, int C, int H, int W, int flags, void *stream);
+int m355_head_tail_bwd(const float *dout, const float *out, void *g_nhwc8, float *dbias, int N, int C, int H, int W, int flags,
+                       void *stream);
+/*      GANLoss('hinge') over the K <= 3 discriminator outputs, code/utils/losses.py:49-120, with divide_pred
+ *      (code/main.py:414-422) done by index: p[k] / m[k] (HOST arrays of K device pointers; m or m[k] NULL = unmasked)
+ *      are [B,hw[k]]; samples [0,split) are the "fake" half (slot 0), [split,B) the "real" half (slot 1).
+ *      mode 1 (discriminator): loss2[0] = loss vs target False on the fake half, loss2[1] = loss vs target True on the real
+ *      half; mode 0 (generator, split = B): loss2[0] = -mean.  w (nullable): per-discriminator weights (main.py:486-489).
+ *      msum [K,B]: per-sample mask sums kept for the backward; _bwd: gl2[2] incoming gradients -> dp[k] [B,hw[k]]. */
+int m355_hinge_fwd(int K, const float *const *p, const float *const *m, const int *hw, const float *w, int B, int split, int mode,
+                   float *loss2, float *msum, void *stream);
+int m355_hinge_bwd(int K, const float *const *p, const float *const *m, const int *hw, const float *w, int B, int split, int mode,
+                   const float *gl2, const float *msum, float *const *dp, void *stream);
 
 /* Projection discriminator (code/models/gan.py:104-116, 216-228): out[n,p] = sum_c feat[n,p,c] * emb[n,c] on the NHWC bf16
  * feature map (C a power of two in 8..2048); backward: dfeat = g * emb (bf16, overwritten), demb[n,c] = sum_p g * feat. */
