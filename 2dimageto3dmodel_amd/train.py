@@ -42,11 +42,14 @@ class GanTrainer(torch.nn.Module):
         # main.py:152,697-705: flat_loss = loss_flat(mesh, compute_normals(get_vertex_positions(pred_mesh))) joins the G loss
         self.mesh_template, self.mesh_regularization = (mesh_template if use_mesh else None), mesh_regularization
         self.args, self.latent_dim, self.d_steps_per_g, self.ema_alpha = args, latent_dim, d_steps_per_g, ema_alpha
+        # main.py:541-545: the discriminator is constructed first (it is an argument of ModelWrapper(...)), then the two
+        # generators -- same order here, so a run under the same torch.manual_seed starts from the reference's weights
+        discriminator = G.MultiScaleDiscriminator(args, 4)
         self.generator = G.Generator(args, latent_dim, symmetric=symmetric_g, mesh_head=use_mesh)
-        self.generator_running_avg = copy.deepcopy(self.generator)          # main.py:453-457
+        self.generator_running_avg = copy.deepcopy(self.generator)          # main.py:453-457 (instantiate + load_state_dict)
         for p in self.generator_running_avg.parameters():
             p.requires_grad = False
-        self.discriminator = G.MultiScaleDiscriminator(args, 4)
+        self.discriminator = discriminator
         self.criterion_gan = G.GANLoss(loss)
         self.to(device)
         for m in (self.generator, self.generator_running_avg, self.discriminator):

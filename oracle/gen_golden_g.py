@@ -191,12 +191,14 @@ def run_train4(ref_gan, GANLoss, name="g_train4", seed=4401, B=2, iters=4, epoch
     args = make_args(texture_resolution=128)
     torch.manual_seed(seed)
     with contextlib.redirect_stdout(io.StringIO()):
+        # construction order of main.py:541-545: the discriminator is an ARGUMENT of ModelWrapper(...) (built first), then
+        # ModelWrapper.__init__ instantiates the generator and the running-average generator (main.py:453-457)
+        D = ref_gan.MultiScaleDiscriminator(args, 4)
         G = ref_gan.Generator(args, 64, symmetric=True, mesh_head=True)
         G_avg = ref_gan.Generator(args, 64, symmetric=True, mesh_head=True)
-        G_avg.load_state_dict(G.state_dict())                                     # main.py:453-457
+        G_avg.load_state_dict(G.state_dict())
         for p in G_avg.parameters():
             p.requires_grad = False
-        D = ref_gan.MultiScaleDiscriminator(args, 4)
     crit = GANLoss("hinge", tensor=torch.FloatTensor)
     opt_g = torch.optim.Adam(G.parameters(), lr=1e-4, betas=(0.0, 0.9))            # main.py:588-589, defaults :109-110
     opt_d = torch.optim.Adam(D.parameters(), lr=4e-4, betas=(0.0, 0.9))

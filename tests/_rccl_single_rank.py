@@ -58,5 +58,6 @@ l1, w1, st, ms = run(True)
 l0, w0, st0, _ = run(False)
 dist.destroy_process_group()
 print(json.dumps({"losses_rccl": l1, "losses_plain": l0, "max_w_diff": float((w1 - w0).abs().max()),
+                  "frac_w_diff": float(((w1 - w0).abs() > 1e-6).float().mean()),
                   "grad_allreduces": st["grad_allreduces"], "n_cbn": st["n_cbn"], "syncbn_collectives": st["syncbn_collectives"],
                   "allreduce_ms": ms, "plain_collectives": st0["grad_allreduces"] + st0["syncbn_collectives"]}))

@@ -138,7 +138,8 @@ def test_head_conv_with_fused_block_activation(symmetric):
     b_r = conv.bias.detach().cpu().clone().requires_grad_()
     mean, var = xr.mean((0, 1, 2)), xr.var((0, 1, 2), unbiased=False)
     hcb = F.leaky_relu((xr - mean) * torch.rsqrt(var + 1e-5) * (1 + gr[:, None, None, :]) + br[:, None, None, :], 0.2) + res.float()
-    t = F.leaky_relu(hcb, 0.2).bfloat16().float() + (F.leaky_relu(hcb, 0.2) - F.leaky_relu(hcb, 0.2).detach())   # bf16 activations, fp32 grads
+    act = F.leaky_relu(hcb, 0.2)
+    t = act.detach().bfloat16().float() + (act - act.detach())   # value: the bf16 activation; gradient: straight through
     tn = t.permute(0, 3, 1, 2)
     tp = F.pad(tn, (2, 2, 0, 0), mode="replicate") if symmetric else torch.cat((tn[..., -2:], tn, tn[..., :2]), 3)
     o = torch.tanh(F.conv2d(tp, wr, b_r, padding=(2, 0)))
