@@ -82,15 +82,21 @@ constexpr int halo_dmas_behind(int tap)
     return n;
 }
 
-template <int BN, int NW, int KS, int UPS, int MODE, int SUB = 1, int RES = 0>
+// PAIR = 1: stride-2 dgrad with 64 input channels (D.conv2): the two column-parity classes (py, 0) and (py, 1) of one row
+// parity share ONE workgroup and ONE dy halo (one column wider): the wave columns wn = 0 / 1, which otherwise hold two
+// 64-channel halves of the output, hold the two classes' 64 channels.  The single-class kernel for this layer is the 4-wave
+// (one wave per SIMD) variant -- 630 TF, nothing to hide its LDS latency behind -- while the 128-channel layers run the 8-wave
+// variant at 1100-1200 TF; pairing the classes gives this layer the same 8-wave shape and halves its dy traffic into LDS.
+template <int BN, int NW, int KS, int UPS, int MODE, int SUB = 1, int RES = 0, int PAIR = 0>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs a, unsigned xbytes, unsigned wbytes)
 {
     static_assert(SUB == 1 || (KS == 2 && !UPS), "stride-2 forward = 2x2 classes");
+    static_assert(!PAIR || (BN == 128 && NW == 8 && KS == 2 && !UPS && SUB == 1 && !RES), "class pairs: 8-wave 2x2 class convs");
     constexpr int NC = SUB == 2 ? 4 : 1;  // classes accumulated into one output tile
     constexpr int TH = 8, TW = 32;
     constexpr int T = KS * KS;
     constexpr int HH = UPS ? TH / 2 + 2 : TH + KS - 1;   // halo rows / columns (stored pixels)
-    constexpr int HWD = UPS ? TW / 2 + 2 : TW + KS - 1;
+    constexpr int HWD = UPS ? TW / 2 + 2 : TW + KS - 1 + PAIR;   // (PAIR: the union of the two classes' column windows)
     constexpr int HR = HH * HWD;                          // LDS rows of a halo buffer
     constexpr int NA = (HR + 7) / 8;                      // DMA instructions per halo
     constexpr int NAW = (NA + NW - 1) / NW;               //   ... per wave
@@ -119,15 +125,22 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
     // ---- persistent workgroup: N tile tn and (blockIdx.y) parity class are fixed, the pixel tiles bp, bp + PS, ...
     // are visited in turn; the stream of (tile, channel chunk) pairs is continuous, so the NEXT tile's first halo is
     // prefetched by the same slice mechanism and the weight ring simply wraps around (same weights for every tile).
-    const int nN = a.CoutP / BN;
+    const int nN = PAIR ? 1 : a.CoutP / BN;
     const int tn = blockIdx.x % nN, bp = blockIdx.x / nN, PS = gridDim.x / nN;
     const int tpx = a.Wo / TW, tpy = a.Ho / TH, tiles_p = a.N * tpx * tpy;
     const int n0 = tn * BN;
     if (bp >= tiles_p) return;
 
     int pad_h = a.pad_h, pad_w = a.pad_w, oy_off = a.oy_off, ox_off = a.ox_off;
+    int xsh = 0;  // PAIR: column of this wave's class window inside the shared halo
     const unsigned short *wv = a.w;
-    if (a.ncls > 1) {
+    if (PAIR) {
+        const int c0 = 2 * blockIdx.y, cls = c0 + (wave % WGN);   // classes (py, 0), (py, 1); this wave's = (py, wn)
+        const int pw = max(a.cpad_w[c0], a.cpad_w[c0 + 1]);
+        pad_h = a.cpad_h[c0]; oy_off = a.coy[c0];                 // (row padding / offset depend on py only)
+        pad_w = pw; xsh = pw - a.cpad_w[cls]; ox_off = a.cox[cls];
+        wv += (size_t)c0 * a.cls_w_elems;
+    } else if (a.ncls > 1) {
         const int cls = blockIdx.y;
         pad_h = a.cpad_h[cls]; pad_w = a.cpad_w[cls]; oy_off = a.coy[cls]; ox_off = a.cox[cls];
         wv += (size_t)cls * a.cls_w_elems;
@@ -186,7 +199,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
     using KN = std::integral_constant<int, NAW>;
     unsigned wrow[NBW];
 #pragma unroll
-    for (int j = 0; j < NBW; ++j) wrow[j] = (unsigned)(n0 + 8 * (NW * j + wave) + (lane >> 3)) * (unsigned)(a.Kp * 2) + csrc * 16;
+    for (int j = 0; j < NBW; ++j) {
+        const unsigned row = (unsigned)(n0 + 8 * (NW * j + wave) + (lane >> 3));
+        // PAIR: LDS rows 0..63 = the 64 output channels of class (py, 0), rows 64..127 = those of class (py, 1)
+        wrow[j] = PAIR ? (row & 63u) * (unsigned)(a.Kp * 2) + (row >> 6) * (a.cls_w_elems * 2u) + csrc * 16
+                       : row * (unsigned)(a.Kp * 2) + csrc * 16;
+    }
 
     const int ncc = a.Cin >> 6, NSEG = NC * ncc;
 
@@ -280,7 +298,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
         const unsigned char *bs = fb + slot_ * BBUF;
 #pragma unroll
         for (int i = 0; i < PI; ++i) {
-            const int ly = 2 * wm + i + kh, lx = tx + kw;
+            const int ly = 2 * wm + i + kh, lx = tx + kw + (PAIR ? xsh : 0);
             const int rho = UPS ? ((ly + ey) >> 1) * HWD + ((lx + ex) >> 1) : ly * HWD + lx;
             const int rowa = rho * 128, swa = (rho >> 1) & 7;
 #pragma unroll
@@ -350,7 +368,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
 #pragma unroll
             for (int i = 0; i < PI; ++i) {
                 const size_t pix = ((size_t)n * a.OH + ((oy0 + 2 * wm + i) * a.oy_mul + oy_off)) * a.OW + ((ox0 + tx) * a.ox_mul + ox_off);
-                rbits_pf[i] = a.bits_in[(pix * (size_t)(a.Cs >> 6) + (size_t)((n0 >> 6) + wn)) * 2 + half];
+                rbits_pf[i] = a.bits_in[(pix * (size_t)(a.Cs >> 6) + (size_t)(PAIR ? 0 : (n0 >> 6) + wn)) * 2 + half];
             }
         }
         for (int sg = 0; sg < NSEG; ++sg) {
@@ -464,13 +482,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                 const size_t pix = (GUARD && a.fold2) ? ((size_t)n * a.OH + (ho >> 1)) * a.OW + (wo >> 1)
                                                       : ((size_t)n * a.OH + (ho * a.oy_mul + oy_off)) * a.OW + (wo * a.ox_mul + ox_off);
                 // bit masks (unguarded variants only): this lane's 32 channels of pixel `pix` are one word
-                const size_t bword = (pix * (size_t)(a.Cs >> 6) + (size_t)((n0 >> 6) + wn)) * 2 + half;
+                const size_t bword = (pix * (size_t)(a.Cs >> 6) + (size_t)(PAIR ? 0 : (n0 >> 6) + wn)) * 2 + half;
                 unsigned wbits = 0, rbits = 0;
                 const bool use_bits = !GUARD && MASK && a.bits_in != nullptr, emit_bits = !GUARD && !PLAIN && a.bits_out != nullptr;
                 if (use_bits) rbits = rbits_pf[i];
 #pragma unroll
                 for (int j = 0; j < CJ; ++j) {
-                    const int cbase = n0 + wn * 64 + 32 * j;
+                    const int cbase = (PAIR ? 0 : n0 + wn * 64) + 32 * j;   // (PAIR: both wave columns write channels 0..63)
                     const bool masked = MASK && (!GUARD || a.mask_x) && !use_bits;
                     uint2 mk[4];
                     if (masked) {
@@ -895,6 +913,23 @@ int conv_halo_launch(const ConvArgs &a, unsigned xb, unsigned wb, hipStream_t st
         else if (a.ups) M355_HM(BN_, NW_, 3, 1);                       \
         else M355_HM(BN_, NW_, 3, 0);                                  \
     } while (0)
+    // class pairs (see k_conv_halo PAIR): the 2x2 class convs of a stride-2 dgrad with 64 input channels
+    const bool pair = a.ncls == 4 && a.CoutP == 64 && a.Cout == 64 && a.stride == 1 && a.KH == 2 && a.KW == 2 && !a.ups && !a.fold2 &&
+                      !a.bias && a.cpad_h[0] == a.cpad_h[1] && a.cpad_h[2] == a.cpad_h[3] && a.coy[0] == a.coy[1] &&
+                      a.coy[2] == a.coy[3] && !getenv("M355_NO_HALO_PAIR");
+    if (pair) {
+        int pp = (wgs ? atoi(wgs) : 256) / 2;
+        if (pp < 1) pp = 1;
+        if (pp > tiles) pp = tiles;
+        pp = (tiles + (tiles + pp - 1) / pp - 1) / ((tiles + pp - 1) / pp);
+        const dim3 gridp((unsigned)pp, 2);
+        const unsigned wb2 = 2u * a.cls_w_elems * 2u;   // the resource spans the two classes of a pair
+        if (a.pad_w_mode == 0) hipLaunchKernelGGL((k_conv_halo<128, 8, 2, 0, 0, 1, 0, 1>), gridp, dim3(512), 0, st, a, xb, wb2);
+        else if (a.pad_w_mode == 1) hipLaunchKernelGGL((k_conv_halo<128, 8, 2, 0, 1, 1, 0, 1>), gridp, dim3(512), 0, st, a, xb, wb2);
+        else hipLaunchKernelGGL((k_conv_halo<128, 8, 2, 0, 2, 1, 0, 1>), gridp, dim3(512), 0, st, a, xb, wb2);
+        note_kernel("k_conv_halo");
+        return check_launch("conv2d (halo, class pairs)");
+    }
     const dim3 grid((unsigned)per * nN, a.ncls);
     // resident weight panel (64 output channels x K <= 576)
     const bool res = a.CoutP == 64 && a.stride == 1 && !a.ups && ((a.KH == 2 && a.Cin <= 128) || (a.KH == 3 && a.Cin == 64)) &&

@@ -252,7 +252,8 @@ class Generator(nn.Module):
             for m in layers:
                 if isinstance(m.norm, G.BatchNorm2d):
                     m.norm._defer_count = True
-                    self.__dict__["_nbt"].append(m.norm.num_batches_tracked)
+                    if not m.norm.sync:   # SynchronizedBatchNorm2d never counts its batches (batchnorm.py:66-98)
+                        self.__dict__["_nbt"].append(m.norm.num_batches_tracked)
         if not layers:
             return None
         ws = [w for m in layers for w in (m.fc_gamma.weight, m.fc_beta.weight)]

@@ -765,7 +765,8 @@ class BatchNorm2d(nn.Module):
             unbiased = var * (cnt / (cnt - 1)) if float(cnt) > 1 else var
             self.running_mean.mul_(1 - self.momentum).add_(mean.detach(), alpha=self.momentum)
             self.running_var.mul_(1 - self.momentum).add_(unbiased.detach(), alpha=self.momentum)
-            self.num_batches_tracked += 1
+            if not self.sync:   # (the reference's SynchronizedBatchNorm2d.forward never counts, batchnorm.py:66-98)
+                self.num_batches_tracked += 1
 
     def forward(self, x, gamma, beta, slope=1.0, res=None, out_slope=1.0):
         """LeakyReLU(BN(x) * (1 + gamma) + beta) [+ res]; gamma / beta [N,C]; res: residual branch, same shape as x.
@@ -778,7 +779,7 @@ class BatchNorm2d(nn.Module):
                 # (Generator.forward batches it over all layers) or here when used stand-alone
                 y = CbnActFn.apply(x, gamma, beta, self.running_mean, self.running_var, self.momentum, self.eps, slope, res,
                                    sync, out_slope)
-                if not getattr(self, "_defer_count", False):
+                if not getattr(self, "_defer_count", False) and not self.sync:
                     self.num_batches_tracked += 1
                 return y
         if out_slope != 1.0:
@@ -821,7 +822,8 @@ class BatchNorm2d(nn.Module):
 
 
 class SynchronizedBatchNorm2d(BatchNorm2d):
-    """sync_batchnorm.SynchronizedBatchNorm2d(ch, affine=False): statistics over the global batch."""
+    """sync_batchnorm.SynchronizedBatchNorm2d(ch, affine=False): statistics over the global batch.  As in the reference
+    (sync_batchnorm/batchnorm.py:66-98: its forward bypasses nn.BatchNorm2d.forward), num_batches_tracked stays 0."""
     sync = True
 
 

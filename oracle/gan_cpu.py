@@ -93,7 +93,7 @@ def cbn(w, name, x, z, norm, training):
     if norm in ("batch", "syncbatch"):   # sync_batchnorm/batchnorm.py:70-73: F.batch_norm on one device
         n = c.sub("norm")
         x = F.batch_norm(x, n["running_mean"], n["running_var"], None, None, training, 0.1, 1e-5)
-        if training:
+        if training and norm == "batch":   # nn.BatchNorm2d counts; SynchronizedBatchNorm2d.forward does not (batchnorm.py:66-98)
             n["num_batches_tracked"].add_(1)
     elif norm == "instance":
         x = F.instance_norm(x)

@@ -240,3 +240,35 @@ def test_wgrad_halo_class_variants(pkg, case, variant, monkeypatch):
     assert (dw - w.grad).abs().max().item() < 2e-4 * w.grad.abs().max().item()
     want = dy.sum((0, 2, 3))
     assert (db.cpu() - want).abs().max().item() < 1e-3 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("wgs", [None, "4"])
+@pytest.mark.parametrize("case", [(3, 32, 128, 64, 128, 4, 2, 1, 1, 2, 0), (2, 16, 64, 64, 256, 4, 2, 1, 1, 0, 0),
+                                  (1, 64, 64, 64, 128, 4, 2, 1, 1, 2, 0)])
+def test_stride2_dgrad_class_pairs(pkg, case, wgs, monkeypatch):
+    """stride-2 dgrad with 64 input channels (D.conv2): the class-pair variant of k_conv_halo (two column-parity classes per
+    workgroup on one shared dy halo) against torch autograd, against the one-class-per-workgroup launch (same MFMA
+    order -> identical bits), and with the fused LeakyReLU backward from the bf16 activation"""
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    if wgs:
+        monkeypatch.setenv("M355_HALO_WGS", wgs)
+    N, H, W, Cin, Cout, k, stride, ph, pw, mode, ups = case
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(N, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).bfloat16().float()
+    xr = x.clone().requires_grad_()
+    y_ref = ref_conv(xr, w, None, stride, ph, pw, mode, ups)
+    dy = torch.randn(y_ref.shape, generator=g).bfloat16().float()
+    y_ref.backward(dy)
+    d = conv.make_desc(N, H, W, Cin, Cout, k, k, stride, ph, pw, mode, ups)
+    _, wd = conv.weight_prep(d, w.to(DEV))
+    dy_nhwc = dy.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    for _ in range(2):
+        dx = conv.conv_dgrad(d, dy_nhwc, wd)
+        assert conv.lib().m355_last_kernel().decode() == "k_conv_halo"
+        assert (dx.float().cpu().permute(0, 3, 1, 2) - xr.grad).abs().max().item() / xr.grad.abs().max().item() < 1.2e-2
+    dxm = conv.conv_dgrad(d, dy_nhwc, wd, mask_x=x_nhwc, mask_slope=0.2)
+    monkeypatch.setenv("M355_NO_HALO_PAIR", "1")
+    assert torch.equal(conv.conv_dgrad(d, dy_nhwc, wd), dx)
+    assert torch.equal(conv.conv_dgrad(d, dy_nhwc, wd, mask_x=x_nhwc, mask_slope=0.2), dxm)

