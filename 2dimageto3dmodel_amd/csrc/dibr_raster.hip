@@ -1,0 +1,325 @@
+// the DIB-R linear rasteriser behind Renderer.forward (rendering/renderer.py:39-77), i.e. the function
+// `kaolin.graphics.dib_renderer.rasterizer.linear_rasterizer(height, width, points3d_bxfx9, points2d_bxfx6,
+// normalz_bxfx1, vertex_attr_bxfx3d)` the reference imports (renderer.py:1,62-69) -- Kaolin is not in this image, so the
+// published algorithm (Chen et al., NeurIPS 2019; kaolin defaults expand 0.02, knum 30, delta 7000) is built here from
+// scratch, MI355X-first; oracle/raster_ref.py states the same algorithm per pixel in torch (parity unpinned, see there).
+//
+//   k_rast_setup   per face: screen-space bounding box grown by `expand` (EMPTY for back-facing / degenerate faces)
+//   k_rast_fwd     one workgroup per 16 x 16 pixel tile, one pixel per lane.  The faces are scanned 256 at a time: a lane
+//                  tests ONE face's box against the tile, the hits are compacted IN FACE ORDER (ballot + popcount: the
+//                  `first knum faces` rule is an order rule) together with their vertices into LDS, and every lane then
+//                  walks that short list for its own pixel:
+//                     hard pass  barycentric inside test, keep the largest interpolated z     -> imidx, imwei, imfeat
+//                     soft pass  prod_j (1 - exp(-delta d_j^2)) over the first knum boxed faces -> improb
+//                  No per-tile face lists in HBM, no [B,H,W,knum] side buffers: the backward recomputes.
+//   k_rast_bwd     same tiling.  Covered pixels scatter d imfeat through their saved weights (to the attributes and,
+//                  through the barycentric weights, to the face's 2-D vertices); uncovered pixels re-walk the boxed faces
+//                  and scatter d improb through exp(-delta d^2) to the two vertices of the closest edge.  fp32 atomics.
+// Arithmetic order of the inside test mirrors the torch expressions of the oracle (file compiled with -ffp-contract=off,
+// IEEE division): the coverage decision of a pixel is the same on both sides.
+// Bound: the face-box scan reads 16 B per (tile, face) from L2 (0.5 GB per batch-64 256^2 render), everything else is
+// per-pixel VALU over ~20 faces; output 24 B per pixel.
+#include "common.h"
+
+namespace m355 {
+
+constexpr int RT = 16;          // tile side (pixels)
+constexpr int RCH = 256;        // faces scanned per round (= threads)
+
+struct RastArgs {
+    const float *p3;     // [B,F,9]
+    const float *p2;     // [B,F,6]
+    const float *nz;     // [B,F]
+    const float *attr;   // [B,F,3*D]
+    const float4 *bbox;  // [B,F] (xmin, ymin, xmax, ymax) grown; empty for culled faces
+    float *imfeat;       // [B,H,W,D]
+    float *improb;       // [B,H,W]
+    int *imidx;          // [B,H,W]
+    float *imwei;        // [B,H,W,3]
+    // backward
+    const float *dfeat;  // [B,H,W,D]
+    const float *dprob;  // [B,H,W]
+    float *dp2;          // [B,F,6]
+    float *dattr;        // [B,F,3*D]
+    int B, F, H, W, D, knum;
+    float delta;
+};
+
+__global__ __launch_bounds__(256) void k_rast_setup(const float *__restrict__ p2, const float *__restrict__ nz,
+                                                    float4 *__restrict__ bbox, int total, float expand)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const float *v = p2 + (size_t)i * 6;
+    const float ax = v[0], ay = v[1], bx = v[2], by = v[3], cx = v[4], cy = v[5];
+    const float e1x = bx - ax, e1y = by - ay, e2x = cx - ax, e2y = cy - ay;
+    const float area = e1x * e2y - e1y * e2x;
+    float4 bb;
+    if (nz[i] >= 0.0f && fabsf(area) > 1e-12f) {
+        bb.x = fminf(fminf(ax, bx), cx) - expand;
+        bb.y = fminf(fminf(ay, by), cy) - expand;
+        bb.z = fmaxf(fmaxf(ax, bx), cx) + expand;
+        bb.w = fmaxf(fmaxf(ay, by), cy) + expand;
+    } else {
+        bb = make_float4(2e30f, 2e30f, -2e30f, -2e30f);   // never contains a pixel
+    }
+    bbox[i] = bb;
+}
+
+__device__ __forceinline__ float cross2(float ax, float ay, float bx, float by) { return ax * by - ay * bx; }
+
+// squared distance from p to segment a-b; *t_out = clamped parameter of the closest point
+__device__ __forceinline__ float seg_d2(float px, float py, float ax, float ay, float bx, float by, float &t_out)
+{
+    const float ex = bx - ax, ey = by - ay;
+    float t = ((px - ax) * ex + (py - ay) * ey) / fmaxf(ex * ex + ey * ey, 1e-30f);
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    const float rx = px - (ax + t * ex), ry = py - (ay + t * ey);
+    t_out = t;
+    return rx * rx + ry * ry;
+}
+
+struct FaceLds {
+    float v[6];      // 2-D vertices
+    float z[3];      // depths
+    float bb[4];     // grown box
+    int id;
+};
+
+// Compacts, in face order, the faces of [base, base + 256) whose grown box overlaps the tile's pixel-centre rectangle.
+// Returns the number of faces placed in `fl`.
+__device__ __forceinline__ int scan_faces(const RastArgs &a, int b, int base, float tx0, float tx1, float ty0, float ty1,
+                                          FaceLds *fl, int *wave_cnt)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f = base + tid;
+    bool hit = false;
+    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < a.F) {
+        bb = a.bbox[(size_t)b * a.F + f];
+        hit = bb.x <= tx1 && bb.z > tx0 && bb.y <= ty1 && bb.w > ty0;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    const int n = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    if (hit) {
+        const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+        const float *v = a.p2 + ((size_t)b * a.F + f) * 6;
+        const float *p3 = a.p3 + ((size_t)b * a.F + f) * 9;
+        FaceLds &o = fl[pos];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o.v[k] = v[k];
+        o.z[0] = p3[2]; o.z[1] = p3[5]; o.z[2] = p3[8];
+        o.bb[0] = bb.x; o.bb[1] = bb.y; o.bb[2] = bb.z; o.bb[3] = bb.w;
+        o.id = f;
+    }
+    __syncthreads();
+    return n;
+}
+
+__global__ __launch_bounds__(256) void k_rast_fwd(RastArgs a)
+{
+    __shared__ FaceLds fl[RCH];
+    __shared__ int wave_cnt[4];
+    const int b = blockIdx.z, tid = threadIdx.x;
+    const int w = blockIdx.x * RT + (tid & (RT - 1)), h = blockIdx.y * RT + (tid >> 4);
+    const bool live = w < a.W && h < a.H;
+    // pixel centre (y up), and the tile's centre rectangle
+    const float px = (float)(2 * w + 1 - a.W) / (float)a.W, py = (float)(a.H - 2 * h - 1) / (float)a.H;
+    const int w0i = blockIdx.x * RT, h0i = blockIdx.y * RT;
+    const int w1i = min(w0i + RT - 1, a.W - 1), h1i = min(h0i + RT - 1, a.H - 1);
+    const float tx0 = (float)(2 * w0i + 1 - a.W) / (float)a.W, tx1 = (float)(2 * w1i + 1 - a.W) / (float)a.W;
+    const float ty1 = (float)(a.H - 2 * h0i - 1) / (float)a.H, ty0 = (float)(a.H - 2 * h1i - 1) / (float)a.H;
+
+    float zbest = -INFINITY, wb0 = 0.f, wb1 = 0.f, wb2 = 0.f, keep = 1.0f;
+    int ibest = -1, kcount = 0;
+    for (int base = 0; base < a.F; base += RCH) {
+        const int n = scan_faces(a, b, base, tx0, tx1, ty0, ty1, fl, wave_cnt);
+        for (int j = 0; j < n; ++j) {
+            const FaceLds &fc = fl[j];
+            if (!(px >= fc.bb[0] && px < fc.bb[2] && py >= fc.bb[1] && py < fc.bb[3])) continue;
+            const float ax = fc.v[0], ay = fc.v[1], bx = fc.v[2], by = fc.v[3], cx = fc.v[4], cy = fc.v[5];
+            const float area = cross2(bx - ax, by - ay, cx - ax, cy - ay);
+            const float w0 = cross2(bx - px, by - py, cx - px, cy - py) / area;
+            const float w1 = cross2(cx - px, cy - py, ax - px, ay - py) / area;
+            const float w2 = 1.0f - w0 - w1;
+            const bool inside = w0 >= 0.0f && w1 >= 0.0f && w2 >= 0.0f;
+            if (inside) {
+                const float z = w0 * fc.z[0] + w1 * fc.z[1] + w2 * fc.z[2];
+                if (z > zbest) {
+                    zbest = z; ibest = fc.id; wb0 = w0; wb1 = w1; wb2 = w2;
+                }
+            }
+            if (kcount < a.knum) {   // the first knum boxed faces, in face order
+                ++kcount;
+                float t;
+                const float d2 = fminf(fminf(seg_d2(px, py, ax, ay, bx, by, t), seg_d2(px, py, bx, by, cx, cy, t)),
+                                       seg_d2(px, py, cx, cy, ax, ay, t));
+                keep *= 1.0f - __expf(-a.delta * d2);
+            }
+        }
+        __syncthreads();   // the list is rebuilt by the next round
+    }
+    if (!live) return;
+    const size_t pix = ((size_t)b * a.H + h) * a.W + w;
+    a.imidx[pix] = ibest;
+    a.imwei[pix * 3] = wb0; a.imwei[pix * 3 + 1] = wb1; a.imwei[pix * 3 + 2] = wb2;
+    a.improb[pix] = ibest >= 0 ? 1.0f : 1.0f - keep;
+    for (int d = 0; d < a.D; ++d) {
+        float v = 0.0f;
+        if (ibest >= 0) {
+            const float *at = a.attr + ((size_t)b * a.F + ibest) * 3 * a.D;
+            v = wb0 * at[d] + wb1 * at[a.D + d] + wb2 * at[2 * a.D + d];
+        }
+        a.imfeat[pix * a.D + d] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rast_bwd(RastArgs a)
+{
+    __shared__ FaceLds fl[RCH];
+    __shared__ int wave_cnt[4];
+    const int b = blockIdx.z, tid = threadIdx.x;
+    const int w = blockIdx.x * RT + (tid & (RT - 1)), h = blockIdx.y * RT + (tid >> 4);
+    const bool live = w < a.W && h < a.H;
+    const float px = (float)(2 * w + 1 - a.W) / (float)a.W, py = (float)(a.H - 2 * h - 1) / (float)a.H;
+    const int w0i = blockIdx.x * RT, h0i = blockIdx.y * RT;
+    const int w1i = min(w0i + RT - 1, a.W - 1), h1i = min(h0i + RT - 1, a.H - 1);
+    const float tx0 = (float)(2 * w0i + 1 - a.W) / (float)a.W, tx1 = (float)(2 * w1i + 1 - a.W) / (float)a.W;
+    const float ty1 = (float)(a.H - 2 * h0i - 1) / (float)a.H, ty0 = (float)(a.H - 2 * h1i - 1) / (float)a.H;
+    const size_t pix = live ? ((size_t)b * a.H + h) * a.W + w : 0;
+    const int idx = live ? a.imidx[pix] : 0;
+
+    // ---- covered pixel: through the saved weights of its face
+    if (live && idx >= 0) {
+        const float *v = a.p2 + ((size_t)b * a.F + idx) * 6;
+        const float ax = v[0], ay = v[1], bx = v[2], by = v[3], cx = v[4], cy = v[5];
+        const float w0 = a.imwei[pix * 3], w1 = a.imwei[pix * 3 + 1], w2 = a.imwei[pix * 3 + 2];
+        const float *at = a.attr + ((size_t)b * a.F + idx) * 3 * a.D;
+        float *da = a.dattr + ((size_t)b * a.F + idx) * 3 * a.D;
+        float dw0 = 0.f, dw1 = 0.f, dw2 = 0.f;
+        for (int d = 0; d < a.D; ++d) {
+            const float g = a.dfeat[pix * a.D + d];
+            dw0 += g * at[d]; dw1 += g * at[a.D + d]; dw2 += g * at[2 * a.D + d];
+            if (g != 0.0f) {
+                atomicAdd(da + d, w0 * g);
+                atomicAdd(da + a.D + d, w1 * g);
+                atomicAdd(da + 2 * a.D + d, w2 * g);
+            }
+        }
+        // w2 = 1 - w0 - w1;  w0 = N0 / A,  w1 = N1 / A
+        const float g0 = dw0 - dw2, g1 = dw1 - dw2;
+        if (g0 != 0.0f || g1 != 0.0f) {
+            const float A = cross2(bx - ax, by - ay, cx - ax, cy - ay);
+            const float dN0 = g0 / A, dN1 = g1 / A, dA = -(g0 * w0 + g1 * w1) / A;
+            // N0 = cross(b - p, c - p), N1 = cross(c - p, a - p), A = cross(b - a, c - a)
+            float *dp = a.dp2 + ((size_t)b * a.F + idx) * 6;
+            atomicAdd(dp + 0, dN1 * (-(cy - py)) + dA * (by - cy));
+            atomicAdd(dp + 1, dN1 * (cx - px) + dA * (cx - bx));
+            atomicAdd(dp + 2, dN0 * (cy - py) + dA * (cy - ay));
+            atomicAdd(dp + 3, dN0 * (-(cx - px)) + dA * (-(cx - ax)));
+            atomicAdd(dp + 4, dN0 * (-(by - py)) + dN1 * (ay - py) + dA * (-(by - ay)));
+            atomicAdd(dp + 5, dN0 * (bx - px) + dN1 * (-(ax - px)) + dA * (bx - ax));
+        }
+    }
+    // ---- uncovered pixels: improb = 1 - prod (1 - a_j), a_j = exp(-delta d_j^2).  (Whole tiles without any incoming
+    // probability gradient on uncovered pixels skip the face scan.)
+    const float gp = (live && idx < 0) ? a.dprob[pix] : 0.0f;
+    if (!__syncthreads_or(gp != 0.0f)) return;
+    const float keep = live ? 1.0f - a.improb[pix] : 1.0f;
+    int kcount = 0;
+    for (int base = 0; base < a.F; base += RCH) {
+        const int n = scan_faces(a, b, base, tx0, tx1, ty0, ty1, fl, wave_cnt);
+        for (int j = 0; j < n; ++j) {
+            const FaceLds &fc = fl[j];
+            if (!(px >= fc.bb[0] && px < fc.bb[2] && py >= fc.bb[1] && py < fc.bb[3])) continue;
+            if (kcount >= a.knum) break;
+            ++kcount;
+            if (gp == 0.0f) continue;
+            const float ax = fc.v[0], ay = fc.v[1], bx = fc.v[2], by = fc.v[3], cx = fc.v[4], cy = fc.v[5];
+            float t0, t1, t2;
+            const float d0 = seg_d2(px, py, ax, ay, bx, by, t0), d1 = seg_d2(px, py, bx, by, cx, cy, t1),
+                        d2c = seg_d2(px, py, cx, cy, ax, ay, t2);
+            // the closest edge (ties: the first, as torch.minimum's gradient convention is irrelevant at measure zero)
+            int e = 0;
+            float dm = d0, t = t0;
+            if (d1 < dm) { dm = d1; t = t1; e = 1; }
+            if (d2c < dm) { dm = d2c; t = t2; e = 2; }
+            const float aj = __expf(-a.delta * dm);
+            const float om = 1.0f - aj;
+            if (om <= 0.0f) continue;
+            const float gd2 = gp * (keep / om) * (a.delta * aj) * -1.0f;   // d improb / d d^2 = -(keep/(1-a)) * delta * a ... sign below
+            // improb = 1 - keep_total;  d improb / d a_j = keep/(1 - a_j);  d a_j / d d^2 = -delta a_j
+            const float sx = e == 0 ? ax : (e == 1 ? bx : cx), sy = e == 0 ? ay : (e == 1 ? by : cy);
+            const float ex_ = e == 0 ? bx : (e == 1 ? cx : ax), ey_ = e == 0 ? by : (e == 1 ? cy : ay);
+            const float rx = px - (sx + t * (ex_ - sx)), ry = py - (sy + t * (ey_ - sy));
+            // d d^2 / d start = -2 (1 - t) r,  d d^2 / d end = -2 t r
+            float *dp = a.dp2 + ((size_t)b * a.F + fc.id) * 6;
+            const int is = 2 * e, ie = 2 * ((e + 1) % 3);
+            atomicAdd(dp + is, gd2 * -2.0f * (1.0f - t) * rx);
+            atomicAdd(dp + is + 1, gd2 * -2.0f * (1.0f - t) * ry);
+            atomicAdd(dp + ie, gd2 * -2.0f * t * rx);
+            atomicAdd(dp + ie + 1, gd2 * -2.0f * t * ry);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace m355
+
+using namespace m355;
+
+extern "C" size_t m355_dibr_ws_bytes(int B, int F) { return (size_t)(B > 0 ? B : 0) * (size_t)(F > 0 ? F : 0) * sizeof(float4); }
+
+static int rast_check(const char *who, int B, int F, int H, int W, int D, int knum)
+{
+    M355_REQUIRE(B > 0 && B <= 65535 && F > 0 && H > 0 && W > 0 && D >= 1 && D <= 8 && knum >= 0,
+                 "%s: bad size B=%d F=%d H=%d W=%d D=%d knum=%d", who, B, F, H, W, D, knum);
+    return 0;
+}
+
+extern "C" int m355_dibr_rasterize_fwd(int height, int width, const float *points3d_bxfx9, const float *points2d_bxfx6,
+                                       const float *normalz_bxfx1, const float *attr_bxfx3d, int B, int F, int D, float expand,
+                                       int knum, float delta, void *ws, float *imfeat, float *improb, int32_t *imidx,
+                                       float *imwei, void *stream)
+{
+    if (int rc = rast_check("dibr_rasterize_fwd", B, F, height, width, D, knum)) return rc;
+    M355_REQUIRE(points3d_bxfx9 && points2d_bxfx6 && normalz_bxfx1 && attr_bxfx3d && ws && imfeat && improb && imidx && imwei,
+                 "dibr_rasterize_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_rast_setup, dim3((B * F + 255) / 256), dim3(256), 0, st, points2d_bxfx6, normalz_bxfx1, (float4 *)ws, B * F,
+                       expand);
+    RastArgs a = {};
+    a.p3 = points3d_bxfx9; a.p2 = points2d_bxfx6; a.nz = normalz_bxfx1; a.attr = attr_bxfx3d; a.bbox = (const float4 *)ws;
+    a.imfeat = imfeat; a.improb = improb; a.imidx = imidx; a.imwei = imwei;
+    a.B = B; a.F = F; a.H = height; a.W = width; a.D = D; a.knum = knum; a.delta = delta;
+    hipLaunchKernelGGL(k_rast_fwd, dim3((width + RT - 1) / RT, (height + RT - 1) / RT, B), dim3(256), 0, st, a);
+    return check_launch("dibr_rasterize_fwd");
+}
+
+extern "C" int m355_dibr_rasterize_bwd(int height, int width, const float *points3d_bxfx9, const float *points2d_bxfx6,
+                                       const float *attr_bxfx3d, int B, int F, int D, int knum, float delta, const void *ws,
+                                       const float *improb, const int32_t *imidx, const float *imwei, const float *dimfeat,
+                                       const float *dimprob, float *dpoints2d_bxfx6, float *dattr_bxfx3d, void *stream)
+{
+    if (int rc = rast_check("dibr_rasterize_bwd", B, F, height, width, D, knum)) return rc;
+    M355_REQUIRE(points3d_bxfx9 && points2d_bxfx6 && attr_bxfx3d && ws && improb && imidx && imwei && dimfeat && dimprob &&
+                     dpoints2d_bxfx6 && dattr_bxfx3d,
+                 "dibr_rasterize_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dpoints2d_bxfx6, 0, sizeof(float) * (size_t)B * F * 6, st) != hipSuccess ||
+        hipMemsetAsync(dattr_bxfx3d, 0, sizeof(float) * (size_t)B * F * 3 * D, st) != hipSuccess) {
+        set_error("dibr_rasterize_bwd: memset failed");
+        return M355_ERR_LAUNCH;
+    }
+    RastArgs a = {};
+    a.p3 = points3d_bxfx9; a.p2 = points2d_bxfx6; a.attr = attr_bxfx3d; a.bbox = (const float4 *)ws;
+    a.improb = (float *)improb; a.imidx = (int *)imidx; a.imwei = (float *)imwei;
+    a.dfeat = dimfeat; a.dprob = dimprob; a.dp2 = dpoints2d_bxfx6; a.dattr = dattr_bxfx3d;
+    a.B = B; a.F = F; a.H = height; a.W = width; a.D = D; a.knum = knum; a.delta = delta;
+    hipLaunchKernelGGL(k_rast_bwd, dim3((width + RT - 1) / RT, (height + RT - 1) / RT, B), dim3(256), 0, st, a);
+    return check_launch("dibr_rasterize_bwd");
+}
