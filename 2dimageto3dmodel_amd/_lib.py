@@ -54,6 +54,13 @@ SIGNATURES = {
     "m355_mesh_normals_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "m355_mesh_flat_fwd": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "m355_mesh_flat_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    "m355_dibr_ws_bytes": (c_size_t, [c_int, c_int]),
+    "m355_dibr_rasterize_fwd": (c_int, [c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P, _P, _P, _P,
+                                        _P, _P]),
+    "m355_dibr_rasterize_bwd": (c_int, [c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P,
+                                        _P, _P, _P]),
+    "m355_dibr_shade_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "m355_dibr_shade_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "m355_weight_prep_entry_bytes": (c_size_t, []),
     "m355_weight_prep_fill_entry": (ctypes.c_longlong, [_P, _P, c_int, _P, _P, _P, _P]),
     "m355_weight_prep_batched": (c_int, [_P, c_int, ctypes.c_longlong, _P]),

@@ -35,6 +35,7 @@ SOURCES = [
     ("gan_glue.hip", []),
     ("gan_io.hip", []),
     ("mesh_deform.hip", STRICT),
+    ("dibr_raster.hip", STRICT),
 ]
 
 

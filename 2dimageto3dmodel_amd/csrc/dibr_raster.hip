@@ -251,8 +251,8 @@ __global__ __launch_bounds__(256) void k_rast_bwd(RastArgs a)
             const float aj = __expf(-a.delta * dm);
             const float om = 1.0f - aj;
             if (om <= 0.0f) continue;
-            const float gd2 = gp * (keep / om) * (a.delta * aj) * -1.0f;   // d improb / d d^2 = -(keep/(1-a)) * delta * a ... sign below
-            // improb = 1 - keep_total;  d improb / d a_j = keep/(1 - a_j);  d a_j / d d^2 = -delta a_j
+            // improb = 1 - prod (1 - a_k):  d improb / d a_j = keep / (1 - a_j),  d a_j / d d^2 = -delta a_j
+            const float gd2 = gp * (keep / om) * (-a.delta * aj);
             const float sx = e == 0 ? ax : (e == 1 ? bx : cx), sy = e == 0 ? ay : (e == 1 ? by : cy);
             const float ex_ = e == 0 ? bx : (e == 1 ? cx : ax), ey_ = e == 0 ? by : (e == 1 ? cy : ay);
             const float rx = px - (sx + t * (ex_ - sx)), ry = py - (sy + t * (ey_ - sy));
@@ -268,9 +268,130 @@ __global__ __launch_bounds__(256) void k_rast_bwd(RastArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- fragment shader
+// fragmentshader (rendering/fragment_shader.py:22-37) with texinterpolation (:6-20) for filtering = 'bilinear':
+//   grid = (uv * 2 - 1) * (1, -1);  tex = grid_sample(texture, grid, bilinear, align_corners=True, zeros padding);
+//   color = tex * hard            (background: lerp(background, tex, hard))
+// uvm [B,H,W,3] = (u, v, hard) as the rasteriser writes it; texture [B,3,TH,TW]; color [B,H,W,3].  One lane per pixel.
+struct ShadeArgs {
+    const float *uvm, *tex, *bg;
+    float *color;
+    const float *dcolor;
+    float *duvm, *dtex, *dbg;
+    int B, H, W, TH, TW;
+};
+
+__device__ __forceinline__ void shade_coords(const ShadeArgs &a, float u, float v, float &fx, float &fy, int &x0, int &y0)
+{
+    const float gx = u * 2.0f - 1.0f, gy = (v * 2.0f - 1.0f) * -1.0f;
+    fx = (gx + 1.0f) * 0.5f * (float)(a.TW - 1);   // align_corners=True
+    fy = (gy + 1.0f) * 0.5f * (float)(a.TH - 1);
+    x0 = (int)floorf(fx);
+    y0 = (int)floorf(fy);
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_shade(ShadeArgs a)
+{
+    const size_t HW = (size_t)a.H * a.W, total = (size_t)a.B * HW, THW = (size_t)a.TH * a.TW;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t b = i / HW;
+        const float u = a.uvm[i * 3], v = a.uvm[i * 3 + 1], hard = a.uvm[i * 3 + 2];
+        float fx, fy;
+        int x0, y0;
+        shade_coords(a, u, v, fx, fy, x0, y0);
+        const float tx = fx - (float)x0, ty = fy - (float)y0;
+        const float wgt[4] = {(1.0f - tx) * (1.0f - ty), tx * (1.0f - ty), (1.0f - tx) * ty, tx * ty};
+        const int xs[4] = {x0, x0 + 1, x0, x0 + 1}, ys[4] = {y0, y0, y0 + 1, y0 + 1};
+        const float *tb = a.tex + b * 3 * THW;
+        float t[3] = {0.f, 0.f, 0.f}, c4[3][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool in = (unsigned)xs[k] < (unsigned)a.TW && (unsigned)ys[k] < (unsigned)a.TH;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                c4[c][k] = in ? tb[c * THW + (size_t)ys[k] * a.TW + xs[k]] : 0.0f;
+                t[c] += c4[c][k] * wgt[k];
+            }
+        }
+        if (!BWD) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float bgv = a.bg ? a.bg[i * 3 + c] : 0.0f;
+                a.color[i * 3 + c] = a.bg ? bgv + hard * (t[c] - bgv) : t[c] * hard;   // torch.lerp: start + w (end - start)
+            }
+        } else {
+            float dt[3], dhard = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float g = a.dcolor[i * 3 + c];
+                const float bgv = a.bg ? a.bg[i * 3 + c] : 0.0f;
+                dt[c] = g * hard;
+                dhard += g * (t[c] - bgv);
+                if (a.dbg) a.dbg[i * 3 + c] = g * (1.0f - hard);
+            }
+            float dfx = 0.0f, dfy = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                dfx += dt[c] * ((c4[c][1] - c4[c][0]) * (1.0f - ty) + (c4[c][3] - c4[c][2]) * ty);
+                dfy += dt[c] * ((c4[c][2] - c4[c][0]) * (1.0f - tx) + (c4[c][3] - c4[c][1]) * tx);
+            }
+            // fx = u (TW - 1),  fy = (1 - v)(TH - 1)
+            a.duvm[i * 3] = dfx * (float)(a.TW - 1);
+            a.duvm[i * 3 + 1] = -dfy * (float)(a.TH - 1);
+            a.duvm[i * 3 + 2] = dhard;
+            if (a.dtex) {
+                float *db = a.dtex + b * 3 * THW;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool in = (unsigned)xs[k] < (unsigned)a.TW && (unsigned)ys[k] < (unsigned)a.TH;
+                    if (in && wgt[k] != 0.0f) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            if (dt[c] != 0.0f) atomicAdd(db + c * THW + (size_t)ys[k] * a.TW + xs[k], dt[c] * wgt[k]);
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace m355
 
 using namespace m355;
+
+extern "C" int m355_dibr_shade_fwd(const float *uvm_bxhxwx3, const float *texture_bx3xthxtw, const float *background_bxhxwx3,
+                                   float *color_bxhxwx3, int B, int H, int W, int TH, int TW, void *stream)
+{
+    M355_REQUIRE(uvm_bxhxwx3 && texture_bx3xthxtw && color_bxhxwx3 && B > 0 && H > 0 && W > 0 && TH > 0 && TW > 0,
+                 "dibr_shade_fwd: bad argument");
+    ShadeArgs a = {};
+    a.uvm = uvm_bxhxwx3; a.tex = texture_bx3xthxtw; a.bg = background_bxhxwx3; a.color = color_bxhxwx3;
+    a.B = B; a.H = H; a.W = W; a.TH = TH; a.TW = TW;
+    const size_t g = ((size_t)B * H * W + 255) / 256;
+    hipLaunchKernelGGL(k_shade<false>, dim3((unsigned)(g > 16384 ? 16384 : g)), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("dibr_shade_fwd");
+}
+
+extern "C" int m355_dibr_shade_bwd(const float *uvm_bxhxwx3, const float *texture_bx3xthxtw, const float *background_bxhxwx3,
+                                   const float *dcolor_bxhxwx3, float *duvm_bxhxwx3, float *dtexture_bx3xthxtw,
+                                   float *dbackground_bxhxwx3, int B, int H, int W, int TH, int TW, void *stream)
+{
+    M355_REQUIRE(uvm_bxhxwx3 && texture_bx3xthxtw && dcolor_bxhxwx3 && duvm_bxhxwx3 && B > 0 && H > 0 && W > 0 && TH > 0 && TW > 0,
+                 "dibr_shade_bwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtexture_bx3xthxtw && hipMemsetAsync(dtexture_bx3xthxtw, 0, sizeof(float) * (size_t)B * 3 * TH * TW, st) != hipSuccess) {
+        set_error("dibr_shade_bwd: memset failed");
+        return M355_ERR_LAUNCH;
+    }
+    ShadeArgs a = {};
+    a.uvm = uvm_bxhxwx3; a.tex = texture_bx3xthxtw; a.bg = background_bxhxwx3; a.dcolor = dcolor_bxhxwx3;
+    a.duvm = duvm_bxhxwx3; a.dtex = dtexture_bx3xthxtw; a.dbg = dbackground_bxhxwx3;
+    a.B = B; a.H = H; a.W = W; a.TH = TH; a.TW = TW;
+    const size_t g = ((size_t)B * H * W + 255) / 256;
+    hipLaunchKernelGGL(k_shade<true>, dim3((unsigned)(g > 16384 ? 16384 : g)), dim3(256), 0, st, a);
+    return check_launch("dibr_shade_bwd");
+}
 
 extern "C" size_t m355_dibr_ws_bytes(int B, int F) { return (size_t)(B > 0 ? B : 0) * (size_t)(F > 0 ? F : 0) * sizeof(float4); }
 

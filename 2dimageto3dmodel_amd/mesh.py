@@ -356,6 +356,15 @@ class MeshTemplate:
             texture = torch.cat((texture, texture[:, :, :, :1]), dim=3)
         return uvs, texture
 
+    def forward_renderer(self, renderer, vertex_positions, texture, num_gpus=1, **kwargs):
+        """rendering/mesh_template.py:172-186: render the deformed template with its texture -> (image, alpha).
+        num_gpus > 1 was nn.DataParallel's replica bookkeeping (the face tables were tiled per replica); one process
+        per GPU here, so it is accepted and ignored."""
+        input_uvs, input_texture = self.adjust_uv_and_texture(texture)
+        image, alpha, _ = renderer(points=[vertex_positions, self.mesh.faces], uv_bxpx2=input_uvs,
+                                   texture_bx3xthxtw=input_texture, ft_fx3=self.mesh.face_textures, **kwargs)
+        return image, alpha
+
     def export_obj(self, path_prefix, vertex_positions, texture=None):
         """OBJ (+MTL) export of one deformed mesh (:188-219); the texture image is written only if imageio is there"""
         assert len(vertex_positions.shape) == 2

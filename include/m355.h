@@ -320,6 +320,35 @@ int m355_hinge_fwd(int K, const float *const *p, const float *const *m, const in
 int m355_hinge_bwd(int K, const float *const *p, const float *const *m, const int *hw, const float *w, int B, int split, int mode,
                    const float *gl2, const float *msum, float *const *dp, void *stream);
 
+/* ---- the DIB-R rasteriser and fragment shader behind Renderer.forward (code/rendering/renderer.py:39-77,
+ *      code/rendering/fragment_shader.py:6-37); csrc/dibr_raster.hip.
+ *      m355_dibr_rasterize_fwd replaces kaolin.graphics.dib_renderer.rasterizer.linear_rasterizer(height, width,
+ *      points3d_bxfx9, points2d_bxfx6, normalz_bxfx1, vertex_attr_bxfx3d) as called at renderer.py:62-69 (Kaolin at the
+ *      commit of code/rendering/monkey_patches.py:4 is not available here: published DIB-R algorithm, kaolin's defaults
+ *      expand = 0.02, knum = 30, delta = 7000; PARITY UNPINNED, oracle = oracle/raster_ref.py):
+ *        imfeat [B,H,W,D]  attributes interpolated with the barycentric weights of the closest front face covering the
+ *                          pixel centre (zero elsewhere);   improb [B,H,W]  soft silhouette probability;
+ *        imidx [B,H,W] int32 covering face or -1, imwei [B,H,W,3] its weights (kept for the backward);
+ *        ws: m355_dibr_ws_bytes(B, F) bytes, written by _fwd and read again by _bwd.
+ *      _bwd: d imfeat, d improb -> d points2d [B,F,6], d attr [B,F,3D] (points3d only selects the face: no gradient). */
+size_t m355_dibr_ws_bytes(int B, int F);
+int m355_dibr_rasterize_fwd(int height, int width, const float *points3d_bxfx9, const float *points2d_bxfx6,
+                            const float *normalz_bxfx1, const float *attr_bxfx3d, int B, int F, int D, float expand, int knum,
+                            float delta, void *ws, float *imfeat, float *improb, int32_t *imidx, float *imwei, void *stream);
+int m355_dibr_rasterize_bwd(int height, int width, const float *points3d_bxfx9, const float *points2d_bxfx6,
+                            const float *attr_bxfx3d, int B, int F, int D, int knum, float delta, const void *ws,
+                            const float *improb, const int32_t *imidx, const float *imwei, const float *dimfeat,
+                            const float *dimprob, float *dpoints2d_bxfx6, float *dattr_bxfx3d, void *stream);
+/*      fragmentshader(imtexcoord, texture, improb, filtering='bilinear', background_image) of fragment_shader.py:22-37:
+ *      uvm [B,H,W,3] = (u, v, hard mask) as the rasteriser writes them; color = grid_sample(texture, (uv*2-1)*(1,-1),
+ *      bilinear, align_corners=True) * hard, or lerp(background, that, hard).  _bwd: d color -> d uvm, d texture (nullable),
+ *      d background (nullable). */
+int m355_dibr_shade_fwd(const float *uvm_bxhxwx3, const float *texture_bx3xthxtw, const float *background_bxhxwx3,
+                        float *color_bxhxwx3, int B, int H, int W, int TH, int TW, void *stream);
+int m355_dibr_shade_bwd(const float *uvm_bxhxwx3, const float *texture_bx3xthxtw, const float *background_bxhxwx3,
+                        const float *dcolor_bxhxwx3, float *duvm_bxhxwx3, float *dtexture_bx3xthxtw, float *dbackground_bxhxwx3,
+                        int B, int H, int W, int TH, int TW, void *stream);
+
 /* Projection discriminator (code/models/gan.py:104-116, 216-228): out[n,p] = sum_c feat[n,p,c] * emb[n,c] on the NHWC bf16
  * feature map (C a power of two in 8..2048); backward: dfeat = g * emb (bf16, overwritten), demb[n,c] = sum_p g * feat. */
 int m355_cproj_fwd(const void *feat, const float *emb, float *out /*[N,HW]*/, int N, int HW, int C, void *stream);

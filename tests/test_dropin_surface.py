@@ -35,6 +35,10 @@ SURFACE = {   # module -> {name: [leading argument names of the callable (method
     "rendering.utils": {"grid_sample_bilinear": ["input", "grid"], "symmetrize_texture": ["x"], "adjust_poles": ["tex"],
                         "circpad": ["x", "amount"], "qrot": ["q", "v"], "qmul": ["q", "r"]},
     "rendering.mesh_template": {"MeshTemplate": ["mesh_path", "is_symmetric"]},
+    "rendering.renderer": {"Renderer": ["height", "width", "filtering"], "ortho_projection": ["points_bxpx3", "faces_fx3"]},
+    "rendering.fragment_shader": {"fragmentshader": ["imtexcoord_bxhxwx2", "texture_bx3xthxtw", "improb_bxhxwx1", "filtering",
+                                                     "background_image"],
+                                  "texinterpolation": ["imtexcoord_bxhxwx2", "texture_bx3xthxtw", "filtering"]},
     "sync_batchnorm": {"SynchronizedBatchNorm2d": None, "DataParallelWithCallback": None},
 }
 METHODS = {   # class -> {method: argument names after self}
@@ -51,6 +55,9 @@ METHODS = {   # class -> {method: argument names after self}
     ("models.supervised_part", "SupervisedLoss"): {"forward": ["projection", "masks"]},
     ("models.unsupervised_part", "UnsupervisedLoss"): {"forward": ["predictions", "masks", "training"]},
     ("models.gan", "Generator"): {"forward": ["z", "c", "caption", "return_attention"]},
+    ("rendering.renderer", "Renderer"): {"forward": ["points", "uv_bxpx2", "texture_bx3xthxtw", "ft_fx3", "background_image",
+                                                     "return_hardmask"]},
+    ("rendering.mesh_template", "MeshTemplate"): {"forward_renderer": ["renderer", "vertex_positions", "texture", "num_gpus"]},
     ("models.gan", "MultiScaleDiscriminator"): {"forward": ["x", "mesh_map", "c", "caption"]},
 }
 

@@ -1,0 +1,164 @@
+"""the DIB-R rasteriser + fragment shader behind Renderer.forward (rendering/renderer.py:39-77).
+
+CPU: the oracle (oracle/raster_ref.py, per-pixel brute force in torch; PARITY UNPINNED -- Kaolin is not available) against
+properties of the published algorithm.  GPU: csrc/dibr_raster.hip against that oracle: coverage index-exact, weights /
+features / probabilities, and the gradients of a loss through image and silhouette (oracle = torch autograd)."""
+import importlib
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import raster_ref as rr
+
+
+def uv_sphere(nlat=10, nlon=16, radius=0.6, squash=(1.0, 0.8, 0.7)):
+    """closed triangle mesh (outward faces), vertices [P,3], faces [F,3], uv [P,2]"""
+    verts, uvs = [[0.0, radius * squash[1], 0.0]], [[0.5, 1.0]]
+    for i in range(1, nlat):
+        th = math.pi * i / nlat
+        for j in range(nlon):
+            ph = 2 * math.pi * j / nlon
+            verts.append([radius * squash[0] * math.sin(th) * math.cos(ph), radius * squash[1] * math.cos(th),
+                          radius * squash[2] * math.sin(th) * math.sin(ph)])
+            uvs.append([j / nlon, 1 - i / nlat])
+    verts.append([0.0, -radius * squash[1], 0.0])
+    uvs.append([0.5, 0.0])
+    faces = []
+    ring = lambda i, j: 1 + (i - 1) * nlon + (j % nlon)
+    for j in range(nlon):
+        faces.append([0, ring(1, j + 1), ring(1, j)])
+        faces.append([len(verts) - 1, ring(nlat - 1, j), ring(nlat - 1, j + 1)])
+    for i in range(1, nlat - 1):
+        for j in range(nlon):
+            faces.append([ring(i, j), ring(i, j + 1), ring(i + 1, j)])
+            faces.append([ring(i, j + 1), ring(i + 1, j + 1), ring(i + 1, j)])
+    return torch.tensor(verts), torch.tensor(faces, dtype=torch.long), torch.tensor(uvs)
+
+
+def scene(B, seed, nlat=8, nlon=12):
+    g = torch.Generator().manual_seed(seed)
+    v, f, uv = uv_sphere(nlat, nlon)
+    pts = v.unsqueeze(0).repeat(B, 1, 1) * (0.8 + 0.4 * torch.rand(B, 1, 1, generator=g))
+    pts = pts + 0.02 * torch.randn(pts.shape, generator=g) + 0.15 * (torch.rand(B, 1, 3, generator=g) - 0.5)
+    pts[..., 2] -= 2.0                                  # in front of a camera looking down -z
+    tex = torch.rand(B, 3, 24, 20, generator=g)
+    return pts, f, uv.unsqueeze(0).repeat(B, 1, 1), tex
+
+
+# ------------------------------------------------------------------------------------------------ CPU: the oracle itself
+def test_oracle_single_triangle_properties():
+    H = W = 32
+    p2 = torch.tensor([[[-0.5, -0.5, 0.6, -0.4, -0.1, 0.7]]], dtype=torch.float64)
+    p3 = torch.tensor([[[-0.5, -0.5, -1.0, 0.6, -0.4, -1.0, -0.1, 0.7, -1.0]]], dtype=torch.float64)
+    attr = torch.tensor([[[1.0, 0.0, 1.0, 0.0, 1.0, 1.0, 0.5, 0.5, 1.0]]], dtype=torch.float64)
+    nz = torch.ones(1, 1, 1, dtype=torch.float64)
+    feat, prob, idx, wei = rr.linear_rasterizer_ref(H, W, p3, p2, nz, attr)
+    cov = idx[0] >= 0
+    area_px = 0.5 * abs((0.6 + 0.5) * (0.7 + 0.5) - (-0.4 + 0.5) * (-0.1 + 0.5)) / 4 * H * W
+    assert abs(cov.sum().item() - area_px) < 0.1 * area_px            # covered pixel count ~ triangle area
+    assert torch.allclose(wei[0][cov].sum(-1), torch.ones(int(cov.sum()), dtype=torch.float64))   # partition of unity
+    assert (wei[0][cov] >= 0).all() and (feat[0][cov][:, 2] - 1).abs().max() < 1e-12           # mask channel = 1 inside
+    assert (feat[0][~cov] == 0).all() and (prob[0, ..., 0][cov] == 1).all()
+    out = prob[0, ..., 0][~cov]
+    assert (out >= 0).all() and (out <= 1).all() and out.max() > 0.3 and out.min() == 0         # decays away from the edge
+    # a back-facing copy (negative normal z) is invisible
+    f2, p2b, _, _ = rr.linear_rasterizer_ref(H, W, p3, p2, -nz, attr)
+    assert (f2 == 0).all() and (p2b == 0).all()
+    # depth test: of two stacked triangles the one with the larger z wins
+    p3n = torch.cat((p3, p3 + torch.tensor([0, 0, 0.5] * 3, dtype=torch.float64)), dim=1)
+    _, _, idx2, _ = rr.linear_rasterizer_ref(H, W, p3n, torch.cat((p2, p2), 1), torch.ones(1, 2, 1, dtype=torch.float64),
+                                             torch.cat((attr, attr), 1))
+    assert (idx2[0][cov] == 1).all()
+
+
+def test_oracle_knum_is_an_order_rule():
+    """only the first knum boxed faces (in face order) feed the soft silhouette"""
+    H = W = 16
+    tri = torch.tensor([-0.5, -0.5, 0.5, -0.5, 0.0, 0.5])
+    p2 = tri.repeat(1, 4, 1) + torch.tensor([0.0, 0.0] * 3).view(1, 1, 6)
+    p2[0, 1:] *= torch.tensor([0.9, 0.8, 0.7]).view(3, 1)             # nested smaller copies later in the list
+    p3 = torch.zeros(1, 4, 9)
+    p3[..., 2::3] = -1.0
+    attr = torch.ones(1, 4, 9)
+    nz = torch.ones(1, 4, 1)
+    _, pa, _, _ = rr.linear_rasterizer_ref(H, W, p3, p2, nz, attr, knum=1)
+    _, pb, _, _ = rr.linear_rasterizer_ref(H, W, p3[:, :1], p2[:, :1], nz[:, :1], attr[:, :1], knum=30)
+    unc = pb[0, ..., 0] < 1
+    assert torch.allclose(pa[0, ..., 0][unc], pb[0, ..., 0][unc])
+
+
+# ------------------------------------------------------------------------------------------------ GPU vs oracle
+def _mods():
+    return importlib.import_module("2dimageto3dmodel_amd.render")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,B", [(64, 64, 2), (48, 80, 1), (128, 128, 2)])
+def test_rasterizer_matches_oracle(H, W, B):
+    R = _mods()
+    pts, faces, uv, tex = scene(B, 7 + H)
+    p3, p2, nrm = rr.ortho_projection_ref(pts, faces)
+    c = [uv[:, faces[:, k], :] for k in range(3)]
+    one = torch.ones_like(c[0][:, :, :1])
+    attr = torch.cat((c[0], one, c[1], one, c[2], one), dim=2)
+    feat_r, prob_r, idx_r, wei_r = rr.linear_rasterizer_ref(H, W, p3, p2, nrm[:, :, 2:3], attr)
+    d = "cuda:0"
+    feat, prob, idx = R.LinearRasterizerFn.apply(H, W, p3.to(d), p2.to(d), nrm[:, :, 2:3].to(d).contiguous(), attr.to(d), R.EXPAND,
+                                                 R.KNUM, R.DELTA)
+    assert idx_r.ge(0).float().mean() > 0.1                                   # the scene covers a good part of the image
+    assert torch.equal(idx.cpu().long(), idx_r)                               # coverage and face choice: index-exact
+    assert (feat.cpu() - feat_r).abs().max().item() < 2e-5
+    assert (prob.cpu() - prob_r).abs().max().item() < 2e-5
+    assert ((prob.cpu() > 0) & (prob.cpu() < 1)).float().mean() > 0.005        # a soft rim exists
+
+
+@pytest.mark.gpu
+def test_renderer_forward_backward_matches_oracle():
+    """Renderer.forward (ortho projection, rasteriser, bilinear fragment shader, hard mask / soft probability) and the
+    gradients of an image + silhouette loss with respect to the vertices and the texture (oracle: torch autograd)"""
+    R = _mods()
+    B, H, W = 2, 64, 64
+    pts, faces, uv, tex = scene(B, 3)
+    g = torch.Generator().manual_seed(1)
+    w_img, w_sil = torch.randn(B, H, W, 3, generator=g), torch.randn(B, H, W, 1, generator=g)
+    pr, tr = pts.clone().requires_grad_(), tex.clone().requires_grad_()
+    img_r, sil_r, nrm_r = rr.renderer_forward_ref([pr, faces], uv, tr, H, W)
+    ((img_r * w_img).sum() + (sil_r * w_sil).sum()).backward()
+    d = "cuda:0"
+    pd, td = pts.to(d).requires_grad_(), tex.to(d).requires_grad_()
+    ren = R.Renderer(H, W)
+    img, sil, nrm = ren([pd, faces.to(d)], uv.to(d), td)
+    assert tuple(img.shape) == (B, H, W, 3) and tuple(sil.shape) == (B, H, W, 1) and tuple(nrm.shape) == tuple(nrm_r.shape)
+    assert (img.cpu() - img_r.detach()).abs().max().item() < 5e-5
+    assert (sil.cpu() - sil_r.detach()).abs().max().item() < 2e-5
+    assert (nrm.cpu() - nrm_r.detach()).abs().max().item() < 1e-5
+    ((img * w_img.to(d)).sum() + (sil * w_sil.to(d)).sum()).backward()
+    assert (td.grad.cpu() - tr.grad).abs().max().item() < 1e-3 * tr.grad.abs().max().item()
+    gp, gr = pd.grad.cpu(), pr.grad
+    assert gr.abs().max() > 0 and gr[..., 2].abs().max() == 0                  # depth only selects the face
+    assert (gp - gr).abs().max().item() < 2e-3 * gr.abs().max().item(), ((gp - gr).abs().max().item(), gr.abs().max().item())
+    # hard mask and background compositing
+    bg = torch.rand(B, H, W, 3, generator=g)
+    img2, hard, _ = ren([pd.detach(), faces.to(d)], uv.to(d), td.detach(), background_image=bg.to(d), return_hardmask=True)
+    img2_r, hard_r, _ = rr.renderer_forward_ref([pts, faces], uv, tex, H, W, background_image=bg, return_hardmask=True)
+    assert torch.equal(hard.cpu(), hard_r) and (img2.cpu() - img2_r).abs().max().item() < 5e-5
+
+
+@pytest.mark.gpu
+def test_mesh_template_forward_renderer(tmp_path):
+    """MeshTemplate.forward_renderer (rendering/mesh_template.py:172-186) on the procedural UV sphere: an image and an alpha"""
+    R = _mods()
+    M = importlib.import_module("2dimageto3dmodel_amd.mesh")
+    tpl = M.MeshTemplate(M.write_uv_sphere_obj(str(tmp_path / "s.obj")), is_symmetric=True, device="cuda:0")
+    B = 2
+    dmap = 0.02 * torch.randn(B, 3, 32, 32, device="cuda:0")
+    vtx = tpl.get_vertex_positions(dmap) * 0.6
+    vtx = vtx - torch.tensor([0.0, 0.0, 2.0], device="cuda:0")
+    tex = torch.rand(B, 3, 64, 32, device="cuda:0", requires_grad=True)
+    img, alpha = tpl.forward_renderer(R.Renderer(96, 96), vtx, tex)
+    assert tuple(img.shape) == (B, 96, 96, 3) and tuple(alpha.shape) == (B, 96, 96, 1)
+    assert 0.05 < (alpha == 1).float().mean().item() < 0.9
+    img.sum().backward()
+    assert torch.isfinite(tex.grad).all() and tex.grad.abs().sum() > 0
