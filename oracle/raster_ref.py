@@ -98,7 +98,7 @@ def renderer_forward_ref(points, uv_bxpx2, texture_bx3xthxtw, height, width, ft_
         ft_fx3 = faces_fx3
     points3d, points2d, normal = ortho_projection_ref(points_bxpx3, faces_fx3)
     normalz = normal[:, :, 2:3]
-    normal1 = normal / (normal.norm(dim=2, keepdim=True) + 1e-10)       # kaolin datanormalize (L2, eps 1e-10)
+    normal1 = normal / (torch.sqrt((normal ** 2).sum(dim=2, keepdim=True)) + 1e-8)   # kaolin datanormalize (L2, 1e-8 guard)
     c = [uv_bxpx2[:, ft_fx3[:, k], :] for k in range(3)]
     one = torch.ones_like(c[0][:, :, :1])
     uv9 = torch.cat((c[0], one, c[1], one, c[2], one), dim=2)
