@@ -65,6 +65,9 @@ __device__ __forceinline__ void wait_vm()
 #ifndef M355_HALO_RB8
 #define M355_HALO_RB8 3
 #endif
+#ifndef M355_NO_EPI_CREDIT
+#define M355_NO_EPI_CREDIT 0
+#endif
 // halo DMAs one wave issues at tap t (slices of NAS on taps 0 .. T-3), and their sum over the D steps before tap t
 template <int T, int NAW, int NAS>
 constexpr int halo_dmas_at(int t)
@@ -354,6 +357,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
         read_frags(cur, lds, 0, std::integral_constant<int, 0>{});
     }
 
+    // VMEM operations one lane issues between the last step of a tile and the first step of the next that are NOT part of
+    // the counted DMA stream: the epilogue's 8 stores in its plain forms (+2 mask-word stores when it emits bit masks; the
+    // +2 mask-word loads at the top of a tile that reads them); other epilogue forms (guarded / bf16 mask reads): no credit
+    const bool epi_simple = !a.fold2 && a.Cout == a.CoutP && !a.mask_x && !M355_NO_EPI_CREDIT;
+    const int epi_vm = !epi_simple ? 0 : (((a.bits_out && a.slope != 1.0f) || a.bits_in) ? 10 : 8);
+    int fresh = 0;                // steps of the current tile still awaiting pre-epilogue weights
     int cls_cur = 0, cc_cur = 0;  // (class, chunk) of the current segment
     int slot = 0;  // ring slot of the current step
     int hb = 0;    // halo buffer of the current chunk
@@ -405,7 +414,18 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                         --warm;
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
-                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(cnt) : "memory");
+                    // The first RB-1+L steps of a tile await weights that were issued BEFORE the previous tile's epilogue:
+                    // its stores (and this tile's mask-word loads) are younger than everything the count was derived from.
+                    // vmcnt retires in order, so without adding them the wave would sit here until nearly all of its
+                    // epilogue stores have been acknowledged -- once per tile, with nothing to overlap it.
+                    if (fresh > 0) {
+                        --fresh;
+                        if (epi_vm == 8) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(cnt + 8 > 63 ? 63 : cnt + 8) : "memory");
+                        else if (epi_vm == 10) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(cnt + 10 > 63 ? 63 : cnt + 10) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(cnt) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(cnt) : "memory");
+                    }
                     __builtin_amdgcn_s_barrier();      // ... the same holds for every wave
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -557,6 +577,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
         if (!has_next) break;
         init_acc();
         tp = tp_next;
+        fresh = RES ? 0 : RB - 1 + L;
     }
     wait_vm<0>();  // the trailing (unused) prefetches
 }

@@ -346,8 +346,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
     constexpr int HBUF = HINS * 1024;
     constexpr int WPITCH = 432, WCH = 26;                                            // weight row: 26 chunks (taps 0..25)
     constexpr int WINS = (64 * 27 + 63) / 64;                                        // 27 DMA instructions ([co][27-chunk] image)
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HBUF + WINS * 1024];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HBUF + WINS * 1024 + 4 * 2048];
     unsigned char *const ldsW = lds + 2 * HBUF;
+    unsigned char *const ldsS = ldsW + WINS * 1024;   // epilogue stage: 2 KB per wave
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -413,7 +414,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
         const int tp_next = tp + PS;
         // the halo of this tile (issued one tile ago) and, first time round, the weights have landed; the 8 epilogue
         // stores of the previous tile are younger and may still be in flight
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        // (vmcnt retires in order: everything but the previous tile's epilogue stores -- 8, or 10 with the bit masks)
+        if (a.bits) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (tp_next < tiles) issue_halo(tp_next, buf ^ 1);
@@ -437,10 +440,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p1, acc[1][1], 0, 0, 0);
         }
-        // epilogue: acc[j][i][r] = channel 64 tn + 32 j + 8 (r>>2) + 4 half + (r&3), pixel (oy0 + 2 wave + i, ox0 + tx)
+        // epilogue: acc[j][i][r] = channel 64 tn + 32 j + 8 (r>>2) + 4 half + (r&3), pixel (oy0 + 2 wave + i, ox0 + tx).
+        // A lane owns ONE pixel (two lanes per pixel), so straight from the registers a store instruction touches 32
+        // different 128-byte rows with 32 bytes each -- the layer is store-issue bound that way (2.8 TB/s of the 1.07 GB it
+        // writes at batch 128).  Each (row i, channel half j) piece -- 32 pixels x 64 bytes -- goes through a wave-private
+        // 2 KB LDS stage instead and leaves as two store instructions of 16 pixels x 64 contiguous bytes.
+        unsigned char *const stg = ldsS + wave * 2048;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const size_t pix = ((size_t)n * a.H + (oy0 + 2 * wave + i)) * a.W + ox0 + tx;
+            const size_t pix0 = ((size_t)n * a.H + (oy0 + 2 * wave + i)) * a.W + ox0;   // pixel of column 0 of this tile row
             unsigned wbits = 0;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -461,16 +469,27 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
                     pk[g].x = pack_bf16(v[0], v[1]);
                     pk[g].y = pack_bf16(v[2], v[3]);
                 }
+                // the previous piece's reads of the stage have returned (their data was stored from registers)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int g = 0; g < 4; g += 2) {
                     auto sx = __builtin_amdgcn_permlane32_swap(pk[g].x, pk[g + 1].x, false, false);
                     auto sy = __builtin_amdgcn_permlane32_swap(pk[g].y, pk[g + 1].y, false, false);
                     uint4 o;
                     o.x = sx[0]; o.y = sy[0]; o.z = sx[1]; o.w = sy[1];
-                    *reinterpret_cast<uint4 *>(a.y + pix * a.Cout + cbase + 8 * (g + half)) = o;
+                    // this lane: channels 32 j + 8 (g + half) ..+7 of pixel tx = 16-byte chunk lc = g + half of the pixel's
+                    // 64-byte piece; slot lc ^ ((tx >> 1) & 3): eight consecutive lanes hit eight different 16-byte banks
+                    *reinterpret_cast<uint4 *>(stg + tx * 64 + (((g + half) ^ ((tx >> 1) & 3)) << 4)) = o;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int u = lane + 64 * k, p = u >> 2, lc = (u & 3) ^ ((p >> 1) & 3);   // unit u of the stage -> (pixel, chunk)
+                    const uint4 o = *reinterpret_cast<const uint4 *>(stg + u * 16);
+                    *reinterpret_cast<uint4 *>(a.y + (pix0 + p) * a.Cout + cbase + 8 * lc) = o;
                 }
             }
-            if (a.bits) a.bits[(pix * (size_t)(a.Cout >> 6) + tn) * 2 + half] = wbits;
+            if (a.bits) a.bits[((pix0 + tx) * (size_t)(a.Cout >> 6) + tn) * 2 + half] = wbits;
         }
         if (tp_next >= tiles) break;
         tp = tp_next;
@@ -500,7 +519,7 @@ int conv_c8_launch(const m355_conv_desc *d, const void *x, const void *w_fwd, co
     a.xbytes = (unsigned)((size_t)d->N * d->H * d->W * 16);
     a.wbytes = (unsigned)wbytes;
     const int tiles = d->N * (d->H / 8) * (d->W / 32), nN = d->Cout / 64;
-    int per = 768 / nN;  // 3 resident workgroups per CU (42 KB of LDS each)
+    int per = 768 / nN;  // 3 resident workgroups per CU (50 KB of LDS each)
     if (per > tiles) per = tiles;
     if (per < 1) per = 1;
     const dim3 grid(per * nN);
