@@ -28,12 +28,12 @@ class BatchNormAct2d(G.BatchNorm2d):
         self.weight = nn.Parameter(torch.ones(ch))
         self.bias = nn.Parameter(torch.zeros(ch))
 
-    def forward(self, x, slope=0.0, res=None):
+    def forward(self, x, slope=0.0, res=None, out_slope=1.0):
         n = x.shape[0]
         # the fused kernels take per-sample (gamma, beta) with y = x_hat * (1 + gamma) + beta
         gamma = (self.weight - 1.0).unsqueeze(0).expand(n, -1)
         beta = self.bias.unsqueeze(0).expand(n, -1)
-        return super().forward(x, gamma, beta, slope, res)
+        return super().forward(x, gamma, beta, slope, res, out_slope)
 
 
 class ResBlock(nn.Module):
@@ -50,12 +50,14 @@ class ResBlock(nn.Module):
         else:
             self.shortcut = _Identity()
 
-    def forward(self, x, upsample=0):
+    def forward(self, x, upsample=0, out_slope=1.0):
         """x: the block input BEFORE the nearest x2 upsample that the caller applied to the previous block's output
-        (upsample=1); the shortcut stays at the input resolution and is read through the upsample by the fused add"""
+        (upsample=1); the shortcut stays at the input resolution and is read through the upsample by the fused add.
+        out_slope = 0: the ReLU the network applies to this block's output in front of a head, fused into the last pass
+        (its backward is applied by the head, gan_ops.head_conv(in_slope=0))"""
         sc = x if isinstance(self.shortcut, _Identity) else self.shortcut(x)
         h = self.bn1(self.conv1(x, upsample=upsample))
-        return self.bn2(self.conv2(h), res=sc)
+        return self.bn2(self.conv2(h), res=sc, out_slope=out_slope)
 
 
 class ReconstructionNetwork(nn.Module):
@@ -70,57 +72,66 @@ class ReconstructionNetwork(nn.Module):
         assert mesh_res >= 32
         assert texture_res >= 64
 
-        self.conv1e = Conv2d(4, 64, 5, stride=2, pad_h=2, pad_w=2, bias=False)       # 256 -> 128
+        # encoder: five stride-2 convolutions halve 256 x 256 down to 8 x 8 (:53-63)
+        self.conv1e = Conv2d(4, 64, 5, stride=2, pad_h=2, pad_w=2, bias=False)
         self.bn1e = BatchNormAct2d(64)
-        self.conv2e = Conv2d(64, 128, 3, stride=2, pad_h=1, pad_w=1, bias=False)     # -> 64
+        self.conv2e = Conv2d(64, 128, 3, stride=2, pad_h=1, pad_w=1, bias=False)
         self.bn2e = BatchNormAct2d(128)
-        self.conv3e = Conv2d(128, 256, 3, stride=2, pad_h=1, pad_w=1, bias=False)    # -> 32
+        self.conv3e = Conv2d(128, 256, 3, stride=2, pad_h=1, pad_w=1, bias=False)
         self.bn3e = BatchNormAct2d(256)
-        self.conv4e = Conv2d(256, 512, 3, stride=2, pad_h=1, pad_w=1, bias=False)    # -> 16
+        self.conv4e = Conv2d(256, 512, 3, stride=2, pad_h=1, pad_w=1, bias=False)
         self.bn4e = BatchNormAct2d(512)
 
         bottleneck_dim = 256
-        self.conv5e = Conv2d(512, 64, 3, stride=2, pad_h=1, pad_w=1, bias=False)     # -> 8
+        self.conv5e = Conv2d(512, 64, 3, stride=2, pad_h=1, pad_w=1, bias=False)
         self.bn5e = BatchNormAct2d(64)
         self.fc1e = nn.Linear(64 * 8 * 8, bottleneck_dim, bias=False)
         self.bnfc1e = nn.BatchNorm1d(bottleneck_dim)
         self.fc3e = nn.Linear(bottleneck_dim, 1024, bias=False)
         self.bnfc3e = nn.BatchNorm1d(1024)
 
-        # texture generation
+        # texture decoder: 4 x (2|4) seed, one x2 upsample after every block but the last (:72-90); texture_res 128 / 256
+        # insert one / two more 256-channel blocks
         self.base_res_h = 4
         self.base_res_w = 2 if symmetric else 4
         self.fc1_tex = nn.Linear(1024, self.base_res_h * self.base_res_w * 256)
-        self.blk1 = ResBlock(256, 512, self.pad)    # 4 -> 8
-        self.blk2 = ResBlock(512, 256, self.pad)    # 8 -> 16
-        self.blk3 = ResBlock(256, 256, self.pad)    # 16 -> 32 (k=1)
+        self.blk1 = ResBlock(256, 512, self.pad)
+        self.blk2 = ResBlock(512, 256, self.pad)
+        self.blk3 = ResBlock(256, 256, self.pad)
         assert texture_res in [64, 128, 256]
         self.texture_res = texture_res
         if texture_res >= 128:
-            self.blk3b_tex = ResBlock(256, 256, self.pad)   # k = 2
+            self.blk3b_tex = ResBlock(256, 256, self.pad)
         if texture_res >= 256:
-            self.blk3c_tex = ResBlock(256, 256, self.pad)   # k = 4
-        self.blk4_tex = ResBlock(256, 128, self.pad)        # k*32 -> k*64
-        self.blk5_tex = ResBlock(128, 64, self.pad)         # k*64 -> k*64 (no upsampling)
+            self.blk3c_tex = ResBlock(256, 256, self.pad)
+        self.blk4_tex = ResBlock(256, 128, self.pad)
+        self.blk5_tex = ResBlock(128, 64, self.pad)
         self.conv_tex = Conv2d(64, 3, 5, pad_h=2, pad_w=2, pad_w_mode=self.pad)
 
-        # mesh generation
-        self.blk4_mesh = ResBlock(256, 64, self.pad)        # 32 -> 32 (no upsampling)
+        # displacement-map decoder branches off at 32 x 32 (:92-99)
+        self.blk4_mesh = ResBlock(256, 64, self.pad)
         self.conv_mesh = Conv2d(64, 3, 5, pad_h=2, pad_w=2, pad_w_mode=self.pad)
         # zero-initialised mesh output layer for stability (avoids self-intersections, :97-99)
         self.conv_mesh.bias.data[:] = 0
         self.conv_mesh.weight.data[:] = 0
 
-    def forward(self, x):
-        """x [B,4,256,256] (RGB + mask, NCHW fp32) -> (tex [B,3,R,R], mesh_map [B,3,32,32]) NCHW fp32 (:106-137)"""
+    def encode_convs(self, x):
+        """conv1e .. bn5e (:108-112): x [B,4,256,256] NCHW fp32 -> [B,64,8,8] NCHW fp32"""
         h = G.to_nhwc_bf16(x, pad_to=8)
         for conv, bn in ((self.conv1e, self.bn1e), (self.conv2e, self.bn2e), (self.conv3e, self.bn3e),
                          (self.conv4e, self.bn4e), (self.conv5e, self.bn5e)):
             h = bn(conv(h))
-        z = G.to_nchw_f32(h).reshape(h.shape[0], -1)            # flatten in the reference's (C,H,W) order
-        z = torch.relu(self.bnfc1e(self.fc1e(z)))
-        z = torch.relu(self.bnfc3e(self.fc3e(z)))
+        return G.to_nchw_f32(h)
 
+    def encode(self, x):
+        """image -> bottleneck code z [B,1024] (:108-116)"""
+        z = self.encode_convs(x).reshape(x.shape[0], -1)        # flatten in the reference's (C,H,W) order
+        z = torch.relu(self.bnfc1e(self.fc1e(z)))
+        return torch.relu(self.bnfc3e(self.fc3e(z)))
+
+    def decode(self, z):
+        """bottleneck code -> (tex [B,3,R,R], mesh_map [B,3,32,32]) NCHW fp32 (:118-137).  The heads are the generator's:
+        ReLU fused into the last block's pass, conv, then tanh_ / adjust_poles / symmetrize in one elementwise kernel."""
         bb = G.to_nhwc_bf16(self.fc1_tex(z).view(z.shape[0], -1, self.base_res_h, self.base_res_w))
         bb = self.blk1(bb)
         bb = self.blk2(bb, upsample=1)      # every later block starts with the x2 upsample of the line before it
@@ -130,15 +141,12 @@ class ReconstructionNetwork(nn.Module):
             bb = self.blk3b_tex(bb, upsample=1)
         if self.texture_res >= 256:
             bb = self.blk3c_tex(bb, upsample=1)
-
-        mesh_map = self.blk4_mesh(bb_mesh, upsample=1)
-        mesh_map = adjust_poles(self.conv_mesh(torch.relu(mesh_map), out_f32_nchw=True))
-
+        sym = G.HT_SYMM if self.symmetric else 0
+        mesh_map = G.head_conv(self.blk4_mesh(bb_mesh, upsample=1, out_slope=0.0), self.conv_mesh, G.HT_POLES | sym, in_slope=0.0)
         tex = self.blk4_tex(bb, upsample=1)
-        tex = self.blk5_tex(tex, upsample=1)
-        tex = torch.tanh(self.conv_tex(torch.relu(tex), out_f32_nchw=True))
-
-        if self.symmetric:
-            tex = symmetrize_texture(tex)
-            mesh_map = symmetrize_texture(mesh_map)
+        tex = G.head_conv(self.blk5_tex(tex, upsample=1, out_slope=0.0), self.conv_tex, G.HT_TANH | sym, in_slope=0.0)
         return tex, mesh_map
+
+    def forward(self, x):
+        """x [B,4,256,256] (RGB + mask, NCHW fp32) -> (tex [B,3,R,R], mesh_map [B,3,32,32]) NCHW fp32 (:106-137)"""
+        return self.decode(self.encode(x))

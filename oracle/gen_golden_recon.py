@@ -55,7 +55,13 @@ def main():
         perturb_mesh_head(net, seed)
         net.train()
         x, g_tex, g_mesh = make_inputs(seed, B, kw["texture_res"], kw["symmetric"])
+        # the two interfaces between encoder / bottleneck / decoder, captured with forward pre-hooks (the reference's code
+        # is not touched): the flattened conv-encoder output that enters fc1e and the bottleneck code z that enters fc1_tex
+        cap = {}
+        h1 = net.fc1e.register_forward_pre_hook(lambda m, a: cap.__setitem__("enc5", a[0].detach().clone()))
+        h2 = net.fc1_tex.register_forward_pre_hook(lambda m, a: cap.__setitem__("z", a[0].detach().clone()))
         tex, mesh = net(x)
+        h1.remove(); h2.remove()
         ((tex * g_tex).sum() + (mesh * g_mesh).sum()).backward()
         keys = list(net.state_dict().keys())
         shapes = [tuple(v.shape) for v in net.state_dict().values()]
@@ -64,6 +70,7 @@ def main():
                             keys=np.array(keys), shapes=np.array([str(s) for s in shapes]),
                             grad_keys=np.array(list(gn.keys())), grad_norms=np.array(list(gn.values()), np.float64),
                             running_mean_bn1e=net.bn1e.running_mean.numpy(), running_var_bn1e=net.bn1e.running_var.numpy(),
+                            enc5=cap["enc5"].numpy().astype(np.float16), z=cap["z"].numpy(),
                             seed=seed, B=B, symmetric=kw["symmetric"], texture_res=kw["texture_res"])
         print(name, tuple(tex.shape), tuple(mesh.shape), "params", sum(p.numel() for p in net.parameters()))
 

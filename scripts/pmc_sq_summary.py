@@ -22,5 +22,10 @@ for (k, g), d in sorted(tab.items()):
     print(f"    grid {g}  wait {pct('SQ_WAIT_ANY')}  stall {pct('SQ_WAIT_INST_ANY')}  active {pct('SQ_ACTIVE_INST_ANY')}  "
           f"lds-issue-stall {pct('SQ_WAIT_INST_LDS')}  lds-active {pct('SQ_ACTIVE_INST_LDS')}  valu-active {pct('SQ_ACTIVE_INST_VALU')}")
     print("    " + "  ".join(f"{c}={v:.4g}" for c, v in sorted(d.items())))
+    req = d.get("TCC_REQ_sum", d.get("TCC_REQ"))
+    if req:
+        hit, miss = d.get("TCC_HIT_sum", d.get("TCC_HIT")), d.get("TCC_MISS_sum", d.get("TCC_MISS"))
+        print(f"    L2 requests {req * 64 / 1e6:.1f} MB (64-byte requests)" + (f", hit {100.0 * hit / req:.1f}%" if hit else "") +
+              (f", misses {miss * 64 / 1e6:.1f} MB" if miss else ""))
     if "SQ_LDS_BANK_CONFLICT" in d and d.get("SQ_ACTIVE_INST_LDS"):
         print(f"    LDS bank-conflict cycles / LDS active cycles = {d['SQ_LDS_BANK_CONFLICT'] / d['SQ_ACTIVE_INST_LDS']:.3f}")
