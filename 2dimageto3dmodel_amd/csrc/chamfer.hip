@@ -1,31 +1,44 @@
 // Chamfer nearest neighbour (BASELINE configs[4]; NEW capability: the reference has no Chamfer code, SURVEY 0.3,
 // so there is no reference oracle -- parity is against the brute-force restatement oracle/p_oracle.c:orc_chamfer_nn).
 //   dist[b,i] = min_j |a[b,i] - b[b,j]|^2,  idx[b,i] = argmin (lowest j on ties)
-// fp32-VALU bound (8 flops per pair, inputs are 2 x 196 KB per cloud): a workgroup owns 64 query points; its 4 waves
-// sweep disjoint quarters of every LDS-staged tile of 1024 target points (each lane reads the same target point: an
-// LDS broadcast), keep a running (min, argmin) per lane, and the 4 partial results are merged through LDS.
-// The squared distance is evaluated exactly as the oracle does (dx*dx + dy*dy + dz*dz, left to right, no FMA:
-// this file is compiled with -ffp-contract=off) so that distances and tie-breaking are bit-identical.
+// fp32-VALU bound (8 flops per pair, inputs are 2 x 196 KB per cloud).  A workgroup owns 64 * QPL query points (QPL per
+// lane); its NW waves sweep disjoint slices of every LDS-staged tile of 1024 target points.  Round 2 (the first version
+// issued 11 VALU + 3 LDS instructions per pair and ran at 6-18 % of the fp32 vector peak):
+//   * targets are staged as x[1024] | y[1024] | z[1024]: ONE ds_read_b128 broadcasts a coordinate of FOUR targets;
+//   * the distance arithmetic runs two targets at a time on the packed fp32 pipe (v_pk_add/mul_f32: each lane of a packed
+//     op rounds on its own, there is no fused op -- this file is compiled with -ffp-contract=off -- so every distance keeps
+//     the oracle's bits: ((dx*dx + dy*dy) + dz*dz));
+//   * the sweep only tracks the running MINIMUM (one v_min3_f32 per two pairs) and, per 64-target chunk, whether it
+//     improved; the index is recovered afterwards by re-scanning that one chunk for the first target attaining the
+//     minimum (lowest j on ties, as the oracle): 4.5 VALU + 0.75 LDS instructions per pair instead of 11 + 3;
+//   * small problems (B = 1) get 16 waves per workgroup over 64 queries instead of a quarter-filled chip.
 #include "common.h"
 
 namespace m355 {
 
 constexpr int kTile = 1024;
+typedef float f2 __attribute__((ext_vector_type(2)));
 
-// QPL query points per lane: every LDS broadcast of a target point is reused for QPL distance evaluations (the
-// single-query version spent a third of its issue slots on the three ds_reads per pair).
-template <int QPL>
-__global__ __launch_bounds__(256) void k_chamfer_nn(const float *__restrict__ a, const float *__restrict__ b,
-                                                    float *__restrict__ dist, int32_t *__restrict__ idx, int N, int M)
+__device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, float by, float bz)
 {
-    __shared__ float tb[kTile * 3];
-    __shared__ float red_d[4][64 * QPL];
-    __shared__ int red_i[4][64 * QPL];
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return dx * dx + dy * dy + dz * dz;
+}
+
+template <int QPL, int NW>
+__global__ __launch_bounds__(NW * 64) void k_chamfer_nn(const float *__restrict__ a, const float *__restrict__ b,
+                                                       float *__restrict__ dist, int32_t *__restrict__ idx, int N, int M)
+{
+    constexpr int SL = kTile / NW;            // targets of a tile one wave sweeps (a multiple of 64)
+    static_assert(SL % 64 == 0, "wave slices are whole chunks");
+    __shared__ __attribute__((aligned(16))) float tb[3][kTile];
+    __shared__ float red_d[NW][64 * QPL];
+    __shared__ int red_i[NW][64 * QPL];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bi = blockIdx.y;
     const float *ab = a + (size_t)bi * N * 3, *bb = b + (size_t)bi * M * 3;
     float ax[QPL], ay[QPL], az[QPL], best[QPL];
-    int besti[QPL];
+    int cstart[QPL];                          // first target of the chunk in which `best` last improved
 #pragma unroll
     for (int k = 0; k < QPL; ++k) {
         const int i = (blockIdx.x * QPL + k) * 64 + lane;
@@ -34,44 +47,75 @@ __global__ __launch_bounds__(256) void k_chamfer_nn(const float *__restrict__ a,
         ay[k] = live ? ab[3 * i + 1] : 0.f;
         az[k] = live ? ab[3 * i + 2] : 0.f;
         best[k] = INFINITY;
-        besti[k] = -1;
+        cstart[k] = -1;
     }
     for (int j0 = 0; j0 < M; j0 += kTile) {
         const int cnt = min(kTile, M - j0);
         __syncthreads();
-        for (int t = tid; t < cnt * 3; t += 256) tb[t] = bb[(size_t)j0 * 3 + t];
+        for (int t = tid; t < kTile; t += NW * 64) {   // structure of arrays; the tail is padded with far-away points (d = inf)
+            const bool in = t < cnt;
+            tb[0][t] = in ? bb[(size_t)(j0 + t) * 3] : 1e30f;
+            tb[1][t] = in ? bb[(size_t)(j0 + t) * 3 + 1] : 1e30f;
+            tb[2][t] = in ? bb[(size_t)(j0 + t) * 3 + 2] : 1e30f;
+        }
         __syncthreads();
-        // wave w sweeps points [w*256, w*256+256) of the tile, in index order (ties keep the lowest j)
-        const int lo = wave * (kTile / 4), hi = min(cnt, lo + kTile / 4);
-#pragma unroll 2
-        for (int j = lo; j < hi; ++j) {
-            const float bx = tb[3 * j], by = tb[3 * j + 1], bz = tb[3 * j + 2];
+        const int lo = wave * SL;
+        if (lo < cnt) {
+            for (int c = 0; c < SL; c += 64) {   // one chunk: 16 groups of 4 targets
+                float prev[QPL];
 #pragma unroll
-            for (int k = 0; k < QPL; ++k) {
-                const float dx = ax[k] - bx, dy = ay[k] - by, dz = az[k] - bz;
-                const float d = dx * dx + dy * dy + dz * dz;
-                if (d < best[k]) {
-                    best[k] = d;
-                    besti[k] = j0 + j;
+                for (int k = 0; k < QPL; ++k) prev[k] = best[k];
+#pragma unroll 4
+                for (int g = 0; g < 64; g += 4) {
+                    const float4 bx = *reinterpret_cast<const float4 *>(&tb[0][lo + c + g]);
+                    const float4 by = *reinterpret_cast<const float4 *>(&tb[1][lo + c + g]);
+                    const float4 bz = *reinterpret_cast<const float4 *>(&tb[2][lo + c + g]);
+                    const f2 bx01 = {bx.x, bx.y}, bx23 = {bx.z, bx.w}, by01 = {by.x, by.y}, by23 = {by.z, by.w},
+                             bz01 = {bz.x, bz.y}, bz23 = {bz.z, bz.w};
+#pragma unroll
+                    for (int k = 0; k < QPL; ++k) {
+                        const f2 qx = {ax[k], ax[k]}, qy = {ay[k], ay[k]}, qz = {az[k], az[k]};
+                        const f2 dx0 = qx - bx01, dy0 = qy - by01, dz0 = qz - bz01;
+                        const f2 dx1 = qx - bx23, dy1 = qy - by23, dz1 = qz - bz23;
+                        const f2 d0 = dx0 * dx0 + dy0 * dy0 + dz0 * dz0;
+                        const f2 d1 = dx1 * dx1 + dy1 * dy1 + dz1 * dz1;
+                        best[k] = fminf(fminf(best[k], d0.x), d0.y);
+                        best[k] = fminf(fminf(best[k], d1.x), d1.y);
+                    }
                 }
+#pragma unroll
+                for (int k = 0; k < QPL; ++k)
+                    if (best[k] < prev[k]) cstart[k] = j0 + lo + c;
             }
         }
     }
+    // ---- recover the index: the first target of the recorded chunk that attains the minimum (same arithmetic)
+    int besti[QPL];
 #pragma unroll
     for (int k = 0; k < QPL; ++k) {
+        besti[k] = -1;
+        if (cstart[k] >= 0) {
+            const int hi = min(cstart[k] + 64, M);
+            for (int j = cstart[k]; j < hi; ++j) {
+                const float d = dist2(ax[k], ay[k], az[k], bb[(size_t)j * 3], bb[(size_t)j * 3 + 1], bb[(size_t)j * 3 + 2]);
+                if (d == best[k]) {
+                    besti[k] = j;
+                    break;
+                }
+            }
+        }
         red_d[wave][k * 64 + lane] = best[k];
         red_i[wave][k * 64 + lane] = besti[k];
     }
     __syncthreads();
     if (wave == 0) {
-        // merge the 4 quarter-sweeps: lower distance wins, equal distance -> lower index
+        // merge the NW slice sweeps: lower distance wins, equal distance -> lower index
 #pragma unroll
         for (int k = 0; k < QPL; ++k) {
             const int i = (blockIdx.x * QPL + k) * 64 + lane;
             float d0 = red_d[0][k * 64 + lane];
             int i0 = red_i[0][k * 64 + lane];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) {
+            for (int w = 1; w < NW; ++w) {
                 const float d1 = red_d[w][k * 64 + lane];
                 const int i1 = red_i[w][k * 64 + lane];
                 if (i1 >= 0 && (d1 < d0 || (d1 == d0 && i1 < i0) || i0 < 0)) {
@@ -96,10 +140,14 @@ extern "C" int m355_chamfer_nn_fwd(const float *a, const float *b, float *dist, 
     if (B == 0 || N == 0) return M355_OK;
     M355_REQUIRE(a && b && dist && idx, "chamfer_nn_fwd: null pointer");
     M355_REQUIRE(B <= 65535, "chamfer_nn_fwd: B=%d exceeds grid.y", B);
-    // 4 queries per lane once that still leaves >= 1 workgroup per CU
+    hipStream_t st = (hipStream_t)stream;
+    // most queries per lane (= most reuse of a broadcast target) that still gives every CU a workgroup; the smaller shapes
+    // make up for it with more waves per workgroup over the same target tile
     if ((long)B * ((N + 255) / 256) >= 256)
-        hipLaunchKernelGGL(m355::k_chamfer_nn<4>, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, a, b, dist, idx, N, M);
+        hipLaunchKernelGGL((m355::k_chamfer_nn<4, 4>), dim3((N + 255) / 256, B), dim3(256), 0, st, a, b, dist, idx, N, M);
+    else if ((long)B * ((N + 127) / 128) >= 256)
+        hipLaunchKernelGGL((m355::k_chamfer_nn<2, 8>), dim3((N + 127) / 128, B), dim3(512), 0, st, a, b, dist, idx, N, M);
     else
-        hipLaunchKernelGGL(m355::k_chamfer_nn<1>, dim3((N + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, a, b, dist, idx, N, M);
+        hipLaunchKernelGGL((m355::k_chamfer_nn<1, 16>), dim3((N + 63) / 64, B), dim3(1024), 0, st, a, b, dist, idx, N, M);
     return m355::check_launch("chamfer_nn_fwd");
 }

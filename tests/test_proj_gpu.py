@@ -260,12 +260,18 @@ def test_size_independent_properties_full_size(pkg):
     assert frac_off(p4, p1) < 1e-3
 
 
-@pytest.mark.parametrize("B,N,M", [(2, 100, 70), (1, 1000, 2500), (3, 64, 1), (1, 16384, 4096)])
+@pytest.mark.parametrize("B,N,M", [(2, 100, 70), (1, 1000, 2500), (3, 64, 1), (1, 16384, 4096),
+                                   (2, 16384, 1500),    # the 8-wave / 2-queries-per-lane shape
+                                   (4, 16384, 2100)])   # the 4-wave / 4-queries-per-lane shape, ragged last tile
 def test_chamfer_nn_bit_exact_vs_oracle(pkg, B, N, M):
     rs = np.random.RandomState(N + M)
     a = rs.rand(B, N, 3).astype(np.float32)
     b = rs.rand(B, M, 3).astype(np.float32)
     b[:, M // 2] = b[:, 0]  # exact duplicate target: ties must resolve to the lowest index
+    if M > 200:
+        b[:, 130] = b[:, 67]        # duplicates in different 64-target chunks / wave slices / tiles
+        b[:, M - 1] = b[:, 5]
+        a[:, 0] = b[:, 67]          # a query sitting exactly on a duplicated target (distance 0, tie)
     d_o, i_o = po.chamfer_nn(a, b)
     d, i = pkg.ops.chamfer_nn(t(a), t(b))
     assert np.array_equal(i.cpu().numpy(), i_o)
