@@ -124,6 +124,16 @@ def run_case(name, seed, B, over, ref_gan, GANLoss):
     if not args.conditional_text:
         caption = None
     w = d_weight(args)
+    # ---- inference mode first (ModelWrapper.forward('inference'), main.py:521-525, under trainer.eval()): running
+    # statistics, no power iteration -- leaves every buffer untouched, so the training goldens below do not move
+    eval_rec = {}
+    if name in ("g_class128", "g_text128", "g_uncond_circ"):
+        G.eval()
+        with torch.no_grad():
+            te, me, att = G(z, c, caption, return_attention=True)
+        eval_rec = dict(eval_tex=te.numpy().astype(np.float16), eval_mesh=me.numpy())
+        if att is not None:
+            eval_rec["eval_att"] = att.numpy()
     G.train(); D.train()
     # ---- G step (main.py:491-498)
     pred_tex, pred_mesh = G(z, c, caption)
@@ -169,6 +179,7 @@ def run_case(name, seed, B, over, ref_gan, GANLoss):
         bn_mean_blk6=(G.blk6.norm2.norm.running_mean.numpy() if getattr(G.blk6.norm2.norm, "running_mean", None) is not None
                       else np.zeros(1)),
     )
+    rec.update(eval_rec)
     for i, t in enumerate(disc):
         rec[f"d{i + 1}"] = t.detach().numpy()
         rec[f"dd{i + 1}"] = disc2[i].detach().numpy()

@@ -107,6 +107,21 @@ def test_g_step_and_d_step_match_reference(name):
     w = d_weight(args)
     nd = args.num_discriminators
     ts = int(g.get("tex_stride", 1))
+    if "eval_tex" in g:
+        # ---- inference mode (ModelWrapper.forward('inference') under trainer.eval()): running statistics, sigma from the stored
+        # u / v without a power iteration; must leave the training-mode goldens below untouched
+        G.eval()
+        with torch.no_grad():
+            te, me, att = G(z, c, caption, return_attention=True)
+        G.train()
+        e = (te.cpu() - torch.from_numpy(g["eval_tex"].astype(np.float32))).abs()
+        assert e.mean().item() < 6e-3 and e.max().item() < 8e-2, (e.mean().item(), e.max().item())
+        assert (me.cpu() - torch.from_numpy(g["eval_mesh"])).abs().max().item() < 1e-6
+        if "eval_att" in g:
+            assert tuple(att.shape) == g["eval_att"].shape
+            assert (att.cpu() - torch.from_numpy(g["eval_att"])).abs().max().item() < 2e-2
+        else:
+            assert att is None
     # ---- G step
     pred_tex, pred_mesh = G(z, c, caption)
     assert pred_tex.dtype == torch.float32 and tuple(pred_tex[:, :, ::ts, ::ts].shape) == g["pred_tex"].shape

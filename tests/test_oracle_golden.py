@@ -128,6 +128,11 @@ def test_gan_cpu_oracle_matches_reference_goldens(name):
     torch.set_num_threads(8)
     g, gc, args, wg, wd, (z, c, x_tex, x_alpha, x_mesh, caption) = _gan_case(name)
     sym = bool(g["symmetric"])
+    if "eval_tex" in g:   # inference mode of the generator (running statistics, stored sigma)
+        with torch.no_grad():
+            te, me = gc.generator(wg, args, z, c, caption, sym, training=False)
+        assert np.abs(te.numpy() - g["eval_tex"].astype(np.float32)).max() < 2e-3
+        assert np.abs(me.numpy() - g["eval_mesh"]).max() < 1e-6
     loss, pred_tex, pred_mesh, disc, mask = gc.g_step(wg, wd, args, z, c, x_alpha, caption, sym)
     ts = int(g.get("tex_stride", 1))
     assert np.abs(pred_tex.detach().numpy()[:, :, ::ts, ::ts] - g["pred_tex"].astype(np.float32)).max() < 2e-3  # fp16 storage
