@@ -178,10 +178,14 @@ __global__ __launch_bounds__(256) void k_rast_fwd(RastArgs a)
     }
 }
 
+// Gradient accumulators of the faces in the tile's current scan round: pixels of one face are neighbours, so their
+// contributions are summed in LDS (ds_add_f32) and leave as ONE global atomic per (tile, face, component) -- with global
+// atomics per pixel the backward was 6x the forward (15 same-address atomics for each of ~34 pixels of a face).
 __global__ __launch_bounds__(256) void k_rast_bwd(RastArgs a)
 {
     __shared__ FaceLds fl[RCH];
     __shared__ int wave_cnt[4];
+    __shared__ float acc[RCH][6 + 3 * 3 + 1];   // D <= 3 on the LDS path (the renderer's uv + mask); wider attributes: global atomics
     const int b = blockIdx.z, tid = threadIdx.x;
     const int w = blockIdx.x * RT + (tid & (RT - 1)), h = blockIdx.y * RT + (tid >> 4);
     const bool live = w < a.W && h < a.H;
@@ -191,48 +195,83 @@ __global__ __launch_bounds__(256) void k_rast_bwd(RastArgs a)
     const float tx0 = (float)(2 * w0i + 1 - a.W) / (float)a.W, tx1 = (float)(2 * w1i + 1 - a.W) / (float)a.W;
     const float ty1 = (float)(a.H - 2 * h0i - 1) / (float)a.H, ty0 = (float)(a.H - 2 * h1i - 1) / (float)a.H;
     const size_t pix = live ? ((size_t)b * a.H + h) * a.W + w : 0;
-    const int idx = live ? a.imidx[pix] : 0;
+    const int idx = live ? a.imidx[pix] : -1;
+    const bool lds_path = a.D <= 3;
+    const int NA = 6 + 3 * a.D;
 
-    // ---- covered pixel: through the saved weights of its face
+    // ---- this pixel's contribution to its covering face (through the saved weights)
+    float gv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ga[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool has = false;
     if (live && idx >= 0) {
         const float *v = a.p2 + ((size_t)b * a.F + idx) * 6;
         const float ax = v[0], ay = v[1], bx = v[2], by = v[3], cx = v[4], cy = v[5];
         const float w0 = a.imwei[pix * 3], w1 = a.imwei[pix * 3 + 1], w2 = a.imwei[pix * 3 + 2];
         const float *at = a.attr + ((size_t)b * a.F + idx) * 3 * a.D;
-        float *da = a.dattr + ((size_t)b * a.F + idx) * 3 * a.D;
         float dw0 = 0.f, dw1 = 0.f, dw2 = 0.f;
         for (int d = 0; d < a.D; ++d) {
             const float g = a.dfeat[pix * a.D + d];
             dw0 += g * at[d]; dw1 += g * at[a.D + d]; dw2 += g * at[2 * a.D + d];
             if (g != 0.0f) {
-                atomicAdd(da + d, w0 * g);
-                atomicAdd(da + a.D + d, w1 * g);
-                atomicAdd(da + 2 * a.D + d, w2 * g);
+                has = true;
+                if (lds_path) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        if (q == d) { ga[q] = w0 * g; ga[3 + q] = w1 * g; ga[6 + q] = w2 * g; }
+                } else {
+                    float *da = a.dattr + ((size_t)b * a.F + idx) * 3 * a.D;
+                    atomicAdd(da + d, w0 * g);
+                    atomicAdd(da + a.D + d, w1 * g);
+                    atomicAdd(da + 2 * a.D + d, w2 * g);
+                }
             }
         }
-        // w2 = 1 - w0 - w1;  w0 = N0 / A,  w1 = N1 / A
+        // w2 = 1 - w0 - w1;  w0 = N0 / A,  w1 = N1 / A;  N0 = cross(b - p, c - p), N1 = cross(c - p, a - p), A = cross(b - a, c - a)
         const float g0 = dw0 - dw2, g1 = dw1 - dw2;
         if (g0 != 0.0f || g1 != 0.0f) {
+            has = true;
             const float A = cross2(bx - ax, by - ay, cx - ax, cy - ay);
             const float dN0 = g0 / A, dN1 = g1 / A, dA = -(g0 * w0 + g1 * w1) / A;
-            // N0 = cross(b - p, c - p), N1 = cross(c - p, a - p), A = cross(b - a, c - a)
-            float *dp = a.dp2 + ((size_t)b * a.F + idx) * 6;
-            atomicAdd(dp + 0, dN1 * (-(cy - py)) + dA * (by - cy));
-            atomicAdd(dp + 1, dN1 * (cx - px) + dA * (cx - bx));
-            atomicAdd(dp + 2, dN0 * (cy - py) + dA * (cy - ay));
-            atomicAdd(dp + 3, dN0 * (-(cx - px)) + dA * (-(cx - ax)));
-            atomicAdd(dp + 4, dN0 * (-(by - py)) + dN1 * (ay - py) + dA * (-(by - ay)));
-            atomicAdd(dp + 5, dN0 * (bx - px) + dN1 * (-(ax - px)) + dA * (bx - ax));
+            gv[0] = dN1 * (-(cy - py)) + dA * (by - cy);
+            gv[1] = dN1 * (cx - px) + dA * (cx - bx);
+            gv[2] = dN0 * (cy - py) + dA * (cy - ay);
+            gv[3] = dN0 * (-(cx - px)) + dA * (-(cx - ax));
+            gv[4] = dN0 * (-(by - py)) + dN1 * (ay - py) + dA * (-(by - ay));
+            gv[5] = dN0 * (bx - px) + dN1 * (-(ax - px)) + dA * (bx - ax);
+            if (!lds_path) {
+                float *dp = a.dp2 + ((size_t)b * a.F + idx) * 6;
+                for (int k = 0; k < 6; ++k) atomicAdd(dp + k, gv[k]);
+            }
         }
     }
-    // ---- uncovered pixels: improb = 1 - prod (1 - a_j), a_j = exp(-delta d_j^2).  (Whole tiles without any incoming
-    // probability gradient on uncovered pixels skip the face scan.)
     const float gp = (live && idx < 0) ? a.dprob[pix] : 0.0f;
-    if (!__syncthreads_or(gp != 0.0f)) return;
+    // whole tiles with nothing to propagate skip the face scan
+    if (!__syncthreads_or((has && lds_path) || gp != 0.0f)) return;
     const float keep = live ? 1.0f - a.improb[pix] : 1.0f;
     int kcount = 0;
     for (int base = 0; base < a.F; base += RCH) {
         const int n = scan_faces(a, b, base, tx0, tx1, ty0, ty1, fl, wave_cnt);
+        for (int t = tid; t < n * 16; t += 256) acc[t >> 4][t & 15] = 0.0f;
+        __syncthreads();
+        // covered pixel: its face is in exactly one round's list (a face covering a pixel of the tile overlaps the tile)
+        if (has && lds_path && idx >= base && idx < base + RCH) {
+            int jf = -1;
+            for (int j = 0; j < n; ++j)
+                if (fl[j].id == idx) { jf = j; break; }
+            if (jf >= 0) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (gv[k] != 0.0f) atomicAdd(&acc[jf][k], gv[k]);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    if (d < a.D) {
+                        if (ga[d] != 0.0f) atomicAdd(&acc[jf][6 + d], ga[d]);
+                        if (ga[3 + d] != 0.0f) atomicAdd(&acc[jf][6 + a.D + d], ga[3 + d]);
+                        if (ga[6 + d] != 0.0f) atomicAdd(&acc[jf][6 + 2 * a.D + d], ga[6 + d]);
+                    }
+                }
+            }
+        }
+        // uncovered pixel: improb = 1 - prod (1 - a_j), a_j = exp(-delta d_j^2) over the first knum boxed faces
         for (int j = 0; j < n; ++j) {
             const FaceLds &fc = fl[j];
             if (!(px >= fc.bb[0] && px < fc.bb[2] && py >= fc.bb[1] && py < fc.bb[3])) continue;
@@ -243,26 +282,35 @@ __global__ __launch_bounds__(256) void k_rast_bwd(RastArgs a)
             float t0, t1, t2;
             const float d0 = seg_d2(px, py, ax, ay, bx, by, t0), d1 = seg_d2(px, py, bx, by, cx, cy, t1),
                         d2c = seg_d2(px, py, cx, cy, ax, ay, t2);
-            // the closest edge (ties: the first, as torch.minimum's gradient convention is irrelevant at measure zero)
-            int e = 0;
+            int e = 0;   // the closest edge (ties: the first)
             float dm = d0, t = t0;
             if (d1 < dm) { dm = d1; t = t1; e = 1; }
             if (d2c < dm) { dm = d2c; t = t2; e = 2; }
             const float aj = __expf(-a.delta * dm);
             const float om = 1.0f - aj;
             if (om <= 0.0f) continue;
-            // improb = 1 - prod (1 - a_k):  d improb / d a_j = keep / (1 - a_j),  d a_j / d d^2 = -delta a_j
+            // d improb / d a_j = keep / (1 - a_j),  d a_j / d d^2 = -delta a_j
             const float gd2 = gp * (keep / om) * (-a.delta * aj);
             const float sx = e == 0 ? ax : (e == 1 ? bx : cx), sy = e == 0 ? ay : (e == 1 ? by : cy);
             const float ex_ = e == 0 ? bx : (e == 1 ? cx : ax), ey_ = e == 0 ? by : (e == 1 ? cy : ay);
             const float rx = px - (sx + t * (ex_ - sx)), ry = py - (sy + t * (ey_ - sy));
             // d d^2 / d start = -2 (1 - t) r,  d d^2 / d end = -2 t r
-            float *dp = a.dp2 + ((size_t)b * a.F + fc.id) * 6;
             const int is = 2 * e, ie = 2 * ((e + 1) % 3);
-            atomicAdd(dp + is, gd2 * -2.0f * (1.0f - t) * rx);
-            atomicAdd(dp + is + 1, gd2 * -2.0f * (1.0f - t) * ry);
-            atomicAdd(dp + ie, gd2 * -2.0f * t * rx);
-            atomicAdd(dp + ie + 1, gd2 * -2.0f * t * ry);
+            atomicAdd(&acc[j][is], gd2 * -2.0f * (1.0f - t) * rx);
+            atomicAdd(&acc[j][is + 1], gd2 * -2.0f * (1.0f - t) * ry);
+            atomicAdd(&acc[j][ie], gd2 * -2.0f * t * rx);
+            atomicAdd(&acc[j][ie + 1], gd2 * -2.0f * t * ry);
+        }
+        __syncthreads();
+        // flush: one global atomic per (face of the round, component) that received something
+        for (int t = tid; t < n * 16; t += 256) {
+            const int jj = t >> 4, k = t & 15;
+            const float v = acc[jj][k];
+            if (k < NA && v != 0.0f) {
+                const int f = fl[jj].id;
+                if (k < 6) atomicAdd(a.dp2 + ((size_t)b * a.F + f) * 6 + k, v);
+                else atomicAdd(a.dattr + ((size_t)b * a.F + f) * 3 * a.D + (k - 6), v);
+            }
         }
         __syncthreads();
     }

@@ -115,6 +115,29 @@ def test_rasterizer_matches_oracle(H, W, B):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("D", [1, 4])
+def test_rasterizer_other_attribute_widths(D):
+    """vertex attributes of width D != 3 (D > 3 takes the global-atomic backward): features and gradients vs the oracle"""
+    R = _mods()
+    B, H, W = 2, 48, 48
+    pts, faces, _, _ = scene(B, 11)
+    g = torch.Generator().manual_seed(D)
+    p3, p2, nrm = rr.ortho_projection_ref(pts, faces)
+    attr = torch.randn(B, faces.shape[0], 3 * D, generator=g)
+    wf, wp = torch.randn(B, H, W, D, generator=g), torch.randn(B, H, W, 1, generator=g)
+    p2r, ar = p2.clone().requires_grad_(), attr.clone().requires_grad_()
+    feat_r, prob_r, _, _ = rr.linear_rasterizer_ref(H, W, p3, p2r, nrm[:, :, 2:3], ar)
+    ((feat_r * wf).sum() + (prob_r * wp).sum()).backward()
+    d = "cuda:0"
+    p2d, ad = p2.to(d).requires_grad_(), attr.to(d).requires_grad_()
+    feat, prob = R.linear_rasterizer(H, W, p3.to(d), p2d, nrm[:, :, 2:3].to(d).contiguous(), ad)
+    assert (feat.cpu() - feat_r.detach()).abs().max().item() < 5e-5 and (prob.cpu() - prob_r.detach()).abs().max().item() < 2e-5
+    ((feat * wf.to(d)).sum() + (prob * wp.to(d)).sum()).backward()
+    assert (ad.grad.cpu() - ar.grad).abs().max().item() < 1e-4 * ar.grad.abs().max().item()
+    assert (p2d.grad.cpu() - p2r.grad).abs().max().item() < 2e-3 * p2r.grad.abs().max().item()
+
+
+@pytest.mark.gpu
 def test_renderer_forward_backward_matches_oracle():
     """Renderer.forward (ortho projection, rasteriser, bilinear fragment shader, hard mask / soft probability) and the
     gradients of an image + silhouette loss with respect to the vertices and the texture (oracle: torch autograd)"""
