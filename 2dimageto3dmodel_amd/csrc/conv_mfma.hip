@@ -589,6 +589,9 @@ int conv_c8_launch(const m355_conv_desc *d, const void *x, const void *w_fwd, co
 bool dgrad_small_eligible(const m355_conv_desc *d, int Cy);
 int dgrad_small_launch(const m355_conv_desc *d, const void *dy, int Cy, const void *w_dgrad, int Kp, size_t wbytes, void *dx,
                        hipStream_t st);
+bool dgrad_c8_replicate_eligible(const m355_conv_desc *d, int Cy);  // csrc/conv_small.hip
+int dgrad_c8_replicate_launch(const m355_conv_desc *d, const void *dy, const void *w_dgrad, int Kp, size_t wbytes, void *dx,
+                              hipStream_t st);
 bool wgrad_c8_eligible(const m355_conv_desc *d, int Cy);  // csrc/conv_small.hip
 int wgrad_c8_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, float *db, hipStream_t st);
 bool wgrad_small_eligible(const m355_conv_desc *d, int Cy);
@@ -863,6 +866,9 @@ static int conv_dgrad_impl(const m355_conv_desc *d, const void *dy, const void *
         return m355::launch_conv(a, st);
     }
     if (probe) return 0;
+    if (!mask_x && !mask_bits && m355::dgrad_c8_replicate_eligible(d, cout32))   // 5x5 heads of the symmetric generator
+        return m355::dgrad_c8_replicate_launch(d, dy, w_dgrad, m355::k_padded(d->kh * d->kw * cout32),
+                                               (size_t)cin64 * m355::k_padded(d->kh * d->kw * cout32) * 2, dx, st);
     const bool need_fold = d->upsample || (d->pad_w_mode != 0 && d->pad_w > 0) || d->stride == 2;
     M355_REQUIRE(!need_fold || ws, "conv2d_dgrad: workspace required");
     if (d->stride == 1) {

@@ -530,6 +530,67 @@ int conv_c8_launch(const m355_conv_desc *d, const void *x, const void *w_fwd, co
     return check_launch("conv2d_fwd (8 input channels)");
 }
 
+// ---- dgrad of a replicate-padded 5x5 head (conv_final / conv_mesh of the symmetric generator, gan.py:328-329,359-368):
+// Cout <= 8 so dy is ONE 16-byte chunk per pixel and the gradient is "a conv with 8 input channels" = k_conv_c8 on dy with
+// the flipped weight view -- for the interior term (zero-padded dy).  The replicate pad adds the gradient of the two pad
+// columns on each side, which lands on image columns 0 and W-1: dx[:, y, 0] += dxp[y, -2] + dxp[y, -1] (and mirrored), where
+// dxp is the same conv evaluated at the pad columns.  Only taps reaching back into the image contribute (1 + 2 of the 5 kw
+// per pad column), so this is 2/W of the layer's work: one thread per (row, side, input channel).
+__global__ __launch_bounds__(256) void k_dgrad_edge5(const unsigned short *__restrict__ dy, const unsigned short *__restrict__ wd,
+                                                     unsigned short *__restrict__ dx, int N, int H, int W, int Cin, int Kp)
+{
+    const size_t total = (size_t)N * H * 2 * Cin;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int ci = (int)(i % Cin);
+        size_t t = i / Cin;
+        const int side = (int)(t & 1);
+        t >>= 1;
+        const int y = (int)(t % H), n = (int)(t / H);
+        const unsigned short *wrow = wd + (size_t)ci * Kp;
+        float acc = 0.0f;
+        for (int pp = 0; pp < 2; ++pp) {
+            const int p = side == 0 ? -2 + pp : W + pp;          // pad column (frame coordinate of the dgrad output)
+            for (int kh = 0; kh < 5; ++kh) {
+                const int yy = y + kh - 2;
+                if ((unsigned)yy >= (unsigned)H) continue;
+                for (int kw = 0; kw < 5; ++kw) {
+                    const int xx = p + kw - 2;
+                    if ((unsigned)xx >= (unsigned)W) continue;
+                    const bf16x8 dv = *reinterpret_cast<const bf16x8 *>(dy + (((size_t)n * H + yy) * W + xx) * 8);
+                    const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(wrow + (kh * 5 + kw) * 8);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc += bf2f((unsigned short)dv[c]) * bf2f((unsigned short)wv[c]);
+                }
+            }
+        }
+        unsigned short *o = dx + (((size_t)n * H + y) * W + (side == 0 ? 0 : W - 1)) * Cin + ci;
+        *o = f2bf(bf2f(*o) + acc);
+    }
+}
+
+bool dgrad_c8_replicate_eligible(const m355_conv_desc *d, int Cy)
+{
+    return Cy == 8 && d->pad_w_mode == 1 && d->stride == 1 && d->upsample == 0 && d->kh == 5 && d->kw == 5 && d->pad_h == 2 &&
+           d->pad_w == 2 && d->Cin % 64 == 0 && d->W % 32 == 0 && d->H % 8 == 0 && d->W >= 4 &&
+           (size_t)d->N * d->H * d->W * 16 < (1ull << 31) && !getenv("M355_NO_C8_DGRAD");
+}
+
+int dgrad_c8_replicate_launch(const m355_conv_desc *d, const void *dy, const void *w_dgrad, int Kp, size_t wbytes, void *dx,
+                              hipStream_t st)
+{
+    m355_conv_desc t = *d;
+    t.Cin = 8;             // the "input" of this conv is dy (3 real channels in an 8-channel chunk)
+    t.Cout = d->Cin;
+    t.pad_w_mode = 0;      // interior term: zero-padded dy
+    if (int rc = conv_c8_launch(&t, dy, w_dgrad, nullptr, dx, 1.0f, Kp, wbytes, nullptr, st)) return rc;
+    const size_t total = (size_t)d->N * d->H * 2 * d->Cin;
+    const size_t g = (total + 255) / 256;
+    hipLaunchKernelGGL(k_dgrad_edge5, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, st, (const unsigned short *)dy,
+                       (const unsigned short *)w_dgrad, (unsigned short *)dx, d->N, d->H, d->W, d->Cin, Kp);
+    note_kernel("k_conv_c8");
+    return check_launch("conv2d_dgrad (replicate 5x5 head)");
+}
+
 // host side: eligibility + launch (called from m355_conv2d_fwd)
 bool conv_small_eligible(const m355_conv_desc *d, int y_f32_nchw)
 {

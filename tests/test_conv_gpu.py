@@ -62,6 +62,9 @@ CASES = [
     # ---- 8-input-channel kernel (conv_small.hip k_conv_c8): D.conv1
     (3, 24, 64, 8, 64, 5, 1, 2, 2, 2, 0),     # circular, several tiles per image
     (2, 16, 32, 8, 128, 5, 1, 2, 2, 0, 0),    # zero W pad, two 64-channel output tiles
+    # ---- replicate-padded 5x5 heads whose dgrad runs on k_conv_c8 + the pad-column edge term
+    (2, 16, 32, 64, 3, 5, 1, 2, 2, 1, 0),     # conv_final / conv_mesh shape class
+    (3, 24, 64, 128, 2, 5, 1, 2, 2, 1, 0),    # two 64-channel tiles of dx, several pixel tiles, 2 output channels
 ]
 
 
