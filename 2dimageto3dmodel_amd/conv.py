@@ -67,6 +67,11 @@ def maskbits_ok(d, role):
     return bool(lib().m355_conv2d_maskbits_ok(ctypes.byref(d), int(role)))
 
 
+def dgrad_mask_ok(d):
+    """can conv_dgrad(mask_x=...) apply the producer's LeakyReLU backward in its epilogue on this layer?"""
+    return bool(lib().m355_conv2d_dgrad_mask_ok(ctypes.byref(d)))
+
+
 def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0, cin_real=None, emit_bits=False):
     """emit_bits: also return the sign bits of the pre-activation ([N,Ho,Wo,Cout/64,2] int32, opaque layout) for
     the consumer's conv_dgrad(mask_bits=...); requires maskbits_ok(d, 0)"""

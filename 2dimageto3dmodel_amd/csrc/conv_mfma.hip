@@ -585,13 +585,13 @@ int conv_small_launch(const m355_conv_desc *d, const void *x, const void *w_fwd,
                       int Kp, size_t wbytes, hipStream_t st);
 bool conv_c8_eligible(const m355_conv_desc *d, int y_f32_nchw);
 int conv_c8_launch(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, float slope, int Kp,
-                   size_t wbytes, unsigned *bits, hipStream_t st);
+                   size_t wbytes, unsigned *bits, hipStream_t st, const void *mask = nullptr, float mask_slope = 1.0f);
 bool dgrad_small_eligible(const m355_conv_desc *d, int Cy);
 int dgrad_small_launch(const m355_conv_desc *d, const void *dy, int Cy, const void *w_dgrad, int Kp, size_t wbytes, void *dx,
                        hipStream_t st);
 bool dgrad_c8_replicate_eligible(const m355_conv_desc *d, int Cy);  // csrc/conv_small.hip
 int dgrad_c8_replicate_launch(const m355_conv_desc *d, const void *dy, const void *w_dgrad, int Kp, size_t wbytes, void *dx,
-                              hipStream_t st);
+                              hipStream_t st, const void *mask_x, float mask_slope);
 bool wgrad_c8_eligible(const m355_conv_desc *d, int Cy);  // csrc/conv_small.hip
 int wgrad_c8_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, float *db, hipStream_t st);
 bool wgrad_small_eligible(const m355_conv_desc *d, int Cy);
@@ -825,8 +825,9 @@ static int conv_dgrad_impl(const m355_conv_desc *d, const void *dy, const void *
     a.Kp = m355::k_padded((d->stride == 1 ? d->kh * d->kw : ((d->kh + 1) / 2) * ((d->kw + 1) / 2)) * cout32);
     const bool direct = dgrad_direct(d);
     if (probe && (!direct || d->pad_w_mode == 1)) return 0;
-    M355_REQUIRE((!mask_x && !mask_bits) || direct, "conv2d_dgrad: the fused activation backward needs the direct form (no "
-                                                    "upsample, no replicate pad, tensors < 2 GiB)");
+    const bool c8rep = !mask_bits && m355::dgrad_c8_replicate_eligible(d, cout32);   // 5x5 heads of the symmetric generator
+    M355_REQUIRE((!mask_x && !mask_bits) || direct || c8rep,
+                 "conv2d_dgrad: the fused activation backward needs the direct form (no upsample, no replicate pad, tensors < 2 GiB)");
     a.mask_x = (const unsigned short *)mask_x;
     a.bits_in = mask_bits;
     a.mask_slope = mask_slope;
@@ -866,9 +867,9 @@ static int conv_dgrad_impl(const m355_conv_desc *d, const void *dy, const void *
         return m355::launch_conv(a, st);
     }
     if (probe) return 0;
-    if (!mask_x && !mask_bits && m355::dgrad_c8_replicate_eligible(d, cout32))   // 5x5 heads of the symmetric generator
+    if (c8rep)
         return m355::dgrad_c8_replicate_launch(d, dy, w_dgrad, m355::k_padded(d->kh * d->kw * cout32),
-                                               (size_t)cin64 * m355::k_padded(d->kh * d->kw * cout32) * 2, dx, st);
+                                               (size_t)cin64 * m355::k_padded(d->kh * d->kw * cout32) * 2, dx, st, mask_x, mask_slope);
     const bool need_fold = d->upsample || (d->pad_w_mode != 0 && d->pad_w > 0) || d->stride == 2;
     M355_REQUIRE(!need_fold || ws, "conv2d_dgrad: workspace required");
     if (d->stride == 1) {
@@ -929,6 +930,14 @@ extern "C" int m355_conv2d_dgrad_bits(const m355_conv_desc *d, const void *dy, c
 {
     M355_REQUIRE(mask_bits, "conv2d_dgrad_bits: null pointer");
     return conv_dgrad_impl(d, dy, w_dgrad, dx, ws, nullptr, (const unsigned *)mask_bits, mask_slope, stream, 0);
+}
+
+/* can m355_conv2d_dgrad apply a fused activation backward (mask_x) on this layer? */
+extern "C" int m355_conv2d_dgrad_mask_ok(const m355_conv_desc *d)
+{
+    if (!d || check_desc(d, "conv2d_dgrad_mask_ok")) return 0;
+    if (m355::dgrad_c8_replicate_eligible(d, m355::dy_channels(d->Cout))) return 1;
+    return dgrad_direct(d) && d->pad_w_mode != 1;
 }
 
 /* role 0: can the forward of this layer (bf16 NHWC output, activation epilogue) write bit masks?

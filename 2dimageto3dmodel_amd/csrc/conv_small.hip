@@ -333,6 +333,8 @@ struct C8Args {
     const float *bias;
     unsigned short *y;        // bf16 NHWC [N,H,W,Cout]
     unsigned *bits;           // optional activation-sign bits [pixel][Cout/64][2] (conv_dma.h: ConvArgs::bits_out)
+    const unsigned short *mask;  // optional bf16 NHWC [N,H,W,Cout]: y *= (mask > 0 ? 1 : mask_slope) -- the LeakyReLU backward of
+    float mask_slope;            // the tensor this conv's output is the gradient of (dgrad of a head, HeadConvFn in_slope)
     int N, H, W, Cout, Kp;
     float slope;
     unsigned xbytes, wbytes;
@@ -446,6 +448,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
         // writes at batch 128).  Each (row i, channel half j) piece -- 32 pixels x 64 bytes -- goes through a wave-private
         // 2 KB LDS stage instead and leaves as two store instructions of 16 pixels x 64 contiguous bytes.
         unsigned char *const stg = ldsS + wave * 2048;
+        // (dgrad of a head) the mask vectors of all eight store units are requested up front: they arrive while the pieces
+        // are converted, instead of one L2 round trip in front of every store
+        uint4 mk[2][2][2];
+        if (a.mask) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int u = lane + 64 * k, p = u >> 2, lc = (u & 3) ^ ((p >> 1) & 3);
+                        const size_t pix0m = ((size_t)n * a.H + (oy0 + 2 * wave + i)) * a.W + ox0;
+                        mk[i][j][k] = *reinterpret_cast<const uint4 *>(a.mask + (pix0m + p) * a.Cout + tn * 64 + 32 * j + 8 * lc);
+                    }
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const size_t pix0 = ((size_t)n * a.H + (oy0 + 2 * wave + i)) * a.W + ox0;   // pixel of column 0 of this tile row
@@ -485,8 +502,22 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const int u = lane + 64 * k, p = u >> 2, lc = (u & 3) ^ ((p >> 1) & 3);   // unit u of the stage -> (pixel, chunk)
-                    const uint4 o = *reinterpret_cast<const uint4 *>(stg + u * 16);
-                    *reinterpret_cast<uint4 *>(a.y + (pix0 + p) * a.Cout + cbase + 8 * lc) = o;
+                    uint4 o = *reinterpret_cast<const uint4 *>(stg + u * 16);
+                    const size_t off = (pix0 + p) * a.Cout + cbase + 8 * lc;
+                    if (a.mask) {
+                        const uint4 m = mk[i][j][k];
+                        const unsigned mw[4] = {m.x, m.y, m.z, m.w};
+                        unsigned ow[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float lo = __uint_as_float(ow[q] << 16), hi = __uint_as_float(ow[q] & 0xffff0000u);
+                            if (!(__uint_as_float(mw[q] << 16) > 0.0f)) lo *= a.mask_slope;
+                            if (!(__uint_as_float(mw[q] & 0xffff0000u) > 0.0f)) hi *= a.mask_slope;
+                            ow[q] = pack_bf16(lo, hi);
+                        }
+                        o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                    }
+                    *reinterpret_cast<uint4 *>(a.y + off) = o;
                 }
             }
             if (a.bits) a.bits[((pix0 + tx) * (size_t)(a.Cout >> 6) + tn) * 2 + half] = wbits;
@@ -506,9 +537,11 @@ bool conv_c8_eligible(const m355_conv_desc *d, int y_f32_nchw)
 }
 
 int conv_c8_launch(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, float slope, int Kp,
-                   size_t wbytes, unsigned *bits, hipStream_t st)
+                   size_t wbytes, unsigned *bits, hipStream_t st, const void *mask = nullptr, float mask_slope = 1.0f)
 {
     C8Args a = {};
+    a.mask = (const unsigned short *)mask;
+    a.mask_slope = mask_slope;
     a.x = (const unsigned short *)x;
     a.w = (const unsigned short *)w_fwd;
     a.bias = bias;
@@ -537,7 +570,8 @@ int conv_c8_launch(const m355_conv_desc *d, const void *x, const void *w_fwd, co
 // dxp is the same conv evaluated at the pad columns.  Only taps reaching back into the image contribute (1 + 2 of the 5 kw
 // per pad column), so this is 2/W of the layer's work: one thread per (row, side, input channel).
 __global__ __launch_bounds__(256) void k_dgrad_edge5(const unsigned short *__restrict__ dy, const unsigned short *__restrict__ wd,
-                                                     unsigned short *__restrict__ dx, int N, int H, int W, int Cin, int Kp)
+                                                     unsigned short *__restrict__ dx, int N, int H, int W, int Cin, int Kp,
+                                                     const unsigned short *__restrict__ mask, float mask_slope)
 {
     const size_t total = (size_t)N * H * 2 * Cin;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -563,8 +597,9 @@ __global__ __launch_bounds__(256) void k_dgrad_edge5(const unsigned short *__res
                 }
             }
         }
-        unsigned short *o = dx + (((size_t)n * H + y) * W + (side == 0 ? 0 : W - 1)) * Cin + ci;
-        *o = f2bf(bf2f(*o) + acc);
+        const size_t off = (((size_t)n * H + y) * W + (side == 0 ? 0 : W - 1)) * Cin + ci;
+        if (mask && !(bf2f(mask[off]) > 0.0f)) acc *= mask_slope;   // (the interior term was masked by k_conv_c8's epilogue)
+        dx[off] = f2bf(bf2f(dx[off]) + acc);
     }
 }
 
@@ -576,17 +611,18 @@ bool dgrad_c8_replicate_eligible(const m355_conv_desc *d, int Cy)
 }
 
 int dgrad_c8_replicate_launch(const m355_conv_desc *d, const void *dy, const void *w_dgrad, int Kp, size_t wbytes, void *dx,
-                              hipStream_t st)
+                              hipStream_t st, const void *mask_x, float mask_slope)
 {
     m355_conv_desc t = *d;
     t.Cin = 8;             // the "input" of this conv is dy (3 real channels in an 8-channel chunk)
     t.Cout = d->Cin;
     t.pad_w_mode = 0;      // interior term: zero-padded dy
-    if (int rc = conv_c8_launch(&t, dy, w_dgrad, nullptr, dx, 1.0f, Kp, wbytes, nullptr, st)) return rc;
+    if (int rc = conv_c8_launch(&t, dy, w_dgrad, nullptr, dx, 1.0f, Kp, wbytes, nullptr, st, mask_x, mask_slope)) return rc;
     const size_t total = (size_t)d->N * d->H * 2 * d->Cin;
     const size_t g = (total + 255) / 256;
     hipLaunchKernelGGL(k_dgrad_edge5, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, st, (const unsigned short *)dy,
-                       (const unsigned short *)w_dgrad, (unsigned short *)dx, d->N, d->H, d->W, d->Cin, Kp);
+                       (const unsigned short *)w_dgrad, (unsigned short *)dx, d->N, d->H, d->W, d->Cin, Kp,
+                       (const unsigned short *)mask_x, mask_slope);
     note_kernel("k_conv_c8");
     return check_launch("conv2d_dgrad (replicate 5x5 head)");
 }

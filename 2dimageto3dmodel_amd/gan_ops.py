@@ -205,11 +205,11 @@ class HeadConvFn(torch.autograd.Function):
         launch("head_tail_bwd", ptr(dout.contiguous()), ptr(out), ptr(g), ptr(db), d.N, d.Cout, d.H, d.W, ctx.flags, stream())
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            if ctx.in_slope != 1.0 and d.pad_w_mode != C.PAD_REPLICATE:
+            if ctx.in_slope != 1.0 and C.dgrad_mask_ok(d):
                 dx = C.conv_dgrad(d, g, wd, cin_real=ctx.cw, mask_x=x, mask_slope=ctx.in_slope)
             else:
                 dx = C.conv_dgrad(d, g, wd, cin_real=ctx.cw)
-                if ctx.in_slope != 1.0:   # (the replicate-pad dgrad has no fused activation backward)
+                if ctx.in_slope != 1.0:   # (shapes whose dgrad has no fused activation backward)
                     dx = lrelu_bwd(dx, x, ctx.in_slope)[0]
         if ctx.needs_input_grad[1]:
             dw = C.wgrad_finish(d, C.conv_wgrad(d, x, g, cin_real=ctx.cw, raw=True), ctx.cw)

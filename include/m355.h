@@ -189,6 +189,8 @@ int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const void *w_dgr
  * _dgrad_bits).  m355_conv2d_maskbits_ok(d, 0): this layer's forward can write them; (d, 1): this layer's dgrad can
  * read them for its input.  Mirrors the autograd pair F.conv2d -> F.leaky_relu of models/gan.py:92-94,210-213. */
 int m355_conv2d_maskbits_ok(const m355_conv_desc *d, int role);
+/*      1 when m355_conv2d_dgrad accepts mask_x for this layer (the direct forms, and the replicate-padded 5x5 heads) */
+int m355_conv2d_dgrad_mask_ok(const m355_conv_desc *d);
 int m355_conv2d_fwd_bits(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
                          float lrelu_slope, void *mask_bits_out, void *stream);
 int m355_conv2d_dgrad_bits(const m355_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, void *ws,

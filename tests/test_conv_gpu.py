@@ -275,3 +275,28 @@ def test_stride2_dgrad_class_pairs(pkg, case, wgs, monkeypatch):
     monkeypatch.setenv("M355_NO_HALO_PAIR", "1")
     assert torch.equal(conv.conv_dgrad(d, dy_nhwc, wd), dx)
     assert torch.equal(conv.conv_dgrad(d, dy_nhwc, wd, mask_x=x_nhwc, mask_slope=0.2), dxm)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 32, 64, 3, 5, 1, 2, 2, 1, 0), (3, 24, 64, 128, 2, 5, 1, 2, 2, 1, 0)])
+def test_head_dgrad_with_fused_activation_backward(pkg, case):
+    """dgrad of a replicate-padded 5x5 head on k_conv_c8 + edge term, with the LeakyReLU backward of the head's input applied in
+    the epilogue (HeadConvFn in_slope): equals the unmasked dgrad times the activation derivative"""
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    N, H, W, Cin, Cout, k, stride, ph, pw, mode, ups = case
+    g = torch.Generator().manual_seed(91)
+    x = torch.randn(N, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).bfloat16().float()
+    xr = x.clone().requires_grad_()
+    y_ref = ref_conv(xr, w, None, stride, ph, pw, mode, ups)
+    dy = torch.randn(y_ref.shape, generator=g).bfloat16().float()
+    y_ref.backward(dy)
+    d = conv.make_desc(N, H, W, Cin, Cout, k, k, stride, ph, pw, mode, ups)
+    assert conv.dgrad_mask_ok(d)
+    _, wd = conv.weight_prep(d, w.to(DEV))
+    dy_nhwc = torch.zeros(N, H, W, conv.dy_channels(Cout))
+    dy_nhwc[..., :Cout] = dy.permute(0, 2, 3, 1)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    dxm = conv.conv_dgrad(d, dy_nhwc.bfloat16().to(DEV), wd, mask_x=x_nhwc, mask_slope=0.2).float().cpu().permute(0, 3, 1, 2)
+    assert conv.lib().m355_last_kernel().decode() == "k_conv_c8"
+    want = xr.grad * torch.where(x > 0, 1.0, 0.2)
+    assert (dxm - want).abs().max().item() / want.abs().max().item() < 1.2e-2
