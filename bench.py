@@ -211,7 +211,7 @@ def _free_port():
 
 def respawn_under_torchrun(args):
     """`bench.py --gpus N` started as ONE process: become N ranks (one per GPU) under torch.distributed.run"""
-    if args.backend == "nccl":
+    if args.backend == "nccl":   # (gloo: the collectives-only workload on CPU, or the shared-GPU test mode)
         have = torch.cuda.device_count()
         if have < args.gpus:
             sys.exit(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible; refusing to run a "
@@ -246,15 +246,18 @@ def main():
         respawn_under_torchrun(args)   # does not return
     if env_world is not None and int(env_world) != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch with --nproc-per-node {args.gpus}")
-    if args.backend == "gloo" and args.workload != "collectives":
+    share_gpu = bool(os.environ.get("M355_SHARE_GPU"))   # tests: all ranks on cuda:0 with gloo as the transport (RCCL refuses two
+    if args.backend == "gloo" and args.workload != "collectives" and not share_gpu:   # ranks on one device)
         sys.exit("bench.py: the projection and GAN workloads are HIP-only (no CPU path); --backend gloo serves "
                  "--workload collectives")
 
     par = importlib.import_module("2dimageto3dmodel_amd.parallel")
     import torch.distributed as dist
-    on_gpu = args.backend == "nccl"
-    rank, local_rank, world = par.init_from_env("cuda" if on_gpu else "cpu")
+    on_gpu = args.backend == "nccl" or share_gpu
+    rank, local_rank, world = par.init_from_env("cuda" if args.backend == "nccl" else "cpu")
     assert world == args.gpus
+    if share_gpu:
+        local_rank = 0
     if on_gpu:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")

@@ -7,6 +7,7 @@ import os
 import socket
 import sys
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -153,3 +154,26 @@ def test_bench_gpus2_fails_loudly_on_one_gpu():
                        capture_output=True, text=True, timeout=550, env=env, cwd=ROOT)
     assert r.returncode != 0 and "GPU(s) are visible" in r.stderr
     assert not any(ln.startswith("{") for ln in r.stdout.splitlines())
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_sharing_one_gpu():
+    """bench.py's whole multi-rank flow (self-spawn under torch.distributed.run, per-rank seeds, parameter broadcast, SyncBN and
+    gradient collectives, barrier + MAX-over-ranks timing, one JSON line from rank 0) with two ranks sharing cuda:0 over gloo
+    (M355_SHARE_GPU=1; RCCL refuses two ranks on one device) at a small batch"""
+    import json
+    import subprocess
+    env = dict(os.environ, M355_SHARE_GPU="1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+                        "--batch", "8", "--no-cpu-baseline"], capture_output=True, text=True, timeout=850, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
+    assert out["grad_allreduces_per_step"] == 3 and out["syncbn_collectives_per_step"] == 56
+    assert abs(out["grad_allreduce_mb_per_step"] - 75.0) < 3.0 and out["allreduce_ms_per_step"] > 0
+    assert out["value"] > 0 and "cpu_baseline" not in out
+    assert all(np.isfinite(v) for v in out["config"]["losses"].values())
