@@ -725,19 +725,11 @@ __device__ __forceinline__ void sfor(F &&f)
     }
 }
 
-// TH x 32-pixel tiles, NST stages.  Round 2: the 8-row / 3-stage shape kept at most two 39 KB tiles in flight per CU and
-// ran at 2.8 TB/s -- one workgroup per CU pulls ~5 B/clk at that depth (latency x bandwidth), while the MFMA pipe was 30 %
-// busy; 4-row tiles with six stages keep five 21 KB tiles in flight behind the one being consumed.
-template <int MODE, int TH = 4, int NST = 6>
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void k_wgrad_c8(C8WgArgs a)
 {
-    static_assert(TH == 8 || TH == 4, "tile rows");
-    constexpr int TW = 32, KS = 5, HS_X = TW + KS - 1, HS_Y = TH + KS - 1, HPIX = HS_X * HS_Y;
-    constexpr int XBUF = 8192, YBUF = TH * TW * 128, STAGE = XBUF + YBUF;
-    constexpr int NDY = TH / 2;            // dy DMA instructions per wave and tile (8 pixels x 128 B each, 8 waves)
-    constexpr int NDMA = NDY + 1;          // ... plus one x instruction
-    constexpr int NKG = TH;                // 16-pixel K groups per wave and tile (the two pixel halves split the rows)
-    static_assert(HPIX <= 512, "one x instruction per wave covers the halo");
+    constexpr int TH = 8, TW = 32, KS = 5, HS_X = TW + KS - 1, HS_Y = TH + KS - 1, HPIX = HS_X * HS_Y;
+    constexpr int XBUF = 8192, YBUF = 256 * 128, STAGE = XBUF + YBUF, NST = 3;
     __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -748,8 +740,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_c8(C8WgArgs a)
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, a.ybytes, 0x00020000);
 
-    // ---- DMA: every wave issues NDY dy instructions (rows 8q .. 8q+7 of the tile, q = 8k + wave, swizzled as k_wgrad_halo)
-    // and 1 x instruction (halo pixels 64 wave + lane; waves past the halo fill the unused tail with zeros): NDMA per tile and wave
+    // ---- DMA: every wave issues 4 dy instructions (rows 8q .. 8q+7 of the tile, q = 8k + wave, swizzled as k_wgrad_halo)
+    // and 1 x instruction (halo pixels 64 wave + lane; wave 7 fills the unused tail with zeros): 5 per tile and wave
     const int csrc = (lane & 7) ^ (((lane >> 4) & 1) << 2);
     auto issue = [&](int tile, int st) {
         const int n = tile / (tpx * tpy), rem = tile - n * (tpx * tpy);
@@ -766,7 +758,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_c8(C8WgArgs a)
             dma16(rx, dX + wave * 1024, ok ? (unsigned)(((n * a.H + gy) * a.W + gx) * 16) : OOB, 0u);
         }
 #pragma unroll
-        for (int k = 0; k < NDY; ++k) {
+        for (int k = 0; k < 4; ++k) {
             const int p = 8 * (8 * k + wave) + (lane >> 3);  // tile pixel = (p >> 5, p & 31)
             const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
             dma16(ry, dY + (8 * k + wave) * 1024, (unsigned)((((n * a.H + oy) * a.W + ox) * a.Cy + co0) * 2 + csrc * 16), 0u);
@@ -774,13 +766,13 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_c8(C8WgArgs a)
     };
 
     // ---- fragment roles
-    const int ph = wave >> 2, cb = wave & 1, cg = (wave >> 1) & 1;  // pixel half (tile rows (TH/2) ph ..), co block, column group
+    const int ph = wave >> 2, cb = wave & 1, cg = (wave >> 1) & 1;  // pixel half (tile rows 4ph..), co block, column group
     const int q = lane & 15, g16 = (lane >> 4) & 1, hh = lane >> 5;
     // dy^T (A operand, rows = 32 co of block cb): as k_wgrad_halo
     const int ybase = (((cb * 4 + g16 * 2 + ((q & 3) >> 1)) ^ (((q >> 3) & 1) << 2)) << 4) + (q & 1) * 8 + (8 * hh + (q >> 2)) * 128 +
-                      ph * NKG * 2048;
+                      ph * 8 * 2048;
     // x (B operand, 32 columns = taps kw0 .. kw0+3 x 8 ci): lane part of the halo address; the rest is an immediate
-    const int xbase = (((TH / 2) * ph) * HS_X + 8 * hh + (q >> 2) + 2 * g16) * 16 + (q & 3) * 8;
+    const int xbase = ((4 * ph) * HS_X + 8 * hh + (q >> 2) + 2 * g16) * 16 + (q & 3) * 8;
 
     f32x16 acc[5];
 #pragma unroll
@@ -788,13 +780,13 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_c8(C8WgArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     const bool do_db = a.db != nullptr;
-    const int dbc = tid & 63, dbq = tid >> 6;  // channel, group of TH * 4 pixels
+    const int dbc = tid & 63, dbq = tid >> 6;  // channel, 32-pixel group
     float dbacc = 0.0f;
 
     auto tile_mma = [&](const unsigned char *bx, const unsigned char *by, auto cgc) {
         constexpr int CG = decltype(cgc)::value;
-        sfor<0, NKG>([&](auto kgc) {
-            constexpr int kg = decltype(kgc)::value;  // 16 pixels: tile row (TH/2) ph + (kg>>1), columns 16(kg&1) ..
+        sfor<0, 8>([&](auto kgc) {
+            constexpr int kg = decltype(kgc)::value;  // 16 pixels: tile row 4ph + (kg>>1), columns 16(kg&1) ..
             const s4w y0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4w *)(by + ybase + kg * 2048));
             const s4w y1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4w *)(by + ybase + kg * 2048 + 512));
             const bf16x8 yf = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -809,39 +801,30 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_c8(C8WgArgs a)
         });
     };
 
-    // ---- tiles blockIdx.x, +G, +2G, ...: NST stages, up to NST - 1 tiles in flight behind the one being consumed.
-    // Iteration t: wait for tile t (everything but the younger tiles t+1 .. t+NST-2), barrier (every wave is also done with
-    // tile t-1, whose stage is the one tile t+NST-1 goes into), issue tile t+NST-1, compute.
+    // ---- tiles blockIdx.x, +G, +2G, ...: three stages, two tiles in flight behind the one being consumed
     int tile = blockIdx.x, st = 0;
-#pragma unroll
-    for (int k = 0; k < NST - 1; ++k)
-        if (tile + k * G < tiles) issue(tile + k * G, k);
+    issue(tile, 0);
+    if (tile + G < tiles) issue(tile + G, 1);
     for (; tile < tiles; tile += G) {
-        int ahead = (tiles - 1 - tile) / G;     // tiles after this one
-        if (ahead > NST - 2) ahead = NST - 2;   // ... of which these are already issued
-        switch (ahead) {   // (the counted wait needs an immediate)
-        case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDMA) : "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * NDMA) : "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * NDMA) : "memory"); break;
-        }
+        // this tile's 5 DMAs per wave were issued two tiles ago; only the next tile's 5 may still be in flight
+        if (tile + G < tiles) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        const int st2 = st == 0 ? NST - 1 : st - 1;  // the stage consumed one tile ago
-        if (tile + (NST - 1) * G < tiles) issue(tile + (NST - 1) * G, st2);
+        const int st2 = st == 0 ? 2 : st - 1;  // the stage consumed one tile ago
+        if (tile + 2 * G < tiles) issue(tile + 2 * G, st2);
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char *bx = lds + st * STAGE, *by = bx + XBUF;
         if (do_db) {
 #pragma unroll 8
-            for (int pp = 0; pp < TH * 4; ++pp) {
-                const int prow = dbq * (TH * 4) + pp;
+            for (int pp = 0; pp < 32; ++pp) {
+                const int prow = dbq * 32 + pp;
                 dbacc += bf2f(*reinterpret_cast<const unsigned short *>(by + prow * 128 + (((dbc >> 3) ^ (((prow >> 1) & 1) << 2)) << 4) + (dbc & 7) * 2));
             }
         }
         if (cg) tile_mma(bx, by, std::integral_constant<int, 1>{});
         else tile_mma(bx, by, std::integral_constant<int, 0>{});
-        st = st == NST - 1 ? 0 : st + 1;
+        st = st == 2 ? 0 : st + 1;
     }
     if (do_db && co0 + dbc < a.Cout) atomicAdd(a.db + co0 + dbc, dbacc);
     // acc[t][r]: co = co0 + 32 cb + (r&3) + 8(r>>2) + 4(lane>>5); column lane&31 of block 5cg + t = (kh, kw0 + (n>>3), n&7)
@@ -874,21 +857,14 @@ int wgrad_c8_launch(const m355_conv_desc *d, const void *x, const void *dy, int 
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cout = d->Cout; a.Cy = Cy;
     a.xbytes = (unsigned)((size_t)d->N * d->H * d->W * 16);
     a.ybytes = (unsigned)((size_t)d->N * d->H * d->W * Cy * 2);
-    const bool deep = !getenv("M355_WGRAD_C8_SHALLOW");   // A/B: the round-1 shape (8-row tiles, 3 stages)
-    const int tiles = d->N * (d->H / (deep ? 4 : 8)) * (d->W / 32), ny = Cy / 64;
-    int gx = 256 / ny;  // one 8-wave workgroup per CU (144 / 120 KB of LDS)
+    const int tiles = d->N * (d->H / 8) * (d->W / 32), ny = Cy / 64;
+    int gx = 256 / ny;  // one 8-wave workgroup per CU (120 KB of LDS)
     if (gx < 1) gx = 1;
     if (gx > tiles) gx = tiles;
     const dim3 grid(gx, ny);
-#define M355_WC8(MD_)                                                                                  \
-    do {                                                                                               \
-        if (deep) hipLaunchKernelGGL((k_wgrad_c8<MD_, 4, 6>), grid, dim3(512), 0, st, a);              \
-        else hipLaunchKernelGGL((k_wgrad_c8<MD_, 8, 3>), grid, dim3(512), 0, st, a);                   \
-    } while (0)
-    if (d->pad_w_mode == 0) M355_WC8(0);
-    else if (d->pad_w_mode == 1) M355_WC8(1);
-    else M355_WC8(2);
-#undef M355_WC8
+    if (d->pad_w_mode == 0) hipLaunchKernelGGL((k_wgrad_c8<0>), grid, dim3(512), 0, st, a);
+    else if (d->pad_w_mode == 1) hipLaunchKernelGGL((k_wgrad_c8<1>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_wgrad_c8<2>), grid, dim3(512), 0, st, a);
     note_kernel("k_wgrad_c8");
     return check_launch("conv2d_wgrad (8 input channels)");
 }
