@@ -166,9 +166,13 @@ __global__ __launch_bounds__(256) void k_sn_bwd_apply(const float *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------- conditional batch norm
-// Block = 32 channels x 8 helper lanes.  part[nblk][2][C] -> mean, rstd (biased variance, eps inside the sqrt =
+// part[nblk][2][C] -> mean, rstd (biased variance, eps inside the sqrt =
 // F.batch_norm, code/sync_batchnorm/batchnorm.py:71-73), running stats (unbiased variance, momentum), and
 // a[n,c] = rstd * (1 + gamma[n,c]),  b[n,c] = beta[n,c] - mean * a[n,c].
+// CW channels per workgroup, 1024 / CW row lanes: with 32 channels per workgroup a C = 64 layer ran on TWO workgroups, each
+// thread walking 32+ dependent-latency rounds of the up-to-1024 partial rows (~10 us per call, 42 calls per cycle); 8
+// channels per workgroup give 4x the workgroups and a quarter of the rows per thread.
+template <int CW>
 __global__ __launch_bounds__(1024) void k_bn_finalize(const float *__restrict__ part, int nblk, float count_h,
                                                      const float *__restrict__ count_dev, const float *__restrict__ gamma,
                                                      const float *__restrict__ beta, int gstride, int N, int C, float eps,
@@ -176,19 +180,18 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float *__restrict__ 
                                                      float *__restrict__ mean_o, float *__restrict__ rstd_o, float *__restrict__ a,
                                                      float *__restrict__ b)
 {
-    // (up to 1024 partial rows: 32 row groups per channel and 4 independent loads in flight per thread -- the serial
-    // version spent ~12 us in dependent-latency loads)
-    __shared__ float red[2][32][32];
-    __shared__ float stat[2][32];
-    const int cl = threadIdx.x & 31, l = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    constexpr int RL = 1024 / CW;
+    __shared__ float red[2][RL][CW];
+    __shared__ float stat[2][CW];
+    const int cl = threadIdx.x % CW, l = threadIdx.x / CW, c = blockIdx.x * CW + cl;
     const float count = count_dev ? *count_dev : count_h;   // SyncBN: the all-reduced pixel count, no host round trip
     float s0 = 0.0f, s1 = 0.0f;
     if (c < C) {
         float p0[4] = {0.f, 0.f, 0.f, 0.f}, p1[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = l; k < nblk; k += 128) {
+        for (int k = l; k < nblk; k += 4 * RL) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int kk = k + 32 * u;
+                const int kk = k + RL * u;
                 if (kk < nblk) {
                     p0[u] += part[((size_t)kk * 2) * C + c];
                     p1[u] += part[((size_t)kk * 2 + 1) * C + c];
@@ -201,13 +204,16 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float *__restrict__ 
     red[0][l][cl] = s0;
     red[1][l][cl] = s1;
     __syncthreads();
-    if (l == 0 && c < C) {
-        float t0 = 0.0f, t1 = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            t0 += red[0][k][cl];
-            t1 += red[1][k][cl];
+    for (int s = RL / 2; s > 0; s >>= 1) {   // fixed-order tree over the row lanes
+        if (l < s) {
+            red[0][l][cl] += red[0][l + s][cl];
+            red[1][l][cl] += red[1][l + s][cl];
         }
+        __syncthreads();
+    }
+    if (l == 0 && c < C) {
+        const float t0 = red[0][0][cl], t1 = red[1][0][cl];
         const float mean = t0 / count;
         const float var = fmaxf(t1 / count - mean * mean, 0.0f);
         const float rstd = rsqrtf(var + eps);
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float *__restrict__ 
     __syncthreads();
     if (c < C) {
         const float mean = stat[0][cl], rstd = stat[1][cl];
-        for (int n = l; n < N; n += 32) {
+        for (int n = l; n < N; n += RL) {
             const float av = rstd * (1.0f + gamma[(size_t)n * gstride + c]);
             a[(size_t)n * C + c] = av;
             b[(size_t)n * C + c] = beta[(size_t)n * gstride + c] - mean * av;
@@ -345,7 +351,7 @@ extern "C" int m355_bn_finalize(const float *part, int nblk, float count, const 
                                 float *mean, float *rstd, float *a, float *b, void *stream)
 {
     M355_REQUIRE(part && gamma && beta && mean && rstd && a && b && nblk > 0 && N > 0 && C > 0, "bn_finalize: bad argument");
-    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, nblk, count, count_dev,
+    hipLaunchKernelGGL(k_bn_finalize<8>, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, part, nblk, count, count_dev,
                        gamma, beta, gstride, N, C, eps, momentum, running_mean, running_var, mean, rstd, a, b);
     return check_launch("bn_finalize");
 }
