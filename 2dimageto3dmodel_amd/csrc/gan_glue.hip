@@ -61,10 +61,25 @@ __global__ __launch_bounds__(256) void k_sn_wv(const m355_sn_layer *__restrict__
     if (i < L.rows) {
         const float *wr = L.w + (size_t)i * L.cols;
         float a4[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int j = lane; j < L.cols; j += 256) {
+        if ((L.cols & 3) == 0 && ((size_t)wr & 15) == 0 && ((size_t)vv & 15) == 0) {
+            // 16-byte loads, four of them in flight per lane: a 4608-column row (18 KB) is two round trips of the wave instead
+            // of eighteen (one wave per row is latency bound: this kernel was 54 us per call)
+            const float4 *w4 = reinterpret_cast<const float4 *>(wr), *v4 = reinterpret_cast<const float4 *>(vv);
+            const int n4 = L.cols >> 2;
+            for (int j = lane; j < n4; j += 256) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (j + 64 * u < L.cols) a4[u] += wr[j + 64 * u] * vv[j + 64 * u];
+                for (int u = 0; u < 4; ++u)
+                    if (j + 64 * u < n4) {
+                        const float4 a = w4[j + 64 * u], b = v4[j + 64 * u];
+                        a4[u] += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+                    }
+            }
+        } else {
+            for (int j = lane; j < L.cols; j += 256) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (j + 64 * u < L.cols) a4[u] += wr[j + 64 * u] * vv[j + 64 * u];
+            }
         }
         acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     }

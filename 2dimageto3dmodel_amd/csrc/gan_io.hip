@@ -13,6 +13,8 @@
 //   k_hinge           GANLoss(hinge) over the list of discriminator outputs (utils/losses.py:49-120) with the
 //                     [fake; real] split of main.py:414-422 done by index instead of slicing
 // All memory-bound elementwise / small-reduction kernels; fp32 arithmetic in the reference's order where it is visible.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace m355 {
@@ -139,6 +141,61 @@ __global__ __launch_bounds__(TW * 4) void k_pool_pack(PoolPackArgs a)
     __syncthreads();
     const int ch = 16 / g;
     for (int t = threadIdx.x; t < ch * cw; t += TW * 4) {
+        const int cy = t / cw, cx = t - cy * cw;
+        float s = 0.0f;
+        for (int i = 0; i < g; ++i) s += rowsum[cy * g + i][cx];
+        const int my = blockIdx.y * ch + cy, mx = blockIdx.x * cw + cx;
+        a.mask[((size_t)m * (a.Ho / g) + my) * (a.Wo / g) + mx] = s / (float)(g * g);
+    }
+}
+
+// F = 1, Wo % 64 == 0 (the full-resolution texture discriminator, the largest of the packs): one thread = one row x FOUR
+// consecutive pixels: every plane is read with 16-byte loads (8 load instructions per thread instead of 32) and the thread's
+// four packed pixels leave as 64 contiguous bytes.  Tile 16 x 64 pixels per 256 threads, as the generic kernel.
+__global__ __launch_bounds__(256) void k_pack1x4(PoolPackArgs a)
+{
+    __shared__ float av[16][64];
+    __shared__ float rowsum[16][16];
+    const int cg = threadIdx.x & 15, row = threadIdx.x >> 4;          // column group (4 pixels), tile row
+    const int m = blockIdx.z, oy = blockIdx.y * 16 + row, ox = blockIdx.x * 64 + 4 * cg;
+    const size_t HW = (size_t)a.H * a.W, po = (size_t)oy * a.W + ox;
+    float4 v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < a.C) t = *reinterpret_cast<const float4 *>(a.x + ((size_t)m * a.C + c) * HW + po);
+        else if (c - a.C < a.E) t = *reinterpret_cast<const float4 *>(a.extra + ((size_t)m * a.E + (c - a.C)) * HW + po);
+        else if (c - a.C - a.E < a.P) t = *reinterpret_cast<const float4 *>(a.pos + (size_t)(c - a.C - a.E) * HW + po);
+        v[c] = t;
+    }
+    short *o = a.out + ((size_t)m * HW + po) * 8;
+    {
+        const float z0[8] = {v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x};
+        const float z1[8] = {v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y};
+        const float z2[8] = {v[0].z, v[1].z, v[2].z, v[3].z, v[4].z, v[5].z, v[6].z, v[7].z};
+        const float z3[8] = {v[0].w, v[1].w, v[2].w, v[3].w, v[4].w, v[5].w, v[6].w, v[7].w};
+        *reinterpret_cast<bf16x8i *>(o) = pack8_i(z0);
+        *reinterpret_cast<bf16x8i *>(o + 8) = pack8_i(z1);
+        *reinterpret_cast<bf16x8i *>(o + 16) = pack8_i(z2);
+        *reinterpret_cast<bf16x8i *>(o + 24) = pack8_i(z3);
+    }
+    if (!a.mask) return;
+    float4 mv = v[0];
+#pragma unroll
+    for (int c = 1; c < 4; ++c)
+        if (c == a.mask_chan) mv = v[c];
+    av[row][4 * cg] = mv.x; av[row][4 * cg + 1] = mv.y; av[row][4 * cg + 2] = mv.z; av[row][4 * cg + 3] = mv.w;
+    __syncthreads();
+    const int g = a.g, cw = 64 / g;
+    for (int t = threadIdx.x; t < 16 * cw; t += 256) {
+        const int y = t / cw, cx = t - y * cw;
+        float s = 0.0f;
+        for (int j = 0; j < g; ++j) s += av[y][cx * g + j];
+        rowsum[y][cx] = s;
+    }
+    __syncthreads();
+    const int ch = 16 / g;
+    for (int t = threadIdx.x; t < ch * cw; t += 256) {
         const int cy = t / cw, cx = t - cy * cw;
         float s = 0.0f;
         for (int i = 0; i < g; ++i) s += rowsum[cy * g + i][cx];
@@ -412,6 +469,10 @@ extern "C" int m355_pool_pack_fwd(const float *x, int M, int C, int H, int W, in
                  "pool_pack_fwd: bad channel layout");
     PoolPackArgs a = {x, extra, pos, (short *)out, mask, M, C, H, W, E, P, CP, H / f, W / f, mask ? g : 16, mask_chan};
     hipStream_t st = (hipStream_t)stream;
+    if (f == 1 && CP == 8 && W % 64 == 0 && !getenv("M355_NO_PACK1X4")) {
+        hipLaunchKernelGGL(k_pack1x4, dim3(W / 64, H / 16, M), dim3(256), 0, st, a);
+        return check_launch("pool_pack_fwd");
+    }
     switch (f) {
     case 1: launch_pool_pack<1>(a, st); break;
     case 2: launch_pool_pack<2>(a, st); break;
