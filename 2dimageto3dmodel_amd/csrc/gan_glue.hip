@@ -86,10 +86,19 @@ __global__ __launch_bounds__(256) void k_sn_wv(const m355_sn_layer *__restrict__
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     acc *= inv;
-    if (lane == 0 && i < L.rows) {
-        L.s[i] = acc;
-        atomicAdd(norms + 2 * blockIdx.y + 1, training ? acc * acc : acc * L.u[i]);
+    // one atomic per workgroup, not per row: 512 same-address atomics per layer serialise in the L2 (that, not the reads, was
+    // most of this kernel's 54 us)
+    __shared__ float wsum[4];
+    if (lane == 0) {
+        float contrib = 0.0f;
+        if (i < L.rows) {
+            L.s[i] = acc;
+            contrib = training ? acc * acc : acc * L.u[i];
+        }
+        wsum[wave] = contrib;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(norms + 2 * blockIdx.y + 1, (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
     if (training && blockIdx.x == 0)
         for (int j = threadIdx.x; j < L.cols; j += 256) {
             const float vn = L.t[j] * inv;
