@@ -118,20 +118,49 @@ def wgrad_fuses_dbias(d):
     return bool(lib().m355_conv2d_wgrad_fuses_dbias(ctypes.byref(d)))
 
 
-def conv_wgrad(d, x, dy, cin_real=None, raw=False, dbias=None):
+class WgradArena:
+    """Zero-filled fp32 scratch for the split-K weight-gradient kernels of ONE backward pass: every wgrad kernel accumulates
+    with atomics into a zeroed buffer, which used to cost one or two memsets per layer (65 per GAN cycle, 5 us each).  The
+    arena is zeroed once, when the first wgrad of a backward pass (identified by autograd's graph-task id) asks for a slice;
+    its size is learnt from the previous pass (a pass that outgrows it falls back to per-layer zero fills and the arena grows
+    for the next one).  Slices are scratch: they are consumed by wgrad_finish inside the same backward call."""
+    _state = {}   # device -> [buffer, used, needed, graph task id]
+
+    @classmethod
+    def take(cls, numel, device):
+        """-> a zeroed fp32 slice of `numel` elements, or None (caller zero-fills its own buffer)"""
+        task = torch._C._current_graph_task_id() if hasattr(torch._C, "_current_graph_task_id") else -1
+        if task < 0:
+            return None
+        st = cls._state.setdefault(device, [None, 0, 0, None])
+        if st[3] != task:   # first wgrad of a new backward pass
+            if st[2] > (0 if st[0] is None else st[0].numel()):
+                st[0] = torch.empty(st[2], dtype=torch.float32, device=device)
+            st[1], st[2], st[3] = 0, 0, task
+            if st[0] is not None:
+                st[0].zero_()
+        numel = (numel + 63) // 64 * 64
+        off = st[1]
+        st[1] += numel
+        st[2] = max(st[2], st[1])
+        if st[0] is None or off + numel > st[0].numel():
+            return None
+        return st[0][off:off + numel]
+
+
+def conv_wgrad(d, x, dy, cin_real=None, raw=False, dbias=None, arena=False):
     """-> dw fp32 in the parameter's layout [Cout,Cin,kh,kw] (a permuted view), or with raw=True the kernel's own
-    [Cout,kh,kw,Cin] buffer"""
+    [Cout,kh,kw,Cin] buffer.  arena=True (with raw=True, from inside a backward pass): the buffer is a slice of the
+    per-pass WgradArena, valid until the next backward pass"""
     x, dy = _req(x, torch.bfloat16, "x"), _req(dy, torch.bfloat16, "dy")
+    n = d.Cout * d.kh * d.kw * d.Cin
+    sl = WgradArena.take(n, x.device) if (arena and raw) else None
+    if sl is not None:
+        dw = sl[:n].view(d.Cout, d.kh, d.kw, d.Cin)
+        if dbias is not None:   # returned to autograd as the bias gradient: never an arena slice
+            dbias.zero_()
+        launch("conv2d_wgrad_acc", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), stream(), work=flops(d, cin_real), tag=tag(d))
+        return dw
     dw = torch.empty((d.Cout, d.kh, d.kw, d.Cin), dtype=torch.float32, device=x.device)
     launch("conv2d_wgrad", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), stream(), work=flops(d, cin_real), tag=tag(d))
     return dw if raw else dw.permute(0, 3, 1, 2)
-
-
-def wgrad_finish(d, g_khwc, cin_real, w_orig=None, u=None, v=None, sigma=None):
-    """[Cout][kh][kw][CinP] wgrad output -> the parameter's gradient [Cout][cin_real][kh][kw]; with spectral-norm
-    state, the gradient with respect to weight_orig (through sigma)"""
-    dw = torch.empty((d.Cout, cin_real, d.kh, d.kw), dtype=torch.float32, device=g_khwc.device)
-    part = torch.empty((256,), dtype=torch.float32, device=g_khwc.device) if sigma is not None else None
-    launch("sn_wgrad_finish", ptr(g_khwc), ptr(w_orig), ptr(u), ptr(v), ptr(sigma), ptr(part), ptr(dw), d.Cout, cin_real,
-           d.Cin, d.kh, d.kw, stream())
-    return dw

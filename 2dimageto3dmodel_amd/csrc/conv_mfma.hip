@@ -1264,8 +1264,26 @@ static bool wgrad_has_dbias(const m355_conv_desc *d)
 }
 extern "C" int m355_conv2d_wgrad_fuses_dbias(const m355_conv_desc *d) { return d && wgrad_has_dbias(d) ? 1 : 0; }
 
+static int conv_wgrad_impl(const m355_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias, void *stream,
+                           bool zero);
+
 extern "C" int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias,
                                  void *stream)
+{
+    return conv_wgrad_impl(d, x, dy, dw, dbias, stream, true);
+}
+
+/* dw (and dbias) += the weight gradient: every wgrad kernel accumulates its split-K partial tiles with fp32 atomics, so the
+ * only difference to m355_conv2d_wgrad is that the caller has zeroed (or wants to accumulate into) the buffers -- e.g. ONE
+ * memset for the gradients of all layers of a backward pass instead of one or two per layer */
+extern "C" int m355_conv2d_wgrad_acc(const m355_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias,
+                                     void *stream)
+{
+    return conv_wgrad_impl(d, x, dy, dw, dbias, stream, false);
+}
+
+static int conv_wgrad_impl(const m355_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias, void *stream,
+                           bool zero)
 {
     if (int rc = check_desc(d, "conv2d_wgrad")) return rc;
     M355_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
@@ -1283,11 +1301,11 @@ extern "C" int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const v
     a.KH = d->kh; a.KW = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
     a.pad_w_mode = d->pad_w_mode;
     const int K = d->kh * d->kw * d->Cin, P = d->N * a.Ho * a.Wo;
-    if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->Cout * K, st) != hipSuccess) {
+    if (zero && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->Cout * K, st) != hipSuccess) {
         m355::set_error("conv2d_wgrad: memset failed");
         return M355_ERR_LAUNCH;
     }
-    if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)d->Cout, st) != hipSuccess) {
+    if (zero && dbias && hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)d->Cout, st) != hipSuccess) {
         m355::set_error("conv2d_wgrad: memset failed");
         return M355_ERR_LAUNCH;
     }

@@ -212,7 +212,7 @@ class HeadConvFn(torch.autograd.Function):
                 if ctx.in_slope != 1.0:   # (shapes whose dgrad has no fused activation backward)
                     dx = lrelu_bwd(dx, x, ctx.in_slope)[0]
         if ctx.needs_input_grad[1]:
-            dw = C.wgrad_finish(d, C.conv_wgrad(d, x, g, cin_real=ctx.cw, raw=True), ctx.cw)
+            dw = C.wgrad_finish(d, C.conv_wgrad(d, x, g, cin_real=ctx.cw, raw=True, arena=True), ctx.cw)
         return dx, dw, (db if ctx.needs_input_grad[2] else None), None, None, None, None, None
 
 
@@ -379,7 +379,7 @@ class Conv2dFn(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             fused_db = db if (ctx.premasked and db is not None and C.wgrad_fuses_dbias(d)) else None
-            graw = C.conv_wgrad(d, x, g, cin_real=ctx.cw, raw=True, dbias=fused_db)
+            graw = C.conv_wgrad(d, x, g, cin_real=ctx.cw, raw=True, dbias=fused_db, arena=True)
             sn = ctx.sn
             if sn is None:
                 dw = C.wgrad_finish(d, graw, ctx.cw)

@@ -201,6 +201,8 @@ int m355_conv2d_dgrad_bits(const m355_conv_desc *d, const void *dy, const void *
  *      the dy tiles anyway; only where m355_conv2d_wgrad_fuses_dbias(d) != 0. */
 int m355_conv2d_wgrad_fuses_dbias(const m355_conv_desc *d);
 int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias, void *stream);
+/*      the same with dw / dbias += (no zero fill: the caller zeroed them, e.g. one memset for all layers of a backward pass) */
+int m355_conv2d_wgrad_acc(const m355_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias, void *stream);
 
 /* ---- G3 / G-bwd  normalisation + conditional affine + LeakyReLU on NHWC bf16 (models/gan.py:264-286, 306-312).
  *      All reductions are two-stage and deterministic; ws >= m355_chan_reduce_ws_bytes(pixels per group, groups,
