@@ -164,3 +164,13 @@ def conv_wgrad(d, x, dy, cin_real=None, raw=False, dbias=None, arena=False):
     dw = torch.empty((d.Cout, d.kh, d.kw, d.Cin), dtype=torch.float32, device=x.device)
     launch("conv2d_wgrad", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), stream(), work=flops(d, cin_real), tag=tag(d))
     return dw if raw else dw.permute(0, 3, 1, 2)
+
+
+def wgrad_finish(d, g_khwc, cin_real, w_orig=None, u=None, v=None, sigma=None):
+    """[Cout][kh][kw][CinP] wgrad output -> the parameter's gradient [Cout][cin_real][kh][kw]; with spectral-norm
+    state, the gradient with respect to weight_orig (through sigma)"""
+    dw = torch.empty((d.Cout, cin_real, d.kh, d.kw), dtype=torch.float32, device=g_khwc.device)
+    part = torch.empty((256,), dtype=torch.float32, device=g_khwc.device) if sigma is not None else None
+    launch("sn_wgrad_finish", ptr(g_khwc), ptr(w_orig), ptr(u), ptr(v), ptr(sigma), ptr(part), ptr(dw), d.Cout, cin_real,
+           d.Cin, d.kh, d.kw, stream())
+    return dw
