@@ -71,6 +71,8 @@ SIGNATURES = {
     "m355_conv2d_fwd_bits": (c_int, [_P, _P, _P, _P, _P, c_float, _P, _P]),
     "m355_conv2d_dgrad_bits": (c_int, [_P, _P, _P, _P, _P, _P, c_float, _P]),
     "m355_conv2d_wgrad_fuses_dbias": (c_int, [_P]),
+    "m355_conv2d_fwd_stats_rows": (c_int, [_P]),
+    "m355_conv2d_fwd_stats": (c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "m355_conv2d_wgrad": (c_int, [_P, _P, _P, _P, _P, _P]),
     "m355_conv2d_wgrad_acc": (c_int, [_P, _P, _P, _P, _P, _P]),
     "m355_chan_reduce_ws_bytes": (c_size_t, [c_size_t, c_int, c_int, c_int]),

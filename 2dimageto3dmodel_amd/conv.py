@@ -94,6 +94,26 @@ def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0, cin_real=Non
     return y
 
 
+def conv_stats_rows(d):
+    """rows of batch-norm partial sums conv_fwd_stats writes for this shape (0: no fused statistics)"""
+    return int(lib().m355_conv2d_fwd_stats_rows(ctypes.byref(d)))
+
+
+def conv_fwd_stats(d, x, w_fwd, bias=None, cin_real=None, rows=None):
+    """-> y, part: the forward (no activation) and part [rows,2,Cout] fp32 = per-workgroup (sum, sum of squares) of the fp32
+    results over the workgroup's pixels -- what bn_finalize reduces; requires conv_stats_rows(d) > 0"""
+    x = _req(x, torch.bfloat16, "x")
+    assert tuple(x.shape) == (d.N, d.H, d.W, d.Cin), (tuple(x.shape), (d.N, d.H, d.W, d.Cin))
+    ho, wo = out_hw(d)
+    rows = conv_stats_rows(d) if rows is None else rows
+    y = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.bfloat16, device=x.device)
+    part = torch.empty((rows, 2, d.Cout), dtype=torch.float32, device=x.device)
+    b = None if bias is None else _req(bias.detach(), torch.float32, "bias")
+    launch("conv2d_fwd_stats", ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(b), ptr(y), ptr(part), stream(),
+           work=flops(d, cin_real), tag=tag(d))
+    return y, part
+
+
 def conv_dgrad(d, dy, w_dgrad, cin_real=None, mask_x=None, mask_slope=1.0, mask_bits=None):
     """mask_x: this conv's input x when it is the output of a fused conv+LeakyReLU(mask_slope): the returned gradient
     is then already multiplied by that activation's derivative; mask_bits: the same from the producer's bit masks

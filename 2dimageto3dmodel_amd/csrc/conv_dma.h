@@ -70,6 +70,9 @@ struct ConvArgs {
     int ncls;
     int cpad_h[4], cpad_w[4], coy[4], cox[4];
     unsigned cls_w_elems;
+    // k_conv_halo, plain unguarded epilogue only: [workgroups along the pixel axis][2][Cout] fp32 partial sums of the results
+    // and of their squares (batch-norm statistics of the output without a pass over it), see conv_halo_stats_rows
+    float *stats;
 };
 
 // launch description of the weight-gradient kernels (csrc/conv_mfma.hip, csrc/conv_halo.hip)

@@ -85,6 +85,40 @@ constexpr int halo_dmas_behind(int tap)
     return n;
 }
 
+// ---- fused batch-norm statistics (ConvArgs::stats): sum over the 32 lanes of a half wave of 32 values per lane at once.
+// A plain DPP reduction would cost 5 steps per value; here every step pairs two values (X, Y) and leaves X's partial sums in
+// the lanes whose bit b is 0 and Y's in the lanes whose bit b is 1, so the number of live values halves with the lane
+// distance: 16 + 8 + 4 + 2 + 1 pair steps, each a lane exchange or two and one add.  The result of lane L is the total
+// (over its 32-lane half) of value k(L), a fixed permutation of the lane bits -- which the kernel does not hard-code but
+// reads off by pushing the value indices through the same network once (stats_probe).
+template <int CTRL, int BANK>
+__device__ __forceinline__ float dpp_mix(float old, float src)
+{   // lanes of the banks in BANK: src[dpp lane]; the others: old
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf, BANK, false));
+}
+__device__ __forceinline__ float lane_reduce32(const float (&v)[32], bool b1, bool b0)
+{
+    float r1[16], r2[8], r3[4], r4[2];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {   // lanes l ^ 16: rows 1 / 3 of X trade places with rows 0 / 2 of Y
+        auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[2 * m]), __float_as_uint(v[2 * m + 1]), false, false);
+        r1[m] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m)      // l ^ 8 (row_ror:8): banks 0,1 end up with X, banks 2,3 with Y
+        r2[m] = dpp_mix<0x128, 0xC>(r1[2 * m], r1[2 * m + 1]) + dpp_mix<0x128, 0x3>(r1[2 * m + 1], r1[2 * m]);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)      // l -> 7 - l inside eight lanes (row_half_mirror): banks 0,2 <- X, banks 1,3 <- Y
+        r3[m] = dpp_mix<0x141, 0xA>(r2[2 * m], r2[2 * m + 1]) + dpp_mix<0x141, 0x5>(r2[2 * m + 1], r2[2 * m]);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {    // l ^ 2 inside a quad
+        const float xs = b1 ? r3[2 * m + 1] : r3[2 * m], ys = b1 ? r3[2 * m] : r3[2 * m + 1];
+        r4[m] = xs + dpp_mix<0x4E, 0xF>(0.0f, ys);
+    }
+    const float xs = b0 ? r4[1] : r4[0], ys = b0 ? r4[0] : r4[1];   // l ^ 1
+    return xs + dpp_mix<0xB1, 0xF>(0.0f, ys);
+}
+
 // PAIR = 1: stride-2 dgrad with 64 input channels (D.conv2): the two column-parity classes (py, 0) and (py, 1) of one row
 // parity share ONE workgroup and ONE dy halo (one column wider): the wave columns wn = 0 / 1, which otherwise hold two
 // 64-channel halves of the output, hold the two classes' 64 channels.  The single-class kernel for this layer is the 4-wave
@@ -286,6 +320,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
         }
     };
     init_acc();
+    // a.stats: per lane, the running totals over this workgroup's tiles of the two values (one per channel group j) the
+    // lane network leaves with it; which (sum / sum of squares, channel) that is, is stats_probe's value in the lane
+    // (the 8-wave variants have no register to spare across the main loop -- two persistent values cost spills in it --
+    // but 16+ KB of LDS: their totals live there; the 4-wave variants fill the LDS and keep them in registers)
+    constexpr bool ST_LDS = NW == 8;
+    __shared__ float st_lds[ST_LDS ? NW * CJ * 64 : 1];
+    float st_tot[CJ];
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) st_tot[j] = 0.0f;
+    if (ST_LDS && a.stats) {
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) st_lds[(wave * CJ + j) * 64 + lane] = 0.0f;   // (only ever touched by this lane)
+    }
     const int ey = UPS ? ((0 - pad_h) & 1) : 0, ex = UPS ? ((0 - pad_w) & 1) : 0;  // tile origins are even
     const unsigned char *fb = ldsB + (wn * 64 + (lane & 31)) * 128;
     const int swzb = (lane >> 1) & 7;
@@ -574,12 +621,56 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
             else if (!a.mask_x && !a.bits_in) store_tile(false_type{}, false_type{}, false_type{});
             else store_tile(false_type{}, true_type{}, true_type{});
         }
+        if (a.stats) {
+            // per channel: sum and sum of squares of the tile's fp32 results (values 0..15 / 16..31 of the lane network),
+            // first over the wave's two pixel rows in the lane, then over its 32 pixel columns; ~250 VALU ops per tile,
+            // issued behind the tile's stores
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) {
+                float v[32];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float y0 = acc[j][0][r], y1 = acc[j][1][r];
+                    v[r] = y0 + y1;
+                    v[16 + r] = fmaf(y1, y1, y0 * y0);
+                }
+                const float t = lane_reduce32(v, (lane & 2) != 0, (lane & 1) != 0);
+                if (ST_LDS) st_lds[(wave * CJ + j) * 64 + lane] += t;
+                else st_tot[j] += t;
+            }
+        }
         if (!has_next) break;
         init_acc();
         tp = tp_next;
         fresh = RES ? 0 : RB - 1 + L;
     }
     wait_vm<0>();  // the trailing (unused) prefetches
+    if (a.stats) {
+        // the four wave rows of the workgroup hold the same channels: one row of partial sums per workgroup,
+        // stats[bp][0 = sum, 1 = sum of squares][Cout] -- the layout m355_bn_finalize reduces
+        __syncthreads();   // (every wave is past its last fragment read)
+        float *red = ST_LDS ? st_lds : reinterpret_cast<float *>(lds);
+        if (!ST_LDS) {
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) red[(wave * CJ + j) * 64 + lane] = st_tot[j];
+        }
+        __syncthreads();
+        if (wave < WGN) {   // wave index = wn of the column it sums
+            float probe[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) probe[k] = (lane & 31) == 0 ? (float)k : 0.0f;
+            const int st_key = (int)lane_reduce32(probe, (lane & 2) != 0, (lane & 1) != 0);
+            const int r = st_key & 15, kind = st_key >> 4;
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) {
+                float t = 0.0f;
+#pragma unroll
+                for (int m = 0; m < NW / WGN; ++m) t += red[((m * WGN + wave) * CJ + j) * 64 + lane];
+                const int ch = n0 + wave * 64 + 32 * j + 8 * (r >> 2) + 4 * half + (r & 3);
+                a.stats[((size_t)bp * 2 + kind) * a.Cout + ch] = t;
+            }
+        }
+    }
 }
 
 // =====================================================================================================
@@ -900,19 +991,43 @@ bool conv_halo_eligible(const ConvArgs &a)
     return true;
 }
 
-int conv_halo_launch(const ConvArgs &a, unsigned xb, unsigned wb, hipStream_t st)
+// workgroups along the pixel-tile axis of the (non-PAIR) launch
+static int halo_grid_per(const ConvArgs &a)
 {
     // persistent workgroups: one per CU (the LDS footprint allows no more), each walking a strided list of pixel tiles
     const int tiles = a.N * (a.Ho / 8) * (a.Wo / 32);
     const int nN = a.CoutP == 64 ? 1 : a.CoutP / 128;
     const char *wgs = getenv("M355_HALO_WGS");       // tests: force few workgroups so that each walks several tiles
     // (the 4-wave variant with the upsample folded in needs only 56 KiB of LDS -> two workgroups per CU, and measured
-    // best with one tile per workgroup: 963 vs 798 TF on G.blk6.conv1 -- the dispatcher staggers them for free)
-    const int resident = (a.CoutP == 64 && a.ups) ? tiles : 256;
-    int per = (wgs ? atoi(wgs) : resident) / (nN * a.ncls);  // workgroups along the pixel-tile axis
+    // best with one tile per workgroup: 963 vs 798 TF on G.blk6.conv1 -- the dispatcher staggers them for free; with fused
+    // statistics every workgroup writes a row of partial sums, so the two resident workgroups of a CU walk their tiles instead:
+    // whole GAN cycle 30.41 ms without fused statistics, 30.30 / 30.00 / 29.99 / 29.88 ms with 8192 / 2048 / 1024 / 512 workgroups)
+    const char *sw = getenv("M355_STATS_UPS_WGS");
+    const int resident = (a.CoutP == 64 && a.ups) ? (a.stats ? (sw ? atoi(sw) : 512) : tiles) : 256;
+    int per = (wgs ? atoi(wgs) : resident) / (nN * a.ncls);
     if (per < 1) per = 1;
     if (per > tiles) per = tiles;
-    per = (tiles + (tiles + per - 1) / per - 1) / ((tiles + per - 1) / per);  // same tiles-per-workgroup, fewer idle ones
+    return (tiles + (tiles + per - 1) / per - 1) / ((tiles + per - 1) / per);  // same tiles-per-workgroup, fewer idle ones
+}
+
+// rows of partial sums a forward with fused batch-norm statistics writes (0: this problem has none -- the kernel that runs it
+// must be k_conv_halo with the plain unguarded epilogue, one class, whole 64-channel groups)
+int conv_halo_stats_rows(const ConvArgs &a)
+{
+    if (!conv_halo_eligible(a) || a.ncls != 1 || a.stride != 1 || a.fold2 || a.Cout != a.CoutP || a.slope != 1.0f || a.mask_x ||
+        a.bits_in || a.bits_out || a.y_f32_nchw || getenv("M355_NO_CONV_STATS"))
+        return 0;
+    ConvArgs b = a;
+    b.stats = reinterpret_cast<float *>(1);
+    return halo_grid_per(b);
+}
+
+int conv_halo_launch(const ConvArgs &a, unsigned xb, unsigned wb, hipStream_t st)
+{
+    const int tiles = a.N * (a.Ho / 8) * (a.Wo / 32);
+    const int nN = a.CoutP == 64 ? 1 : a.CoutP / 128;
+    const char *wgs = getenv("M355_HALO_WGS");
+    const int per = halo_grid_per(a);
 #define M355_HL(BN_, NW_, KS_, UPS_, MD_) \
     hipLaunchKernelGGL((k_conv_halo<BN_, NW_, KS_, UPS_, MD_>), grid, dim3(NW_ * 64), 0, st, a, xb, wb)
 #define M355_HM(BN_, NW_, KS_, UPS_)                                   \

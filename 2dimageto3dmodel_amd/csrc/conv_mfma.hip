@@ -474,6 +474,7 @@ static inline int dy_channels(int cout) { return cout <= 8 ? 8 : (cout + 31) / 3
 
 bool conv_halo_eligible(const ConvArgs &a);  // csrc/conv_halo.hip
 int conv_halo_launch(const ConvArgs &a, unsigned xb, unsigned wb, hipStream_t st);
+int conv_halo_stats_rows(const ConvArgs &a);
 
 bool dgrad_direct_replicate_eligible(const m355_conv_desc *d, int Cy);  // csrc/conv_halo.hip
 int dgrad_direct_replicate_launch(const m355_conv_desc *d, const void *dy, int Cy, const void *w_dgrad, int Kp, int rows_p,
@@ -726,11 +727,19 @@ extern "C" int m355_weight_prep_batched(const void *table_dev, int L, long long 
 }
 
 // probe != 0: do not launch, return 1 / 0 = this forward can / cannot write the activation bit masks
+// probe 1: can this forward emit / read bit masks?  probe 2: rows of fused batch-norm partial sums (0 = none)
 static int conv_fwd_impl(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, int y_f32_nchw,
-                         float lrelu_slope, unsigned *bits_out, void *stream, int probe)
+                         float lrelu_slope, unsigned *bits_out, void *stream, int probe, float *stats = nullptr)
 {
     if (int rc = check_desc(d, "conv2d_fwd")) return probe ? 0 : rc;
     if (!probe) M355_REQUIRE(x && w_fwd && y, "conv2d_fwd: null pointer");
+    if (probe == 2 || stats) {
+        if (m355::conv_small_eligible(d, y_f32_nchw) || (m355::conv_c8_eligible(d, y_f32_nchw) && !getenv("M355_NO_C8"))) {
+            if (probe) return 0;
+            m355::set_error("conv2d_fwd_stats: this shape has no fused statistics (ask m355_conv2d_fwd_stats_rows first)");
+            return M355_ERR_BAD_ARG;
+        }
+    }
     if (m355::conv_small_eligible(d, y_f32_nchw)) {  // heads: 1..4 output channels, HBM-bound halo kernel
         if (probe) return 0;
         M355_REQUIRE(!bits_out, "conv2d_fwd: no bit masks on the small-Cout kernel");
@@ -761,8 +770,37 @@ static int conv_fwd_impl(const m355_conv_desc *d, const void *x, const void *w_f
     a.Kp = m355::k_padded(d->kh * d->kw * d->Cin);
     a.slope = lrelu_slope;
     a.bits_out = bits_out;
+    if (probe == 2 || stats) {
+        ConvArgs b = a;
+        b.CoutP = m355::rows_padded(b.Cout);
+        b.ncls = 1;
+        const char *h = getenv("M355_CONV_HALO");
+        const int rows = (m355::dma_eligible(b) && !(h && h[0] == '0')) ? m355::conv_halo_stats_rows(b) : 0;
+        if (probe) return rows;
+        if (!rows) {
+            m355::set_error("conv2d_fwd_stats: this shape has no fused statistics (ask m355_conv2d_fwd_stats_rows first)");
+            return M355_ERR_BAD_ARG;
+        }
+        a.stats = stats;
+    }
     if (probe) return m355::halo_takes_bits(a) ? 1 : 0;
     return m355::launch_conv(a, (hipStream_t)stream);
+}
+
+/* Forward of a conv whose output feeds batch-norm statistics: besides y, every persistent workgroup writes the sums of its fp32
+ * results and of their squares, part[rows][2][Cout] fp32 with rows = m355_conv2d_fwd_stats_rows(d) -- the layout
+ * m355_bn_finalize reduces -- so the statistics cost no pass over y.  rows == 0: this shape has no fused statistics (run
+ * m355_bn_stats_partial on y).  No activation epilogue (the statistics are those of the conv's own output). */
+extern "C" int m355_conv2d_fwd_stats_rows(const m355_conv_desc *d)
+{
+    return conv_fwd_impl(d, nullptr, nullptr, nullptr, nullptr, 0, 1.0f, nullptr, nullptr, 2);
+}
+
+extern "C" int m355_conv2d_fwd_stats(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
+                                     float *part, void *stream)
+{
+    M355_REQUIRE(part, "conv2d_fwd_stats: null pointer");
+    return conv_fwd_impl(d, x, w_fwd, bias, y, 0, 1.0f, nullptr, stream, 0, part);
 }
 
 extern "C" int m355_conv2d_fwd(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,

@@ -211,10 +211,11 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float *__restrict__ 
     const float count = count_dev ? *count_dev : count_h;   // SyncBN: the all-reduced pixel count, no host round trip
     float s0 = 0.0f, s1 = 0.0f;
     if (c < C) {
-        float p0[4] = {0.f, 0.f, 0.f, 0.f}, p1[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = l; k < nblk; k += 4 * RL) {
+        // 8 rows (16 loads) in flight per thread: a conv with fused statistics hands over one row per workgroup (up to 2048)
+        float p0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, p1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int k = l; k < nblk; k += 8 * RL) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int kk = k + RL * u;
                 if (kk < nblk) {
                     p0[u] += part[((size_t)kk * 2) * C + c];
@@ -222,8 +223,8 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float *__restrict__ 
                 }
             }
         }
-        s0 = (p0[0] + p0[1]) + (p0[2] + p0[3]);
-        s1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
+        s0 = ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p0[4] + p0[5]) + (p0[6] + p0[7]));
+        s1 = ((p1[0] + p1[1]) + (p1[2] + p1[3])) + ((p1[4] + p1[5]) + (p1[6] + p1[7]));
     }
     red[0][l][cl] = s0;
     red[1][l][cl] = s1;

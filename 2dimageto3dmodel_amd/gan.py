@@ -63,7 +63,7 @@ class Conv2d(nn.Conv2d):
         self._sn_state = None
         self._sn_own = None
 
-    def forward(self, x, upsample=0, slope=1.0, out_f32_nchw=False, in_slope=1.0, premasked=False):
+    def forward(self, x, upsample=0, slope=1.0, out_f32_nchw=False, in_slope=1.0, premasked=False, want_stats=False):
         stride, pad_h, pad_w, mode = self.m355
         sn, weight = None, None
         if "weight_orig" in self._parameters:
@@ -77,7 +77,7 @@ class Conv2d(nn.Conv2d):
         else:
             weight = self.weight
         return G.conv2d(x, weight, self.bias, stride, pad_h, pad_w, mode, upsample, slope, out_f32_nchw, sn, in_slope,
-                        premasked)
+                        premasked, want_stats)
 
 
 def spectral_norm(conv):
@@ -151,8 +151,11 @@ class ResBlockUp(nn.Module):
         sc = x if isinstance(self.shortcut, _Identity) else self.shortcut(x)
         g1 = gb.get(self.norm1) if gb is not None else None
         g2 = gb.get(self.norm2) if gb is not None else None
-        h = self.norm1(self.conv1(x, upsample=upsample), z, LRELU, g1)
-        return self.norm2(self.conv2(h), z, LRELU, g2, sc, out_slope)
+        # batch statistics of the two conv outputs come out of the conv launches where the kernel can (conv_fwd_stats)
+        st1 = self.training and isinstance(self.norm1.norm, G.BatchNorm2d) and g1 is not None and g1[0].dtype == torch.float32
+        st2 = self.training and isinstance(self.norm2.norm, G.BatchNorm2d) and g2 is not None and g2[0].dtype == torch.float32
+        h = self.norm1(self.conv1(x, upsample=upsample, want_stats=st1), z, LRELU, g1)
+        return self.norm2(self.conv2(h, want_stats=st2), z, LRELU, g2, sc, out_slope)
 
 
 class Generator(nn.Module):

@@ -306,7 +306,7 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad_h, pad_w, mode, ups, slope, out_f32_nchw, sn, in_slope=1.0,
-                premasked=False, in_bits=None):
+                premasked=False, in_bits=None, want_stats=False):
         n, h, w, cx = x.shape
         cout, cw, kh, kw = weight.shape
         if cx % 8 or cx < cw:
@@ -320,8 +320,13 @@ class Conv2dFn(torch.autograd.Function):
             wf, wd = C.weight_prep(d, weight, want_dgrad=need_dx, sigma=sigma)
         # premasked = the only consumer's dgrad applies this activation's backward: hand it 1 bit per element instead of
         # making it re-read the bf16 activation (csrc/conv_dma.h: ConvArgs::bits_out)
-        bits = None
-        if premasked and slope != 1.0 and not out_f32_nchw and any(ctx.needs_input_grad[:3]) and C.maskbits_ok(d, 0):
+        bits = part = None
+        rows = C.conv_stats_rows(d) if (want_stats and slope == 1.0 and not out_f32_nchw) else 0
+        if rows:
+            # the consumer is a batch norm in training mode: its (sum, sum of squares) partials come out of this launch
+            y, part = C.conv_fwd_stats(d, x.detach(), wf, None if bias is None else bias.detach(), cin_real=cw, rows=rows)
+            ctx.mark_non_differentiable(part)
+        elif premasked and slope != 1.0 and not out_f32_nchw and any(ctx.needs_input_grad[:3]) and C.maskbits_ok(d, 0):
             y, bits = C.conv_fwd(d, x.detach(), wf, None if bias is None else bias.detach(), False, slope, cin_real=cw,
                                  emit_bits=True)
             ctx.mark_non_differentiable(bits)
@@ -333,10 +338,10 @@ class Conv2dFn(torch.autograd.Function):
         use_bits = in_bits is not None and in_slope != 1.0 and C.maskbits_ok(d, 1)
         ctx.save_for_backward(x.detach(), wd, y if (slope != 1.0 and not premasked) else None,
                               weight.detach() if sn is not None else None, in_bits if use_bits else None)
-        return y, bits
+        return y, bits, part
 
     @staticmethod
-    def backward(ctx, dy, _dbits=None):
+    def backward(ctx, dy, _dbits=None, _dpart=None):
         x, wd, y, w_orig, in_bits = ctx.saved_tensors
         d = ctx.d
         if ctx.sn is not None:
@@ -385,18 +390,23 @@ class Conv2dFn(torch.autograd.Function):
                 dw = C.wgrad_finish(d, graw, ctx.cw)
             else:
                 dw = C.wgrad_finish(d, graw, ctx.cw, w_orig, sn.u, sn.v, sn.sigma)
-        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias, stride, pad_h, pad_w, mode, upsample=0, slope=1.0, out_f32_nchw=False, sn=None, in_slope=1.0,
-           premasked=False):
+           premasked=False, want_stats=False):
     """in_slope != 1: x is the output of a fused conv+LeakyReLU(in_slope) whose ONLY consumer is this conv: the
     returned grad_x is pre-multiplied by that activation's derivative, and that producer must be called with
     premasked=True (it then skips its own activation backward).  Both flags are set by the discriminators."""
-    y, bits = Conv2dFn.apply(x, weight, bias, stride, pad_h, pad_w, mode, int(upsample), float(slope), bool(out_f32_nchw), sn,
-                             float(in_slope), bool(premasked), getattr(x, "_m355_bits", None) if in_slope != 1.0 else None)
+    """want_stats: the output's only use is a batch norm in training mode -- where the kernel can, the norm's partial sums are
+    produced by the conv launch and travel on the returned tensor (BatchNorm2d.forward picks them up)"""
+    y, bits, part = Conv2dFn.apply(x, weight, bias, stride, pad_h, pad_w, mode, int(upsample), float(slope), bool(out_f32_nchw),
+                                   sn, float(in_slope), bool(premasked),
+                                   getattr(x, "_m355_bits", None) if in_slope != 1.0 else None, bool(want_stats))
     if bits is not None:
         y._m355_bits = bits  # picked up by the consumer conv (same Python tensor object, see the discriminators' _act)
+    if part is not None:
+        y._m355_stats = part
     return y
 
 
@@ -599,9 +609,11 @@ class CbnActFn(torch.autograd.Function):
     one of the two moment sums backward (RCCL), replacing code/sync_batchnorm/batchnorm.py:110-131's pipes."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope, res=None, sync=False, out_slope=1.0):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope, res=None, sync=False, out_slope=1.0,
+                part=None):
         """out_slope != 1: y = LeakyReLU_out_slope(...) on top (the activation in front of a generator head); its backward is
-        NOT applied here -- the consuming head applies it to the gradient it returns (HeadConvFn in_slope)"""
+        NOT applied here -- the consuming head applies it to the gradient it returns (HeadConvFn in_slope).
+        part: [rows,2,C] partial (sum, sum of squares) of x already produced by the conv that wrote x (conv_fwd_stats)"""
         n, h, w, c = x.shape
         x = x.contiguous()
         res_w = 0
@@ -615,9 +627,13 @@ class CbnActFn(torch.autograd.Function):
         dev = x.device
         P = n * h * w
         count = float(P)
-        nblk = lib().m355_chan_reduce_nblk(P, c)
-        part = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev)
-        launch("bn_stats_partial", ptr(x), ptr(part), P, c, stream())
+        if part is not None:
+            assert part.dtype == torch.float32 and part.dim() == 3 and tuple(part.shape[1:]) == (2, c) and part.is_contiguous()
+            nblk = part.shape[0]
+        else:
+            nblk = lib().m355_chan_reduce_nblk(P, c)
+            part = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev)
+            launch("bn_stats_partial", ptr(x), ptr(part), P, c, stream())
         cnt_dev = None
         if sync:
             # one all-reduce of [sum | sumsq | count]: the global pixel count comes back with the sums and stays on the
@@ -668,7 +684,7 @@ class CbnActFn(torch.autograd.Function):
         elif has_res == 2:   # adjoint of the nearest x2 upsample: sum of each 2x2 block
             dres = torch.empty((n, h // 2, w // 2, c), dtype=dy.dtype, device=dy.device)
             launch("fold2x2", ptr(dy), ptr(dres), n, h // 2, w // 2, c, stream())
-        return (dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None, None, None, None, None, dres, None, None)
+        return (dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None, None, None, None, None, dres, None, None, None)
 
 
 def _count_syncbn():
@@ -778,7 +794,7 @@ class BatchNorm2d(nn.Module):
                 # single-launch coefficient algebra (csrc/gan_glue.hip); num_batches_tracked is bumped by the owner
                 # (Generator.forward batches it over all layers) or here when used stand-alone
                 y = CbnActFn.apply(x, gamma, beta, self.running_mean, self.running_var, self.momentum, self.eps, slope, res,
-                                   sync, out_slope)
+                                   sync, out_slope, getattr(x, "_m355_stats", None))
                 if not getattr(self, "_defer_count", False) and not self.sync:
                     self.num_batches_tracked += 1
                 return y

@@ -193,6 +193,14 @@ int m355_conv2d_maskbits_ok(const m355_conv_desc *d, int role);
 int m355_conv2d_dgrad_mask_ok(const m355_conv_desc *d);
 int m355_conv2d_fwd_bits(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
                          float lrelu_slope, void *mask_bits_out, void *stream);
+/*      forward of a conv whose output feeds batch-norm statistics (the generator's ResBlockUp convs in front of the
+ *      ConditionalBatchNorm2d layers, /root/reference/code/models/gan.py:264-312): besides y, every persistent workgroup writes
+ *      the sums of its fp32 results and of their squares, part[rows][2][Cout] fp32 with rows =
+ *      m355_conv2d_fwd_stats_rows(d) -- the layout m355_bn_finalize reduces -- so the statistics cost no pass over y.
+ *      rows == 0: this shape has no fused statistics (run m355_bn_stats_partial on y).  No activation epilogue. */
+int m355_conv2d_fwd_stats_rows(const m355_conv_desc *d);
+int m355_conv2d_fwd_stats(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, float *part,
+                          void *stream);
 int m355_conv2d_dgrad_bits(const m355_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, void *ws,
                            const void *mask_bits, float mask_slope, void *stream);
 /*      x[N,H,W,Cin], dy[N,Ho,Wo,dy_channels(Cout)] -> dw fp32 [Cout][kh][kw][Cin] (overwritten; split-K partial tiles are

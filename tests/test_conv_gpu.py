@@ -346,3 +346,72 @@ def test_wgrad_arena_accumulates_inside_backward(pkg, case):
         # (split-K atomics: the summation order differs from launch to launch)
         assert (a - want).abs().max().item() < 1e-4 * scale and (b - want).abs().max().item() < 1e-4 * scale
         assert (db - want_db).abs().max().item() < 1e-3 * max(1.0, want_db.abs().max().item())
+
+
+@pytest.mark.parametrize("wgs", [None, "5"])
+@pytest.mark.parametrize("case", [(3, 16, 64, 128, 128, 3, 1, 1, 1, 1, 0),    # 8 waves, 3x3
+                                  (2, 16, 32, 256, 256, 3, 1, 1, 1, 2, 1),    # 8 waves, two 128-channel tiles, upsample, circular
+                                  (2, 16, 16, 128, 64, 3, 1, 1, 1, 1, 1),     # 4 waves, upsample (two workgroups per CU)
+                                  (3, 24, 32, 64, 64, 3, 1, 1, 1, 1, 0),      # 4 waves, resident weights
+                                  (2, 16, 64, 128, 64, 3, 1, 1, 1, 0, 0)])    # 4 waves, streamed weights, zero pad, bias
+def test_conv_fwd_fused_bn_statistics(pkg, case, wgs, monkeypatch):
+    """m355_conv2d_fwd_stats: y is bit-identical to m355_conv2d_fwd and the per-workgroup partial rows add up to the per-channel
+    sum / sum of squares of the conv's fp32 results (fp32 reference conv on the same bf16 operands: only the summation order
+    differs) -- channel by channel, so a permuted lane -> channel map cannot pass; bn_finalize on the rows gives mean / rstd"""
+    if wgs:
+        monkeypatch.setenv("M355_HALO_WGS", wgs)
+        monkeypatch.setenv("M355_STATS_UPS_WGS", wgs)
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    lib = importlib.import_module("2dimageto3dmodel_amd._lib")
+    N, H, W, Cin, Cout, k, stride, ph, pw, mode, ups = case
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(N, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).bfloat16().float()
+    b = (torch.randn(Cout, generator=g) * 0.5) if mode == 0 else None
+    # channel-dependent scale and offset: every channel has its own statistics
+    w = w * (0.5 + torch.arange(Cout).float().view(-1, 1, 1, 1) / Cout)
+    w = w.bfloat16().float()
+    y_ref = ref_conv(x, w, b, stride, ph, pw, mode, ups)
+    d = conv.make_desc(N, H, W, Cin, Cout, k, k, stride, ph, pw, mode, ups)
+    rows = conv.conv_stats_rows(d)
+    assert rows > 0
+    wf, _ = conv.weight_prep(d, w.to(DEV))
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    bd = None if b is None else b.to(DEV)
+    y0 = conv.conv_fwd(d, x_nhwc, wf, bd)
+    want_s = y_ref.double().sum((0, 2, 3))
+    want_q = (y_ref.double() ** 2).sum((0, 2, 3))
+    P = N * y_ref.shape[2] * y_ref.shape[3]
+    for _ in range(2):
+        y, part = conv.conv_fwd_stats(d, x_nhwc, wf, bd)
+        assert tuple(part.shape) == (rows, 2, Cout)
+        assert torch.equal(y.view(torch.int16), y0.view(torch.int16))
+        tot = part.double().sum(0).cpu()
+        scale_s = y_ref.abs().double().sum((0, 2, 3))
+        assert ((tot[0] - want_s).abs() / scale_s).max().item() < 2e-5, ((tot[0] - want_s).abs() / scale_s).max().item()
+        assert ((tot[1] - want_q).abs() / want_q).max().item() < 2e-5, ((tot[1] - want_q).abs() / want_q).max().item()
+    # ... and through bn_finalize (the consumer of the rows)
+    n = N
+    gamma = torch.zeros(n, Cout, device=DEV)
+    beta = torch.zeros(n, Cout, device=DEV)
+    coef = torch.empty(2 * n + 2, Cout, device=DEV)
+    lib.launch("bn_finalize", lib.ptr(part), rows, float(P), None, lib.ptr(gamma), lib.ptr(beta), Cout, n, Cout, 1e-5, 0.1, None, None,
+               lib.ptr(coef[2 * n]), lib.ptr(coef[2 * n + 1]), lib.ptr(coef[:n]), lib.ptr(coef[n:2 * n]), lib.stream())
+    mean = (want_s / P).float()
+    var = (want_q / P - (want_s / P) ** 2).float()
+    assert (coef[2 * n].cpu() - mean).abs().max().item() < 1e-4 * max(1.0, mean.abs().max().item())
+    assert (coef[2 * n + 1].cpu() * torch.sqrt(var + 1e-5) - 1).abs().max().item() < 1e-3
+
+
+def test_conv_fwd_stats_refused_where_not_fused(pkg):
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    lib = importlib.import_module("2dimageto3dmodel_amd._lib")
+    for case in [(2, 8, 4, 64, 64, 3, 1, 1, 1, 1, 0), (2, 16, 16, 8, 64, 5, 1, 2, 2, 2, 0), (2, 32, 64, 64, 128, 4, 2, 1, 1, 0, 0),
+                 (2, 16, 32, 64, 3, 5, 1, 2, 2, 1, 0)]:
+        N, H, W, Cin, Cout, k, stride, ph, pw, mode, ups = case
+        d = conv.make_desc(N, H, W, Cin, Cout, k, k, stride, ph, pw, mode, ups)
+        assert conv.conv_stats_rows(d) == 0
+        x = torch.zeros(N, H, W, Cin, dtype=torch.bfloat16, device=DEV)
+        wf, _ = conv.weight_prep(d, torch.zeros(Cout, Cin, k, k, device=DEV))
+        with pytest.raises(lib.M355Error):
+            conv.conv_fwd_stats(d, x, wf, rows=4)
