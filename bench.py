@@ -227,8 +227,8 @@ def respawn_under_torchrun(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
     ap.add_argument("--points", type=int, default=2048)
     ap.add_argument("--grid", type=int, default=128)
