@@ -68,6 +68,12 @@ __device__ __forceinline__ void wait_vm()
 #ifndef M355_NO_EPI_CREDIT
 #define M355_NO_EPI_CREDIT 0
 #endif
+// TG2: the 8-wave 2x2 variants (class convs of the stride-2 layers, forward and dgrad) meet at a barrier every SECOND tap:
+// four weight slots instead of three (two being read, two in flight), the weights of two steps and the whole next halo are
+// issued behind the barrier that frees their slots, and every wait is a drain (nothing younger is ever in flight).
+#ifndef M355_HALO_TG2
+#define M355_HALO_TG2 1
+#endif
 // halo DMAs one wave issues at tap t (slices of NAS on taps 0 .. T-3), and their sum over the D steps before tap t
 template <int T, int NAW, int NAS>
 constexpr int halo_dmas_at(int t)
@@ -138,13 +144,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
     constexpr int NA = (HR + 7) / 8;                      // DMA instructions per halo
     constexpr int NAW = (NA + NW - 1) / NW;               //   ... per wave
     // halo-slice DMAs per step (taps 0 .. T-3 carry the slices); EARLY: the whole next halo at tap 0
-    constexpr int NAS = M355_HALO_EARLY ? NAW : (NAW + T - 3) / (T - 2);
+    constexpr bool TG2 = M355_HALO_TG2 && NW == 8 && KS == 2 && !RES;   // one barrier per two taps (see M355_HALO_TG2)
+    constexpr int NAS = (M355_HALO_EARLY || TG2) ? NAW : (NAW + T - 3) / (T - 2);
     // RES: the WHOLE weight panel of the workgroup's output channels stays resident in LDS (64 channels x K <= 576: the
     // class convs of a stride-2 dgrad with <= 128 dy channels, a 3x3 conv of 64 channels) -- those layers are bound by
     // the bytes DMA'd into LDS per flop, and the weights were half of them or more.  No weight DMAs in the loop, and one
     // barrier per channel chunk (the one that publishes the next halo) instead of one per tap.
     static_assert(!RES || (BN == 64 && NW == 4 && SUB == 1 && !UPS), "resident weights: 4-wave variant only");
-    constexpr int RB = RES ? (KS == 2 ? 8 : 9) : (NW == 4 ? M355_HALO_RB4 : M355_HALO_RB8);  // weight slots (ring / panel)
+    constexpr int RB = RES ? (KS == 2 ? 8 : 9) : (TG2 ? 4 : (NW == 4 ? M355_HALO_RB4 : M355_HALO_RB8));  // weight slots (ring / panel)
     // software pipeline (one wave per SIMD has no partner wave to hide its LDS-read latency): fragments of step s+1 are
     // read during step s.  The 8-wave variant (2 waves per SIMD, 256 registers each) does the same for the 2x2 class
     // convs (+3-5 %); with 9 taps unrolled it would spill ~30 registers (-5 %), so 3x3 reads them in the step itself.
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
             static_for<0, T>([&](auto tapc) { issue_B(0, cc, tapc, cc * T + decltype(tapc)::value); });
     } else {
         int cls = 0, cc = 0;
-        static_for<0, RB - 1 + L>([&](auto qc) {
+        static_for<0, TG2 ? RB - 1 : RB - 1 + L>([&](auto qc) {   // (TG2: step 0 itself issues steps RB-1 and RB)
             constexpr int q = decltype(qc)::value;
             issue_B(cls, cc, std::integral_constant<int, q % T>{}, q);
             if (q % T == T - 1) advance(cls, cc);
@@ -456,6 +463,21 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();
                     }
+                } else if (TG2) {
+                    // even taps: everything this wave has issued is awaited (the weights of this and the next step, issued
+                    // two steps ago, and at tap 2 the next halo, issued at tap 0) except, first thing in a tile, the previous
+                    // tile's epilogue stores, which are younger than the weights awaited there
+                    if (tap % 2 == 0) {
+                        if (fresh > 0) {
+                            --fresh;
+                            if (epi_vm == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                            else if (epi_vm == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        } else {
+                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        }
+                        __builtin_amdgcn_s_barrier();
+                    }
                 } else {
                     if (warm) {
                         --warm;
@@ -490,7 +512,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                 mma(0);  // the DMA issue below (scalar address work, M0 writes) runs in the shadow of these MFMAs
 #endif
                 __builtin_amdgcn_sched_barrier(0);
-                if (!RES) {
+                if (TG2) {
+                    // behind an even tap's barrier the slots of the previous and of this step are free (their fragments were
+                    // read one step before they are used): steps s+3 and s+4 go there, to be published two steps from now
+                    if (tap % 2 == 0) {
+                        constexpr int a1 = tap + RB - 1, a2 = tap + RB;
+                        int cls_b = cls_cur, cc_b = cc_cur;
+#pragma unroll
+                        for (int q = 0; q < a1 / T; ++q) advance(cls_b, cc_b);
+                        issue_B(cls_b, cc_b, std::integral_constant<int, a1 % T>{}, slot_p);
+                        if (a2 / T > a1 / T) advance(cls_b, cc_b);
+                        issue_B(cls_b, cc_b, std::integral_constant<int, a2 % T>{}, slot);
+                    }
+                } else if (!RES) {
                     constexpr int ahead = tap + RB - 1 + L;  // the weight stream's step, relative to this segment's tap 0
                     int cls_b = cls_cur, cc_b = cc_cur;
 #pragma unroll
@@ -642,7 +676,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
         if (!has_next) break;
         init_acc();
         tp = tp_next;
-        fresh = RES ? 0 : RB - 1 + L;
+        fresh = RES ? 0 : (TG2 ? 1 : RB - 1 + L);
     }
     wait_vm<0>();  // the trailing (unused) prefetches
     if (a.stats) {
