@@ -14,6 +14,8 @@
 //   * accumulators stay in registers across the channel chunks; fp32 NCHW output (what the heads return) with
 //     bias and optional LeakyReLU.
 // Algorithmic traffic: input once (x 1.56 halo overlap) + output; LDS-read bound (1 KiB pixel fragment per MFMA).
+#include <type_traits>
+
 #include "conv_dma.h"
 
 namespace m355 {
@@ -150,6 +152,156 @@ __global__ __launch_bounds__(256, 2) void k_conv_smallco(SmallArgs a)
                 }
             }
         }
+    }
+}
+
+// ---- conv_final / conv_mesh (64 -> 1..4 channels, 5x5): the "scatter" form, no LDS at all.
+// k_conv_smallco serves every tap of every pixel with its own 1 KiB fragment read from LDS (25 taps x 2 k-halves per 16
+// pixels) for an MFMA that uses 3 of its 16 columns: LDS-read bound at 1.7 TB/s of input (147-177 us at batch 64 against a
+// 50 us HBM floor).  Here the GEMM runs the other way round: for a ROW of 32 input pixels (one wave; 28 of them are the
+// strip's output columns, 2 + 2 halo) ONE pass over the pixel's 64 channels -- 4 B fragments loaded straight from global
+// memory, 16 bytes per lane -- is multiplied with ALL 25 taps x Cout weight rows (the A operand: 128 (slot, half) rows
+// resident in 64 registers), giving z[tap][co][pixel] for the whole row in 16 MFMAs.  The convolution is then
+//     y[r][c][co] = sum_{kh,kw} z_{row r + kh - 2}[kh,kw][co][c + kw - 2]:
+// kw - 2 is a LANE shift (pixels are lanes: DPP wave_shl / wave_shr, the same instruction for both halves of the wave because
+// the weight rows are ordered so that a register holds the same kw in both) and kh selects which of five rolling output-row
+// accumulators takes the value; the wave walks down its strip, and output row q - 2 is complete after input row q.
+// Lane halves hold different output channels (co = 2 cp + half), so nothing has to be exchanged between them.
+// Per input row: 4 x 16-byte loads, 16 MFMA 32x32x16, ~75 VALU ops, 2 stores -- the kernel is bound by its reads of x.
+struct Head5Args {
+    const unsigned short *x;  // bf16 NHWC [N,H,W,64]
+    const unsigned short *w;  // bf16 forward view [rows][Kp], row = output channel, K ordered (kh, kw, ci)
+    const float *bias;        // [Cout] or null
+    float *y;                 // fp32 NCHW [N,Cout,H,W]
+    int N, H, W, Cout, Kp;
+    int nsx, nsy, rs;         // strips of 28 columns, row segments of rs rows
+    float slope;
+    unsigned xbytes, wbytes;
+};
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void head5_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        head5_for<I + 1, N>(f);
+    }
+}
+
+template <int S>
+__device__ __forceinline__ float lane_from(float v)
+{   // value of lane (l + S) for S in -2..2, across the whole wave (the two lanes next to a half boundary receive the other half's)
+    if (S == 0) return v;
+    int x = __float_as_int(v);
+    if (S > 0) {
+        x = __builtin_amdgcn_update_dpp(0, x, 0x130, 0xf, 0xf, true);            // wave_shl:1
+        if (S == 2) x = __builtin_amdgcn_update_dpp(0, x, 0x130, 0xf, 0xf, true);
+    } else {
+        x = __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, true);            // wave_shr:1
+        if (S == -2) x = __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, true);
+    }
+    return __int_as_float(x);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_head5(Head5Args a)
+{
+    constexpr int SW = 28;   // output columns of a strip (32 lanes - 2 - 2)
+    const int lane = threadIdx.x & 63, c = lane & 31, half = lane >> 5;
+    const int item = blockIdx.x, per_img = a.nsx * a.nsy;   // one wave per workgroup: no LDS, nothing shared -- the dispatcher
+    if (item >= a.N * per_img) return;                       // spreads the ~2000 waves evenly over the SIMDs
+    const int n = item / per_img, rem = item - n * per_img, sy = rem / a.nsx, sx = rem - sy * a.nsx;
+    const int r0 = sy * a.rs, r1 = min(a.H, r0 + a.rs);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.wbytes, 0x00020000);
+
+    // ---- weights: A rows m = 32 b + (lane & 31) = 32 b + 8 g + 4 h' + e  <->  D register i = 4 g + e of block b in lane half h'.
+    // value index u = 16 b + i: kw = u % 5, slot j = u / 5 (< 10), kh = j % 5, channel pair cp = j / 5, co = 2 cp + h'
+    bf16x8 wf[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int g = c >> 3, hp = (c >> 2) & 1, e = c & 3;
+        const int u = 16 * b + 4 * g + e, j = u / 5, kw = u - 5 * j, kh = j % 5, co = 2 * (j / 5) + hp;
+        const bool ok = j < 10 && co < a.Cout;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const unsigned off = ok ? (unsigned)((co * a.Kp + (kh * 5 + kw) * 64 + 16 * kk + 8 * half) * 2) : OOB;
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0);
+            wf[b][kk] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+
+    // ---- this lane's pixel column (W pad resolved on the index; zero pad = out-of-range offset = zeros)
+    const int gx = sx * SW + c - 2;
+    int gxc = gx;
+    if (MODE == 1) gxc = min(max(gx, 0), a.W - 1);
+    else if (MODE == 2) gxc = gx < 0 ? gx + a.W : (gx >= a.W ? gx - a.W : gx);
+    const bool col_ok = (unsigned)gxc < (unsigned)a.W;
+    const unsigned colb = (unsigned)gxc * 128u + 16u * half;
+    auto load_row = [&](int q, bf16x8 (&xf)[4]) {
+        const bool ok = col_ok && (unsigned)q < (unsigned)a.H;   // (rows outside the image: zero padding)
+        const unsigned base = ok ? (unsigned)((n * a.H + q) * a.W) * 128u + colb : OOB;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) xf[kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx, base, 32 * kk, 0));
+    };
+
+    float R[5][2];   // R[k][cp]: output row (current input row) - 2 + k, channel 2 cp + half, column gx
+#pragma unroll
+    for (int k = 0; k < 5; ++k) R[k][0] = R[k][1] = 0.0f;
+    const bool st_col = c >= 2 && c < 2 + SW && gx < a.W;
+    float bv[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp)
+        if (a.bias && 2 * cp + half < a.Cout) bv[cp] = a.bias[2 * cp + half];
+
+    // rows in flight: a row costs ~0.4 us of MFMA + VALU but ~2 us of memory latency, and a wave has only its own loads to
+    // hide it behind -- PD rows (PD x 4 KiB per wave) are requested ahead of the one being multiplied
+    constexpr int PD = 4;
+    bf16x8 buf[PD][4];
+    const int q0 = r0 - 2, qend = r1 + 2;
+#pragma unroll
+    for (int k = 0; k < PD; ++k) load_row(q0 + k, buf[k]);   // (rows past the segment are rows past the image or unused)
+    for (int qb = q0; qb < qend; qb += PD) {
+        head5_for<0, PD>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const int q = qb + k;
+            if (q < qend) {
+                if (q >= 0 && q < a.H) {   // (a zero row contributes nothing)
+                    head5_for<0, 4>([&](auto bc) {
+                        constexpr int b = decltype(bc)::value;
+                        f32x16 d;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) d[i] = 0.0f;
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[b][kk], buf[k][kk], d, 0, 0, 0);
+                        head5_for<0, 16>([&](auto ic) {
+                            constexpr int i = decltype(ic)::value, u = 16 * b + i;
+                            if constexpr (u < 50) {
+                                constexpr int j = u / 5, kw = u - 5 * j, kh = j % 5, cp = j / 5;
+                                R[4 - kh][cp] += lane_from<kw - 2>(d[i]);
+                            }
+                        });
+                    });
+                }
+                if (q + PD < qend) load_row(q + PD, buf[k]);
+                // output row q - 2 is complete
+                const int r = q - 2;
+                if (r >= r0 && r < r1 && st_col) {
+#pragma unroll
+                    for (int cp = 0; cp < 2; ++cp) {
+                        const int co = 2 * cp + half;
+                        if (co < a.Cout) {
+                            float v = R[0][cp] + bv[cp];
+                            v = v >= 0.0f ? v : v * a.slope;
+                            a.y[(((size_t)n * a.Cout + co) * a.H + r) * a.W + gx] = v;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { R[t][0] = R[t + 1][0]; R[t][1] = R[t + 1][1]; }
+                R[4][0] = R[4][1] = 0.0f;
+            }
+        });
     }
 }
 
@@ -675,6 +827,31 @@ int dgrad_small_launch(const m355_conv_desc *d, const void *dy, int Cy, const vo
 int conv_small_launch(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, float slope,
                       int Kp, size_t wbytes, hipStream_t st)
 {
+    if (d->Cin == 64 && d->kh == 5 && !getenv("M355_NO_HEAD5")) {   // conv_final / conv_mesh: the scatter form (k_head5)
+        Head5Args h = {};
+        h.x = (const unsigned short *)x;
+        h.w = (const unsigned short *)w_fwd;
+        h.bias = bias;
+        h.y = (float *)y;
+        h.N = d->N; h.H = d->H; h.W = d->W; h.Cout = d->Cout; h.Kp = Kp;
+        h.nsx = (d->W + 27) / 28;
+        // row segments: (rs + 4) / rs of the input is read, so as few as fill the chip ONCE (2 waves per SIMD = 2048 waves:
+        // a second, partial round of waves would double the kernel's time), but at least 8 rows each
+        long nsy = 2048 / ((long)d->N * h.nsx);
+        if (nsy < 1) nsy = 1;
+        if (nsy > (d->H + 7) / 8) nsy = (d->H + 7) / 8;
+        h.rs = (int)((d->H + nsy - 1) / nsy);
+        h.nsy = (d->H + h.rs - 1) / h.rs;
+        h.slope = slope;
+        h.xbytes = (unsigned)((size_t)d->N * d->H * d->W * d->Cin * 2);
+        h.wbytes = (unsigned)wbytes;
+        const dim3 grid((unsigned)((long)d->N * h.nsx * h.nsy));
+        if (d->pad_w_mode == 0) hipLaunchKernelGGL((k_head5<0>), grid, dim3(64), 0, st, h);
+        else if (d->pad_w_mode == 1) hipLaunchKernelGGL((k_head5<1>), grid, dim3(64), 0, st, h);
+        else hipLaunchKernelGGL((k_head5<2>), grid, dim3(64), 0, st, h);
+        note_kernel("k_head5");
+        return check_launch("conv2d_fwd (5x5 head)");
+    }
     SmallArgs a = {};
     a.x = (const unsigned short *)x;
     a.w = (const unsigned short *)w_fwd;

@@ -65,6 +65,10 @@ CASES = [
     # ---- replicate-padded 5x5 heads whose dgrad runs on k_conv_c8 + the pad-column edge term
     (2, 16, 32, 64, 3, 5, 1, 2, 2, 1, 0),     # conv_final / conv_mesh shape class
     (3, 24, 64, 128, 2, 5, 1, 2, 2, 1, 0),    # two 64-channel tiles of dx, several pixel tiles, 2 output channels
+    # ---- 64 -> 1..4 channel 5x5 heads in the scatter form (conv_small.hip k_head5): strips of 28 columns, row segments
+    (2, 33, 70, 64, 3, 5, 1, 2, 2, 0, 0),     # zero W pad, three strips (ragged), ragged row segments
+    (1, 64, 30, 64, 4, 5, 1, 2, 2, 2, 0),     # circular, 4 output channels, two strips
+    (3, 12, 28, 64, 1, 5, 1, 2, 2, 1, 0),     # replicate, one output channel, exactly one strip
 ]
 
 
