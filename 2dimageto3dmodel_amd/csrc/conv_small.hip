@@ -559,6 +559,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
     const unsigned char *wfrag = ldsW + (lane & 31) * WPITCH + half * 16;
 
     f32x16 acc[2][2];  // [co block j][pixel row i]
+    // The bias lives in registers for the whole kernel and is the accumulators' initial value.  (A global load inside the tile
+    // loop -- the epilogue used to fetch the bias per tile -- is awaited with an in-order vmcnt: behind the NEXT tile's halo
+    // DMA issued just before it, i.e. one full HBM round trip per tile with nothing to overlap it; the counters showed the
+    // waves parked on s_waitcnt half of the time, profiles/r02_pmc_sq_c8.txt.)
+    float4 bias_r[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            bias_r[j][g] = a.bias ? *reinterpret_cast<const float4 *>(a.bias + tn * 64 + 32 * j + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
     int tp = bp, buf = 0;
     issue_halo(tp, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // weights + first halo (the in-loop wait only covers later halos)
@@ -573,6 +583,22 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
         else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        // (dgrad of a head) the mask vectors of all eight store units are requested NOW, ahead of the next tile's halo DMA:
+        // they are older than it in the in-order vmcnt, and have the whole MFMA phase to arrive
+        uint4 mk[2][2][2];
+        if (a.mask) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int u = lane + 64 * k, p = u >> 2, lc = (u & 3) ^ ((p >> 1) & 3);
+                        const size_t pix0m = ((size_t)n * a.H + (oy0 + 2 * wave + i)) * a.W + ox0;
+                        mk[i][j][k] = *reinterpret_cast<const uint4 *>(a.mask + (pix0m + p) * a.Cout + tn * 64 + 32 * j + 8 * lc);
+                    }
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (tp_next < tiles) issue_halo(tp_next, buf ^ 1);
         else issue_halo(tp, buf ^ 1);  // keep the DMA count per tile constant (harmless re-load into the idle buffer)
         __builtin_amdgcn_sched_barrier(0);
@@ -581,7 +607,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
+                for (int g = 0; g < 4; ++g) {
+                    acc[j][i][4 * g] = bias_r[j][g].x; acc[j][i][4 * g + 1] = bias_r[j][g].y;
+                    acc[j][i][4 * g + 2] = bias_r[j][g].z; acc[j][i][4 * g + 3] = bias_r[j][g].w;
+                }
         const unsigned char *hb = lds + buf * HBUF + ((2 * wave) * HS_X + tx) * 16;
 #pragma unroll
         for (int ks = 0; ks < 13; ++ks) {
@@ -600,21 +629,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
         // writes at batch 128).  Each (row i, channel half j) piece -- 32 pixels x 64 bytes -- goes through a wave-private
         // 2 KB LDS stage instead and leaves as two store instructions of 16 pixels x 64 contiguous bytes.
         unsigned char *const stg = ldsS + wave * 2048;
-        // (dgrad of a head) the mask vectors of all eight store units are requested up front: they arrive while the pieces
-        // are converted, instead of one L2 round trip in front of every store
-        uint4 mk[2][2][2];
-        if (a.mask) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const int u = lane + 64 * k, p = u >> 2, lc = (u & 3) ^ ((p >> 1) & 3);
-                        const size_t pix0m = ((size_t)n * a.H + (oy0 + 2 * wave + i)) * a.W + ox0;
-                        mk[i][j][k] = *reinterpret_cast<const uint4 *>(a.mask + (pix0m + p) * a.Cout + tn * 64 + 32 * j + 8 * lc);
-                    }
-        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const size_t pix0 = ((size_t)n * a.H + (oy0 + 2 * wave + i)) * a.W + ox0;   // pixel of column 0 of this tile row
@@ -625,10 +639,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
                 uint2 pk[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (a.bias) b4 = *reinterpret_cast<const float4 *>(a.bias + cbase + 8 * g + 4 * half);
-                    float v[4] = {acc[j][i][4 * g] + b4.x, acc[j][i][4 * g + 1] + b4.y, acc[j][i][4 * g + 2] + b4.z,
-                                  acc[j][i][4 * g + 3] + b4.w};
+                    float v[4] = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
                     if (a.bits) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) wbits |= (v[e] > 0.0f ? 1u : 0u) << (16 * j + 4 * g + e);
