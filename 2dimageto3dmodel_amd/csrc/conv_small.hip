@@ -913,11 +913,14 @@ __device__ __forceinline__ void sfor(F &&f)
     }
 }
 
+#ifndef M355_WGC8_NST
+#define M355_WGC8_NST 3
+#endif
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void k_wgrad_c8(C8WgArgs a)
 {
     constexpr int TH = 8, TW = 32, KS = 5, HS_X = TW + KS - 1, HS_Y = TH + KS - 1, HPIX = HS_X * HS_Y;
-    constexpr int XBUF = 8192, YBUF = 256 * 128, STAGE = XBUF + YBUF, NST = 3;
+    constexpr int XBUF = 8192, YBUF = 256 * 128, STAGE = XBUF + YBUF, NST = M355_WGC8_NST;
     __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -992,15 +995,18 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_c8(C8WgArgs a)
     // ---- tiles blockIdx.x, +G, +2G, ...: three stages, two tiles in flight behind the one being consumed
     int tile = blockIdx.x, st = 0;
     issue(tile, 0);
-    if (tile + G < tiles) issue(tile + G, 1);
+#pragma unroll
+    for (int k = 1; k < NST - 1; ++k)
+        if (tile + k * G < tiles) issue(tile + k * G, k);
     for (; tile < tiles; tile += G) {
-        // this tile's 5 DMAs per wave were issued two tiles ago; only the next tile's 5 may still be in flight
-        if (tile + G < tiles) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        // this tile's 5 DMAs per wave were issued NST-1 tiles ago; only those of the next NST-2 tiles may still be in flight
+        if (NST >= 4 && tile + 2 * G < tiles) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+        else if (tile + G < tiles) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        const int st2 = st == 0 ? 2 : st - 1;  // the stage consumed one tile ago
-        if (tile + 2 * G < tiles) issue(tile + 2 * G, st2);
+        const int st2 = st == 0 ? NST - 1 : st - 1;  // the stage consumed one tile ago
+        if (tile + (NST - 1) * G < tiles) issue(tile + (NST - 1) * G, st2);
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char *bx = lds + st * STAGE, *by = bx + XBUF;
         if (do_db) {
@@ -1012,7 +1018,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_c8(C8WgArgs a)
         }
         if (cg) tile_mma(bx, by, std::integral_constant<int, 1>{});
         else tile_mma(bx, by, std::integral_constant<int, 0>{});
-        st = st == 2 ? 0 : st + 1;
+        st = st == NST - 1 ? 0 : st + 1;
     }
     if (do_db && co0 + dbc < a.Cout) atomicAdd(a.db + co0 + dbc, dbacc);
     // acc[t][r]: co = co0 + 32 cb + (r&3) + 8(r>>2) + 4(lane>>5); column lane&31 of block 5cg + t = (kh, kw0 + (n>>3), n&7)
