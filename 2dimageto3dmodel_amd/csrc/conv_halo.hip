@@ -68,12 +68,15 @@ __device__ __forceinline__ void wait_vm()
 #ifndef M355_NO_EPI_CREDIT
 #define M355_NO_EPI_CREDIT 0
 #endif
-// TG2: the 8-wave 2x2 variants (class convs of the stride-2 layers, forward and dgrad) meet at a barrier every SECOND tap:
-// four weight slots instead of three (two being read, two in flight), the weights of two steps and the whole next halo are
-// issued behind the barrier that frees their slots, and every wait is a drain (nothing younger is ever in flight).
+// TG2 (A/B build option, OFF): the 8-wave 2x2 variants meet at a barrier every SECOND tap -- four weight slots instead of
+// three (two being read, two in flight), the weights of two steps and the whole next halo issued behind the barrier that
+// frees their slots, every wait a plain drain.  Bit-identical results; measured same-box against the three-slot, barrier-per-
+// tap scheme with its counted waits: GAN cycle 29.14 -> 29.26 ms, D.conv3 / conv4 forward 517 / 460 -> 519 / 468 us.  Half
+// the barriers do not pay for giving up the counted vmcnt (loads in flight across the barrier) and the slices' spread.
 #ifndef M355_HALO_TG2
-#define M355_HALO_TG2 1
+#define M355_HALO_TG2 0
 #endif
+
 // halo DMAs one wave issues at tap t (slices of NAS on taps 0 .. T-3), and their sum over the D steps before tap t
 template <int T, int NAW, int NAS>
 constexpr int halo_dmas_at(int t)
@@ -130,9 +133,14 @@ __device__ __forceinline__ float lane_reduce32(const float (&v)[32], bool b1, bo
 // 64-channel halves of the output, hold the two classes' 64 channels.  The single-class kernel for this layer is the 4-wave
 // (one wave per SIMD) variant -- 630 TF, nothing to hide its LDS latency behind -- while the 128-channel layers run the 8-wave
 // variant at 1100-1200 TF; pairing the classes gives this layer the same 8-wave shape and halves its dy traffic into LDS.
-template <int BN, int NW, int KS, int UPS, int MODE, int SUB = 1, int RES = 0, int PAIR = 0>
+// STATS = 1: the instantiations that also emit batch-norm partial sums (ConvArgs::stats; 3x3 forward only).  A template
+// parameter, not a run-time branch: with the statistics code merely PRESENT in the kernel body the 2x2 class variants ran 20 %
+// slower (same-box A/B of three builds: D.conv3 forward 498 -> 618 us, whole GAN cycle 29.7 -> 31.7 ms) -- they sit at 256
+// registers and their software-pipelined main loop does not survive a different allocation.
+template <int BN, int NW, int KS, int UPS, int MODE, int SUB = 1, int RES = 0, int PAIR = 0, int STATS = 0>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs a, unsigned xbytes, unsigned wbytes)
 {
+    static_assert(!STATS || (KS == 3 && SUB == 1 && !PAIR), "fused statistics: 3x3 forward");
     static_assert(SUB == 1 || (KS == 2 && !UPS), "stride-2 forward = 2x2 classes");
     static_assert(!PAIR || (BN == 128 && NW == 8 && KS == 2 && !UPS && SUB == 1 && !RES), "class pairs: 8-wave 2x2 class convs");
     constexpr int NC = SUB == 2 ? 4 : 1;  // classes accumulated into one output tile
@@ -332,11 +340,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
     // (the 8-wave variants have no register to spare across the main loop -- two persistent values cost spills in it --
     // but 16+ KB of LDS: their totals live there; the 4-wave variants fill the LDS and keep them in registers)
     constexpr bool ST_LDS = NW == 8;
-    __shared__ float st_lds[ST_LDS ? NW * CJ * 64 : 1];
+    float *const st_ptr = STATS ? a.stats : nullptr;
+    __shared__ float st_lds[(ST_LDS && STATS) ? NW * CJ * 64 : 1];
     float st_tot[CJ];
 #pragma unroll
     for (int j = 0; j < CJ; ++j) st_tot[j] = 0.0f;
-    if (ST_LDS && a.stats) {
+    if (STATS && ST_LDS && st_ptr) {
 #pragma unroll
         for (int j = 0; j < CJ; ++j) st_lds[(wave * CJ + j) * 64 + lane] = 0.0f;   // (only ever touched by this lane)
     }
@@ -655,7 +664,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
             else if (!a.mask_x && !a.bits_in) store_tile(false_type{}, false_type{}, false_type{});
             else store_tile(false_type{}, true_type{}, true_type{});
         }
-        if (a.stats) {
+        if (STATS && st_ptr) {
             // per channel: sum and sum of squares of the tile's fp32 results (values 0..15 / 16..31 of the lane network),
             // first over the wave's two pixel rows in the lane, then over its 32 pixel columns; ~250 VALU ops per tile,
             // issued behind the tile's stores
@@ -679,7 +688,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
         fresh = RES ? 0 : (TG2 ? 1 : RB - 1 + L);
     }
     wait_vm<0>();  // the trailing (unused) prefetches
-    if (a.stats) {
+    if (STATS && st_ptr) {
         // the four wave rows of the workgroup hold the same channels: one row of partial sums per workgroup,
         // stats[bp][0 = sum, 1 = sum of squares][Cout] -- the layout m355_bn_finalize reduces
         __syncthreads();   // (every wave is past its last fragment read)
@@ -701,7 +710,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
 #pragma unroll
                 for (int m = 0; m < NW / WGN; ++m) t += red[((m * WGN + wave) * CJ + j) * 64 + lane];
                 const int ch = n0 + wave * 64 + 32 * j + 8 * (r >> 2) + 4 * half + (r & 3);
-                a.stats[((size_t)bp * 2 + kind) * a.Cout + ch] = t;
+                st_ptr[((size_t)bp * 2 + kind) * a.Cout + ch] = t;
             }
         }
     }
@@ -1048,7 +1057,7 @@ static int halo_grid_per(const ConvArgs &a)
 // must be k_conv_halo with the plain unguarded epilogue, one class, whole 64-channel groups)
 int conv_halo_stats_rows(const ConvArgs &a)
 {
-    if (!conv_halo_eligible(a) || a.ncls != 1 || a.stride != 1 || a.fold2 || a.Cout != a.CoutP || a.slope != 1.0f || a.mask_x ||
+    if (!conv_halo_eligible(a) || a.KH != 3 || a.ncls != 1 || a.stride != 1 || a.fold2 || a.Cout != a.CoutP || a.slope != 1.0f || a.mask_x ||
         a.bits_in || a.bits_out || a.y_f32_nchw || getenv("M355_NO_CONV_STATS"))
         return 0;
     ConvArgs b = a;
@@ -1062,8 +1071,12 @@ int conv_halo_launch(const ConvArgs &a, unsigned xb, unsigned wb, hipStream_t st
     const int nN = a.CoutP == 64 ? 1 : a.CoutP / 128;
     const char *wgs = getenv("M355_HALO_WGS");
     const int per = halo_grid_per(a);
-#define M355_HL(BN_, NW_, KS_, UPS_, MD_) \
-    hipLaunchKernelGGL((k_conv_halo<BN_, NW_, KS_, UPS_, MD_>), grid, dim3(NW_ * 64), 0, st, a, xb, wb)
+#define M355_HL(BN_, NW_, KS_, UPS_, MD_)                                                                                      \
+    do {                                                                                                                       \
+        if (KS_ == 3 && a.stats)                                                                                               \
+            hipLaunchKernelGGL((k_conv_halo<BN_, NW_, 3, UPS_, MD_, 1, 0, 0, 1>), grid, dim3(NW_ * 64), 0, st, a, xb, wb);      \
+        else hipLaunchKernelGGL((k_conv_halo<BN_, NW_, KS_, UPS_, MD_>), grid, dim3(NW_ * 64), 0, st, a, xb, wb);              \
+    } while (0)
 #define M355_HM(BN_, NW_, KS_, UPS_)                                   \
     do {                                                               \
         if (a.pad_w_mode == 0) M355_HL(BN_, NW_, KS_, UPS_, 0);        \
@@ -1104,7 +1117,12 @@ int conv_halo_launch(const ConvArgs &a, unsigned xb, unsigned wb, hipStream_t st
     // resident weight panel (64 output channels x K <= 576)
     const bool res = a.CoutP == 64 && a.stride == 1 && !a.ups && ((a.KH == 2 && a.Cin <= 128) || (a.KH == 3 && a.Cin == 64)) &&
                      !getenv("M355_NO_HALO_RES");
-#define M355_HR(KS_, MD_) hipLaunchKernelGGL((k_conv_halo<64, 4, KS_, 0, MD_, 1, 1>), grid, dim3(256), 0, st, a, xb, wb)
+#define M355_HR(KS_, MD_)                                                                                         \
+    do {                                                                                                          \
+        if (KS_ == 3 && a.stats)                                                                                  \
+            hipLaunchKernelGGL((k_conv_halo<64, 4, 3, 0, MD_, 1, 1, 0, 1>), grid, dim3(256), 0, st, a, xb, wb);    \
+        else hipLaunchKernelGGL((k_conv_halo<64, 4, KS_, 0, MD_, 1, 1>), grid, dim3(256), 0, st, a, xb, wb);      \
+    } while (0)
     if (res) {
         if (a.KH == 2) {
             if (a.pad_w_mode == 0) M355_HR(2, 0);
