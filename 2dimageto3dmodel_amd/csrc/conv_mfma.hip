@@ -1356,9 +1356,14 @@ static int conv_wgrad_impl(const m355_conv_desc *d, const void *x, const void *d
     if (wgrad_dma_ok(d)) {
         const int TM = d->Cout > 64 ? 128 : 64, TN = d->Cout > 64 ? 128 : 256;
         const int gx = (d->Cout + TM - 1) / TM, gy = (K + TN - 1) / TN;
-        // split the pixel axis: ~1024 workgroups in flight (2 resident per CU), at least 4 K steps each
-        int splits = (1024 + gx * gy - 1) / (gx * gy);
-        const int max_splits = (P + 4 * 64 - 1) / (4 * 64);
+        // split the pixel axis: ~256 workgroups (one per CU), at least 4 K steps each.  Every workgroup ends with TM x TN fp32
+        // atomics, so on the small layers this kernel is left with (mesh discriminator, the generator's 8x4 .. 32x16 stages,
+        // 1x1 shortcuts) the split count is the cost: all its launches of a GAN cycle together 1.17 / 0.87 / 0.77 ms at
+        // 1024 / 512 / 256 workgroups
+        static const int wg_target = getenv("M355_WGRAD_SPLIT_WGS") ? atoi(getenv("M355_WGRAD_SPLIT_WGS")) : 256;
+        static const int min_steps = getenv("M355_WGRAD_SPLIT_STEPS") ? atoi(getenv("M355_WGRAD_SPLIT_STEPS")) : 4;
+        int splits = (wg_target + gx * gy - 1) / (gx * gy);
+        const int max_splits = (P + min_steps * 64 - 1) / (min_steps * 64);
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
         a.chunk = ((P + splits - 1) / splits + 63) / 64 * 64;
