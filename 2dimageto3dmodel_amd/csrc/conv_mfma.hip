@@ -166,7 +166,20 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
 //     share input halo rows and all tiles share the weights.
 // FAST (Cin % 64 == 0): a K step is one tap x 64 channels -> tap arithmetic is scalar.  Otherwise (Cin % 8 == 0,
 // D conv1's 8 channels, dgrad of the 1/3-channel heads) every 16-byte chunk derives its own tap.
-template <int BM, int BN, int NW, int WGN, bool FAST, int MODE>
+// NST: LDS stages.  2 = the DMA of step t+1 is issued before the MFMAs of step t and a __syncthreads() per step drains it (two
+// workgroups per CU cover each other's waits).  The 64 x 64 tiles exist for problems too small to give every CU two
+// workgroups (the generator's 8x4 .. 32x16 stages, the mesh discriminator: one workgroup per CU or fewer), where each step then
+// exposes a full DMA round trip (~1500 cycles for 128 cycles of MFMA): they run NST = 4 -- three steps in flight, a counted
+// s_waitcnt vmcnt and one raw barrier per step.
+template <int N>
+__device__ __forceinline__ void glds_wait()
+{
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+#ifndef M355_GLDS_SMALL_NST
+#define M355_GLDS_SMALL_NST 4
+#endif
+template <int BM, int BN, int NW, int WGN, bool FAST, int MODE, int NST = 2>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void k_conv_glds(ConvArgs a, unsigned xbytes, unsigned wbytes)
 {
     // NW waves arranged (NW / WGN) x WGN over the BM x BN tile; each wave owns a WTM x WTN sub-tile
@@ -174,7 +187,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void k_conv_glds(ConvArgs
     constexpr int RA = BM / (8 * NW), RB = BN / (8 * NW);  // DMA instructions per wave per stage
     constexpr int STAGE = (BM + BN) * 128;
     static_assert(WTM % 32 == 0 && WTN % 32 == 0 && RA >= 1 && RB >= 1 && NW % 2 == 0, "tile shape");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -276,11 +289,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void k_conv_glds(ConvArgs
     const unsigned char *fa = lds + (wm * WTM + (lane & 31)) * 128;             // pixel rows of this wave
     const unsigned char *fb = lds + BM * 128 + (wn * WTN + (lane & 31)) * 128;  // weight rows of this wave
 
-    stage(0, 0);
-    __syncthreads();  // (the barrier's fence drains the DMA: vmcnt(0))
-    for (int t = 0; t < nsteps; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nsteps) stage(t + 1, buf ^ 1);
+    auto step_mma = [&](int buf) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int co16 = ((kk * 2 + half) ^ swz) << 4;
@@ -295,7 +304,36 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void k_conv_glds(ConvArgs
                 for (int i = 0; i < PI; ++i)
                     acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], pf[i], acc[j][i], 0, 0, 0);
         }
-        __syncthreads();
+    };
+    if constexpr (NST > 2) {
+        static_assert(NST == 4, "counted waits are written out for four stages");
+        constexpr int PER = RA + RB;   // DMAs one wave issues per step
+#pragma unroll
+        for (int s = 0; s < NST - 1; ++s)
+            if (s < nsteps) stage(s, s);
+        int buf = 0, nbuf = NST - 1;   // buffer of step t / the one step t + NST - 1 goes to (= that of step t - 1)
+        for (int t = 0; t < nsteps; ++t) {
+            // step t's DMAs were issued NST-1 steps ago; those of the (up to) NST-2 following steps may stay in flight.
+            // The barrier: every wave's part of step t has landed, and every wave is done reading the buffer refilled next
+            const int younger = nsteps - 1 - t;
+            if (younger >= 2) glds_wait<2 * PER>();
+            else if (younger == 1) glds_wait<PER>();
+            else glds_wait<0>();
+            __builtin_amdgcn_s_barrier();
+            if (t + NST - 1 < nsteps) stage(t + NST - 1, nbuf);
+            step_mma(buf);
+            buf = buf == NST - 1 ? 0 : buf + 1;
+            nbuf = nbuf == NST - 1 ? 0 : nbuf + 1;
+        }
+    } else {
+        stage(0, 0);
+        __syncthreads();  // (the barrier's fence drains the DMA: vmcnt(0))
+        for (int t = 0; t < nsteps; ++t) {
+            const int buf = t & 1;
+            if (t + 1 < nsteps) stage(t + 1, buf ^ 1);
+            step_mma(buf);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue.  acc[j][i][r]: channel n0 + wn*WTN + 32j + 8*(r>>2) + 4*half + (r&3), pixel m0 + wm*WTM + 32i + (lane&31)
@@ -524,7 +562,7 @@ static int launch_conv(ConvArgs a, hipStream_t st)
             if (!(h && h[0] == '0') && conv_halo_eligible(a)) return conv_halo_launch(a, xb, wb, st);
         }
 #define M355_GO(BM_, BN_, NW_, WGN_, F_, MD_) \
-    hipLaunchKernelGGL((k_conv_glds<BM_, BN_, NW_, WGN_, F_, MD_>), grid, dim3(NW_ * 64), 0, st, a, xb, wb)
+    hipLaunchKernelGGL((k_conv_glds<BM_, BN_, NW_, WGN_, F_, MD_, (BM_ == 64 ? M355_GLDS_SMALL_NST : 2)>), grid, dim3(NW_ * 64), 0, st, a, xb, wb)
 #define M355_MODES(BM_, BN_, NW_, WGN_, F_)                                   \
     do {                                                                      \
         if (a.pad_w_mode == 0) M355_GO(BM_, BN_, NW_, WGN_, F_, 0);           \
