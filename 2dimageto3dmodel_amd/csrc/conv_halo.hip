@@ -345,6 +345,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
     float st_tot[CJ];
 #pragma unroll
     for (int j = 0; j < CJ; ++j) st_tot[j] = 0.0f;
+    // 4 waves (one per SIMD: every epilogue VALU op is exposed, but half of the 512 registers are free): per tile only the
+    // in-lane part -- this lane's pixels added to 64 running values -- and ONE pass through the lane network at the end
+    constexpr bool ST_REG = STATS && NW == 4;
+    float st_v[ST_REG ? CJ : 1][32];
+    if (ST_REG) {
+#pragma unroll
+        for (int j = 0; j < CJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 32; ++r) st_v[ST_REG ? j : 0][r] = 0.0f;
+    }
     if (STATS && ST_LDS && st_ptr) {
 #pragma unroll
         for (int j = 0; j < CJ; ++j) st_lds[(wave * CJ + j) * 64 + lane] = 0.0f;   // (only ever touched by this lane)
@@ -670,16 +680,25 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
             // issued behind the tile's stores
 #pragma unroll
             for (int j = 0; j < CJ; ++j) {
-                float v[32];
+                if constexpr (ST_REG) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float y0 = acc[j][0][r], y1 = acc[j][1][r];
-                    v[r] = y0 + y1;
-                    v[16 + r] = fmaf(y1, y1, y0 * y0);
+                    for (int r = 0; r < 16; ++r) {
+                        const float y0 = acc[j][0][r], y1 = acc[j][1][r];
+                        st_v[j][r] += y0 + y1;
+                        st_v[j][16 + r] = fmaf(y1, y1, fmaf(y0, y0, st_v[j][16 + r]));
+                    }
+                } else {
+                    float v[32];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float y0 = acc[j][0][r], y1 = acc[j][1][r];
+                        v[r] = y0 + y1;
+                        v[16 + r] = fmaf(y1, y1, y0 * y0);
+                    }
+                    const float t = lane_reduce32(v, (lane & 2) != 0, (lane & 1) != 0);
+                    if (ST_LDS) st_lds[(wave * CJ + j) * 64 + lane] += t;
+                    else st_tot[j] += t;
                 }
-                const float t = lane_reduce32(v, (lane & 2) != 0, (lane & 1) != 0);
-                if (ST_LDS) st_lds[(wave * CJ + j) * 64 + lane] += t;
-                else st_tot[j] += t;
             }
         }
         if (!has_next) break;
@@ -693,6 +712,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
         // stats[bp][0 = sum, 1 = sum of squares][Cout] -- the layout m355_bn_finalize reduces
         __syncthreads();   // (every wave is past its last fragment read)
         float *red = ST_LDS ? st_lds : reinterpret_cast<float *>(lds);
+        if constexpr (ST_REG) {
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) st_tot[j] = lane_reduce32(st_v[j], (lane & 2) != 0, (lane & 1) != 0);
+        }
         if (!ST_LDS) {
 #pragma unroll
             for (int j = 0; j < CJ; ++j) red[(wave * CJ + j) * 64 + lane] = st_tot[j];
