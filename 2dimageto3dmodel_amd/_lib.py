@@ -65,7 +65,7 @@ SIGNATURES = {
     "m355_weight_prep_fill_entry": (ctypes.c_longlong, [_P, _P, c_int, _P, _P, _P, _P]),
     "m355_weight_prep_batched": (c_int, [_P, c_int, ctypes.c_longlong, _P]),
     "m355_cproj_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
-    "m355_cproj_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "m355_cproj_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "m355_conv2d_maskbits_ok": (c_int, [_P, c_int]),
     "m355_conv2d_dgrad_mask_ok": (c_int, [_P]),
     "m355_conv2d_fwd_bits": (c_int, [_P, _P, _P, _P, _P, c_float, _P, _P]),

@@ -343,10 +343,13 @@ __global__ __launch_bounds__(256) void k_cproj_fwd(const short *__restrict__ fea
     if (lane == 0) o[(size_t)n * HW + p] = acc;
 }
 
-// backward: dfeat[n,p,c] = g[n,p] * emb[n,c] (bf16), demb[n,c] += sum_p g[n,p] * feat[n,p,c]   (demb zeroed by the caller)
+// backward: dfeat[n,p,c] = g[n,p] * emb[n,c] (bf16), demb[n,c] += sum_p g[n,p] * feat[n,p,c]   (demb zeroed by the caller).
+// mask_slope != 1: feat is the output of a fused conv + LeakyReLU(mask_slope) whose backward is applied HERE (dfeat *= feat > 0
+// ? 1 : mask_slope) -- masking is linear, so when every consumer of that activation masks its own branch of the gradient the
+// producer needs no activation-backward pass over the summed gradient (TextureDiscriminator.conv4 -> conv5 + projection)
 __global__ __launch_bounds__(256) void k_cproj_bwd(const short *__restrict__ feat, const float *__restrict__ emb,
                                                    const float *__restrict__ g, short *__restrict__ dfeat, float *__restrict__ demb,
-                                                   int HW, int C, int ppb)
+                                                   int HW, int C, int ppb, float mask_slope)
 {
     __shared__ float red[256 * 8];
     const int n = blockIdx.y, tid = threadIdx.x;
@@ -366,8 +369,9 @@ __global__ __launch_bounds__(256) void k_cproj_bwd(const short *__restrict__ fea
             float d[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                d[j] = gp * ev[j];
-                acc[j] += gp * bf2f_e(x[j]);
+                const float xv = bf2f_e(x[j]);
+                d[j] = gp * ev[j] * (xv > 0.0f ? 1.0f : mask_slope);
+                acc[j] += gp * xv;
             }
             *reinterpret_cast<bf16x8e *>(dfeat + off) = pack8_e(d);
         }
@@ -534,7 +538,7 @@ extern "C" int m355_cproj_fwd(const void *feat, const float *emb, float *out /*[
 }
 
 extern "C" int m355_cproj_bwd(const void *feat, const float *emb, const float *g /*[N,HW]*/, void *dfeat, float *demb /*[N,C]*/,
-                              int N, int HW, int C, void *stream)
+                              int N, int HW, int C, float mask_slope, void *stream)
 {
     M355_REQUIRE(feat && emb && g && dfeat && demb && N > 0 && HW > 0 && N <= 65535, "cproj_bwd: bad argument");
     if (int rc = check_c(C, "cproj_bwd")) return rc;
@@ -545,6 +549,6 @@ extern "C" int m355_cproj_bwd(const void *feat, const float *emb, const float *g
     }
     const int ppb = pix_per_block((size_t)HW, C);
     hipLaunchKernelGGL(k_cproj_bwd, dim3((HW + ppb - 1) / ppb, N), dim3(256), 0, st, (const short *)feat, emb, g, (short *)dfeat, demb,
-                       HW, C, ppb);
+                       HW, C, ppb, mask_slope);
     return check_launch("cproj_bwd");
 }

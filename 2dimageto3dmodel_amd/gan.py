@@ -346,14 +346,37 @@ class _DiscBase(nn.Module):
         y = G.to_nchw_f32(conv(x))
         return G.to_nhwc_bf16(F.leaky_relu(norm(y), LRELU))
 
-    def _project(self, y, feat, c, caption):
+    def _tail(self, conv_feat, norm_feat, conv_out, h, in_act, c, caption):
+        """last feature conv -> LeakyReLU -> (logit conv, projection term).  The activation has two consumers, so its
+        backward cannot ride on ONE consumer's dgrad -- but masking is linear: when BOTH consumers mask their own branch of the
+        gradient (the logit conv's dgrad via mask_x, the projection kernel via mask_slope), the feature conv is `premasked`
+        and the separate activation-backward pass over the summed gradient (134 MB at batch 128) disappears."""
+        a = self.args
+        pm = False
+        if (norm_feat is None and h.is_cuda and conv_feat.m355[3] != C.PAD_REPLICATE and not a.conditional_text
+                and torch.is_grad_enabled()):
+            cf = conv_feat.out_channels
+            st, ph, pw, _ = conv_feat.m355
+            kh, kw = conv_feat.kernel_size
+            hf, wf = (h.shape[1] + 2 * ph - kh) // st + 1, (h.shape[2] + 2 * pw - kw) // st + 1
+            so, pho, pwo, mo = conv_out.m355
+            d = C.make_desc(h.shape[0], hf, wf, cf, conv_out.out_channels, conv_out.kernel_size[0], conv_out.kernel_size[1], so,
+                            pho, pwo, mo, 0)
+            proj_ok = (not a.conditional_class) or (self.projector.weight.dtype == torch.float32 and cf % 8 == 0 and cf <= 2048
+                                                     and 256 % (cf // 8) == 0)
+            pm = bool(proj_ok and C.dgrad_mask_ok(d))
+        h = self._act(conv_feat, norm_feat, h, in_act, pm)
+        y = conv_out(h, out_f32_nchw=True, in_slope=LRELU if pm else 1.0)
+        return self._project(y, h, c, caption, LRELU if pm else 1.0)
+
+    def _project(self, y, feat, c, caption, in_slope=1.0):
         """projection discriminator (gan.py:104-116, 216-228): y += sum_c feat * emb"""
         a = self.args
         if a.conditional_class:
             c_emb = self.projector(c[:, 0])
             if a.conditional_color:
                 c_emb = c_emb + self.projector_col1(c[:, 1])
-            y = y + G.class_projection(feat, c_emb).unsqueeze(1)
+            y = y + G.class_projection(feat, c_emb, in_slope).unsqueeze(1)
         elif a.conditional_text:
             att_out, _ = self.att(G.to_nchw_f32(feat), *caption)
             y = y + torch.sum(G.to_nchw_f32(feat) * att_out, dim=1, keepdim=True)
@@ -421,9 +444,7 @@ class MeshDiscriminator(_DiscBase):
         n2, n3 = getattr(self, "bn2", None), getattr(self, "bn3", None)
         h = self._act(self.conv1, None, h, False, n2 is None)
         h = self._act(self.conv2, n2, h, True, n3 is None)
-        h = self._act(self.conv3, n3, h, n2 is None and True, False)
-        y = self.conv4(h, out_f32_nchw=True)
-        return self._project(y, h, c, caption), mask
+        return self._tail(self.conv3, n3, self.conv4, h, n2 is None, c, caption), mask
 
 
 class TextureDiscriminator(_DiscBase):
@@ -494,9 +515,7 @@ class TextureDiscriminator(_DiscBase):
         h = self._act(self.conv1, None, h, False, n2 is None)
         h = self._act(self.conv2, n2, h, True, n3 is None)
         h = self._act(self.conv3, n3, h, n2 is None, n4 is None)
-        h = self._act(self.conv4, n4, h, n3 is None, False)
-        y = self.conv5(h, out_f32_nchw=True)
-        return self._project(y, h, c, caption), mask
+        return self._tail(self.conv4, n4, self.conv5, h, n3 is None, c, caption), mask
 
 
 class MultiScaleDiscriminator(nn.Module):

@@ -707,12 +707,13 @@ class ClassProjection(torch.autograd.Function):
     = sum_c feat * emb, on the bf16 feature map (csrc/gan_elem.hip k_cproj_*)"""
 
     @staticmethod
-    def forward(ctx, feat, emb):
+    def forward(ctx, feat, emb, in_slope=1.0):
         feat, emb = feat.detach().contiguous(), emb.detach().float().contiguous()
         n, h, w, c = feat.shape
         out = torch.empty((n, h, w), dtype=torch.float32, device=feat.device)
         launch("cproj_fwd", ptr(feat), ptr(emb), ptr(out), n, h * w, c, stream())
         ctx.save_for_backward(feat, emb)
+        ctx.in_slope = float(in_slope)
         return out
 
     @staticmethod
@@ -721,14 +722,22 @@ class ClassProjection(torch.autograd.Function):
         n, h, w, c = feat.shape
         dfeat = torch.empty_like(feat)
         demb = torch.empty((n, c), dtype=torch.float32, device=feat.device)
-        launch("cproj_bwd", ptr(feat), ptr(emb), ptr(g.contiguous().float()), ptr(dfeat), ptr(demb), n, h * w, c, stream())
-        return dfeat, demb
+        launch("cproj_bwd", ptr(feat), ptr(emb), ptr(g.contiguous().float()), ptr(dfeat), ptr(demb), n, h * w, c, ctx.in_slope,
+               stream())
+        return dfeat, demb, None
 
 
-def class_projection(feat, emb):
-    """sum_c feat[n,h,w,c] * emb[n,c] -> [N,H,W] fp32"""
-    if _fused_ok(feat) and emb.dtype == torch.float32:
-        return ClassProjection.apply(feat, emb)
+def class_projection_fused(feat, emb):
+    return _fused_ok(feat) and emb.dtype == torch.float32
+
+
+def class_projection(feat, emb, in_slope=1.0):
+    """sum_c feat[n,h,w,c] * emb[n,c] -> [N,H,W] fp32.  in_slope != 1 (only where class_projection_fused): feat is a fused
+    conv + LeakyReLU(in_slope) output whose producer was called with premasked=True -- the returned grad_feat is multiplied by
+    that activation's derivative (every consumer of feat must do the same)"""
+    if class_projection_fused(feat, emb):
+        return ClassProjection.apply(feat, emb, float(in_slope))
+    assert in_slope == 1.0
     return torch.einsum("nhwc,nc->nhw", feat.float(), emb)
 
 

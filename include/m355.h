@@ -362,10 +362,12 @@ int m355_dibr_shade_bwd(const float *uvm_bxhxwx3, const float *texture_bx3xthxtw
                         int B, int H, int W, int TH, int TW, void *stream);
 
 /* Projection discriminator (code/models/gan.py:104-116, 216-228): out[n,p] = sum_c feat[n,p,c] * emb[n,c] on the NHWC bf16
- * feature map (C a power of two in 8..2048); backward: dfeat = g * emb (bf16, overwritten), demb[n,c] = sum_p g * feat. */
+ * feature map (C a power of two in 8..2048); backward: dfeat = g * emb (bf16, overwritten), demb[n,c] = sum_p g * feat.
+ * mask_slope != 1: feat is a fused conv + LeakyReLU(mask_slope) output and dfeat is multiplied by that activation's derivative
+ * (feat > 0 ? 1 : mask_slope), as m355_conv2d_dgrad does with mask_x for the other consumer of the same tensor. */
 int m355_cproj_fwd(const void *feat, const float *emb, float *out /*[N,HW]*/, int N, int HW, int C, void *stream);
 int m355_cproj_bwd(const void *feat, const float *emb, const float *g /*[N,HW]*/, void *dfeat, float *demb /*[N,C]*/,
-                   int N, int HW, int C, void *stream);
+                   int N, int HW, int C, float mask_slope, void *stream);
 
 /* ---- mesh-template deformation, face normals, flat (smoothness) loss -- code/main.py:697-699 ----
  * Replaces MeshTemplate.get_vertex_positions / deform / compute_normals (code/rendering/mesh_template.py:106-149) and
