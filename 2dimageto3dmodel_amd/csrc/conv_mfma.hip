@@ -914,6 +914,18 @@ static int conv_dgrad_impl(const m355_conv_desc *d, const void *dy, const void *
     }
     if (!probe && direct && !mask_x && !mask_bits && m355::dgrad_small_eligible(d, cout32) && !getenv("M355_NO_C8"))
         return m355::dgrad_small_launch(d, dy, cout32, w_dgrad, a.Kp, (size_t)cin64 * a.Kp * 2, dx, st);
+    // 5x5 "same" convs with <= 8 output channels and a zero / circular W pad (TextureDiscriminator.conv5): the gradient is a
+    // conv of the 8-channel dy onto Cin channels with the same pad mode -- k_conv_c8, with the activation backward of the
+    // producer of x (mask_x) in its epilogue (k_conv_glds pads the 1..8 channels of dy to a 64-wide K step)
+    if (!probe && direct && d->stride == 1 && !mask_bits && d->pad_w_mode != 1 && cout32 == 8 && d->kh == 5 && d->kw == 5 &&
+        d->pad_h == 2 && d->pad_w == 2 && !d->upsample && !getenv("M355_NO_C8_DGRAD")) {
+        m355_conv_desc t = *d;
+        t.Cin = 8;
+        t.Cout = d->Cin;
+        if (m355::conv_c8_eligible(&t, 0))
+            return m355::conv_c8_launch(&t, dy, w_dgrad, nullptr, dx, 1.0f, a.Kp, (size_t)cin64 * a.Kp * 2, nullptr, st, mask_x,
+                                        mask_slope);
+    }
     if (direct && d->stride == 1) {
         a.w = (const unsigned short *)w_dgrad;
         a.KH = d->kh; a.KW = d->kw;
