@@ -165,6 +165,10 @@ def launch(name, *args, work=0.0, tag=None):
     """call m355_<name>(*args), raise on a non-zero status; optionally bracket it with HIP events"""
     fn = getattr(lib(), "m355_" + name)
     if _TIMERS_ON:
+        if callable(work):   # (callers pass thunks: a launch costs no ctypes round trip / string formatting for a timer that is off)
+            work = work()
+        if callable(tag):
+            tag = tag()
         if TIMER_TAGS and tag:
             name_t = name + " " + tag
         else:

@@ -20,15 +20,25 @@ def make_desc(N, H, W, Cin, Cout, kh, kw, stride=1, pad_h=0, pad_w=0, pad_w_mode
     return ConvDesc(N, H, W, Cin, Cout, kh, kw, stride, pad_h, pad_w, pad_w_mode, upsample)
 
 
+_OUT_HW, _DY_CH = {}, {}   # pure geometry (no environment switches behind them): memoised, the hot loop calls them per launch
+
+
 def out_hw(d):
-    ho, wo = ctypes.c_int(), ctypes.c_int()
-    check(lib().m355_conv2d_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), "conv2d_out_hw")
-    return ho.value, wo.value
+    key = bytes(d)
+    r = _OUT_HW.get(key)
+    if r is None:
+        ho, wo = ctypes.c_int(), ctypes.c_int()
+        check(lib().m355_conv2d_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), "conv2d_out_hw")
+        r = _OUT_HW[key] = (ho.value, wo.value)
+    return r
 
 
 def dy_channels(cout):
     """channel stride the backward entry points expect of dy (8 for the 1..8-channel heads, else ceil32)"""
-    return lib().m355_conv2d_dy_channels(int(cout))
+    r = _DY_CH.get(cout)
+    if r is None:
+        r = _DY_CH[cout] = lib().m355_conv2d_dy_channels(int(cout))
+    return r
 
 
 def flops(d, cin_real=None):
@@ -87,10 +97,10 @@ def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0, cin_real=Non
         assert not out_f32_nchw
         bits = torch.empty((d.N, ho, wo, d.Cout // 64, 2), dtype=torch.int32, device=x.device)
         launch("conv2d_fwd_bits", ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(b), ptr(y), float(slope), ptr(bits), stream(),
-               work=flops(d, cin_real), tag=tag(d))
+               work=lambda: flops(d, cin_real), tag=lambda: tag(d))
         return y, bits
     launch("conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(b), ptr(y), int(out_f32_nchw), float(slope), stream(),
-           work=flops(d, cin_real), tag=tag(d))
+           work=lambda: flops(d, cin_real), tag=lambda: tag(d))
     return y
 
 
@@ -110,7 +120,7 @@ def conv_fwd_stats(d, x, w_fwd, bias=None, cin_real=None, rows=None):
     part = torch.empty((rows, 2, d.Cout), dtype=torch.float32, device=x.device)
     b = None if bias is None else _req(bias.detach(), torch.float32, "bias")
     launch("conv2d_fwd_stats", ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(b), ptr(y), ptr(part), stream(),
-           work=flops(d, cin_real), tag=tag(d))
+           work=lambda: flops(d, cin_real), tag=lambda: tag(d))
     return y, part
 
 
@@ -127,10 +137,10 @@ def conv_dgrad(d, dy, w_dgrad, cin_real=None, mask_x=None, mask_slope=1.0, mask_
     if mask_bits is not None:
         assert tuple(mask_bits.shape) == (d.N, d.H, d.W, d.Cin // 64, 2), (tuple(mask_bits.shape), d.Cin)
         launch("conv2d_dgrad_bits", ctypes.byref(d), ptr(dy), ptr(w_dgrad), ptr(dx), ptr(ws), ptr(mask_bits), float(mask_slope),
-               stream(), work=flops(d, cin_real), tag=tag(d))
+               stream(), work=lambda: flops(d, cin_real), tag=lambda: tag(d))
         return dx
     launch("conv2d_dgrad", ctypes.byref(d), ptr(dy), ptr(w_dgrad), ptr(dx), ptr(ws), ptr(mask_x), float(mask_slope), stream(),
-           work=flops(d, cin_real), tag=tag(d))
+           work=lambda: flops(d, cin_real), tag=lambda: tag(d))
     return dx
 
 
@@ -179,10 +189,10 @@ def conv_wgrad(d, x, dy, cin_real=None, raw=False, dbias=None, arena=False):
         dw = sl[:n].view(d.Cout, d.kh, d.kw, d.Cin)
         if dbias is not None:   # returned to autograd as the bias gradient: never an arena slice
             dbias.zero_()
-        launch("conv2d_wgrad_acc", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), stream(), work=flops(d, cin_real), tag=tag(d))
+        launch("conv2d_wgrad_acc", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), stream(), work=lambda: flops(d, cin_real), tag=lambda: tag(d))
         return dw
     dw = torch.empty((d.Cout, d.kh, d.kw, d.Cin), dtype=torch.float32, device=x.device)
-    launch("conv2d_wgrad", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), stream(), work=flops(d, cin_real), tag=tag(d))
+    launch("conv2d_wgrad", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), stream(), work=lambda: flops(d, cin_real), tag=lambda: tag(d))
     return dw if raw else dw.permute(0, 3, 1, 2)
 
 
