@@ -194,7 +194,19 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def stream():
-    import torch
+_RAW_STREAM = None
 
-    return torch.cuda.current_stream().cuda_stream
+
+def stream():
+    """the current HIP stream as an integer handle.  torch.cuda.current_stream() builds a Stream object through several Python
+    layers (9 us per call, 2 ms per GAN cycle -- as much as the host can spare at small batch); the raw accessor is a C call"""
+    global _RAW_STREAM
+    if _RAW_STREAM is None:
+        import torch
+
+        raw, dev = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
+        if raw is not None and dev is not None:
+            _RAW_STREAM = lambda: raw(dev())
+        else:
+            _RAW_STREAM = lambda: torch.cuda.current_stream().cuda_stream
+    return _RAW_STREAM()
