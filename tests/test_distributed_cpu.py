@@ -133,3 +133,34 @@ def test_bench_rejects_world_size_mismatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True, timeout=200,
                        env=env, cwd=ROOT)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_wgrad_arena_bookkeeping_cpu(pkg):
+    """conv.WgradArena (host logic, no kernel): outside a backward pass there is no arena; inside, the first pass only learns
+    its size, later passes hand out disjoint, zeroed, 64-element-aligned slices of one buffer that is zero-filled once per pass"""
+    import importlib
+    import torch
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    dev = torch.device("cpu")
+    conv.WgradArena._state.pop(dev, None)
+    assert conv.WgradArena.take(100, dev) is None   # not inside autograd's backward
+    seen = []
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            a, b = conv.WgradArena.take(100, dev), conv.WgradArena.take(1000, dev)
+            if a is not None:
+                assert a.numel() == 128 and b.numel() == 1024 and float(a.abs().sum()) == 0 and float(b.abs().sum()) == 0
+                assert a.data_ptr() + 4 * 128 <= b.data_ptr() or b.data_ptr() + 4 * 1024 <= a.data_ptr()
+                a.fill_(1.0); b.fill_(2.0)   # the next pass must find zeros again
+            seen.append(None if a is None else (a.data_ptr(), b.data_ptr()))
+            return g
+
+    for _ in range(3):
+        Probe.apply(torch.zeros(1, requires_grad=True)).sum().backward()
+    assert seen[0] is None and seen[1] is not None and seen[1] == seen[2], seen
