@@ -65,6 +65,12 @@ __device__ __forceinline__ void wait_vm()
 #ifndef M355_HALO_RB8
 #define M355_HALO_RB8 3
 #endif
+// weight slots of the 8-wave 2x2 variants.  Their LDS has room for a fourth (weights three steps ahead instead of two): measured
+// same-box, D.conv3 / conv4 forward 497 / 450 -> 496 / 450 us, all k_conv_halo launches of a cycle 10.41 -> 10.36 ms: the waits of
+// these kernels are not weight-DMA latency.  Left at three.
+#ifndef M355_HALO_RB8_K2
+#define M355_HALO_RB8_K2 3
+#endif
 #ifndef M355_NO_EPI_CREDIT
 #define M355_NO_EPI_CREDIT 0
 #endif
@@ -159,7 +165,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
     // the bytes DMA'd into LDS per flop, and the weights were half of them or more.  No weight DMAs in the loop, and one
     // barrier per channel chunk (the one that publishes the next halo) instead of one per tap.
     static_assert(!RES || (BN == 64 && NW == 4 && SUB == 1 && !UPS), "resident weights: 4-wave variant only");
-    constexpr int RB = RES ? (KS == 2 ? 8 : 9) : (TG2 ? 4 : (NW == 4 ? M355_HALO_RB4 : M355_HALO_RB8));  // weight slots (ring / panel)
+    constexpr int RB = RES ? (KS == 2 ? 8 : 9)
+                           : (TG2 ? 4 : (NW == 4 ? M355_HALO_RB4 : (KS == 2 ? M355_HALO_RB8_K2 : M355_HALO_RB8)));  // weight slots (ring / panel)
     // software pipeline (one wave per SIMD has no partner wave to hide its LDS-read latency): fragments of step s+1 are
     // read during step s.  The 8-wave variant (2 waves per SIMD, 256 registers each) does the same for the 2x2 class
     // convs (+3-5 %); with 9 taps unrolled it would spill ~30 registers (-5 %), so 3x3 reads them in the step itself.
