@@ -96,6 +96,7 @@ SIGNATURES = {
     "m355_unpack_nhwc8": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "m355_chan_reduce_nblk": (c_int, [c_size_t, c_int]),
     "m355_bn_stats_partial": (c_int, [_P, _P, c_size_t, c_int, _P]),
+    "m355_bn_sync_pack": (c_int, [_P, c_int, c_int, c_float, _P, _P]),
     "m355_affine_act_bwd_partial": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "m355_sn_power_iter": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_float, _P]),
     "m355_sn_wgrad_finish": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -263,6 +263,25 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float *__restrict__ 
     }
 }
 
+// vec[0 .. C2) = column sums of part[nblk][C2], vec[C2] = count (the forward message of SyncBN: m355_bn_sync_pack)
+__global__ __launch_bounds__(256) void k_bn_sync_pack(const float *__restrict__ part, int nblk, int C2, float count,
+                                                      float *__restrict__ vec)
+{
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < C2)
+        for (int k = rl; k < nblk; k += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k + 4 * u < nblk) a4[u] += part[(size_t)(k + 4 * u) * C2 + c];
+        }
+    red[rl][cl] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    __syncthreads();
+    if (rl == 0 && c < C2) vec[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) vec[C2] = count;
+}
+
 // backward: part[N][nblk][2][C] = per-workgroup (sum dz, sum dz*x)  ->
 //   dgamma[n,c] = rstd (s2 - mean s1),  dbeta[n,c] = s1,  A[n,c] = rstd (1+gamma),
 //   m1 = sum_n (1+gamma) s1 / count,  m2 = sum_n (1+gamma) dgamma / count,
@@ -390,6 +409,15 @@ extern "C" int m355_bn_bwd_finalize(const float *part, int nblk, float count, co
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, nblk, count, gamma,
                        gstride, N, C, mean, rstd, batch_stats, dgamma, dbeta, A, Bc, Cc, m_out);
     return check_launch("bn_bwd_finalize");
+}
+
+/* SyncBN: the message of the forward all-reduce, vec[2C + 1] = [ sum over the partial rows of (sum x | sum x^2) | pixel count ],
+ * in one launch (was a row reduction and a fill) */
+extern "C" int m355_bn_sync_pack(const float *part, int nblk, int C, float count, float *vec, void *stream)
+{
+    M355_REQUIRE(part && vec && nblk > 0 && C > 0, "bn_sync_pack: bad argument");
+    hipLaunchKernelGGL(k_bn_sync_pack, dim3((2 * C + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, nblk, 2 * C, count, vec);
+    return check_launch("bn_sync_pack");
 }
 
 extern "C" int m355_bn_bwd_coeffs(const float *m, float count, const float *count_dev, const float *mean, const float *rstd,

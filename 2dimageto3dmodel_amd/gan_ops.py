@@ -639,8 +639,7 @@ class CbnActFn(torch.autograd.Function):
             # one all-reduce of [sum | sumsq | count]: the global pixel count comes back with the sums and stays on the
             # device (ragged shards are handled like the reference's _data_parallel_master, no host round trip)
             vec = torch.empty(2 * c + 1, dtype=torch.float32, device=dev)
-            torch.sum(part.view(nblk, 2 * c), dim=0, out=vec[:2 * c])
-            vec[2 * c:].fill_(count)
+            launch("bn_sync_pack", ptr(part), nblk, c, count, ptr(vec), stream())
             dist.all_reduce(vec, op=dist.ReduceOp.SUM)
             _count_syncbn()
             part, nblk, cnt_dev = vec, 1, vec[2 * c:]

@@ -243,6 +243,9 @@ int m355_lrelu_bwd(const void *dy, const void *y, void *g, float *dbias, void *w
  *      part[m355_chan_reduce_nblk(P, C)][2][C] resp. part[N][m355_chan_reduce_nblk(HW, C)][2][C] */
 int m355_chan_reduce_nblk(size_t pixels_per_group, int C);
 int m355_bn_stats_partial(const void *x, float *part, size_t P, int C, void *stream);
+/*      SynchronizedBatchNorm2d (code/sync_batchnorm/batchnorm.py:110-131 sends (sum, ssum, size) to the master): the message of
+ *      the one all-reduce that replaces it, vec[2C + 1] = [ column sums of part[nblk][2][C] | pixel count ] */
+int m355_bn_sync_pack(const float *part, int nblk, int C, float count, float *vec, void *stream);
 int m355_affine_act_bwd_partial(const void *dy, const void *x, const float *a, const float *b, float *part, int N, int HW,
                                 int C, float slope, void *stream);
 
