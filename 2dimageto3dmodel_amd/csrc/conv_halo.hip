@@ -350,6 +350,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
     float *const st_ptr = STATS ? a.stats : nullptr;
     __shared__ float st_lds[(ST_LDS && STATS) ? NW * CJ * 64 : 1];
     float st_tot[CJ];
+#ifdef M355_DBG_STAMP
+    // debug build only (scripts/stamp_halo.py): shader-clock stamps of the main loop's phases, per wave and step, of workgroup (0,0)
+    constexpr int DBG_STEPS = 96;
+    __shared__ unsigned dbg_lds[8 * DBG_STEPS * 4];
+    unsigned dbg_i = 0, dbg_t0 = 0, dbg_t1 = 0, dbg_t2 = 0, dbg_t3 = 0, dbg_n0 = 0;
+    const bool dbg_on = NW == 8 && !STATS && a.stats != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
+#endif
 #pragma unroll
     for (int j = 0; j < CJ; ++j) st_tot[j] = 0.0f;
     // 4 waves (one per SIMD: every epilogue VALU op is exposed, but half of the 512 registers are free): per tile only the
@@ -482,6 +489,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                 static_assert(TL <= T - 3 && RB >= 2, "halo slices must be out by tap T-3");
                 constexpr int cnt_a = (T - 1 - L - TL) * NBW;
                 constexpr int cnt = (tap == (T - L) % T && cnt_a < cnt_b) ? cnt_a : cnt_b;
+#ifdef M355_DBG_STAMP
+                if (dbg_on) dbg_n0 = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
                 if (RES) {
                     // only the halo is in flight: the step that first touches the next chunk's halo drains this wave's
                     // DMAs and meets the others (which also retires every read of the buffer refilled next)
@@ -523,6 +533,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                     }
                     __builtin_amdgcn_s_barrier();      // ... the same holds for every wave
                 }
+#ifdef M355_DBG_STAMP
+                if (dbg_on) {
+                    if (dbg_i > 0 && dbg_i <= DBG_STEPS) {
+                        unsigned *q = dbg_lds + (wave * DBG_STEPS + (dbg_i - 1)) * 4;
+                        q[0] = dbg_t0; q[1] = dbg_t1; q[2] = dbg_t2; q[3] = dbg_t3;
+                    }
+                    ++dbg_i;
+                    dbg_t0 = dbg_n0;
+                    dbg_t1 = (unsigned)__builtin_amdgcn_s_memtime();
+                }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 const int slot_n = slot == nslot - 1 ? 0 : slot + 1;
                 const int slot_p = slot == 0 ? nslot - 1 : slot - 1;
@@ -559,6 +580,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                 }
                 issue_A(hb ^ 1, chunk_next, tapc);  // taps T-2, T-1 issue none
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef M355_DBG_STAMP
+                if (dbg_on) dbg_t2 = (unsigned)__builtin_amdgcn_s_memtime();
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 if (tap == T - 2 && replan) compute_aoff(tg, K0{}, KH{});  // (VALU work in the MFMA shadow below)
                 if (tap == T - 1 && replan) compute_aoff(tg, KH{}, KN{});
 #ifndef M355_DBG_NO_MMA
@@ -576,6 +601,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                     }
                     cur = nxt;
                 }
+#endif
+#ifdef M355_DBG_STAMP
+                __builtin_amdgcn_sched_barrier(0);
+                if (dbg_on) dbg_t3 = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
                 slot = slot_n;
             });
@@ -714,6 +743,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
         fresh = RES ? 0 : (TG2 ? 1 : RB - 1 + L);
     }
     wait_vm<0>();  // the trailing (unused) prefetches
+#ifdef M355_DBG_STAMP
+    if (dbg_on) {
+        __syncthreads();
+        unsigned *out = reinterpret_cast<unsigned *>(a.stats);
+        for (int k = tid; k < 8 * DBG_STEPS * 4; k += NW * 64) out[k] = dbg_lds[k];
+    }
+#endif
     if (STATS && st_ptr) {
         // the four wave rows of the workgroup hold the same channels: one row of partial sums per workgroup,
         // stats[bp][0 = sum, 1 = sum of squares][Cout] -- the layout m355_bn_finalize reduces
@@ -1095,8 +1131,15 @@ int conv_halo_stats_rows(const ConvArgs &a)
     return halo_grid_per(b);
 }
 
-int conv_halo_launch(const ConvArgs &a, unsigned xb, unsigned wb, hipStream_t st)
+int conv_halo_launch(const ConvArgs &a_in, unsigned xb, unsigned wb, hipStream_t st)
 {
+    ConvArgs a = a_in;
+#ifdef M355_DBG_STAMP
+    if (!a.stats && (a.KH == 2 || a.stride == 2)) {   // (KS 3 selects its instantiation by a.stats)
+        const char *sp = getenv("M355_STAMP_PTR");
+        if (sp) a.stats = reinterpret_cast<float *>(strtoull(sp, nullptr, 0));
+    }
+#endif
     const int tiles = a.N * (a.Ho / 8) * (a.Wo / 32);
     const int nN = a.CoutP == 64 ? 1 : a.CoutP / 128;
     const char *wgs = getenv("M355_HALO_WGS");

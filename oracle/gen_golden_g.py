@@ -262,6 +262,10 @@ def run_train4(ref_gan, GANLoss, name="g_train4", seed=4401, B=2, iters=4, epoch
                 rec[f"it{it}:avg:{k}"] = (ap[k].detach() - w0[k]).numpy()
             for k in track_d:
                 rec[f"it{it}:D:{k}"] = (dp[k].detach() - w0[k]).numpy()
+            if it == iters - 1:
+                # Adam's second-moment estimates (smooth in the gradients, unlike the sign-step deltas above)
+                rec[f"it{it}:G:exp_avg_sq:blk6.conv2.weight_orig"] = opt_g.state[gp["blk6.conv2.weight_orig"]]["exp_avg_sq"].numpy().copy()
+                rec[f"it{it}:D:exp_avg_sq:d1.conv2.weight_orig"] = opt_d.state[dp["d1.conv2.weight_orig"]]["exp_avg_sq"].numpy().copy()
             rec[f"it{it}:avg_bn_mean"] = G_avg.blk6.norm2.norm.running_mean.numpy().copy()
             rec[f"it{it}:avg_nbt"] = int(G_avg.blk6.norm2.norm.num_batches_tracked)
     rec["losses"] = np.array(losses, np.float32)

@@ -323,6 +323,16 @@ def test_trainer_four_iterations_match_reference():
             bn = tr.generator_running_avg.blk6.norm2.norm
             assert np.abs(bn.running_mean.cpu().numpy() - g[f"it{it}:avg_bn_mean"]).max() < 2e-2
             assert int(bn.num_batches_tracked) == int(g[f"it{it}:avg_nbt"])
+    # NOT sign-dominated: Adam's second-moment estimate after the last iteration (two optimiser steps each) is smooth in the
+    # gradients -- exp_avg_sq = 0.9 * 0.1 g1^2 + 0.1 g2^2 (main.py:588-589: betas (0, 0.9)) -- a wrong beta2 / a squared-twice /
+    # a missing step shows here although the parameter deltas above are +-lr sign steps
+    for opt, mod_params, kind, k in ((tr.optimizer_g, gp, "G", "blk6.conv2.weight_orig"), (tr.optimizer_d, dp, "D", "d1.conv2.weight_orig")):
+        want = torch.from_numpy(g[f"it{int(g['iters']) - 1}:{kind}:exp_avg_sq:{k}"]).flatten().double()
+        got = opt.state[mod_params[k]]["exp_avg_sq"].detach().cpu().flatten().double()
+        rel = float((got - want).norm() / want.norm())
+        assert rel <= 0.10, (kind, k, rel)
+        assert abs(float(got.sum() / want.sum()) - 1) < 5e-2, (kind, k)
+        assert float(opt.state[mod_params[k]]["step"]) == 2.0
     # (the later losses are computed on weights that differ by the flipped first Adam steps: relative tolerance)
     # measured over repeated runs: first iteration <= 2e-3, later ones up to 3.7e-2 (lr_d = 4e-4 sign steps on flipped entries)
     tol = np.array([[1e-2, 1e-2]] + [[8e-2, 8e-2]] * (len(losses) - 1))
@@ -369,3 +379,52 @@ def test_headline_batch8_vs_cpu_oracle():
         report[k] = (float(torch.dot(a, b) / (a.norm() * b.norm())), float((a - b).norm() / b.norm()))
     worst = min(v[0] for v in report.values())
     assert worst >= 0.995 and max(v[1] for v in report.values()) <= 0.10, report
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_headline_batch8_dstep_vs_cpu_oracle():
+    """The D step of the benchmarked network (ModelWrapper.forward('d'), code/main.py:499-520: generator forward without grad,
+    discriminators on the [fake; real] batch of 2B = 16, the two hinge terms) at batch 8 against the pinned fp32 CPU oracle
+    (oracle/gan_cpu.py:d_step): logits, both losses and FULL discriminator gradient tensors elementwise.  Covers what the G-step
+    test above does not touch: mask_cat with the real half, d_losses (divide_pred by index), the bit-mask dgrad chain of
+    conv1..conv3, the premasked tail (conv4 -> conv5 + projection), every discriminator wgrad and the fused bias gradients."""
+    from oracle import gan_cpu as gc
+    gan = importlib.import_module("2dimageto3dmodel_amd.gan")
+    G_ops = importlib.import_module("2dimageto3dmodel_amd.gan_ops")
+    args = _trainer_args(texture_resolution=256)
+    torch.manual_seed(8643)
+    Gm, Dm = gan.Generator(args, 64, symmetric=True, mesh_head=True), gan.MultiScaleDiscriminator(args, 4)
+    wg, wd = gc.Weights(Gm.state_dict(), grad=False), gc.Weights(Dm.state_dict())
+    B, R = 8, 256
+    z, c, x_tex, x_alpha, x_mesh = make_inputs(8643, B, R, 200)
+    torch.set_num_threads(min(32, max(1, (torch.get_num_threads()))))
+    lf_r, lr_r, disc_r = gc.d_step(wg, wd, args, z, c, x_tex, x_alpha, x_mesh)
+    (lf_r.mean() + lr_r.mean()).backward()
+    Gm.to("cuda:0").train()
+    Dm.to("cuda:0").train()
+    crit = gan.GANLoss("hinge")
+    zd, cd, td, ad, md = (t.cuda() for t in (z, c, x_tex, x_alpha, x_mesh))
+    with torch.no_grad():
+        pred_tex, pred_mesh = Gm(zd, cd)
+        X_comb = G_ops.mask_cat(pred_tex, ad, td)
+        C_comb, M_comb = torch.cat((cd, cd), dim=0), torch.cat((pred_mesh, md), dim=0)
+    disc, mask = Dm(X_comb, M_comb, C_comb)
+    for got, want in zip(disc, disc_r):
+        assert got.shape == want.shape
+        # (the fake half sees a bf16 generator's texture: same tolerance as the G-step test's logits)
+        assert (got.detach().cpu() - want.detach()).abs().max().item() < 4e-2 * max(1.0, want.abs().max().item())
+    loss_fake, loss_real = crit.d_losses(disc, mask, None)
+    assert abs(loss_fake.item() - lf_r.item()) < 1e-2 and abs(loss_real.item() - lr_r.item()) < 1e-2, \
+        (loss_fake.item(), lf_r.item(), loss_real.item(), lr_r.item())
+    (loss_fake.mean() + loss_real.mean()).backward()
+    ref = wd.grads()
+    named = dict(Dm.named_parameters())
+    report = {}
+    for k in ("d1.conv1.weight_orig", "d1.conv2.weight_orig", "d1.conv3.weight_orig", "d1.conv4.weight_orig", "d1.conv5.weight_orig",
+              "d2.conv2.weight_orig", "d2.conv1.weight_orig", "d1.projector.weight", "d1.conv2.bias", "d1.conv4.bias", "d1.conv1.bias"):
+        a, b = named[k].grad.detach().cpu().flatten().double(), ref[k].flatten().double()
+        report[k] = (float(torch.dot(a, b) / (a.norm() * b.norm())), float((a - b).norm() / b.norm()))
+    worst = min(v[0] for v in report.values())
+    assert worst >= 0.995 and max(v[1] for v in report.values()) <= 0.10, report
+    assert all(p.grad is None for p in Gm.parameters())   # the generator ran without grad
