@@ -92,8 +92,9 @@ class MaskCatFn(torch.autograd.Function):
 
 def mask_cat(fake, alpha, real=None):
     """discriminator input of main.py:493 (real=None) / :503-507 (fake and real halves stacked on the batch axis)"""
-    ok = _plain_f32(fake, alpha, real) and fake.dim() == 4 and fake.shape[1] == 3 and alpha.shape[1] == 1 and \
-        (fake.shape[2] * fake.shape[3]) % 4 == 0 and (real is None or real.shape == fake.shape)
+    ok = _plain_f32(fake, alpha, real) and fake.dim() == 4 and fake.shape[1] == 3 and \
+        tuple(alpha.shape) == (fake.shape[0], 1, fake.shape[2], fake.shape[3]) and \
+        (fake.shape[2] * fake.shape[3]) % 4 == 0 and (real is None or real.shape == fake.shape)   # (a broadcast alpha: torch path)
     if ok:
         return MaskCatFn.apply(fake, alpha, real)
     x = torch.cat((fake * alpha, alpha), dim=1)
@@ -143,8 +144,9 @@ class DiscInputsFn(torch.autograd.Function):
             for g, sp in zip(dhs, ctx.specs):
                 if sp[1] and g is not None:
                     _, e, eh, ew = ctx.eshape
-                    dextra = torch.empty(ctx.eshape, dtype=torch.float32, device=g.device)
-                    launch("unpack_range", ptr(g.contiguous()), ptr(dextra), m, eh * ew, sp[3], c, e, stream())
+                    part = torch.empty(ctx.eshape, dtype=torch.float32, device=g.device)
+                    launch("unpack_range", ptr(g.contiguous()), ptr(part), m, eh * ew, sp[3], c, e, stream())
+                    dextra = part if dextra is None else dextra + part   # (several members may take the mesh map)
         return dx, dextra, None
 
 
@@ -156,6 +158,8 @@ def disc_inputs_ok(x, extra, specs):
         e = extra.shape[1] if has_extra else 0
         p = 0 if pos is None else pos.shape[0]
         if not lib().m355_pool_pack_ok(c, h, w, f, e, p, g) or c + e + p > cp:
+            return False
+        if pos is not None and tuple(pos.shape[1:]) != (h // f, w // f):   # (the members cache their planes at the first call's size)
             return False
         if has_extra and tuple(extra.shape[2:]) != (h // f, w // f):
             return False

@@ -37,7 +37,16 @@ def init_from_env(device_type="cuda", force=False):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:
+            # the launcher (torch.distributed.run, bench.py's respawn) owns the rendezvous port; only the launcher-less single-rank
+            # path (force: the 1-GPU RCCL smoke test) picks one itself -- a free one, two jobs on a host must not collide
+            if world > 1:
+                raise RuntimeError("parallel.init_from_env: WORLD_SIZE > 1 without MASTER_PORT (start the ranks under "
+                                   "torch.distributed.run, or through `bench.py --gpus N`)")
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if device_type == "cuda":
             if local_rank >= torch.cuda.device_count():
                 raise RuntimeError(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible "
@@ -58,7 +67,7 @@ def collectives_on():
     initialised group (single-rank RCCL smoke test: same calls, trivially correct result)"""
     if not (dist.is_available() and dist.is_initialized()):
         return False
-    return dist.get_world_size() > 1 or bool(os.environ.get("M355_FORCE_COLLECTIVES"))
+    return dist.get_world_size() > 1 or os.environ.get("M355_FORCE_COLLECTIVES", "") == "1"   # ("0" / "false" do not force)
 
 
 def broadcast_parameters(module, src=0):
@@ -98,6 +107,8 @@ class FlatGradReducer:
             import time
             t0 = time.perf_counter()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if timed and len(stats["events"]) >= 4096:   # a measurement window, not a log: never grows without bound
+            del stats["events"][:2048]
         if timed and self.flat.is_cuda:
             e1.record()   # the collective runs on RCCL's stream; the current stream waits for it, so e1 lands after it
             stats["events"].append((e0, e1))

@@ -3,8 +3,8 @@ modules: schedule 1 generator step : d_steps_per_g discriminator steps, Adam(bet
 
 The mesh smoothness regulariser of the G step (main.py:697-705) is applied when the trainer is given a
 `mesh_template` (2dimageto3dmodel_amd.mesh.MeshTemplate).  Not reproduced: the text encoder."""
-import copy
 import math
+import warnings
 
 import torch
 
@@ -46,7 +46,10 @@ class GanTrainer(torch.nn.Module):
         # generators -- same order here, so a run under the same torch.manual_seed starts from the reference's weights
         discriminator = G.MultiScaleDiscriminator(args, 4)
         self.generator = G.Generator(args, latent_dim, symmetric=symmetric_g, mesh_head=use_mesh)
-        self.generator_running_avg = copy.deepcopy(self.generator)          # main.py:453-457 (instantiate + load_state_dict)
+        # main.py:453-457: a SECOND Generator(...) is instantiated (drawing its own initial weights from the global RNG, as the
+        # reference does -- so the RNG stream after construction is the reference's) and then overwritten with the first one's
+        self.generator_running_avg = G.Generator(args, latent_dim, symmetric=symmetric_g, mesh_head=use_mesh)
+        self.generator_running_avg.load_state_dict(self.generator.state_dict())
         for p in self.generator_running_avg.parameters():
             p.requires_grad = False
         self.discriminator = discriminator
@@ -66,7 +69,8 @@ class GanTrainer(torch.nn.Module):
         self.reduce_g = P.FlatGradReducer(self.generator.parameters())
         self.reduce_d = P.FlatGradReducer(self.discriminator.parameters())
         self.total_it = 0
-        self.epoch = 0    # the caller's epoch counter (main.py:668); only the running-average ramp reads it
+        self._epoch, self._epoch_set = 0, False   # the caller's epoch counter (main.py:668); only the running-average ramp reads it
+        self.capturable = capturable
 
     def _d_weight(self):
         a = self.args
@@ -108,6 +112,10 @@ class GanTrainer(torch.nn.Module):
     def update_generator_running_avg(self, epoch=None):
         """main.py:431-447, including the alpha ramp over the first 100 epochs.  The (dst, src) tensor lists are
         collected once: state_dict() on two 300-entry modules per step is pure host overhead."""
+        if epoch is None and not self._epoch_set and not self.__dict__.get("_warned_epoch"):
+            self.__dict__["_warned_epoch"] = True
+            warnings.warn("GanTrainer: the running-average ramp (main.py:433-438) reads the epoch, which was never given "
+                          "(iteration(..., epoch=e) or trainer.epoch = e): staying on the epoch-0 alpha")
         alpha = ema_alpha(self.ema_alpha, self.epoch if epoch is None else epoch)
         ema = self.__dict__.get("_ema_lists")
         if ema is None:
@@ -125,6 +133,23 @@ class GanTrainer(torch.nn.Module):
             v.copy_(sv)
         torch._foreach_mul_(fl_dst, alpha)
         torch._foreach_add_(fl_dst, fl_src, alpha=1 - alpha)
+
+    @property
+    def epoch(self):
+        return self._epoch
+
+    @epoch.setter
+    def epoch(self, e):
+        self._epoch, self._epoch_set = int(e), True
+
+    def capture_cycle(self, batches, epoch=None, warmup=2, noises=None):
+        """One training cycle (1 G step + d_steps_per_g D steps, optimiser steps and the running-average update included) as ONE
+        hipGraph: returns a CycleGraph whose replay() costs one graph launch instead of ~750 kernel launches issued from Python
+        (13 ms of host time per cycle regardless of the batch: the limit below batch ~24 per GPU).  Needs
+        GanTrainer(capturable=True) (Adam's step counters on the device).  `batches`: 1 + d_steps_per_g loader batches
+        (X_tex, X_alpha, X_mesh, C); their storage is copied into static buffers that CycleGraph.load() refills.  noises: one
+        fixed latent batch per iteration (tests); default: fresh torch.randn noise on every replay."""
+        return CycleGraph(self, batches, epoch, warmup, noises)
 
     def iteration(self, X_tex, X_alpha, X_mesh, C, caption=None, noise=None, epoch=None):
         """one pass of the loop body main.py:691-723 on one loader batch; returns the scalar losses.  `noise` fixes the
@@ -168,3 +193,66 @@ class GanTrainer(torch.nn.Module):
             out = {"d_fake": loss_fake.detach(), "d_real": loss_real.detach()}
         self.total_it += 1
         return out
+
+
+class CycleGraph:
+    """A captured training cycle of a GanTrainer (GanTrainer.capture_cycle).  What is baked into the graph: the tensor
+    addresses of the static input buffers, the spectral-norm slots the cycle's six network forwards rotate through, the
+    running-average alpha of the epoch it was captured at (replay(epoch=...) re-captures when the ramp of main.py:433-438
+    moves to another value), the batch shapes.  What stays live across replays: parameters, optimiser state, spectral-norm
+    vectors, batch-norm running statistics, and the latent noise -- torch.randn inside a capture draws from the graph-safe
+    Philox state, so every replay sees fresh noise.  The returned losses are tensors of the graph's memory pool, overwritten
+    by every replay."""
+
+    def __init__(self, trainer, batches, epoch=None, warmup=2, noises=None):
+        if not trainer.capturable:
+            raise RuntimeError("capture_cycle needs GanTrainer(capturable=True): Adam's step counters must live on the device")
+        n = 1 + trainer.d_steps_per_g
+        if len(batches) != n:
+            raise ValueError(f"capture_cycle: {n} loader batches per cycle (1 G step + {trainer.d_steps_per_g} D steps), got {len(batches)}")
+        if trainer.total_it % n:
+            raise RuntimeError("capture_cycle: the trainer is in the middle of a cycle")
+        self.trainer, self.n = trainer, n
+        self.static = [[None if t is None else t.clone() for t in b] for b in batches]
+        self.noises = [None] * n if noises is None else [z.clone() for z in noises]
+        self.epoch = trainer.epoch if epoch is None else epoch
+        self.alpha = ema_alpha(trainer.ema_alpha, self.epoch)
+        self.out = None
+        self._capture(warmup)
+
+    def _run(self):
+        out = {}
+        for b, z in zip(self.static, self.noises):
+            out.update(self.trainer.iteration(*b, noise=z, epoch=self.epoch))
+        return out
+
+    def _capture(self, warmup):
+        # warm-up on a side stream (torch's capture protocol): allocator pools, the weight-gradient arena, the lazily uploaded
+        # positional planes and the optimiser state all exist before the capture starts
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._run()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._run()
+        self.trainer.total_it -= self.n   # (the capture pass executed nothing)
+
+    def load(self, batches):
+        """copy the next cycle's loader batches into the static buffers (device-to-device, on the current stream)"""
+        for dst, src in zip(self.static, batches):
+            for d, t in zip(dst, src):
+                if d is not None:
+                    d.copy_(t, non_blocking=True)
+
+    def replay(self, batches=None, epoch=None):
+        if epoch is not None and ema_alpha(self.trainer.ema_alpha, epoch) != self.alpha:
+            self.epoch, self.alpha = epoch, ema_alpha(self.trainer.ema_alpha, epoch)
+            self._capture(0)          # the ramp moved: the new alpha has to be baked in
+        if batches is not None:
+            self.load(batches)
+        self.graph.replay()
+        self.trainer.total_it += self.n
+        return self.out

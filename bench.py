@@ -238,6 +238,12 @@ def main():
                          "the one workload that also runs with --backend gloo on CPU)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI (the product path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch samples on EVERY GPU (global = N x batch); strong: --batch is the GLOBAL batch, split N ways "
+                         "(SURVEY 8d cfg 4: global 64 split 8 ways)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the GAN cycle from ONE captured hipGraph (GanTrainer.capture_cycle) instead of ~750 launches "
+                         "issued from Python: the host needs ~13 ms per cycle whatever the batch, which bounds small per-GPU batches")
     args = ap.parse_args()
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
@@ -261,12 +267,14 @@ def main():
     if on_gpu:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+    if args.scaling == "strong" and args.batch % world:
+        sys.exit(f"bench.py: --scaling strong splits the global batch {args.batch} over {world} GPUs: not divisible")
     if args.workload == "collectives":
         return bench_collectives(args, par, dist, rank, world, dev)
     pkg = importlib.import_module("2dimageto3dmodel_amd")
     train = importlib.import_module("2dimageto3dmodel_amd.train")
 
-    B, N, S, R = args.batch, args.points, args.grid, args.res
+    B, N, S, R = (args.batch // world if args.scaling == "strong" else args.batch), args.points, args.grid, args.res
     do_p, do_g = args.workload in ("both", "proj"), args.workload in ("both", "gan")
 
     if do_p:
@@ -287,8 +295,9 @@ def main():
         with tempfile.TemporaryDirectory() as tmp:
             template = mesh_mod.MeshTemplate(mesh_mod.write_uv_sphere_obj(os.path.join(tmp, "uvsphere_16rings.obj")),
                                              is_symmetric=True, device=dev)
-        trainer = train.GanTrainer(gargs, device=dev, mesh_template=template)
+        trainer = train.GanTrainer(gargs, device=dev, mesh_template=template, capturable=args.graph)
         trainer.train()
+        trainer.epoch = 0
         batches = [make_textures(B, R, 1234 + 3 + 17 * rank + i, dev) for i in range(3)]
         # the weights above are identical on every rank (same seed + broadcast); the latent noise must NOT be:
         # GanTrainer draws it from the default generators, re-seeded here per rank
@@ -305,6 +314,16 @@ def main():
     def step_g():
         for x_tex, x_alpha, x_mesh, c in batches:  # 1 G step + 2 D steps, one loader batch each
             last.update(trainer.iteration(x_tex, x_alpha, x_mesh, c))
+
+    cyc = None
+    if do_g and args.graph:
+        # per-rank noise first (the capture's warm-up cycles already draw it), then ONE graph for the whole cycle
+        torch.manual_seed(1234 + 3 + 17 * rank)
+        cyc = trainer.capture_cycle(batches, epoch=0)
+        step_g_eager = step_g
+
+        def step_g():   # noqa: F811  (the timed region replays; the per-kernel HIP-event pass below runs the eager cycle)
+            last.update(cyc.replay())
 
     def step():
         if do_p:
@@ -341,7 +360,10 @@ def main():
     pkg._lib.enable_kernel_timers(True)
     par.reset_stats(time_allreduce=True)
     for _ in range(args.steps):
-        step()
+        if do_p:
+            step_p()
+        if do_g:
+            (step_g_eager if cyc is not None else step_g)()   # (HIP events cannot be recorded into a replayed graph)
     torch.cuda.synchronize()
     kt = pkg._lib.collect_kernel_timers()  # name -> (launches, total_ms, total algorithmic work)
     allreduce_ms = par.allreduce_ms() / args.steps
@@ -373,15 +395,18 @@ def main():
         out = {
             "metric": "train-step samples/sec (proj+loss+GAN fwd/bwd), batch 64", "value": world * B * args.steps / dt,
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "bf16" if do_g else "f32", "data": "synthetic",
             "config": {"workload": " + ".join(workload), "global_batch": world * B, "points": N, "grid": S,
-                       "texture_resolution": R, "parallelism": f"dp{world}",
+                       "texture_resolution": R, "parallelism": f"dp{world}", "per_gpu_batch": B,
+                       "gan_launch": "hipGraph replay (1 graph per cycle)" if cyc is not None else "eager (one launch per kernel)",
                        "losses": {k: float(v) for k, v in last.items()}},
             "allreduce_ms_per_step": allreduce_ms,
             "grad_allreduces_per_step": coll["grad_allreduces"] / args.steps,
             "grad_allreduce_mb_per_step": coll["grad_allreduce_bytes"] / args.steps / 1e6,
             "syncbn_collectives_per_step": coll["syncbn_collectives"] / args.steps,
+            "proj_ms_per_step": (dt_p / args.steps * 1e3) if do_p else None,
+            "gan_ms_per_cycle": (dt_g / args.steps * 1e3) if do_g else None,
             "proj_samples_per_s": (world * B * args.steps / dt_p) if do_p else None,
             "gan_samples_per_s": (world * 3 * B * args.steps / dt_g) if do_g else None,
             "roofline": {"bound": "mfma" if is_conv else "hbm", "kernel": dom, "achieved": rate, "peak": peak,
@@ -450,9 +475,10 @@ def bench_collectives(args, par, dist, rank, world, dev):
         print(json.dumps({
             "metric": "gradient all-reduce GB/s (algorithmic bytes of the flat fp32 buffers)", "unit": "GB/s",
             "value": (nbytes / 1e9) / (ar_ms * 1e-3) if ar_ms > 0 else None, "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": t.item() / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": t.item() / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "backend": args.backend,
-            "config": {"workload": "collectives: flat all-reduce of 47 MB + 14 MB fp32 gradient buffers", "parallelism": f"dp{world}"},
+            "config": {"workload": "collectives: flat all-reduce of 47 MB + 14 MB fp32 gradient buffers", "parallelism": f"dp{world}",
+                       "per_gpu_batch": args.batch // world if args.scaling == "strong" else args.batch},
             "allreduce_ms_per_step": ar_ms, "grad_allreduces_per_step": par.stats["grad_allreduces"] / max(args.steps, 1),
             "grad_allreduce_mb_per_step": nbytes / 1e6, "averaged_correctly": bool(ok)}), flush=True)
     if world > 1:

@@ -120,6 +120,21 @@ def test_bench_gpus2_spawns_two_ranks_gloo():
     assert abs(out["grad_allreduce_mb_per_step"] - 61.0) < 1e-6
 
 
+@pytest.mark.timeout(400)
+def test_bench_strong_scaling_two_ranks_gloo():
+    """`--scaling strong`: --batch is the GLOBAL batch, split over the ranks (SURVEY 8d cfg 4: global 64 split N ways); the line
+    says so, and a batch the ranks cannot share is refused"""
+    import json
+    r = _run_bench("--gpus", "2", "--backend", "gloo", "--workload", "collectives", "--steps", "1", "--warmup", "0", "--scaling",
+                   "strong", "--batch", "64")
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["scaling"] == "strong" and out["n_gpus"] == 2 and out["config"]["per_gpu_batch"] == 32
+    r = _run_bench("--gpus", "2", "--backend", "gloo", "--workload", "collectives", "--steps", "1", "--warmup", "0", "--scaling",
+                   "strong", "--batch", "63")
+    assert r.returncode != 0 and "not divisible" in r.stderr
+
+
 def test_bench_refuses_more_gpus_than_visible():
     """`bench.py --gpus 9` on a box with fewer GPUs must fail loudly, never fall back to a 1-GPU measurement"""
     r = _run_bench("--gpus", "9", "--steps", "1", "--warmup", "0", timeout=200)

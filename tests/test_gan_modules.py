@@ -428,3 +428,57 @@ def test_headline_batch8_dstep_vs_cpu_oracle():
     worst = min(v[0] for v in report.values())
     assert worst >= 0.995 and max(v[1] for v in report.values()) <= 0.10, report
     assert all(p.grad is None for p in Gm.parameters())   # the generator ran without grad
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_captured_cycle_replays_like_eager():
+    """GanTrainer.capture_cycle: one training cycle (G, D, D with their Adam steps and the running-average update) recorded
+    into a hipGraph.  Two trainers from the same seed, the same loader batches and the same latent batches: A runs five
+    cycles eagerly, B two warm-up cycles inside capture_cycle and three replays.  The split-K weight gradients accumulate
+    with fp32 atomics (order-dependent in the last bits), so the comparison is not bitwise: every loss of the last cycle
+    within 2e-2, parameter displacements cosine >= 0.99, the device-side Adam step counters equal."""
+    train = importlib.import_module("2dimageto3dmodel_amd.train")
+    B, R = 4, 128
+    batches = []
+    for i in range(3):
+        z, c, x_tex, x_alpha, x_mesh = make_inputs(5150 + i, B, R, 200)
+        batches.append(([x_tex.cuda(), x_alpha.cuda(), x_mesh.cuda(), c.cuda()], z.cuda()))
+
+    def fresh():
+        torch.manual_seed(515)
+        tr = train.GanTrainer(_trainer_args(), device="cuda:0", mesh_template=None, capturable=True)
+        tr.train()
+        return tr
+
+    A, Bt = fresh(), fresh()
+    keys_g, keys_d = ["blk6.conv2.weight_orig", "blk1.conv1.weight_orig", "conv_final.weight"], ["d1.conv2.weight_orig", "d2.conv3.bias"]
+    w0 = {k: dict(A.generator.named_parameters())[k].detach().clone() for k in keys_g}
+    w0.update({k: dict(A.discriminator.named_parameters())[k].detach().clone() for k in keys_d})
+    out_a = {}
+    for _ in range(5):
+        for b, z in batches:
+            out_a.update(A.iteration(*b, noise=z, epoch=0))
+    cyc = Bt.capture_cycle([b for b, _ in batches], epoch=0, warmup=2, noises=[z for _, z in batches])
+    for _ in range(3):
+        out_b = cyc.replay()
+    torch.cuda.synchronize()
+    assert Bt.total_it == A.total_it == 15
+    for k in ("g", "d_fake", "d_real"):
+        assert abs(float(out_a[k]) - float(out_b[k])) <= 2e-2 * max(1.0, abs(float(out_a[k]))), (k, float(out_a[k]), float(out_b[k]))
+    for mod_a, mod_b, keys in ((A.generator, Bt.generator, keys_g), (A.discriminator, Bt.discriminator, keys_d),
+                               (A.generator_running_avg, Bt.generator_running_avg, keys_g)):
+        pa, pb = dict(mod_a.named_parameters()), dict(mod_b.named_parameters())
+        for k in keys:
+            da, db = (pa[k].detach() - w0[k]).flatten().double(), (pb[k].detach() - w0[k]).flatten().double()
+            cos = float(torch.dot(da, db) / (da.norm() * db.norm() + 1e-300))
+            assert cos >= 0.99, (k, cos)
+    sa = A.optimizer_g.state[dict(A.generator.named_parameters())["blk6.conv2.weight_orig"]]["step"]
+    sb = Bt.optimizer_g.state[dict(Bt.generator.named_parameters())["blk6.conv2.weight_orig"]]["step"]
+    assert float(sa) == float(sb) == 5.0
+    # a replay with new loader batches refills the static buffers
+    out_c = cyc.replay([b for b, _ in batches[::-1]])
+    torch.cuda.synchronize()
+    assert all(np.isfinite(float(v)) for v in out_c.values())
+    with pytest.raises(RuntimeError):
+        train.GanTrainer(_trainer_args(), device="cuda:0", mesh_template=None).capture_cycle([b for b, _ in batches])
