@@ -31,6 +31,7 @@ SOURCES = [
     ("conv_mfma.hip", []),
     ("conv_small.hip", []),
     ("conv_halo.hip", []),
+    ("conv_halo2.hip", []),
     ("gan_elem.hip", []),
     ("gan_glue.hip", []),
     ("gan_io.hip", []),

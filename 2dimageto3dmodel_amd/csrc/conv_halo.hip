@@ -1131,9 +1131,13 @@ int conv_halo_stats_rows(const ConvArgs &a)
     return halo_grid_per(b);
 }
 
+bool conv_tb_eligible(const ConvArgs &a);   // csrc/conv_halo2.hip: the 8-wave 2x2 class kernels on pairs of pixel tiles
+int conv_tb_launch(const ConvArgs &a, unsigned xb, unsigned wb, hipStream_t st);
+
 int conv_halo_launch(const ConvArgs &a_in, unsigned xb, unsigned wb, hipStream_t st)
 {
     ConvArgs a = a_in;
+    if (conv_tb_eligible(a)) return conv_tb_launch(a, xb, wb, st);
 #ifdef M355_DBG_STAMP
     if (!a.stats && (a.KH == 2 || a.stride == 2)) {   // (KS 3 selects its instantiation by a.stats)
         const char *sp = getenv("M355_STAMP_PTR");
