@@ -251,6 +251,14 @@ __global__ __launch_bounds__(512, 2) void k_conv_tb(ConvArgs a, unsigned xbytes,
     // Software pipeline by HALF a step: the MFMAs of k-groups 2, 3 of step s run at the head of step s+1, behind that step's
     // first eight fragment reads (whose latency they hide); k-groups 2, 3 of the fragments are carried across the barrier.
     // Zero fragments = no-op MFMAs: before the first step and after a pair's epilogue has flushed the tail.
+#ifdef M355_DBG_STAMP
+    // debug build only (scripts/stamp_halo.py): shader-clock stamps of the step phases, per wave, of workgroup (0,0)
+    constexpr int DBG_STEPS = 96;
+    __shared__ unsigned dbg_lds[8 * DBG_STEPS * 4];
+    unsigned dbg_i = 0, dbg_t0 = 0, dbg_t1 = 0, dbg_t2 = 0, dbg_t3 = 0, dbg_n0 = 0;
+    const bool dbg_on = a.stats != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
+    const unsigned long long dbg_c0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     Frags f;
     auto zero_tail = [&]() {
         const bf16x8 z = {};
@@ -297,6 +305,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_tb(ConvArgs a, unsigned xbytes,
                     constexpr int tap = decltype(tapc)::value;
                     constexpr int s = 4 * sub + tap;
                     constexpr int cnt = s == 0 ? 4 : (s == 1 || s == 2) ? 7 : s == 3 ? 5 : s == 4 ? 0 : -1;
+#ifdef M355_DBG_STAMP
+                    if (dbg_on) dbg_n0 = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
                     if constexpr (cnt < 0) {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     } else if constexpr (s < 3) {
@@ -312,6 +323,18 @@ __global__ __launch_bounds__(512, 2) void k_conv_tb(ConvArgs a, unsigned xbytes,
                     }
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
+#ifdef M355_DBG_STAMP
+                    if (dbg_on) {
+                        if (dbg_i > 0 && dbg_i <= DBG_STEPS) {
+                            unsigned *q = dbg_lds + (wave * DBG_STEPS + (dbg_i - 1)) * 4;
+                            q[0] = dbg_t0; q[1] = dbg_t1; q[2] = dbg_t2; q[3] = dbg_t3;
+                        }
+                        ++dbg_i;
+                        dbg_t0 = dbg_n0;
+                        dbg_t1 = (unsigned)__builtin_amdgcn_s_memtime();
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
                     using I0 = std::integral_constant<int, 0>;
                     using I2 = std::integral_constant<int, 2>;
                     using I4 = std::integral_constant<int, 4>;
@@ -327,25 +350,35 @@ __global__ __launch_bounds__(512, 2) void k_conv_tb(ConvArgs a, unsigned xbytes,
                     };
                     mma(std::integral_constant<int, psub>{}, 2);   // the previous step's tail, behind this step's first reads
                     mma(std::integral_constant<int, psub>{}, 3);
-                    mma(subc, 0);   // the DMA issue below (scalar address work, M0 writes) runs in the shadow of these MFMAs
                     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // all eight reads in flight first
-                    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (s == 0) issue_B(cls_cur, cc_cur, std::integral_constant<int, 3>{});
-                    if constexpr (s >= 5) issue_B(cls_n, cc_n, std::integral_constant<int, s - 5>{});
-                    if constexpr (tap <= 1) issue_A(sub ^ 1, sub == 0 ? cc_cur : cc_n, tapc);
-                    __builtin_amdgcn_sched_barrier(0);
-                    read_frags(f, lds + sub * ABUF, tapc, I2{}, I4{});   // (consumed at the head of the next step)
-                    if constexpr (tap == 2) compute_aoff(sub == 0 ? tg_top : tg_bot, K0{}, KH{});
-                    if constexpr (tap == 3) compute_aoff(sub == 0 ? tg_top : tg_bot, KH{}, KN{});
-                    mma(subc, 1);
-                    // the second half's eight reads ride in the issue gaps of mma(1), whose fragments are already here
+                    // k-groups 2, 3 (their registers are free now) ride in the issue gaps of mma(0): they have the DMA issue and
+                    // mma(1) to land before the step's closing lgkmcnt(0)
+                    read_frags(f, lds + sub * ABUF, tapc, I2{}, I4{});
+                    mma(subc, 0);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (s == 0) issue_B(cls_cur, cc_cur, std::integral_constant<int, 3>{});
+                    if constexpr (s >= 5) issue_B(cls_n, cc_n, std::integral_constant<int, s - 5>{});
+                    if constexpr (tap <= 1) issue_A(sub ^ 1, sub == 0 ? cc_cur : cc_n, tapc);
+                    __builtin_amdgcn_sched_barrier(0);
+#ifdef M355_DBG_STAMP
+                    if (dbg_on) dbg_t2 = (unsigned)__builtin_amdgcn_s_memtime();
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                    if constexpr (tap == 2) compute_aoff(sub == 0 ? tg_top : tg_bot, K0{}, KH{});
+                    if constexpr (tap == 3) compute_aoff(sub == 0 ? tg_top : tg_bot, KH{}, KN{});
+                    mma(subc, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#ifdef M355_DBG_STAMP
+                    if (dbg_on) dbg_t3 = (unsigned)__builtin_amdgcn_s_memtime();
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
                 });
             });
             cls_cur = cls_n;
@@ -430,13 +463,35 @@ __global__ __launch_bounds__(512, 2) void k_conv_tb(ConvArgs a, unsigned xbytes,
         fresh = has_B ? 3 : 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (unused) prefetches
+#ifdef M355_DBG_STAMP
+    if (dbg_on) {
+        __syncthreads();
+        unsigned *out = reinterpret_cast<unsigned *>(a.stats);
+        for (int k = tid; k < 8 * DBG_STEPS * 4; k += NW * 64) out[k] = dbg_lds[k];
+        if (tid == 0) {   // whole-kernel shader cycles and 100 MHz reference ticks of this workgroup -> the effective clock
+            out[8 * DBG_STEPS * 4] = (unsigned)(__builtin_amdgcn_s_memtime() - dbg_c0);
+            out[8 * DBG_STEPS * 4 + 1] = (unsigned)(__builtin_amdgcn_s_memrealtime() - dbg_r0);
+        }
+    }
+#endif
 }
 
 // which k_conv_halo problems run on tile pairs: the 8-wave 2x2 class kernels with the unguarded epilogue
 bool conv_tb_eligible(const ConvArgs &a)
 {
-    if (getenv("M355_NO_TB")) return false;
-    if (a.y_f32_nchw || a.fold2 || a.mask_x || a.stats || a.ups || a.Cout != a.CoutP || a.Cin % 64 || a.Wo % 32 || a.Ho % 8 || a.Cs % 8)
+    // OPT-IN (M355_TB=1).  Measured (profiles/r03_power_tb_vs_halo.txt, D.conv3 at batch 128 back to back for 4 s): the socket sits
+    // at its 1400 W cap under either kernel; this one needs 31 % fewer DMA instructions and runs at a higher clock (1829 vs
+    // 1707 MHz) but spends more cycles per step (1831 vs 1648: no full-step register double buffer next to 128 accumulator
+    // registers) -- 1073 vs 1112 TF forward, 1044 vs 1092 TF dgrad.  Under the power cap the step's ENERGY decides, and the
+    // weight DMAs it saves are a small part of it.  Kept for the A/B and as the starting point of a 128 x 64 wave tile.
+    const char *on = getenv("M355_TB");
+    if (!on || on[0] == '0' || getenv("M355_NO_TB")) return false;
+#ifdef M355_DBG_STAMP
+    const bool stats = false;   // (a.stats carries the stamp buffer)
+#else
+    const bool stats = a.stats != nullptr;
+#endif
+    if (a.y_f32_nchw || a.fold2 || a.mask_x || stats || a.ups || a.Cout != a.CoutP || a.Cin % 64 || a.Wo % 32 || a.Ho % 8 || a.Cs % 8)
         return false;
     // at least one full pair per workgroup of the launch (M355_HALO_WGS: tests force few workgroups)
     const int tiles = a.N * (a.Ho / 8) * (a.Wo / 32);

@@ -12,12 +12,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 conv = importlib.import_module("2dimageto3dmodel_amd.conv")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 STEPS = 96
-buf = torch.zeros(8 * STEPS * 4, dtype=torch.int32, device="cuda")
+buf = torch.zeros(8 * STEPS * 4 + 2, dtype=torch.int32, device="cuda")
 
 
 def report(name):
     torch.cuda.synchronize()
-    a = buf.cpu().numpy().astype(np.uint32).astype(np.int64).reshape(8, STEPS, 4)
+    raw = buf.cpu().numpy().astype(np.uint32).astype(np.int64)
+    a, (kc, kr) = raw[:8 * STEPS * 4].reshape(8, STEPS, 4), raw[8 * STEPS * 4:]
     buf.zero_()
     n = int((a[0, :, 1] != 0).sum())
     if n < 8:
@@ -28,6 +29,9 @@ def report(name):
     tail = d(a[:, 1:, 0], a[:, :-1, 3])
     step = d(a[:, 1:, 1], a[:, :-1, 1])
     print(f"== {name}: {n} steps stamped; cycles per step (median over steps 8..) per wave")
+    if kr > 0:
+        print(f"  whole kernel, workgroup (0,0): {kc} shader cycles in {kr} ticks of the 100 MHz reference = {kr / 100.0:.1f} us -> "
+              f"effective shader clock {kc / kr * 0.1:.3f} GHz")
     for w in range(8):
         s = slice(8, n - 1)
         print(f"  wave {w}: step {np.median(step[w, s]):7.0f}  wait {np.median(wait[w, s]):6.0f}  p1(4 mfma + dma issue) {np.median(p1[w, s]):6.0f}"
@@ -36,6 +40,15 @@ def report(name):
     for k in range(8, min(24, n - 1)):
         print(f"    {k:3d} {step[0, k]:6d} {wait[0, k]:6d} {p1[0, k]:6d} {p2[0, k]:6d} {tail[0, k]:6d}")
     print("  barrier release skew across waves (t1 - min t1), step 10:", (a[:, 10, 1] - a[:, 10, 1].min()).tolist())
+
+
+def timeit(f, n=20):
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
 
 
 os.environ["M355_STAMP_PTR"] = hex(buf.data_ptr())
@@ -47,7 +60,9 @@ for name, H, Cin, Cout in (("D.conv3 128->256 4x4 s2", 128, 128, 256), ("D.conv4
     dy = torch.randn(B, H // 2, H // 2, Cout, device="cuda").bfloat16()
     for _ in range(2):
         conv.conv_fwd(d, x, wf, slope=0.2)
-    report(name + " fwd (SUB=2)")
+    print("  HIP-event time fwd %.1f us" % timeit(lambda: conv.conv_fwd(d, x, wf, slope=0.2)))
+    report(name + " fwd (SUB=2) " + conv.lib().m355_last_kernel().decode())
     for _ in range(2):
         conv.conv_dgrad(d, dy, wd)
-    report(name + " dgrad (4 classes)")
+    print("  HIP-event time dgrad %.1f us" % timeit(lambda: conv.conv_dgrad(d, dy, wd)))
+    report(name + " dgrad (4 classes) " + conv.lib().m355_last_kernel().decode())

@@ -296,6 +296,7 @@ def test_conv_tile_pairs_match_single_tiles(pkg, case, wgs, monkeypatch):
     forces few workgroups so that each walks several pairs (ring wrap-around, pair boundaries, half-empty last pair)."""
     conv = importlib.import_module("2dimageto3dmodel_amd.conv")
     monkeypatch.setenv("M355_HALO_WGS", wgs)
+    monkeypatch.setenv("M355_TB", "1")   # (opt-in: under the socket's power cap it measures 4 % behind k_conv_halo, csrc/conv_halo2.hip)
     N, H, W, Cin, Cout, mode = case
     g = torch.Generator().manual_seed(31 * Cin + Cout + int(wgs))
     d = conv.make_desc(N, H, W, Cin, Cout, 4, 4, 2, 1, 1, mode, 0)
