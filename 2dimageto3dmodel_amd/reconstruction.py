@@ -9,7 +9,9 @@ execution, not of meaning:
     first conv and shortcut (index arithmetic in the conv loader), the replicate / circular W pads likewise;
   * BatchNorm2d + ReLU (+ the residual add of ResBlock.forward :24-25) is one fused pass;
   * stride-2 5x5 / 3x3 encoder convs: forward on the generic implicit-GEMM kernel, dgrad through the padded even kernel.
-Only interpolation_mode='nearest' (the default) is supported.
+interpolation_mode='bilinear' (:43-44, non-default): the x2 upsample cannot be folded into a conv loader (it mixes four
+pixels); it runs between the blocks as F.interpolate on the NHWC bf16 activation, everything else is unchanged.
+`DatasetParams` (:140-180): the per-image translation / scale / z0 offsets run_reconstruction.py optimises next to the network.
 """
 import torch
 import torch.nn as nn
@@ -60,6 +62,44 @@ class ResBlock(nn.Module):
         return self.bn2(self.conv2(h), res=sc, out_slope=out_slope)
 
 
+def _up_bilinear(x_nhwc):
+    """F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False) (models/reconstruction.py:44) of an NHWC bf16
+    activation: the interpolation itself in fp32 (as the reference's fp32 activations), stored back as bf16"""
+    y = torch.nn.functional.interpolate(x_nhwc.permute(0, 3, 1, 2).float(), scale_factor=2, mode='bilinear', align_corners=False)
+    return y.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+
+
+class DatasetParams(nn.Module):
+    """models/reconstruction.py:140-180: learnable per-image corrections of the (noisy) ground-truth poses --
+    ds_translation [N,2], ds_scale [N,1] (args.optimize_deltas) and ds_z0 [N,1] (args.optimize_z0, perspective strength).
+    forward(indices, 'deltas') -> (translation_delta [B,3] with z = 0, scale_delta [B,1]); forward(indices, 'z0') ->
+    1 + exp(z0) [B,1].  indices in [N, 2N) address the mirrored copy of image index - N (data augmentation): the x translation
+    changes sign.  indices None: the dataset mean (evaluation of unseen images).  Same parameter names and shapes as the
+    reference, so its checkpoints load."""
+
+    def __init__(self, args, dataset_size):
+        super().__init__()
+        self.dataset_size = dataset_size
+        if args.optimize_deltas:
+            self.ds_translation = nn.Parameter(torch.zeros(dataset_size, 2))
+            self.ds_scale = nn.Parameter(torch.zeros(dataset_size, 1))
+        if args.optimize_z0:
+            self.ds_z0 = nn.Parameter(torch.ones(dataset_size, 1))
+
+    def forward(self, indices, mode):
+        assert mode in ['deltas', 'z0']
+        mirrored_sign = 1
+        if indices is not None:
+            mirrored_sign = (1 - 2 * torch.div(indices, self.dataset_size, rounding_mode='floor').float()).unsqueeze(-1)
+            indices = indices % self.dataset_size
+        pick = (lambda table: table[indices]) if indices is not None else (lambda table: table.mean(dim=0, keepdim=True))
+        if mode == 'z0':
+            return 1 + torch.exp(pick(self.ds_z0))
+        t = pick(self.ds_translation)
+        translation_delta = torch.cat((t[:, :1] * mirrored_sign, t[:, 1:2], torch.zeros_like(t[:, :1])), dim=1)
+        return translation_delta, pick(self.ds_scale)
+
+
 class ReconstructionNetwork(nn.Module):
     """models/reconstruction.py:28-137"""
 
@@ -67,8 +107,9 @@ class ReconstructionNetwork(nn.Module):
         super().__init__()
         self.symmetric = symmetric
         self.pad = C.PAD_REPLICATE if symmetric else C.PAD_CIRCULAR   # (:34-37)
-        if interpolation_mode != 'nearest':
-            raise NotImplementedError("ReconstructionNetwork: only interpolation_mode='nearest' runs on the fused kernels")
+        if interpolation_mode not in ('nearest', 'bilinear'):
+            raise ValueError(f"interpolation_mode={interpolation_mode!r}")   # (the reference: a bare `raise`, :45-46)
+        self.interpolation_mode = interpolation_mode
         assert mesh_res >= 32
         assert texture_res >= 64
 
@@ -133,18 +174,24 @@ class ReconstructionNetwork(nn.Module):
         """bottleneck code -> (tex [B,3,R,R], mesh_map [B,3,32,32]) NCHW fp32 (:118-137).  The heads are the generator's:
         ReLU fused into the last block's pass, conv, then tanh_ / adjust_poles / symmetrize in one elementwise kernel."""
         bb = G.to_nhwc_bf16(self.fc1_tex(z).view(z.shape[0], -1, self.base_res_h, self.base_res_w))
-        bb = self.blk1(bb)
-        bb = self.blk2(bb, upsample=1)      # every later block starts with the x2 upsample of the line before it
-        bb = self.blk3(bb, upsample=1)
+        # nearest: every later block starts with the x2 upsample of the line before it, folded into its first conv (u = 1);
+        # bilinear: the upsample is a pass of its own between the blocks (up), the blocks run at u = 0
+        nearest = self.interpolation_mode == 'nearest'
+        u = 1 if nearest else 0
+        up = (lambda t: t) if nearest else _up_bilinear
+        bb = up(self.blk1(bb))
+        bb = up(self.blk2(bb, upsample=u))
+        bb = up(self.blk3(bb, upsample=u))
         bb_mesh = bb
         if self.texture_res >= 128:
-            bb = self.blk3b_tex(bb, upsample=1)
+            bb = up(self.blk3b_tex(bb, upsample=u))
         if self.texture_res >= 256:
-            bb = self.blk3c_tex(bb, upsample=1)
+            bb = up(self.blk3c_tex(bb, upsample=u))
         sym = G.HT_SYMM if self.symmetric else 0
-        mesh_map = G.head_conv(self.blk4_mesh(bb_mesh, upsample=1, out_slope=0.0), self.conv_mesh, G.HT_POLES | sym, in_slope=0.0)
-        tex = self.blk4_tex(bb, upsample=1)
-        tex = G.head_conv(self.blk5_tex(tex, upsample=1, out_slope=0.0), self.conv_tex, G.HT_TANH | sym, in_slope=0.0)
+        # (:126, :133: blk4_mesh and blk5_tex are NOT followed by an upsample; blk4_tex is)
+        mesh_map = G.head_conv(self.blk4_mesh(bb_mesh, upsample=u, out_slope=0.0), self.conv_mesh, G.HT_POLES | sym, in_slope=0.0)
+        tex = up(self.blk4_tex(bb, upsample=u))
+        tex = G.head_conv(self.blk5_tex(tex, upsample=u, out_slope=0.0), self.conv_tex, G.HT_TANH | sym, in_slope=0.0)
         return tex, mesh_map
 
     def forward(self, x):

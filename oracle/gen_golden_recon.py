@@ -23,7 +23,14 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 # batch 8 / 6: the two BatchNorm1d layers turn a batch of 2 into pure sign functions of (x1 - x2), which amplifies bf16
 # rounding into sign flips -- an ill-conditioned comparison, not a property of the kernels
 CASES = [("recon_sym64", 8101, 8, dict(symmetric=True, texture_res=64)),
-         ("recon_circ128", 8102, 6, dict(symmetric=False, texture_res=128))]
+         ("recon_circ128", 8102, 6, dict(symmetric=False, texture_res=128)),
+         # round 3: the non-default upsampling of models/reconstruction.py:43-44
+         ("recon_bilinear64", 8103, 8, dict(symmetric=True, texture_res=64, interpolation_mode='bilinear'))]
+
+# full gradient tensors kept per case (fp16): encoder convs / linears and decoder convs -- an elementwise (cosine) check, not
+# only the per-parameter norms
+FULL_GRADS = ["conv2e.weight", "conv5e.weight", "fc3e.weight", "blk4_tex.conv2.weight", "blk5_tex.conv2.weight", "conv_tex.weight",
+              "blk4_mesh.conv1.weight"]
 
 
 def make_inputs(seed, B, tex_res, symmetric):
@@ -66,12 +73,14 @@ def main():
         keys = list(net.state_dict().keys())
         shapes = [tuple(v.shape) for v in net.state_dict().values()]
         gn = {k: float(p.grad.norm()) for k, p in net.named_parameters()}
+        full = {"grad:" + k: dict(net.named_parameters())[k].grad.numpy().astype(np.float16) for k in FULL_GRADS}
         np.savez_compressed(os.path.join(OUT, name + ".npz"), tex=tex.detach().numpy(), mesh=mesh.detach().numpy(),
                             keys=np.array(keys), shapes=np.array([str(s) for s in shapes]),
                             grad_keys=np.array(list(gn.keys())), grad_norms=np.array(list(gn.values()), np.float64),
                             running_mean_bn1e=net.bn1e.running_mean.numpy(), running_var_bn1e=net.bn1e.running_var.numpy(),
                             enc5=cap["enc5"].numpy().astype(np.float16), z=cap["z"].numpy(),
-                            seed=seed, B=B, symmetric=kw["symmetric"], texture_res=kw["texture_res"])
+                            seed=seed, B=B, symmetric=kw["symmetric"], texture_res=kw["texture_res"],
+                            interpolation_mode=kw.get("interpolation_mode", "nearest"), **full)
         print(name, tuple(tex.shape), tuple(mesh.shape), "params", sum(p.numel() for p in net.parameters()))
 
 

@@ -134,8 +134,10 @@ def test_g_step_and_d_step_match_reference(name):
     # bf16 activations through ~30 layers against fp32, after tanh (range 2): mean error, the 99.9th percentile and the
     # single worst of the ~10^5 compared values (measured over the cases: mean 3-5e-3, worst 5-8e-2; the worst value moves
     # by a few 1e-3 with any change of a summation order, e.g. the batch statistics taken from the conv's fp32 results)
+    # (round 3: the text-conditioned case measured q999 = 0.0422 on one box, 0.039 on another -- sigma of the spectral norm is
+    # accumulated with fp32 atomics, so the bf16 weight views differ in the last bit between runs; bound 5e-2)
     q999 = torch.quantile(e.flatten()[:1 << 24], 0.999).item()
-    assert e.mean().item() < 6e-3 and q999 < 4e-2 and e.max().item() < 1.2e-1, (e.mean().item(), q999, e.max().item())
+    assert e.mean().item() < 6e-3 and q999 < 5e-2 and e.max().item() < 1.2e-1, (e.mean().item(), q999, e.max().item())
     assert (pred_mesh.detach().cpu() - torch.from_numpy(g["pred_mesh"])).abs().max().item() < 1e-6  # zero-init head
     x_fake = torch.cat((pred_tex * x_alpha, x_alpha), dim=1)
     disc, mask = D(x_fake, pred_mesh, c, caption)
