@@ -233,9 +233,11 @@ def main():
     ap.add_argument("--points", type=int, default=2048)
     ap.add_argument("--grid", type=int, default=128)
     ap.add_argument("--res", type=int, default=256, help="texture resolution of the GAN half")
-    ap.add_argument("--workload", choices=["both", "proj", "gan", "collectives"], default="both",
+    ap.add_argument("--workload", choices=["both", "proj", "gan", "collectives", "recon"], default="both",
                     help="collectives: only the gradient all-reduce of the GAN half on a 61 MB flat buffer (launch-path test; "
-                         "the one workload that also runs with --backend gloo on CPU)")
+                         "the one workload that also runs with --backend gloo on CPU); recon: the mesh-estimation training step of "
+                         "run_reconstruction.py:409-445 (ReconstructionNetwork -> template deformation -> pose -> DIB-R render -> MSE + "
+                         "flat loss, Adam) -- SURVEY 8f rows 1, 2, 4 composed; not part of the headline metric")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI (the product path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
@@ -272,6 +274,8 @@ def main():
     if args.workload == "collectives":
         return bench_collectives(args, par, dist, rank, world, dev)
     pkg = importlib.import_module("2dimageto3dmodel_amd")
+    if args.workload == "recon":
+        return bench_recon(args, pkg, par, dist, rank, world, dev)
     train = importlib.import_module("2dimageto3dmodel_amd.train")
 
     B, N, S, R = (args.batch // world if args.scaling == "strong" else args.batch), args.points, args.grid, args.res
@@ -431,6 +435,79 @@ def main():
             if do_g:
                 out["cpu_baseline_gan"] = cpu_baseline_gan(trainer, R)
         print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_recon(args, pkg, par, dist, rank, world, dev):
+    """The composed mesh-estimation step (2dimageto3dmodel_amd/recon_train.py): per-GPU batch --batch (the script's default is
+    50), 256 x 256 input and render, texture --res (script default 128), learnable per-image pose offsets.  Data-parallel
+    gradient averaging of this path is not wired (single-GPU workload: N > 1 runs N independent replicas)."""
+    import tempfile
+    rt = importlib.import_module("2dimageto3dmodel_amd.recon_train")
+    mesh_mod = importlib.import_module("2dimageto3dmodel_amd.mesh")
+    B = args.batch // world if args.scaling == "strong" else args.batch
+    R = args.res if args.res in (64, 128, 256) else 128
+    with tempfile.TemporaryDirectory() as tmp:
+        tpl = mesh_mod.MeshTemplate(mesh_mod.write_uv_sphere_obj(os.path.join(tmp, "uvsphere_16rings.obj")), is_symmetric=True, device=dev)
+    torch.manual_seed(4321)
+    n_data = 4096
+    tr = rt.ReconTrainer(tpl, dataset_size=n_data, texture_resolution=R, device=dev)
+    with torch.no_grad():   # a non-degenerate mesh (the head is zero-initialised) so that every kernel has real work
+        tr.generator.conv_mesh.weight.normal_(0, 0.005)
+    tr.train()
+    g = torch.Generator().manual_seed(99 + rank)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 256), torch.linspace(-1, 1, 256), indexing="ij")
+    alpha = ((xx ** 2 + yy ** 2) < 0.25).float().expand(B, 1, -1, -1)
+    X = torch.cat((torch.tanh(torch.nn.functional.interpolate(torch.randn(B, 3, 8, 8, generator=g), size=(256, 256), mode="bilinear")) * alpha,
+                   alpha), dim=1).to(dev)
+    gt_scale = (0.5 + 0.15 * torch.rand(B, 1, generator=g)).to(dev)
+    gt_translation = torch.cat((0.2 * (torch.rand(B, 2, generator=g) - 0.5), torch.zeros(B, 1)), dim=1).to(dev)
+    q = torch.randn(B, 4, generator=g) * torch.tensor([0.3, 1.0, 0.3, 0.3]) + torch.tensor([1.0, 0.0, 0.0, 0.0])
+    gt_rot = (q / q.norm(dim=1, keepdim=True)).to(dev)
+    gt_idx = torch.randint(0, 2 * n_data, (B,), generator=g).to(dev)
+    last = {}
+
+    def step():
+        last.update(tr.iteration(X, gt_scale, gt_translation, gt_rot, gt_idx))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+    pkg._lib.enable_kernel_timers(True)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    kt = pkg._lib.collect_kernel_timers()
+    pkg._lib.enable_kernel_timers(False)
+    if rank == 0:
+        conv_ms = sum(v[1] for k, v in kt.items() if k.startswith("k_conv") or k.startswith("k_wgrad"))
+        conv_fl = sum(v[2] for k, v in kt.items() if k.startswith("k_conv") or k.startswith("k_wgrad"))
+        print(json.dumps({
+            "metric": "mesh-estimation train-step samples/sec (run_reconstruction.py:409-445: network + template + pose + DIB-R render + losses + Adam)",
+            "value": world * B * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"ReconstructionNetwork(texture {R}) -> 482-vertex template -> pose (+ learnable offsets) -> 256x256 DIB-R "
+                                   f"render -> MSE + flat loss, batch {B}/GPU", "per_gpu_batch": B, "parallelism": f"replicas x{world}",
+                       "losses": {k: float(v) for k, v in last.items()}},
+            "kernel_ms_per_step": sum(v[1] for v in kt.values()) / args.steps,
+            "all_conv_tflops": (conv_fl / (conv_ms * 1e-3) / 1e12) if conv_ms else None,
+            "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(kt.items(), key=lambda kv: -kv[1][1])}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,152 @@
+"""Generates tests/golden/recon_step.npz: ONE iteration of the mesh-estimation training loop of code/run_reconstruction.py
+(:409-445) on CPU in fp32, composed of the REFERENCE's own pieces wherever they can run here:
+
+    python oracle/gen_golden_recon_step.py        (build container only; needs /root/reference; ~3 min, < 8 GB)
+
+  pinned by executed reference code : ReconstructionNetwork.forward / DatasetParams.forward (models/reconstruction.py),
+      MeshTemplate.get_vertex_positions / compute_normals / adjust_uv_and_texture (rendering/mesh_template.py, called on an
+      object whose template fields come from 2dimageto3dmodel_amd.mesh.MeshTemplate as in gen_golden_mesh.py; `kaolin` stubbed
+      at import only), rendering.utils.qrot, utils.losses.loss_flat, nn.MSELoss;
+  restated (run_reconstruction.py parses argv and opens datasets at import): transform_vertices (:237-252), mean_iou
+      (:225-231), the loss composition (:431-441) -- a dozen lines below, each citing its source;
+  UNPINNED : the rasteriser + fragment shader behind Renderer.forward = oracle/raster_ref.py (Kaolin's DIB-R is not available),
+      rendered and differentiated in bands of 8 pixel rows (the per-pixel brute force holds B x rows x W x F intermediates).
+
+The fixture keeps inputs that cannot be re-drawn from the seed (none: everything is seeded), the step's intermediate results
+(texture, displacement map, vertices, rendered image + silhouette at stride 2), the three losses, the IoU, the norms of all
+parameter gradients and FULL gradient tensors of a few network parameters and of the dataset parameters.
+"""
+import argparse
+import contextlib
+import importlib
+import io
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference/code"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+SEED, B, N_DATA, TEX_RES, RES = 9101, 8, 10, 64, 256
+FULL_GRADS = ["conv2e.weight", "conv5e.weight", "blk5_tex.conv2.weight", "conv_tex.weight", "conv_mesh.weight", "blk4_mesh.conv2.weight"]
+
+
+def make_inputs(seed=SEED, B=B):
+    """synthetic loader batch (run_reconstruction.py:411): image + mask in [-1,1] x {0,1}, poses, dataset indices (two mirrored)"""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, RES), torch.linspace(-1, 1, RES), indexing="ij")
+    cx, cy, rad = 0.2 * (torch.rand(B, 1, 1, generator=g) - 0.5), 0.2 * (torch.rand(B, 1, 1, generator=g) - 0.5), 0.45 + 0.1 * torch.rand(B, 1, 1, generator=g)
+    alpha = (((xx - cx) ** 2 + (yy - cy) ** 2) < rad ** 2).float().unsqueeze(1)
+    low = torch.nn.functional.interpolate(torch.randn(B, 3, 8, 8, generator=g), size=(RES, RES), mode="bilinear", align_corners=False)
+    X = torch.cat((torch.tanh(low) * alpha, alpha), dim=1)
+    gt_scale = 0.5 + 0.15 * torch.rand(B, 1, generator=g)
+    gt_translation = torch.cat((0.2 * (torch.rand(B, 2, generator=g) - 0.5), torch.zeros(B, 1)), dim=1)
+    q = torch.randn(B, 4, generator=g) * torch.tensor([0.3, 1.0, 0.3, 0.3]) + torch.tensor([1.0, 0.0, 0.0, 0.0])
+    gt_rot = q / q.norm(dim=1, keepdim=True)
+    gt_idx = torch.tensor([1, N_DATA + 2, 5, 2 * N_DATA - 1, 0, 7, N_DATA + 7, 3])[:B]
+    return X, gt_scale, gt_translation, gt_rot, gt_idx
+
+
+def init_side_params(net, dp, seed=SEED):
+    """conv_mesh is zero-initialised in the reference (models/reconstruction.py:97-99) and the dataset offsets start at 0 / 1:
+    both sides overwrite them from manual_seed(seed + 1) so that the mesh deforms and every gradient path carries signal"""
+    torch.manual_seed(seed + 1)
+    with torch.no_grad():
+        net.conv_mesh.weight.normal_(0, 0.005)
+        net.conv_mesh.bias.normal_(0, 0.005)
+        dp.ds_translation.normal_(0, 0.03)
+        dp.ds_scale.normal_(0, 0.03)
+        dp.ds_z0.normal_(1.0, 0.1)
+
+
+def main():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, ROOT)
+    from oracle import raster_ref as rr
+    mesh_mod = importlib.import_module("2dimageto3dmodel_amd.mesh")
+    sys.path.insert(0, REF)
+    sys.modules.setdefault("kaolin", types.ModuleType("kaolin"))   # import-time stub; nothing of it is called
+    with contextlib.redirect_stdout(io.StringIO()):
+        from models.reconstruction import DatasetParams, ReconstructionNetwork
+        from rendering.mesh_template import MeshTemplate as RefTemplate
+        from rendering.utils import qrot
+        from utils.losses import loss_flat
+    torch.set_num_threads(8)
+    with tempfile.TemporaryDirectory() as tmp:
+        mine = mesh_mod.MeshTemplate(mesh_mod.write_uv_sphere_obj(os.path.join(tmp, "uvsphere_16rings.obj")), is_symmetric=True,
+                                     device="cpu")
+    tpl = object.__new__(RefTemplate)
+    for k in ("mesh", "topo_map", "nonneg_topo_map", "nonneg_indices", "neg_indices", "pos_indices", "symmetry_mask", "tangent_map",
+              "nonneg_tangent_map", "is_symmetric"):
+        setattr(tpl, k, getattr(mine, k))
+
+    args = argparse.Namespace(optimize_deltas=True, optimize_z0=True, mesh_regularization=0.00005)
+    torch.manual_seed(SEED)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ReconstructionNetwork(symmetric=True, texture_res=TEX_RES, mesh_res=32)       # run_reconstruction.py:332-335
+    dp = DatasetParams(args, N_DATA)                                                          # :340
+    init_side_params(net, dp)
+    net.train()
+    X_real, gt_scale, gt_translation, gt_rot, gt_idx = make_inputs()
+    criterion = torch.nn.MSELoss()                                                            # :346-351
+    flat_warmup = 10                                                                          # :355
+
+    pred_tex, mesh_map = net(X_real)                                                          # :421
+    raw_vtx = tpl.get_vertex_positions(mesh_map)                                              # :422
+    # ---- transform_vertices, run_reconstruction.py:237-252 (optimize_deltas and optimize_z0 on)
+    translation_delta, scale_delta = dp(gt_idx, 'deltas')
+    vtx = qrot(gt_rot, (gt_scale + scale_delta).unsqueeze(-1) * raw_vtx) + (gt_translation + translation_delta).unsqueeze(1)
+    vtx = vtx * torch.Tensor([1, -1, -1])
+    z0 = dp(gt_idx, 'z0').unsqueeze(-1)
+    z = vtx[:, :, 2:]
+    vtx = torch.cat((vtx[:, :, :2] * ((z0 + z / 2) / (z0 - z / 2)), z), dim=2)
+    # ---- forward_renderer (mesh_template.py:172-186) on the oracle renderer, in row bands, differentiated band by band:
+    # the MSE over the whole image is a sum over bands, so d loss / d (vtx, texture) accumulates linearly
+    flat_loss = loss_flat(tpl.mesh, tpl.compute_normals(raw_vtx))                            # :432
+    v_leaf, t_leaf = vtx.detach().requires_grad_(), pred_tex.detach().requires_grad_()
+    uvs, tex_in = tpl.adjust_uv_and_texture(t_leaf)
+    X_fake = torch.empty(B, 4, RES, RES)
+    recon_sum = 0.0
+    BAND = 8
+    for r0 in range(0, RES, BAND):
+        uvs, tex_in = tpl.adjust_uv_and_texture(t_leaf)
+        img, alpha, _ = rr.renderer_forward_ref([v_leaf, tpl.mesh.faces], uvs, tex_in, RES, RES, ft_fx3=tpl.mesh.face_textures,
+                                                rows=(r0, r0 + BAND))
+        band = torch.cat((img, alpha), dim=3).permute(0, 3, 1, 2)                             # :429
+        part = ((band - X_real[:, :, r0:r0 + BAND]) ** 2).sum() / X_real.numel()             # nn.MSELoss (mean), this band's share
+        part.backward()
+        recon_sum += float(part)
+        X_fake[:, :, r0:r0 + BAND] = band.detach()
+        print(f"band {r0}", end="\r", flush=True)
+    recon_loss = criterion(X_fake, X_real)                                                    # :431
+    assert abs(float(recon_loss) - recon_sum) < 1e-6 * max(1.0, recon_sum)
+    alpha_pred, alpha_real = X_fake[:, 3] > 0.5, X_real[:, 3] > 0.5                           # mean_iou, :225-231
+    miou = torch.mean((alpha_pred & alpha_real).float().sum(dim=[1, 2]) / (alpha_pred | alpha_real).float().sum(dim=[1, 2]))
+    flat_coeff = args.mesh_regularization * flat_warmup                                       # :439
+    loss = float(recon_loss) + flat_coeff * float(flat_loss)                                  # :441
+    # second stage of the backward: through the template, the pose transform, the dataset parameters and the network
+    torch.autograd.backward([vtx, pred_tex, flat_coeff * flat_loss], [v_leaf.grad, t_leaf.grad, torch.ones(())])
+
+    named = dict(net.named_parameters())
+    rec = dict(seed=SEED, B=B, n_data=N_DATA, texture_res=TEX_RES, res=RES,
+               pred_tex=pred_tex.detach().numpy().astype(np.float16), mesh_map=mesh_map.detach().numpy(),
+               raw_vtx=raw_vtx.detach().numpy(), vtx=vtx.detach().numpy(), x_fake_s2=X_fake[:, :, ::2, ::2].numpy().astype(np.float16),
+               recon_loss=float(recon_loss), flat_loss=float(flat_loss), loss=loss, miou=float(miou), flat_coeff=flat_coeff,
+               d_vtx=v_leaf.grad.numpy(), d_tex=t_leaf.grad.numpy().astype(np.float32),
+               grad_keys=np.array(list(named.keys())), grad_norms=np.array([float(p.grad.norm()) for p in named.values()], np.float64),
+               g_ds_translation=dp.ds_translation.grad.numpy(), g_ds_scale=dp.ds_scale.grad.numpy(), g_ds_z0=dp.ds_z0.grad.numpy())
+    for k in FULL_GRADS:
+        rec["grad:" + k] = named[k].grad.numpy().astype(np.float16)
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, "recon_step.npz")
+    np.savez_compressed(path, **rec)
+    print(f"recon_step: recon {float(recon_loss):.5f} flat {float(flat_loss):.5f} total {loss:.5f} miou {float(miou):.4f} "
+          f"covered {float((X_fake[:, 3] > 0.5).float().mean()):.3f} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -34,13 +34,18 @@ def _seg_dist2(p, a, b):
 
 
 def linear_rasterizer_ref(height, width, points3d_bxfx9, points2d_bxfx6, normalz_bxfx1, attr_bxfxd3, expand=0.02, knum=30,
-                          delta=7000.0):
-    """-> imfeat [B,H,W,D], improb [B,H,W,1], imidx [B,H,W] (covering face or -1), imwei [B,H,W,3]"""
+                          delta=7000.0, rows=None):
+    """-> imfeat [B,H,W,D], improb [B,H,W,1], imidx [B,H,W] (covering face or -1), imwei [B,H,W,3].
+    rows = (r0, r1): only the pixel rows r0 .. r1-1 of the height x width image (outputs [B,r1-r0,W,...]) -- the per-pixel
+    brute force holds B x rows x W x F intermediates, so large images are rendered (and differentiated) in row bands"""
     B, F, _ = points2d_bxfx6.shape
     D = attr_bxfxd3.shape[2] // 3
     dt, dev = points2d_bxfx6.dtype, points2d_bxfx6.device
     xs = (2 * torch.arange(width, dtype=dt, device=dev) + 1 - width) / width
     ys = (height - 2 * torch.arange(height, dtype=dt, device=dev) - 1) / height
+    if rows is not None:
+        ys = ys[rows[0]:rows[1]]
+    height = ys.shape[0]   # (from here on: the number of rows rendered)
     P = torch.stack((xs[None, :].expand(height, width), ys[:, None].expand(height, width)), dim=-1)   # [H,W,2]
     p = P[None, :, :, None, :]                                                                        # [1,H,W,1,2]
     v = points2d_bxfx6.view(B, 1, 1, F, 3, 2)
@@ -90,7 +95,7 @@ def ortho_projection_ref(points_bxpx3, faces_fx3):
 
 
 def renderer_forward_ref(points, uv_bxpx2, texture_bx3xthxtw, height, width, ft_fx3=None, background_image=None,
-                         return_hardmask=False):
+                         return_hardmask=False, rows=None):
     """Renderer.forward (renderer.py:39-77) + fragmentshader (fragment_shader.py:6-37) on the rasteriser above"""
     import torch.nn.functional as F
     points_bxpx3, faces_fx3 = points
@@ -102,7 +107,7 @@ def renderer_forward_ref(points, uv_bxpx2, texture_bx3xthxtw, height, width, ft_
     c = [uv_bxpx2[:, ft_fx3[:, k], :] for k in range(3)]
     one = torch.ones_like(c[0][:, :, :1])
     uv9 = torch.cat((c[0], one, c[1], one, c[2], one), dim=2)
-    imfeat, improb, _, _ = linear_rasterizer_ref(height, width, points3d, points2d, normalz, uv9)
+    imfeat, improb, _, _ = linear_rasterizer_ref(height, width, points3d, points2d, normalz, uv9, rows=rows)
     tc, hard = imfeat[..., :2], imfeat[..., 2:3]
     grid = (tc * 2 - 1) * tc.new_tensor([1.0, -1.0])
     tex = F.grid_sample(texture_bx3xthxtw, grid, mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
