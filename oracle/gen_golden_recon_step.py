@@ -55,12 +55,10 @@ def init_side_params(net, dp, seed=SEED):
     """conv_mesh is zero-initialised in the reference (models/reconstruction.py:97-99) and the dataset offsets start at 0 / 1:
     both sides overwrite them from manual_seed(seed + 1) so that the mesh deforms and every gradient path carries signal"""
     torch.manual_seed(seed + 1)
-    with torch.no_grad():
-        net.conv_mesh.weight.normal_(0, 0.005)
-        net.conv_mesh.bias.normal_(0, 0.005)
-        dp.ds_translation.normal_(0, 0.03)
-        dp.ds_scale.normal_(0, 0.03)
-        dp.ds_z0.normal_(1.0, 0.1)
+    with torch.no_grad():   # drawn on the CPU generator whatever device the parameters live on (same values on both sides)
+        for p, mean, std in ((net.conv_mesh.weight, 0.0, 0.005), (net.conv_mesh.bias, 0.0, 0.005), (dp.ds_translation, 0.0, 0.03),
+                             (dp.ds_scale, 0.0, 0.03), (dp.ds_z0, 1.0, 0.1)):
+            p.copy_(torch.empty(p.shape).normal_(mean, std))
 
 
 def main():
