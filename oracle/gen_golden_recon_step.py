@@ -93,7 +93,19 @@ def main():
     criterion = torch.nn.MSELoss()                                                            # :346-351
     flat_warmup = 10                                                                          # :355
 
+    # gradients INSIDE the mesh branch (localise a disagreement): d loss / d (blk4_mesh output) and / d (its input), by hooks
+    cap = {}
+    # (tensor hooks: the in-place ReLU the network applies to the block's output rules out module backward hooks; the hook
+    # registered before that ReLU sees the gradient of the pre-ReLU value; the input is cloned -- numerically a no-op -- so that
+    # its gradient is the mesh branch's share only, bb also feeds the texture branch)
+    def _pre(m, inp):
+        x = inp[0].clone()
+        x.register_hook(lambda gr: cap.update(d_blk4_mesh_in=gr.detach().clone()))
+        return (x,)
+    hk = net.blk4_mesh.register_forward_pre_hook(_pre)
+    hk2 = net.blk4_mesh.register_forward_hook(lambda m, inp, out: out.register_hook(lambda gr: cap.update(d_blk4_mesh_out=gr.detach().clone())) and None)
     pred_tex, mesh_map = net(X_real)                                                          # :421
+    mesh_map.register_hook(lambda gr: cap.update(d_mesh_map=gr.detach().clone()))
     raw_vtx = tpl.get_vertex_positions(mesh_map)                                              # :422
     # ---- transform_vertices, run_reconstruction.py:237-252 (optimize_deltas and optimize_z0 on)
     translation_delta, scale_delta = dp(gt_idx, 'deltas')
@@ -136,7 +148,10 @@ def main():
                recon_loss=float(recon_loss), flat_loss=float(flat_loss), loss=loss, miou=float(miou), flat_coeff=flat_coeff,
                d_vtx=v_leaf.grad.numpy(), d_tex=t_leaf.grad.numpy().astype(np.float32),
                grad_keys=np.array(list(named.keys())), grad_norms=np.array([float(p.grad.norm()) for p in named.values()], np.float64),
-               g_ds_translation=dp.ds_translation.grad.numpy(), g_ds_scale=dp.ds_scale.grad.numpy(), g_ds_z0=dp.ds_z0.grad.numpy())
+               g_ds_translation=dp.ds_translation.grad.numpy(), g_ds_scale=dp.ds_scale.grad.numpy(), g_ds_z0=dp.ds_z0.grad.numpy(),
+               d_mesh_map=cap["d_mesh_map"].numpy(), d_blk4_mesh_out=cap["d_blk4_mesh_out"].numpy().astype(np.float32),
+               d_blk4_mesh_in=cap["d_blk4_mesh_in"].numpy().astype(np.float16))
+    hk.remove(); hk2.remove()
     for k in FULL_GRADS:
         rec["grad:" + k] = named[k].grad.numpy().astype(np.float16)
     os.makedirs(OUT, exist_ok=True)
