@@ -100,6 +100,7 @@ SIGNATURES = {
     "m355_affine_act_bwd_partial": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "m355_sn_power_iter": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_float, _P]),
     "m355_sn_wgrad_finish": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "m355_sn_wgrad_finish_batched": (c_int, [_P, c_int, _P]),
     "m355_bn_finalize": (c_int, [_P, c_int, c_float, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P,
                                  _P, _P]),
     "m355_bn_bwd_finalize": (c_int, [_P, c_int, c_float, _P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P,
@@ -112,6 +113,15 @@ class ConvDesc(ctypes.Structure):
     """m355_conv_desc (include/m355.h)"""
     _fields_ = [(n, c_int) for n in ("N", "H", "W", "Cin", "Cout", "kh", "kw", "stride", "pad_h", "pad_w",
                                       "pad_w_mode", "upsample")]
+
+
+class SnFinEntry(ctypes.Structure):
+    """m355_snfin_entry (include/m355.h)"""
+    _fields_ = [(n, c_void_p) for n in ("g_khwc", "w_orig", "u", "v", "sigma", "part", "dw")] + \
+               [(n, c_int) for n in ("Cout", "Cin", "CinP", "kh", "kw", "pad_")]
+
+
+SNFIN_MAX = 24
 
 
 def lib():

@@ -196,10 +196,60 @@ def conv_wgrad(d, x, dy, cin_real=None, raw=False, dbias=None, arena=False):
     return dw if raw else dw.permute(0, 3, 1, 2)
 
 
+class _DeferredFinish:
+    """weight-gradient epilogues queued inside `deferred_wgrad_finish()`: (entry fields, tensors kept alive)"""
+    active = False
+    items = []
+    part = {}      # device -> scratch [SNFIN_MAX * 64] fp32
+
+
+class deferred_wgrad_finish:
+    """Context manager around a backward pass whose parameter gradients nobody reads before the pass is over (GanTrainer:
+    zero_grad(set_to_none=True) -> backward -> reducer -> optimiser): every wgrad_finish() of the pass returns its output tensor
+    at once and the arithmetic of ALL of them runs in two launches at exit (m355_sn_wgrad_finish_batched) instead of two per
+    layer.  The raw gradients are slices of the per-pass WgradArena, valid until the next backward pass.  NOT for callers that
+    accumulate into existing .grad tensors or read gradients from hooks during the pass: autograd would read the output before
+    it is written."""
+
+    def __enter__(self):
+        self.prev, _DeferredFinish.active = _DeferredFinish.active, True
+        return self
+
+    def __exit__(self, *exc):
+        _DeferredFinish.active = self.prev
+        if not self.prev:
+            flush_wgrad_finish(discard=exc[0] is not None)
+        return False
+
+
+def flush_wgrad_finish(discard=False):
+    items, _DeferredFinish.items = _DeferredFinish.items, []
+    if discard or not items:
+        return
+    for i0 in range(0, len(items), _lib.SNFIN_MAX):
+        chunk = items[i0:i0 + _lib.SNFIN_MAX]
+        arr = (_lib.SnFinEntry * len(chunk))()
+        dev = chunk[0][1][0].device
+        part = _DeferredFinish.part.get(dev)
+        if part is None:
+            part = _DeferredFinish.part[dev] = torch.empty(_lib.SNFIN_MAX * 64, dtype=torch.float32, device=dev)
+        for k, (f, _keep) in enumerate(chunk):
+            e = arr[k]
+            e.g_khwc, e.w_orig, e.u, e.v, e.sigma, e.dw = f[0], f[1], f[2], f[3], f[4], f[5]
+            e.part = part.data_ptr() + 4 * 64 * k if f[4] else None
+            e.Cout, e.Cin, e.CinP, e.kh, e.kw = f[6:11]
+        launch("sn_wgrad_finish_batched", arr, len(chunk), stream())
+
+
 def wgrad_finish(d, g_khwc, cin_real, w_orig=None, u=None, v=None, sigma=None):
     """[Cout][kh][kw][CinP] wgrad output -> the parameter's gradient [Cout][cin_real][kh][kw]; with spectral-norm
-    state, the gradient with respect to weight_orig (through sigma)"""
+    state, the gradient with respect to weight_orig (through sigma).  Inside `deferred_wgrad_finish()` the returned tensor is
+    filled when the context exits."""
     dw = torch.empty((d.Cout, cin_real, d.kh, d.kw), dtype=torch.float32, device=g_khwc.device)
+    if _DeferredFinish.active:
+        _DeferredFinish.items.append(((ptr(g_khwc), ptr(w_orig), ptr(u), ptr(v), ptr(sigma), ptr(dw), d.Cout, cin_real, d.Cin,
+                                       d.kh, d.kw), (g_khwc, w_orig, u, v, sigma, dw)))
+        return dw
     part = torch.empty((256,), dtype=torch.float32, device=g_khwc.device) if sigma is not None else None
     launch("sn_wgrad_finish", ptr(g_khwc), ptr(w_orig), ptr(u), ptr(v), ptr(sigma), ptr(part), ptr(dw), d.Cout, cin_real,
            d.Cin, d.kh, d.kw, stream())

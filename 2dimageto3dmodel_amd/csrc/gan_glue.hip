@@ -390,6 +390,82 @@ extern "C" int m355_sn_wgrad_finish(const float *g_khwc, const float *w_orig, co
     return check_launch("sn_wgrad_finish");
 }
 
+// All weight-gradient epilogues of ONE backward pass in two launches (was two launches per layer, 76 per GAN cycle at ~7 us each:
+// latency, not bytes).  The entries travel as a kernel argument (<= 24 layers x 72 bytes): no device table to upload, capturable.
+struct SnFinBatch {
+    m355_snfin_entry e[M355_SNFIN_MAX];
+};
+
+__global__ __launch_bounds__(256) void k_sn_bwd_dot_batched(SnFinBatch b)
+{
+    const m355_snfin_entry &e = b.e[blockIdx.y];
+    if (!e.sigma) return;
+    __shared__ float red[4];
+    const int KK = e.kh * e.kw;
+    const size_t total = (size_t)e.Cout * e.Cin * KK;
+    float acc = 0.0f;
+    for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int tap = (int)(idx % KK);
+        const size_t r = idx / KK;
+        const int ci = (int)(r % e.Cin), co = (int)(r / e.Cin);
+        acc += e.w_orig[idx] * e.g_khwc[((size_t)co * KK + tap) * e.CinP + ci];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) e.part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void k_sn_bwd_apply_batched(SnFinBatch b, int npart)
+{
+    const m355_snfin_entry &e = b.e[blockIdx.y];
+    __shared__ float sh;
+    float inv = 1.0f, coef = 0.0f;
+    if (e.sigma) {
+        if (threadIdx.x < 64) {
+            float d = 0.0f;
+            for (int i = threadIdx.x; i < npart; i += 64) d += e.part[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+            if (threadIdx.x == 0) sh = d;
+        }
+        __syncthreads();
+        inv = 1.0f / e.sigma[0];
+        coef = sh * inv * inv;
+    }
+    const int KK = e.kh * e.kw;
+    const size_t total = (size_t)e.Cout * e.Cin * KK;
+    for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int tap = (int)(idx % KK);
+        const size_t r = idx / KK;
+        const int ci = (int)(r % e.Cin), co = (int)(r / e.Cin);
+        float val = e.g_khwc[((size_t)co * KK + tap) * e.CinP + ci] * inv;
+        if (e.sigma) val -= coef * e.u[co] * e.v[(size_t)ci * KK + tap];
+        e.dw[idx] = val;
+    }
+}
+
+extern "C" int m355_sn_wgrad_finish_batched(const m355_snfin_entry *entries_host, int L, void *stream)
+{
+    M355_REQUIRE(entries_host && L > 0 && L <= M355_SNFIN_MAX, "sn_wgrad_finish_batched: 1..%d layers per call", M355_SNFIN_MAX);
+    SnFinBatch b;
+    bool any_sn = false;
+    for (int i = 0; i < L; ++i) {
+        const m355_snfin_entry &e = entries_host[i];
+        M355_REQUIRE(e.g_khwc && e.dw && e.Cout > 0 && e.Cin > 0 && e.CinP >= e.Cin && e.kh > 0 && e.kw > 0,
+                     "sn_wgrad_finish_batched: bad entry %d", i);
+        M355_REQUIRE(!e.sigma || (e.w_orig && e.u && e.v && e.part), "sn_wgrad_finish_batched: spectral-norm state missing in entry %d", i);
+        b.e[i] = e;
+        any_sn = any_sn || e.sigma;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int NPART = 64;   // partial dot products per layer (part[64] each)
+    if (any_sn) hipLaunchKernelGGL(k_sn_bwd_dot_batched, dim3(NPART, L), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(k_sn_bwd_apply_batched, dim3(256, L), dim3(256), 0, st, b, NPART);
+    return check_launch("sn_wgrad_finish_batched");
+}
+
 extern "C" int m355_bn_finalize(const float *part, int nblk, float count, const float *count_dev, const float *gamma, const float *beta, int gstride,
                                 int N, int C, float eps, float momentum, float *running_mean, float *running_var,
                                 float *mean, float *rstd, float *a, float *b, void *stream)

@@ -8,6 +8,7 @@ import warnings
 
 import torch
 
+from . import conv as C
 from . import gan as G
 from . import gan_ops as O
 from . import parallel as P
@@ -171,9 +172,11 @@ class GanTrainer(torch.nn.Module):
                     from . import mesh as M
                     vtx = self.mesh_template.get_vertex_positions(pred_mesh)
                     flat = M.loss_flat(self.mesh_template.mesh, self.mesh_template.compute_normals(vtx))
-                    (loss + self.mesh_regularization * flat).backward()
+                    with C.deferred_wgrad_finish():   # (gradients are first read by the reducer / optimiser below)
+                        (loss + self.mesh_regularization * flat).backward()
                 else:
-                    loss.backward()
+                    with C.deferred_wgrad_finish():
+                        loss.backward()
             finally:
                 for p in d_params:
                     p.requires_grad_(True)
@@ -187,7 +190,8 @@ class GanTrainer(torch.nn.Module):
             self.optimizer_d.zero_grad(set_to_none=True)
             loss_fake, loss_real, _, _ = self('d', X_tex, X_alpha, X_mesh, C, caption, noise)
             loss_fake, loss_real = loss_fake.mean(), loss_real.mean()
-            (loss_fake + loss_real).backward()
+            with C.deferred_wgrad_finish():
+                (loss_fake + loss_real).backward()
             self.reduce_d()
             self.optimizer_d.step()
             out = {"d_fake": loss_fake.detach(), "d_real": loss_real.detach()}

@@ -273,6 +273,17 @@ int m355_sn_power_iter(const m355_sn_layer *table, int L, int max_rows, int max_
  *      part: scratch of 256 floats. */
 int m355_sn_wgrad_finish(const float *g_khwc, const float *w_orig, const float *u, const float *v, const float *sigma,
                          float *part, float *dw, int Cout, int Cin, int CinP, int kh, int kw, void *stream);
+/*      the same for up to M355_SNFIN_MAX layers of one backward pass in two launches (the per-layer form costs two launches of
+ *      ~7 us per nn.Conv2d: 76 per training cycle).  entries_host: HOST array, copied into the kernel arguments (device
+ *      pointers inside); part: 64 floats of scratch per entry with sigma. */
+#define M355_SNFIN_MAX 24
+typedef struct {
+    const float *g_khwc, *w_orig, *u, *v, *sigma;
+    float *part, *dw;
+    int Cout, Cin, CinP, kh, kw;
+    int pad_;
+} m355_snfin_entry;
+int m355_sn_wgrad_finish_batched(const m355_snfin_entry *entries_host, int L, void *stream);
 
 /* ---- G3  conditional batch norm coefficient algebra (gan.py:264-286) in one launch each way.
  *      forward:  part[nblk][2][C] (sum, sum of squares over `count` pixels) -> mean[C], rstd[C] (biased variance,

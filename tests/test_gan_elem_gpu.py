@@ -109,6 +109,25 @@ def test_spectral_norm_group_matches_torch(pkg):
         assert (got - wr.grad).abs().max().item() < 2e-4 * wr.grad.abs().max().item()
         plain = conv.wgrad_finish(d, g_khwc, cin)
         assert torch.equal(plain, g_khwc[..., :cin].permute(0, 3, 1, 2).contiguous())
+    # the batched form (m355_sn_wgrad_finish_batched: every layer of a backward pass in two launches, run when the
+    # deferred_wgrad_finish() context exits): same results up to the summation order of <g, w_orig> (64 partials per layer)
+    cases, want = [], []
+    for c, st, (w, u, v) in zip(convs, states, ref):
+        cout, cin, kh, kw = w.shape
+        cinp = (cin + 7) // 8 * 8
+        g_khwc = torch.randn(cout, kh, kw, cinp, device=DEV)
+        d = conv.make_desc(1, 8, 8, cinp, cout, kh, kw, 1, kh // 2, kw // 2, 0, 0)
+        cases.append((d, g_khwc, cin, w, st))
+        want.append((conv.wgrad_finish(d, g_khwc, cin, w, st.u, st.v, st.sigma), conv.wgrad_finish(d, g_khwc, cin)))
+    with conv.deferred_wgrad_finish():
+        got = [(conv.wgrad_finish(d, g, cin, w, st.u, st.v, st.sigma), conv.wgrad_finish(d, g, cin)) for d, g, cin, w, st in cases]
+        got += [(conv.wgrad_finish(d, g, cin, w, st.u, st.v, st.sigma), conv.wgrad_finish(d, g, cin)) for d, g, cin, w, st in cases * 5]   # > 24 entries
+    torch.cuda.synchronize()
+    for k, (a_sn, a_plain) in enumerate(got):
+        w_sn, w_plain = want[k % len(want)]
+        assert torch.equal(a_plain, w_plain)
+        assert (a_sn - w_sn).abs().max().item() < 1e-5 * w_sn.abs().max().item()
+    assert not conv._DeferredFinish.items and not conv._DeferredFinish.active
 
 
 @pytest.mark.parametrize("shape", [(3, 8, 8, 256), (2, 32, 32, 512), (5, 7, 3, 64)])
