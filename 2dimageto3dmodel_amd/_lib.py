@@ -40,6 +40,8 @@ SIGNATURES = {
     "m355_sil_loss_ws_bytes": (c_size_t, [c_int, c_int]),
     "m355_sil_loss_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P]),
     "m355_chamfer_nn_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "m355_chamfer_nn_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "m355_chamfer_nn_fwd_ws": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
     "m355_conv2d_out_hw": (c_int, [_P, _P, _P]),
     "m355_conv2d_dy_channels": (c_int, [c_int]),
     "m355_fold2x2": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -212,7 +212,9 @@ class deferred_wgrad_finish:
     it is written."""
 
     def __enter__(self):
-        self.prev, _DeferredFinish.active = _DeferredFinish.active, True
+        import os
+        self.prev = _DeferredFinish.active
+        _DeferredFinish.active = not os.environ.get("M355_NO_DEFER_FINISH")   # (A/B switch: the per-layer launches)
         return self
 
     def __exit__(self, *exc):

@@ -25,9 +25,14 @@ __device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, f
     return dx * dx + dy * dy + dz * dz;
 }
 
-template <int QPL, int NW>
+// SPLIT (round 3, small batches): gridDim.z workgroups share one block of queries, each sweeping a contiguous slice of the
+// targets [z * mslice, (z+1) * mslice) (whole LDS tiles); the slices are merged by ONE 64-bit atomicMin per query on the key
+// (distance bits << 32 | index): distances are >= 0, so their float bits order like the values, and among equal distances the
+// lowest index wins -- exactly the oracle's tie rule.  keys[B*N] is pre-filled with 0xff bytes; k_chamfer_unpack splits it.
+template <int QPL, int NW, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64) void k_chamfer_nn(const float *__restrict__ a, const float *__restrict__ b,
-                                                       float *__restrict__ dist, int32_t *__restrict__ idx, int N, int M)
+                                                       float *__restrict__ dist, int32_t *__restrict__ idx, int N, int M,
+                                                       unsigned long long *__restrict__ keys = nullptr, int mslice = 0)
 {
     constexpr int SL = kTile / NW;            // targets of a tile one wave sweeps (a multiple of 64)
     static_assert(SL % 64 == 0, "wave slices are whole chunks");
@@ -49,8 +54,9 @@ __global__ __launch_bounds__(NW * 64) void k_chamfer_nn(const float *__restrict_
         best[k] = INFINITY;
         cstart[k] = -1;
     }
-    for (int j0 = 0; j0 < M; j0 += kTile) {
-        const int cnt = min(kTile, M - j0);
+    const int jbeg = SPLIT ? (int)blockIdx.z * mslice : 0, jend = SPLIT ? min(M, jbeg + mslice) : M;
+    for (int j0 = jbeg; j0 < jend; j0 += kTile) {
+        const int cnt = min(kTile, jend - j0);
         __syncthreads();
         for (int t = tid; t < kTile; t += NW * 64) {   // structure of arrays; the tail is padded with far-away points (d = inf)
             const bool in = t < cnt;
@@ -124,14 +130,71 @@ __global__ __launch_bounds__(NW * 64) void k_chamfer_nn(const float *__restrict_
                 }
             }
             if (i < N) {
-                dist[(size_t)bi * N + i] = d0;
-                idx[(size_t)bi * N + i] = i0;
+                if (SPLIT) {
+                    if (i0 >= 0)
+                        atomicMin(keys + (size_t)bi * N + i, ((unsigned long long)__float_as_uint(d0) << 32) | (unsigned)i0);
+                } else {
+                    dist[(size_t)bi * N + i] = d0;
+                    idx[(size_t)bi * N + i] = i0;
+                }
             }
         }
     }
 }
 
+__global__ __launch_bounds__(256) void k_chamfer_unpack(const unsigned long long *__restrict__ keys, float *__restrict__ dist,
+                                                        int32_t *__restrict__ idx, size_t n)
+{
+    const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (i < n) {
+        const unsigned long long k = keys[i];
+        dist[i] = __uint_as_float((unsigned)(k >> 32));
+        idx[i] = (int32_t)(unsigned)(k & 0xffffffffull);
+    }
+}
+
+// target slices per query block for the split form (0: the one-pass form fills the chip already)
+static int chamfer_slices(int B, int N, int M)
+{
+    const long blocks = (long)B * ((N + 255) / 256);   // 4 queries per lane: the most reuse of a broadcast target
+    if (blocks >= 256 || M < 2 * kTile) return 0;
+    long ts = (512 + blocks - 1) / blocks;              // aim at two workgroups per CU
+    const long tiles = (M + kTile - 1) / kTile;
+    if (ts > tiles) ts = tiles;
+    return ts >= 2 ? (int)ts : 0;
+}
+
 }  // namespace m355
+
+extern "C" size_t m355_chamfer_nn_ws_bytes(int B, int N, int M)
+{
+    if (B <= 0 || N <= 0 || M <= 0) return 0;
+    return m355::chamfer_slices(B, N, M) ? (size_t)B * N * sizeof(unsigned long long) : 0;
+}
+
+extern "C" int m355_chamfer_nn_fwd_ws(const float *a, const float *b, float *dist, int32_t *idx, int B, int N, int M, void *ws,
+                                      void *stream)
+{
+    M355_REQUIRE(B >= 0 && N >= 0 && M >= 1, "chamfer_nn_fwd_ws: bad size B=%d N=%d M=%d", B, N, M);
+    if (B == 0 || N == 0) return M355_OK;
+    const int ts = m355::chamfer_slices(B, N, M);
+    if (!ts || !ws) return m355_chamfer_nn_fwd(a, b, dist, idx, B, N, M, stream);
+    M355_REQUIRE(a && b && dist && idx, "chamfer_nn_fwd_ws: null pointer");
+    M355_REQUIRE(B <= 65535, "chamfer_nn_fwd_ws: B=%d exceeds grid.y", B);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *keys = (unsigned long long *)ws;
+    if (hipMemsetAsync(keys, 0xff, (size_t)B * N * sizeof(unsigned long long), st) != hipSuccess) {
+        m355::set_error("chamfer_nn_fwd_ws: memset failed");
+        return M355_ERR_LAUNCH;
+    }
+    const int tiles = (M + m355::kTile - 1) / m355::kTile;
+    const int mslice = ((tiles + ts - 1) / ts) * m355::kTile;          // whole tiles per slice
+    const int nz = (M + mslice - 1) / mslice;
+    hipLaunchKernelGGL((m355::k_chamfer_nn<4, 4, true>), dim3((N + 255) / 256, B, nz), dim3(256), 0, st, a, b, dist, idx, N, M, keys, mslice);
+    const size_t n = (size_t)B * N;
+    hipLaunchKernelGGL(m355::k_chamfer_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, dist, idx, n);
+    return m355::check_launch("chamfer_nn_fwd_ws");
+}
 
 extern "C" int m355_chamfer_nn_fwd(const float *a, const float *b, float *dist, int32_t *idx, int B, int N, int M,
                                    void *stream)

@@ -209,7 +209,9 @@ def chamfer_nn(a, b):
     M = b.shape[1]
     dist = torch.empty((B, N), dtype=torch.float32, device=a.device)
     idx = torch.empty((B, N), dtype=torch.int32, device=a.device)
-    _launch("chamfer_nn_fwd", ptr(a), ptr(b), ptr(dist), ptr(idx), B, N, M, stream(), work=8.0 * B * N * M)
+    nws = lib().m355_chamfer_nn_ws_bytes(B, N, M)   # small batches: the target sweep is split over workgroups too
+    ws = torch.empty((nws,), dtype=torch.uint8, device=a.device) if nws else None
+    _launch("chamfer_nn_fwd_ws", ptr(a), ptr(b), ptr(dist), ptr(idx), B, N, M, ptr(ws), stream(), work=8.0 * B * N * M)
     return dist, idx
 
 

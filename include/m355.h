@@ -133,6 +133,13 @@ int m355_sil_loss_fwd(const float *proj, const float *mask, int Hin, int Win, in
  *      a[B,N,3], b[B,M,3] -> dist[B,N] = min_j |a_i-b_j|^2, idx[B,N] = argmin (lowest j on ties). */
 int m355_chamfer_nn_fwd(const float *a, const float *b, float *dist, int32_t *idx, int B, int N, int M,
                         void *stream);
+/*      the same with a workspace: when B * ceil(N / 256) < 256 query blocks would leave most of the chip idle (B = 1, 16384
+ *      points: 64), the TARGET sweep is split over workgroups as well and merged by one 64-bit atomicMin per query on
+ *      (distance bits << 32 | index) -- the lowest-index tie rule is that key's order.  ws >= m355_chamfer_nn_ws_bytes(B,N,M)
+ *      (0: not needed, ws may be NULL). */
+size_t m355_chamfer_nn_ws_bytes(int B, int N, int M);
+int m355_chamfer_nn_fwd_ws(const float *a, const float *b, float *dist, int32_t *idx, int B, int N, int M, void *ws,
+                           void *stream);
 
 /* ---- G  conv2d of the GAN stacks (models/gan.py:57-65,163-177,294-302,359,364 -> F.conv2d) as a bf16 MFMA
  *      implicit GEMM with fp32 accumulation.  Activations are NHWC bf16, weights bf16 views built by

@@ -262,7 +262,9 @@ def test_size_independent_properties_full_size(pkg):
 
 @pytest.mark.parametrize("B,N,M", [(2, 100, 70), (1, 1000, 2500), (3, 64, 1), (1, 16384, 4096),
                                    (2, 16384, 1500),    # the 8-wave / 2-queries-per-lane shape
-                                   (4, 16384, 2100)])   # the 4-wave / 4-queries-per-lane shape, ragged last tile
+                                   (4, 16384, 2100),    # the 4-wave / 4-queries-per-lane shape, ragged last tile
+                                   (1, 5000, 9000), (3, 300, 3000),   # target sweep split over workgroups (9 / 3 slices, ragged)
+                                   (1, 16384, 16384)])   # BASELINE configs[4] at B = 1: 8 slices of 2 tiles
 def test_chamfer_nn_bit_exact_vs_oracle(pkg, B, N, M):
     rs = np.random.RandomState(N + M)
     a = rs.rand(B, N, 3).astype(np.float32)
@@ -276,6 +278,14 @@ def test_chamfer_nn_bit_exact_vs_oracle(pkg, B, N, M):
     d, i = pkg.ops.chamfer_nn(t(a), t(b))
     assert np.array_equal(i.cpu().numpy(), i_o)
     assert np.array_equal(d.cpu().numpy().view(np.uint32), d_o.view(np.uint32))
+    # the entry point without a workspace (one pass over the targets per query block) gives the same bits
+    import ctypes
+    ta, tb = t(a), t(b)
+    d1, i1 = torch.empty_like(d), torch.empty_like(i)
+    L = pkg._lib.lib()
+    pkg._lib.check(L.m355_chamfer_nn_fwd(ta.data_ptr(), tb.data_ptr(), d1.data_ptr(), i1.data_ptr(), B, N, M, pkg._lib.stream()), "chamfer")
+    assert torch.equal(d1, d) and torch.equal(i1, i)
+    assert (L.m355_chamfer_nn_ws_bytes(B, N, M) > 0) == (B * ((N + 255) // 256) < 256 and M >= 2048)
 
 
 def test_chamfer_distance_gradients(pkg):
