@@ -197,19 +197,20 @@ def conv_wgrad(d, x, dy, cin_real=None, raw=False, dbias=None, arena=False):
 
 
 class _DeferredFinish:
-    """weight-gradient epilogues queued inside `deferred_wgrad_finish()`: (entry fields, tensors kept alive)"""
+    """weight-gradient epilogues queued inside `deferred_wgrad_finish()`: (entry fields, tensors kept alive, parameter)"""
     active = False
     items = []
-    part = {}      # device -> scratch [SNFIN_MAX * 64] fp32
+    part = {}      # device -> fp32 scratch (one float per output channel of the queued layers)
 
 
 class deferred_wgrad_finish:
     """Context manager around a backward pass whose parameter gradients nobody reads before the pass is over (GanTrainer:
-    zero_grad(set_to_none=True) -> backward -> reducer -> optimiser): every wgrad_finish() of the pass returns its output tensor
-    at once and the arithmetic of ALL of them runs in two launches at exit (m355_sn_wgrad_finish_batched) instead of two per
-    layer.  The raw gradients are slices of the per-pass WgradArena, valid until the next backward pass.  NOT for callers that
-    accumulate into existing .grad tensors or read gradients from hooks during the pass: autograd would read the output before
-    it is written."""
+    zero_grad(set_to_none=True) -> backward -> reducer -> optimiser): wgrad_finish(..., param=p) of the pass only queues its
+    work and returns None to autograd; at exit ALL of them run in two launches (m355_sn_wgrad_finish_batched) instead of two
+    per layer, and every result is accumulated into its parameter's .grad here (p.grad = dw, or += if one exists) -- not
+    through autograd's AccumulateGrad, which would have to read the tensor before it is written (and clones any gradient
+    somebody else still references).  Gradient hooks of those parameters therefore do not fire; the trainer reduces and steps
+    after the pass.  The raw gradients are slices of the per-pass WgradArena, valid until the next backward pass."""
 
     def __enter__(self):
         import os
@@ -232,26 +233,37 @@ def flush_wgrad_finish(discard=False):
         chunk = items[i0:i0 + _lib.SNFIN_MAX]
         arr = (_lib.SnFinEntry * len(chunk))()
         dev = chunk[0][1][0].device
+        rows = sum(f[6] for f, _k, _p in chunk)    # one partial of <g, w_orig> per output channel
         part = _DeferredFinish.part.get(dev)
-        if part is None:
-            part = _DeferredFinish.part[dev] = torch.empty(_lib.SNFIN_MAX * 64, dtype=torch.float32, device=dev)
-        for k, (f, _keep) in enumerate(chunk):
+        if part is None or part.numel() < rows:
+            part = _DeferredFinish.part[dev] = torch.empty(max(rows, 8192), dtype=torch.float32, device=dev)
+        row = 0
+        for k, (f, _keep, _param) in enumerate(chunk):
             e = arr[k]
             e.g_khwc, e.w_orig, e.u, e.v, e.sigma, e.dw = f[0], f[1], f[2], f[3], f[4], f[5]
-            e.part = part.data_ptr() + 4 * 64 * k if f[4] else None
+            e.part = part.data_ptr() + 4 * row if f[4] else None
             e.Cout, e.Cin, e.CinP, e.kh, e.kw = f[6:11]
+            row += f[6]
         launch("sn_wgrad_finish_batched", arr, len(chunk), stream())
+    with torch.no_grad():
+        for f, keep, param in items:
+            dw = keep[-1]
+            if param.grad is None:
+                param.grad = dw
+            else:
+                param.grad += dw
 
 
-def wgrad_finish(d, g_khwc, cin_real, w_orig=None, u=None, v=None, sigma=None):
+def wgrad_finish(d, g_khwc, cin_real, w_orig=None, u=None, v=None, sigma=None, param=None):
     """[Cout][kh][kw][CinP] wgrad output -> the parameter's gradient [Cout][cin_real][kh][kw]; with spectral-norm
-    state, the gradient with respect to weight_orig (through sigma).  Inside `deferred_wgrad_finish()` the returned tensor is
-    filled when the context exits."""
+    state, the gradient with respect to weight_orig (through sigma).  param (a leaf Parameter) inside
+    `deferred_wgrad_finish()`: the work is queued, the result is accumulated into param.grad when the context exits, and
+    None is returned (autograd gets no gradient for it from this call)."""
     dw = torch.empty((d.Cout, cin_real, d.kh, d.kw), dtype=torch.float32, device=g_khwc.device)
-    if _DeferredFinish.active:
+    if _DeferredFinish.active and param is not None and param.is_leaf and param.requires_grad:
         _DeferredFinish.items.append(((ptr(g_khwc), ptr(w_orig), ptr(u), ptr(v), ptr(sigma), ptr(dw), d.Cout, cin_real, d.Cin,
-                                       d.kh, d.kw), (g_khwc, w_orig, u, v, sigma, dw)))
-        return dw
+                                       d.kh, d.kw), (g_khwc, w_orig, u, v, sigma, dw), param))
+        return None
     part = torch.empty((256,), dtype=torch.float32, device=g_khwc.device) if sigma is not None else None
     launch("sn_wgrad_finish", ptr(g_khwc), ptr(w_orig), ptr(u), ptr(v), ptr(sigma), ptr(part), ptr(dw), d.Cout, cin_real,
            d.Cin, d.kh, d.kw, stream())

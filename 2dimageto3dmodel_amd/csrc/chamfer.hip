@@ -95,12 +95,14 @@ __global__ __launch_bounds__(NW * 64) void k_chamfer_nn(const float *__restrict_
             }
         }
     }
-    // ---- recover the index: the first target of the recorded chunk that attains the minimum (same arithmetic)
+    // ---- recover the index: the first target of the recorded chunk that attains the minimum (same arithmetic).  SPLIT: the
+    // slices are merged on (distance, chunk start) -- among equal distances the lowest chunk holds the lowest index -- and the
+    // ONE re-scan per query happens in k_chamfer_unpack, not once per slice
     int besti[QPL];
 #pragma unroll
     for (int k = 0; k < QPL; ++k) {
-        besti[k] = -1;
-        if (cstart[k] >= 0) {
+        besti[k] = SPLIT ? cstart[k] : -1;
+        if (!SPLIT && cstart[k] >= 0) {
             const int hi = min(cstart[k] + 64, M);
             for (int j = cstart[k]; j < hi; ++j) {
                 const float d = dist2(ax[k], ay[k], az[k], bb[(size_t)j * 3], bb[(size_t)j * 3 + 1], bb[(size_t)j * 3 + 2]);
@@ -142,15 +144,27 @@ __global__ __launch_bounds__(NW * 64) void k_chamfer_nn(const float *__restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void k_chamfer_unpack(const unsigned long long *__restrict__ keys, float *__restrict__ dist,
-                                                        int32_t *__restrict__ idx, size_t n)
+// key = (distance bits << 32 | start of the winning 64-target chunk) -> distance, and the first target of that chunk attaining it
+__global__ __launch_bounds__(256) void k_chamfer_unpack(const unsigned long long *__restrict__ keys, const float *__restrict__ a,
+                                                        const float *__restrict__ b, float *__restrict__ dist,
+                                                        int32_t *__restrict__ idx, int N, int M)
 {
-    const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
-    if (i < n) {
-        const unsigned long long k = keys[i];
-        dist[i] = __uint_as_float((unsigned)(k >> 32));
-        idx[i] = (int32_t)(unsigned)(k & 0xffffffffull);
-    }
+    const int i = blockIdx.x * 256 + threadIdx.x, bi = blockIdx.y;
+    if (i >= N) return;
+    const unsigned long long k = keys[(size_t)bi * N + i];
+    const float d = __uint_as_float((unsigned)(k >> 32));
+    const int cs = (int)(unsigned)(k & 0xffffffffull);
+    const float *q = a + ((size_t)bi * N + i) * 3, *bb = b + (size_t)bi * M * 3;
+    const float ax = q[0], ay = q[1], az = q[2];
+    int best = -1;
+    const int hi = min(cs + 64, M);
+    for (int j = cs; j < hi; ++j)
+        if (dist2(ax, ay, az, bb[(size_t)j * 3], bb[(size_t)j * 3 + 1], bb[(size_t)j * 3 + 2]) == d) {
+            best = j;
+            break;
+        }
+    dist[(size_t)bi * N + i] = d;
+    idx[(size_t)bi * N + i] = best;
 }
 
 // target slices per query block for the split form (0: the one-pass form fills the chip already)
@@ -158,7 +172,7 @@ static int chamfer_slices(int B, int N, int M)
 {
     const long blocks = (long)B * ((N + 255) / 256);   // 4 queries per lane: the most reuse of a broadcast target
     if (blocks >= 256 || M < 2 * kTile) return 0;
-    long ts = (512 + blocks - 1) / blocks;              // aim at two workgroups per CU
+    long ts = (256 + blocks - 1) / blocks;              // one 4-wave workgroup per CU; every slice pays a merge + 64 atomics
     const long tiles = (M + kTile - 1) / kTile;
     if (ts > tiles) ts = tiles;
     return ts >= 2 ? (int)ts : 0;
@@ -191,8 +205,7 @@ extern "C" int m355_chamfer_nn_fwd_ws(const float *a, const float *b, float *dis
     const int mslice = ((tiles + ts - 1) / ts) * m355::kTile;          // whole tiles per slice
     const int nz = (M + mslice - 1) / mslice;
     hipLaunchKernelGGL((m355::k_chamfer_nn<4, 4, true>), dim3((N + 255) / 256, B, nz), dim3(256), 0, st, a, b, dist, idx, N, M, keys, mslice);
-    const size_t n = (size_t)B * N;
-    hipLaunchKernelGGL(m355::k_chamfer_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, dist, idx, n);
+    hipLaunchKernelGGL(m355::k_chamfer_unpack, dim3((N + 255) / 256, B), dim3(256), 0, st, keys, a, b, dist, idx, N, M);
     return m355::check_launch("chamfer_nn_fwd_ws");
 }
 

@@ -390,59 +390,75 @@ extern "C" int m355_sn_wgrad_finish(const float *g_khwc, const float *w_orig, co
     return check_launch("sn_wgrad_finish");
 }
 
-// All weight-gradient epilogues of ONE backward pass in two launches (was two launches per layer, 76 per GAN cycle at ~7 us each:
-// latency, not bytes).  The entries travel as a kernel argument (<= 24 layers x 72 bytes): no device table to upload, capturable.
+// All weight-gradient epilogues of ONE backward pass in two launches (was two launches per layer, 76 per GAN cycle: latency,
+// and a re-layout whose reads were strided by CinP floats).  One workgroup per (layer, output channel): the channel's raw
+// gradient g[co][tap][ci] is read ONCE per launch, coalesced, into LDS (row stride CinP + 1: conflict-free transposed reads) and
+// leaves as dw[co][ci][tap] in coalesced stores; w_orig and v are read in their own (linear) order.  The entries travel as a
+// kernel argument (<= 24 layers): no device table to upload, capturable.  Deterministic: <g, w_orig> = a fixed-order sum of one
+// partial per output channel.
 struct SnFinBatch {
     m355_snfin_entry e[M355_SNFIN_MAX];
+    int row0[M355_SNFIN_MAX + 1];   // first workgroup of every layer (prefix sum of Cout)
+    int L;
 };
+constexpr int kSnFinLds = 12832;    // floats: (CinP + 1) * kh * kw of the widest row (512 channels x 5 x 5)
 
-__global__ __launch_bounds__(256) void k_sn_bwd_dot_batched(SnFinBatch b)
+__device__ __forceinline__ int snfin_layer(const SnFinBatch &b, int row)
 {
-    const m355_snfin_entry &e = b.e[blockIdx.y];
-    if (!e.sigma) return;
-    __shared__ float red[4];
-    const int KK = e.kh * e.kw;
-    const size_t total = (size_t)e.Cout * e.Cin * KK;
-    float acc = 0.0f;
-    for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int tap = (int)(idx % KK);
-        const size_t r = idx / KK;
-        const int ci = (int)(r % e.Cin), co = (int)(r / e.Cin);
-        acc += e.w_orig[idx] * e.g_khwc[((size_t)co * KK + tap) * e.CinP + ci];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) e.part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    int l = 0;
+    while (l + 1 < b.L && row >= b.row0[l + 1]) ++l;
+    return l;
 }
 
-__global__ __launch_bounds__(256) void k_sn_bwd_apply_batched(SnFinBatch b, int npart)
+template <bool APPLY>
+__global__ __launch_bounds__(256) void k_sn_fin(SnFinBatch b)
 {
-    const m355_snfin_entry &e = b.e[blockIdx.y];
-    __shared__ float sh;
-    float inv = 1.0f, coef = 0.0f;
-    if (e.sigma) {
-        if (threadIdx.x < 64) {
-            float d = 0.0f;
-            for (int i = threadIdx.x; i < npart; i += 64) d += e.part[i];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
-            if (threadIdx.x == 0) sh = d;
-        }
-        __syncthreads();
-        inv = 1.0f / e.sigma[0];
-        coef = sh * inv * inv;
+    __shared__ float gl[kSnFinLds];
+    __shared__ float red[4];
+    const int l = snfin_layer(b, blockIdx.x);
+    const m355_snfin_entry &e = b.e[l];
+    if (!APPLY && !e.sigma) return;
+    const int co = blockIdx.x - b.row0[l], KK = e.kh * e.kw, n = e.Cin * KK, ld = e.CinP + 1;
+    const float *g = e.g_khwc + (size_t)co * KK * e.CinP;
+    for (int t = threadIdx.x; t < KK * e.CinP; t += 256) {
+        const int tap = t / e.CinP, ci = t - tap * e.CinP;
+        gl[tap * ld + ci] = g[t];
     }
-    const int KK = e.kh * e.kw;
-    const size_t total = (size_t)e.Cout * e.Cin * KK;
-    for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int tap = (int)(idx % KK);
-        const size_t r = idx / KK;
-        const int ci = (int)(r % e.Cin), co = (int)(r / e.Cin);
-        float val = e.g_khwc[((size_t)co * KK + tap) * e.CinP + ci] * inv;
-        if (e.sigma) val -= coef * e.u[co] * e.v[(size_t)ci * KK + tap];
-        e.dw[idx] = val;
+    float inv = 1.0f, coef = 0.0f;
+    if (APPLY && e.sigma) {   // <g, w_orig> = the per-channel partials of the first launch, summed in a fixed order
+        float d = 0.0f;
+        for (int i = threadIdx.x; i < e.Cout; i += 256) d += e.part[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    }
+    __syncthreads();
+    if (APPLY && e.sigma) {
+        inv = 1.0f / e.sigma[0];
+        coef = (red[0] + red[1] + red[2] + red[3]) * inv * inv;
+    }
+    if (APPLY) {
+        const float uc = e.sigma ? e.u[co] : 0.0f;
+        float *dw = e.dw + (size_t)co * n;
+        for (int idx = threadIdx.x; idx < n; idx += 256) {
+            const int ci = idx / KK, tap = idx - ci * KK;
+            float val = gl[tap * ld + ci] * inv;
+            if (e.sigma) val -= coef * uc * e.v[idx];
+            dw[idx] = val;
+        }
+    } else {
+        const float *w = e.w_orig + (size_t)co * n;
+        float acc = 0.0f;
+        for (int idx = threadIdx.x; idx < n; idx += 256) {
+            const int ci = idx / KK, tap = idx - ci * KK;
+            acc += w[idx] * gl[tap * ld + ci];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) e.part[co] = red[0] + red[1] + red[2] + red[3];
     }
 }
 
@@ -451,18 +467,24 @@ extern "C" int m355_sn_wgrad_finish_batched(const m355_snfin_entry *entries_host
     M355_REQUIRE(entries_host && L > 0 && L <= M355_SNFIN_MAX, "sn_wgrad_finish_batched: 1..%d layers per call", M355_SNFIN_MAX);
     SnFinBatch b;
     bool any_sn = false;
+    int rows = 0;
     for (int i = 0; i < L; ++i) {
         const m355_snfin_entry &e = entries_host[i];
         M355_REQUIRE(e.g_khwc && e.dw && e.Cout > 0 && e.Cin > 0 && e.CinP >= e.Cin && e.kh > 0 && e.kw > 0,
                      "sn_wgrad_finish_batched: bad entry %d", i);
+        M355_REQUIRE((e.CinP + 1) * e.kh * e.kw <= kSnFinLds, "sn_wgrad_finish_batched: entry %d: %d x %d x %d exceeds the LDS row", i,
+                     e.CinP, e.kh, e.kw);
         M355_REQUIRE(!e.sigma || (e.w_orig && e.u && e.v && e.part), "sn_wgrad_finish_batched: spectral-norm state missing in entry %d", i);
         b.e[i] = e;
+        b.row0[i] = rows;
+        rows += e.Cout;
         any_sn = any_sn || e.sigma;
     }
+    b.row0[L] = rows;
+    b.L = L;
     hipStream_t st = (hipStream_t)stream;
-    constexpr int NPART = 64;   // partial dot products per layer (part[64] each)
-    if (any_sn) hipLaunchKernelGGL(k_sn_bwd_dot_batched, dim3(NPART, L), dim3(256), 0, st, b);
-    hipLaunchKernelGGL(k_sn_bwd_apply_batched, dim3(256, L), dim3(256), 0, st, b, NPART);
+    if (any_sn) hipLaunchKernelGGL(k_sn_fin<false>, dim3(rows), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(k_sn_fin<true>, dim3(rows), dim3(256), 0, st, b);
     return check_launch("sn_wgrad_finish_batched");
 }
 

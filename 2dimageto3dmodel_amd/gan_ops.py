@@ -197,6 +197,7 @@ class HeadConvFn(torch.autograd.Function):
         out = torch.empty((n, cout, h, 2 * w if flags & HT_SYMM else w), dtype=torch.float32, device=x.device)
         launch("head_tail_fwd", ptr(y), ptr(out), n, cout, h, w, flags, stream())
         ctx.d, ctx.cw, ctx.flags, ctx.in_slope = d, cw, flags, in_slope
+        ctx.wparam = weight if isinstance(weight, torch.nn.Parameter) else None   # (conv.deferred_wgrad_finish)
         ctx.save_for_backward(x.detach(), wd, out)
         return out
 
@@ -216,7 +217,7 @@ class HeadConvFn(torch.autograd.Function):
                 if ctx.in_slope != 1.0:   # (shapes whose dgrad has no fused activation backward)
                     dx = lrelu_bwd(dx, x, ctx.in_slope)[0]
         if ctx.needs_input_grad[1]:
-            dw = C.wgrad_finish(d, C.conv_wgrad(d, x, g, cin_real=ctx.cw, raw=True, arena=True), ctx.cw)
+            dw = C.wgrad_finish(d, C.conv_wgrad(d, x, g, cin_real=ctx.cw, raw=True, arena=True), ctx.cw, param=ctx.wparam)
         return dx, dw, (db if ctx.needs_input_grad[2] else None), None, None, None, None, None
 
 
@@ -338,6 +339,7 @@ class Conv2dFn(torch.autograd.Function):
             y = C.conv_fwd(d, x.detach(), wf, None if bias is None else bias.detach(), out_f32_nchw, slope, cin_real=cw)
         ctx.d, ctx.cw, ctx.slope, ctx.f32, ctx.sn = d, cw, slope, out_f32_nchw, sn
         ctx.in_slope, ctx.premasked = in_slope, premasked
+        ctx.wparam = weight if isinstance(weight, torch.nn.Parameter) else None   # (conv.deferred_wgrad_finish)
         ctx.has_bias = bias is not None
         use_bits = in_bits is not None and in_slope != 1.0 and C.maskbits_ok(d, 1)
         ctx.save_for_backward(x.detach(), wd, y if (slope != 1.0 and not premasked) else None,
@@ -391,9 +393,9 @@ class Conv2dFn(torch.autograd.Function):
             graw = C.conv_wgrad(d, x, g, cin_real=ctx.cw, raw=True, dbias=fused_db, arena=True)
             sn = ctx.sn
             if sn is None:
-                dw = C.wgrad_finish(d, graw, ctx.cw)
+                dw = C.wgrad_finish(d, graw, ctx.cw, param=ctx.wparam)
             else:
-                dw = C.wgrad_finish(d, graw, ctx.cw, w_orig, sn.u, sn.v, sn.sigma)
+                dw = C.wgrad_finish(d, graw, ctx.cw, w_orig, sn.u, sn.v, sn.sigma, param=ctx.wparam)
         return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
 
 

@@ -8,7 +8,7 @@ import warnings
 
 import torch
 
-from . import conv as C
+from . import conv as CV
 from . import gan as G
 from . import gan_ops as O
 from . import parallel as P
@@ -172,10 +172,10 @@ class GanTrainer(torch.nn.Module):
                     from . import mesh as M
                     vtx = self.mesh_template.get_vertex_positions(pred_mesh)
                     flat = M.loss_flat(self.mesh_template.mesh, self.mesh_template.compute_normals(vtx))
-                    with C.deferred_wgrad_finish():   # (gradients are first read by the reducer / optimiser below)
+                    with CV.deferred_wgrad_finish():   # (gradients are first read by the reducer / optimiser below)
                         (loss + self.mesh_regularization * flat).backward()
                 else:
-                    with C.deferred_wgrad_finish():
+                    with CV.deferred_wgrad_finish():
                         loss.backward()
             finally:
                 for p in d_params:
@@ -190,7 +190,7 @@ class GanTrainer(torch.nn.Module):
             self.optimizer_d.zero_grad(set_to_none=True)
             loss_fake, loss_real, _, _ = self('d', X_tex, X_alpha, X_mesh, C, caption, noise)
             loss_fake, loss_real = loss_fake.mean(), loss_real.mean()
-            with C.deferred_wgrad_finish():
+            with CV.deferred_wgrad_finish():
                 (loss_fake + loss_real).backward()
             self.reduce_d()
             self.optimizer_d.step()

@@ -282,7 +282,7 @@ int m355_sn_wgrad_finish(const float *g_khwc, const float *w_orig, const float *
                          float *part, float *dw, int Cout, int Cin, int CinP, int kh, int kw, void *stream);
 /*      the same for up to M355_SNFIN_MAX layers of one backward pass in two launches (the per-layer form costs two launches of
  *      ~7 us per nn.Conv2d: 76 per training cycle).  entries_host: HOST array, copied into the kernel arguments (device
- *      pointers inside); part: 64 floats of scratch per entry with sigma. */
+ *      pointers inside); part: Cout floats of scratch per entry with sigma; (CinP + 1) * kh * kw <= 12832. */
 #define M355_SNFIN_MAX 24
 typedef struct {
     const float *g_khwc, *w_orig, *u, *v, *sigma;

@@ -119,14 +119,23 @@ def test_spectral_norm_group_matches_torch(pkg):
         d = conv.make_desc(1, 8, 8, cinp, cout, kh, kw, 1, kh // 2, kw // 2, 0, 0)
         cases.append((d, g_khwc, cin, w, st))
         want.append((conv.wgrad_finish(d, g_khwc, cin, w, st.u, st.v, st.sigma), conv.wgrad_finish(d, g_khwc, cin)))
+    params = [(torch.nn.Parameter(torch.zeros_like(ws)), torch.nn.Parameter(torch.zeros_like(wp))) for ws, wp in want * 6]   # > 24 entries
+    params[1][0].grad = torch.ones_like(params[1][0])    # an existing gradient is accumulated into, not replaced
     with conv.deferred_wgrad_finish():
-        got = [(conv.wgrad_finish(d, g, cin, w, st.u, st.v, st.sigma), conv.wgrad_finish(d, g, cin)) for d, g, cin, w, st in cases]
-        got += [(conv.wgrad_finish(d, g, cin, w, st.u, st.v, st.sigma), conv.wgrad_finish(d, g, cin)) for d, g, cin, w, st in cases * 5]   # > 24 entries
+        for k, (p_sn, p_plain) in enumerate(params):
+            d, g, cin, w, st = cases[k % len(cases)]
+            assert conv.wgrad_finish(d, g, cin, w, st.u, st.v, st.sigma, param=p_sn) is None
+            assert conv.wgrad_finish(d, g, cin, param=p_plain) is None
+            assert p_plain.grad is None                  # nothing is written before the context exits
+        assert len(conv._DeferredFinish.items) == 2 * len(params)
     torch.cuda.synchronize()
-    for k, (a_sn, a_plain) in enumerate(got):
+    for k, (p_sn, p_plain) in enumerate(params):
         w_sn, w_plain = want[k % len(want)]
-        assert torch.equal(a_plain, w_plain)
-        assert (a_sn - w_sn).abs().max().item() < 1e-5 * w_sn.abs().max().item()
+        assert torch.equal(p_plain.grad, w_plain)
+        extra = 1.0 if k == 1 else 0.0
+        assert (p_sn.grad - extra - w_sn).abs().max().item() < 1e-5 * w_sn.abs().max().item()
+    # outside the context (or without a parameter) the call is immediate
+    assert torch.equal(conv.wgrad_finish(*cases[0][:3]), want[0][1])
     assert not conv._DeferredFinish.items and not conv._DeferredFinish.active
 
 
