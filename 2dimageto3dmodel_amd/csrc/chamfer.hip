@@ -171,8 +171,8 @@ __global__ __launch_bounds__(256) void k_chamfer_unpack(const unsigned long long
 static int chamfer_slices(int B, int N, int M)
 {
     const long blocks = (long)B * ((N + 255) / 256);   // 4 queries per lane: the most reuse of a broadcast target
-    if (blocks >= 256 || M < 2 * kTile) return 0;
-    long ts = (256 + blocks - 1) / blocks;              // one 4-wave workgroup per CU; every slice pays a merge + 64 atomics
+    if (blocks >= 384 || M < 2 * kTile) return 0;
+    long ts = (384 + blocks - 1) / blocks;              // ~1.5 four-wave workgroups per CU; every slice pays a merge + 256 atomics
     const long tiles = (M + kTile - 1) / kTile;
     if (ts > tiles) ts = tiles;
     return ts >= 2 ? (int)ts : 0;
