@@ -115,12 +115,13 @@ class ConditionalBatchNorm2d(nn.Module):
         self.fc_gamma = nn.Linear(emb_dim, ch)
         self.fc_beta = nn.Linear(emb_dim, ch)
 
-    def forward(self, x, z, slope=1.0, gb=None, res=None, out_slope=1.0):
+    def forward(self, x, z, slope=1.0, gb=None, res=None, out_slope=1.0, part=None):
         """gb: (gamma, beta) of this layer when the owner evaluated all fc_gamma / fc_beta in one GEMM;
         res: tensor added after the activation (the block's shortcut branch), fused into the same pass;
-        out_slope: a LeakyReLU on top of everything whose backward the (single) consumer applies (gan_ops.head_conv)"""
+        out_slope: a LeakyReLU on top of everything whose backward the (single) consumer applies (gan_ops.head_conv);
+        part: batch-statistics partial sums of x from the conv launch that produced it (gan_ops.conv2d(want_stats=True))"""
         gamma, beta = gb if gb is not None else (self.fc_gamma(z), self.fc_beta(z))
-        return self.norm(x, gamma, beta, slope, res, out_slope)
+        return self.norm(x, gamma, beta, slope, res, out_slope, part)
 
 
 class ResBlockUp(nn.Module):
@@ -154,8 +155,10 @@ class ResBlockUp(nn.Module):
         # batch statistics of the two conv outputs come out of the conv launches where the kernel can (conv_fwd_stats)
         st1 = self.training and isinstance(self.norm1.norm, G.BatchNorm2d) and g1 is not None and g1[0].dtype == torch.float32
         st2 = self.training and isinstance(self.norm2.norm, G.BatchNorm2d) and g2 is not None and g2[0].dtype == torch.float32
-        h = self.norm1(self.conv1(x, upsample=upsample, want_stats=st1), z, LRELU, g1)
-        return self.norm2(self.conv2(h, want_stats=st2), z, LRELU, g2, sc, out_slope)
+        y1, p1 = self.conv1(x, upsample=upsample, want_stats=True) if st1 else (self.conv1(x, upsample=upsample), None)
+        h = self.norm1(y1, z, LRELU, g1, part=p1)
+        y2, p2 = self.conv2(h, want_stats=True) if st2 else (self.conv2(h), None)
+        return self.norm2(y2, z, LRELU, g2, sc, out_slope, part=p2)
 
 
 class Generator(nn.Module):

@@ -404,15 +404,15 @@ def conv2d(x, weight, bias, stride, pad_h, pad_w, mode, upsample=0, slope=1.0, o
     """in_slope != 1: x is the output of a fused conv+LeakyReLU(in_slope) whose ONLY consumer is this conv: the
     returned grad_x is pre-multiplied by that activation's derivative, and that producer must be called with
     premasked=True (it then skips its own activation backward).  Both flags are set by the discriminators."""
-    """want_stats: the output's only use is a batch norm in training mode -- where the kernel can, the norm's partial sums are
-    produced by the conv launch and travel on the returned tensor (BatchNorm2d.forward picks them up)"""
+    """want_stats: the output's only use is a batch norm in training mode -- returns (y, part): where the kernel can, part is the
+    norm's [rows,2,C] partial sums produced by the conv launch (else None); the caller passes it to BatchNorm2d.forward(part=)"""
     y, bits, part = Conv2dFn.apply(x, weight, bias, stride, pad_h, pad_w, mode, int(upsample), float(slope), bool(out_f32_nchw),
                                    sn, float(in_slope), bool(premasked),
                                    getattr(x, "_m355_bits", None) if in_slope != 1.0 else None, bool(want_stats))
     if bits is not None:
         y._m355_bits = bits  # picked up by the consumer conv (same Python tensor object, see the discriminators' _act)
-    if part is not None:
-        y._m355_stats = part
+    if want_stats:
+        return y, part   # (part None: this shape has no fused statistics) -- handed to the norm EXPLICITLY, not on the tensor
     return y
 
 
@@ -798,17 +798,20 @@ class BatchNorm2d(nn.Module):
             if not self.sync:   # (the reference's SynchronizedBatchNorm2d.forward never counts, batchnorm.py:66-98)
                 self.num_batches_tracked += 1
 
-    def forward(self, x, gamma, beta, slope=1.0, res=None, out_slope=1.0):
+    def forward(self, x, gamma, beta, slope=1.0, res=None, out_slope=1.0, part=None):
         """LeakyReLU(BN(x) * (1 + gamma) + beta) [+ res]; gamma / beta [N,C]; res: residual branch, same shape as x.
         out_slope != 1: a second LeakyReLU on the result whose BACKWARD IS LEFT TO THE CONSUMER (a generator head,
-        gan_ops.head_conv(in_slope=...)): the returned tensor must have no other consumer."""
+        gan_ops.head_conv(in_slope=...)): the returned tensor must have no other consumer.
+        part: partial (sum, sum of squares) of THIS x from the conv launch that produced it (conv2d(want_stats=True)); the
+        statistics are then those of the conv's fp32 results, not of the bf16-rounded x (relative difference <= 2^-9 of the
+        spread, tests/test_gan_elem_gpu.py::test_fused_conv_statistics_match_a_pass_over_the_tensor)"""
         if _fused_ok(x):
             sync = self._is_sync()
             if self.training and gamma.dtype == torch.float32:
                 # single-launch coefficient algebra (csrc/gan_glue.hip); num_batches_tracked is bumped by the owner
                 # (Generator.forward batches it over all layers) or here when used stand-alone
                 y = CbnActFn.apply(x, gamma, beta, self.running_mean, self.running_var, self.momentum, self.eps, slope, res,
-                                   sync, out_slope, getattr(x, "_m355_stats", None))
+                                   sync, out_slope, part)
                 if not getattr(self, "_defer_count", False) and not self.sync:
                     self.num_batches_tracked += 1
                 return y
@@ -875,7 +878,7 @@ class InstanceNorm2d(nn.Module):
         super().__init__()
         self.eps = eps
 
-    def forward(self, x, gamma, beta, slope=1.0, res=None, out_slope=1.0):
+    def forward(self, x, gamma, beta, slope=1.0, res=None, out_slope=1.0, part=None):
         if out_slope != 1.0:
             return _OutAct.apply(self.forward(x, gamma, beta, slope, res), out_slope)
         if res is not None:
@@ -887,7 +890,7 @@ class InstanceNorm2d(nn.Module):
 
 
 class NoNorm(nn.Module):
-    def forward(self, x, gamma, beta, slope=1.0, res=None, out_slope=1.0):
+    def forward(self, x, gamma, beta, slope=1.0, res=None, out_slope=1.0, part=None):
         if out_slope != 1.0:
             return _OutAct.apply(self.forward(x, gamma, beta, slope, res), out_slope)
         if res is not None:
