@@ -202,6 +202,39 @@ def cpu_baseline_gan(trainer, R, seconds_budget=10.0):
                            "sample": f"{out['one'][1]} cycle(s), {out['one'][2]:.1f} s"}}
 
 
+def sample_clock_power(fn, seconds=2.5):
+    """average shader clock / socket power of GPU 0 while `fn` runs back to back (rocm-smi from a thread); None if unavailable"""
+    import re
+    import subprocess
+    import threading
+    samples, stop = [], [False]
+
+    def sampler():
+        while not stop[0]:
+            try:
+                out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+            except Exception:
+                return
+            m, p = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out), re.search(r"Power \(W\): ([\d.]+)", out)
+            if m and p:
+                samples.append((int(m.group(1)), float(p.group(1))))
+            time.sleep(0.1)
+
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        fn()
+        torch.cuda.synchronize()
+    stop[0] = True
+    th.join(timeout=15)
+    s = samples[1:] if len(samples) > 2 else samples
+    if not s:
+        return None
+    return {"sclk_mhz": sum(a for a, _ in s) / len(s), "power_w": sum(b for _, b in s) / len(s), "samples": len(s),
+            "how": "rocm-smi --showclocks --showpower every ~0.4 s over %.1f s of back-to-back steps" % seconds}
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -374,6 +407,7 @@ def main():
     par.reset_stats()
     pkg._lib.enable_kernel_timers(False)
 
+    sustained = sample_clock_power(step, seconds=2.5) if rank == 0 else None
     if rank == 0:
         # the conv entry points are timed per KERNEL FAMILY they dispatched to (m355_last_kernel: k_conv_glds, k_conv_halo,
         # k_wgrad_dma, ...), i.e. under the names rocprofv3 lists
@@ -428,6 +462,11 @@ def main():
                                  "(2*FETCH+WRITE)*1024, gfx950 fetch correction), null if not collected",
                          "traffic_source": "profiles/pmc_traffic.json" if traffic is not None else None},
             "roofline_proj": roofline_proj(kt, B, N, S) if do_p else None,
+            # what the silicon grants under THIS load (rocm-smi sampled while the step loops, outside the timed region): the conv
+            # kernels sit at the package power limit, the 2.5 PF peak assumes 2.4 GHz (DESIGN.md 5 "Round 3")
+            "sustained": None if sustained is None else dict(sustained, **{
+                "mfma_peak_at_sclk_TF": MFMA_BF16_PEAK_TF * sustained["sclk_mhz"] / 2400.0,
+                "dominant_frac_at_sclk": (rate / (MFMA_BF16_PEAK_TF * sustained["sclk_mhz"] / 2400.0)) if is_conv else None}),
             "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(kt.items(), key=lambda kv: -kv[1][1])},
         }
         if not args.no_cpu_baseline and world == 1:
