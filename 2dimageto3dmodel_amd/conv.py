@@ -178,7 +178,31 @@ class WgradArena:
         return st[0][off:off + numel]
 
 
-def conv_wgrad(d, x, dy, cin_real=None, raw=False, dbias=None, arena=False):
+class DbiasBlock:
+    """Bias gradients the wgrad kernels accumulate with atomics need a zeroed buffer each: here they are slices of ONE block per
+    backward pass, zero-filled in one launch.  Unlike the WgradArena the block is a FRESH tensor every pass (sized from the
+    previous one) -- its slices are returned to autograd as the parameters' .grad and must outlive the pass."""
+    _state = {}   # device -> [block, used, needed, graph task id]
+
+    @classmethod
+    def take(cls, numel, device):
+        task = torch._C._current_graph_task_id() if hasattr(torch._C, "_current_graph_task_id") else -1
+        if task < 0:
+            return None
+        st = cls._state.setdefault(device, [None, 0, 0, None])
+        if st[3] != task:
+            st[0] = torch.zeros(st[2], dtype=torch.float32, device=device) if st[2] else None
+            st[1], st[2], st[3] = 0, 0, task
+        numel_p = (numel + 63) // 64 * 64
+        off = st[1]
+        st[1] += numel_p
+        st[2] = max(st[2], st[1])
+        if st[0] is None or off + numel_p > st[0].numel():
+            return None
+        return st[0][off:off + numel]
+
+
+def conv_wgrad(d, x, dy, cin_real=None, raw=False, dbias=None, arena=False, dbias_zeroed=False):
     """-> dw fp32 in the parameter's layout [Cout,Cin,kh,kw] (a permuted view), or with raw=True the kernel's own
     [Cout,kh,kw,Cin] buffer.  arena=True (with raw=True, from inside a backward pass): the buffer is a slice of the
     per-pass WgradArena, valid until the next backward pass"""
@@ -187,7 +211,7 @@ def conv_wgrad(d, x, dy, cin_real=None, raw=False, dbias=None, arena=False):
     sl = WgradArena.take(n, x.device) if (arena and raw) else None
     if sl is not None:
         dw = sl[:n].view(d.Cout, d.kh, d.kw, d.Cin)
-        if dbias is not None:   # returned to autograd as the bias gradient: never an arena slice
+        if dbias is not None and not dbias_zeroed:   # returned to autograd as the bias gradient: never an arena slice
             dbias.zero_()
         launch("conv2d_wgrad_acc", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), stream(), work=lambda: flops(d, cin_real), tag=lambda: tag(d))
         return dw

@@ -1138,6 +1138,8 @@ int conv_halo_stats_rows(const ConvArgs &a)
 
 bool conv_tb_eligible(const ConvArgs &a);   // csrc/conv_halo2.hip: the 8-wave 2x2 class kernels on pairs of pixel tiles
 int conv_tb_launch(const ConvArgs &a, unsigned xb, unsigned wb, hipStream_t st);
+bool conv_wt_eligible(const ConvArgs &a);   // csrc/conv_halo3.hip: the same families on 128-pixel x 64-channel wave tiles
+int conv_wt_launch(const ConvArgs &a, unsigned xb, unsigned wb, hipStream_t st);
 
 int conv_halo_launch(const ConvArgs &a_in, unsigned xb, unsigned wb, hipStream_t st)
 {
@@ -1149,6 +1151,7 @@ int conv_halo_launch(const ConvArgs &a_in, unsigned xb, unsigned wb, hipStream_t
     }
 #endif
     if (conv_tb_eligible(a)) return conv_tb_launch(a, xb, wb, st);
+    if (conv_wt_eligible(a)) return conv_wt_launch(a, xb, wb, st);
     const int tiles = a.N * (a.Ho / 8) * (a.Wo / 32);
     const int nN = a.CoutP == 64 ? 1 : a.CoutP / 128;
     const char *wgs = getenv("M355_HALO_WGS");

@@ -339,6 +339,9 @@ class Conv2dFn(torch.autograd.Function):
             y = C.conv_fwd(d, x.detach(), wf, None if bias is None else bias.detach(), out_f32_nchw, slope, cin_real=cw)
         ctx.d, ctx.cw, ctx.slope, ctx.f32, ctx.sn = d, cw, slope, out_f32_nchw, sn
         ctx.in_slope, ctx.premasked = in_slope, premasked
+        # `bits` / `part` never get a gradient: without this autograd hands backward a zero-FILLED tensor of their shape for each
+        # (17 fills per GAN cycle, the bit masks of D.conv2 at batch 128 alone 67 MB)
+        ctx.set_materialize_grads(False)
         ctx.wparam = weight if isinstance(weight, torch.nn.Parameter) else None   # (conv.deferred_wgrad_finish)
         ctx.has_bias = bias is not None
         use_bits = in_bits is not None and in_slope != 1.0 and C.maskbits_ok(d, 1)
@@ -348,6 +351,8 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dbits=None, _dpart=None):
+        if dy is None:   # (set_materialize_grads(False): nobody used y)
+            return (None,) * 15
         x, wd, y, w_orig, in_bits = ctx.saved_tensors
         d = ctx.d
         if ctx.sn is not None:
@@ -355,6 +360,7 @@ class Conv2dFn(torch.autograd.Function):
             # version counters): both the dgrad and the wgrad branch must see this forward's snapshot
             ctx.sn.check()
         c32 = C.dy_channels(d.Cout)
+        db_zeroed = False
         if ctx.premasked:
             # the consumer's dgrad already applied this layer's LeakyReLU derivative (mask_x below): dy IS g
             assert not ctx.f32 and c32 == d.Cout
@@ -362,7 +368,11 @@ class Conv2dFn(torch.autograd.Function):
             db = None
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 if ctx.needs_input_grad[1] and C.wgrad_fuses_dbias(d):
-                    db = torch.empty((d.Cout,), dtype=torch.float32, device=g.device)   # filled by the wgrad kernel
+                    # accumulated by the wgrad kernel: a zeroed slice of the pass's bias-gradient block, or our own buffer
+                    db = C.DbiasBlock.take(d.Cout, g.device)
+                    db_zeroed = db is not None
+                    if db is None:
+                        db = torch.empty((d.Cout,), dtype=torch.float32, device=g.device)
                 else:
                     db = chan_sum(g)
         elif ctx.slope != 1.0 and not ctx.f32 and c32 == d.Cout and 256 % (d.Cout // 8) == 0:
@@ -370,6 +380,13 @@ class Conv2dFn(torch.autograd.Function):
             g, db = lrelu_bwd(dy.contiguous(), y, ctx.slope)
             if not (ctx.has_bias and ctx.needs_input_grad[2]):
                 db = None
+        elif ctx.f32 and ctx.slope == 1.0 and d.Cout <= 8 and dy.is_cuda and dy.dtype == torch.float32:
+            # a logit head (D.conv5: one channel, fp32 NCHW): NCHW -> zero-padded 8-channel NHWC bf16 in ONE pass (k_pack_nhwc8)
+            # instead of permute / pad (fill + copy) / cast
+            dyc = dy.contiguous()
+            db = dyc.sum((0, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+            g = torch.empty((d.N, dyc.shape[2], dyc.shape[3], 8), dtype=torch.bfloat16, device=dy.device)
+            launch("pack_nhwc8", ptr(dyc), ptr(None), ptr(g), d.N, d.Cout, 0, dyc.shape[2], dyc.shape[3], stream())
         else:
             g = dy.permute(0, 2, 3, 1) if ctx.f32 else dy       # -> NHWC view
             if ctx.slope != 1.0:
@@ -390,7 +407,8 @@ class Conv2dFn(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             fused_db = db if (ctx.premasked and db is not None and C.wgrad_fuses_dbias(d)) else None
-            graw = C.conv_wgrad(d, x, g, cin_real=ctx.cw, raw=True, dbias=fused_db, arena=True)
+            graw = C.conv_wgrad(d, x, g, cin_real=ctx.cw, raw=True, dbias=fused_db, arena=True,
+                                dbias_zeroed=fused_db is not None and db_zeroed)
             sn = ctx.sn
             if sn is None:
                 dw = C.wgrad_finish(d, graw, ctx.cw, param=ctx.wparam)

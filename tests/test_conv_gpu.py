@@ -297,6 +297,7 @@ def test_conv_tile_pairs_match_single_tiles(pkg, case, wgs, monkeypatch):
     conv = importlib.import_module("2dimageto3dmodel_amd.conv")
     monkeypatch.setenv("M355_HALO_WGS", wgs)
     monkeypatch.setenv("M355_TB", "1")   # (opt-in: under the socket's power cap it measures 4 % behind k_conv_halo, csrc/conv_halo2.hip)
+    monkeypatch.setenv("M355_NO_WT", "1")   # (the comparison is against k_conv_halo itself, not the 128x64 wave-tile kernel)
     N, H, W, Cin, Cout, mode = case
     g = torch.Generator().manual_seed(31 * Cin + Cout + int(wgs))
     d = conv.make_desc(N, H, W, Cin, Cout, 4, 4, 2, 1, 1, mode, 0)
@@ -474,3 +475,77 @@ def test_conv_fwd_stats_refused_where_not_fused(pkg):
         wf, _ = conv.weight_prep(d, torch.zeros(Cout, Cin, k, k, device=DEV))
         with pytest.raises(lib.M355Error):
             conv.conv_fwd_stats(d, x, wf, rows=4)
+
+
+@pytest.mark.parametrize("wgs", ["3", "256"])
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, Cout (4x4 stride-2 convs of the discriminators), pad mode
+    (2, 64, 64, 64, 128, 2),     # D.conv2 shape: forward 2 chunks x 4 classes, one N tile (its dgrad has 64 channels: k_conv_halo pairs)
+    (3, 64, 64, 128, 256, 2),    # D.conv3 shape: two N tiles, four chunks; dgrad = four classes x one N tile, eight chunks
+    (2, 32, 64, 256, 512, 0),    # D.conv4 shape, zero pad: four N tiles; one row of tiles
+    (5, 32, 128, 128, 128, 1),   # replicate pad, odd tile count
+])
+def test_conv_wide_wave_tiles_match_k_conv_halo(pkg, case, wgs, monkeypatch):
+    """k_conv_wt (csrc/conv_halo3.hip: 128-pixel x 64-channel wave tiles, 32-channel chunks, one barrier per segment) against
+    k_conv_halo on the same problem.  The accumulation order differs (32- instead of 64-channel chunks), so the comparison is
+    to fp32-accumulation rounding: bf16 results within one ulp of each other almost everywhere, sign bits equal wherever the
+    pre-activation is not at the rounding level.  M355_HALO_WGS=3 makes every workgroup walk several tiles (cross-tile prefetch)."""
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    monkeypatch.setenv("M355_HALO_WGS", wgs)
+    monkeypatch.setenv("M355_WT", "1")   # (opt-in: it measures equal to k_conv_halo under the socket's power cap, csrc/conv_halo3.hip)
+    N, H, W, Cin, Cout, mode = case
+    g = torch.Generator().manual_seed(17 * Cin + Cout + int(wgs))
+    d = conv.make_desc(N, H, W, Cin, Cout, 4, 4, 2, 1, 1, mode, 0)
+    x = torch.randn(N, H, W, Cin, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(Cout, Cin, 4, 4, generator=g) / (Cin * 16) ** 0.5).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    wf, wd = conv.weight_prep(d, w)
+    ho, wo = conv.out_hw(d)
+    dy = torch.randn(N, ho, wo, Cout, generator=g).bfloat16().to(DEV)
+    bits_in = torch.randint(-2 ** 31, 2 ** 31 - 1, (N, H, W, Cin // 64, 2), generator=g, dtype=torch.int32).to(DEV)
+
+    def run():
+        out, kern = [], []
+        for _ in range(2):   # (twice: stale LDS from the previous launch must not matter)
+            y, bits = conv.conv_fwd(d, x, wf, b, slope=0.2, emit_bits=True)
+            kern.append(conv.lib().m355_last_kernel().decode())
+            y0 = conv.conv_fwd(d, x, wf, None, slope=1.0)
+            dx = conv.conv_dgrad(d, dy, wd)
+            kern.append(conv.lib().m355_last_kernel().decode())
+            # (the fused activation backward needs the direct dgrad form: not with a replicate pad)
+            dxm = conv.conv_dgrad(d, dy, wd, mask_bits=bits_in, mask_slope=0.2) if mode != 1 else dx
+            out.append((y, bits, y0, dx, dxm))
+        for a_, b_ in zip(out[0], out[1]):
+            assert torch.equal(a_, b_)
+        return out[0], kern
+
+    got, kern = run()
+    assert kern[0] == "k_conv_wt", kern
+    if mode != 1:   # (dgrad: dx has Cin channels; 64 -> the class-pair k_conv_halo; replicate pad -> the padded-frame dgrad)
+        assert (kern[1] == "k_conv_wt") == (Cin % 128 == 0), kern
+    monkeypatch.setenv("M355_NO_WT", "1")
+    want, kern0 = run()
+    assert "k_conv_wt" not in kern0
+    for name, a_, b_ in zip(("y", "bits", "y_plain", "dx", "dx_masked"), got, want):
+        if name == "bits":
+            continue
+        af, bf = a_.float(), b_.float()
+        err = (af - bf).abs()
+        tol = 2.0 ** -7 * bf.abs() + 1e-3      # one bf16 ulp (2^-8 relative) with margin
+        assert (err <= tol).float().mean().item() > 0.9999, (name, err.max().item())
+        assert err.max().item() <= 0.03 * bf.abs().max().item(), (name, err.max().item())
+    # the activation-sign bits: equal wherever the pre-activation is clear of zero
+    def unpack(bits, y_plain_like):
+        n, hh, ww, c = y_plain_like.shape
+        bw = bits.view(n, hh, ww, c // 64, 2).to(torch.int64) & 0xffffffff
+        return bw
+    pre = F.leaky_relu(want[0].float(), 1.0 / 0.2)   # undo the LeakyReLU: the pre-activation the bits were taken from
+    ba, bb = unpack(got[1], pre), unpack(want[1], pre)
+    diff = (ba ^ bb)
+    nd = sum(int(((diff >> k) & 1).sum().item()) for k in range(32))
+    assert nd <= max(4, int(1e-4 * pre.numel())), nd
+    # and directly against torch
+    xr = x.float().cpu().permute(0, 3, 1, 2)
+    y_ref = F.leaky_relu(ref_conv(xr, w.cpu().bfloat16().float(), b.cpu(), 2, 1, 1, mode, 0), 0.2)
+    yg = got[0].float().cpu().permute(0, 3, 1, 2)
+    assert (yg - y_ref).abs().max().item() <= 2e-2 * max(1.0, y_ref.abs().max().item())
