@@ -12,6 +12,7 @@
 //     improved; the index is recovered afterwards by re-scanning that one chunk for the first target attaining the
 //     minimum (lowest j on ties, as the oracle): 4.5 VALU + 0.75 LDS instructions per pair instead of 11 + 3;
 //   * small problems (B = 1) get 16 waves per workgroup over 64 queries instead of a quarter-filled chip.
+#include <stdlib.h>
 #include "common.h"
 
 namespace m355 {
@@ -170,11 +171,20 @@ __global__ __launch_bounds__(256) void k_chamfer_unpack(const unsigned long long
 // target slices per query block for the split form (0: the one-pass form fills the chip already)
 static int chamfer_slices(int B, int N, int M)
 {
+    // Measured at N = M = 16384 (scripts/chamfer_rate.py, TFLOP/s of 8 B N M, host clock over three launches): one pass 26 / 33 /
+    // 43.5 at B = 1 / 4 / 8; sliced so that the launch has ~2048 workgroups, at most 8 slices: 32.8 / 40.6 / 45.5 / 49.8 / 52.3 at
+    // B = 1 / 2 / 4 / 8 / 16 -- a slice's targets stay in L1 and the tail of the launch is shorter.  More than 8 slices gain
+    // nothing (every slice pays a merge and 256 atomics per block, the unpack rescans one chunk per query).
+    static const long target = getenv("M355_CHAMFER_WGS") ? atol(getenv("M355_CHAMFER_WGS")) : 2048;
+    static const long max_ts = getenv("M355_CHAMFER_MAXTS") ? atol(getenv("M355_CHAMFER_MAXTS")) : 8;
     const long blocks = (long)B * ((N + 255) / 256);   // 4 queries per lane: the most reuse of a broadcast target
-    if (blocks >= 384 || M < 2 * kTile) return 0;
-    long ts = (384 + blocks - 1) / blocks;              // ~1.5 four-wave workgroups per CU; every slice pays a merge + 256 atomics
+    if (blocks >= target || M < 2 * kTile) return 0;
+    long ts = (target + blocks - 1) / blocks;
+    if (ts > max_ts) ts = max_ts;
     const long tiles = (M + kTile - 1) / kTile;
     if (ts > tiles) ts = tiles;
+    while (ts & (ts - 1)) ts &= ts - 1;   // a power of two: equal slices of the (usually power-of-two) tile count -- 3 or 6 slices measured
+                                          // 20 % behind 4 (the last slice's workgroups finish alone)
     return ts >= 2 ? (int)ts : 0;
 }
 

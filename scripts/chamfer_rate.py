@@ -1,7 +1,7 @@
 import importlib, sys, time, torch
 sys.path.insert(0, "/root/repo")
 ops = importlib.import_module("2dimageto3dmodel_amd.ops")
-for B in (1, 2, 4, 8):
+for B in (1, 2, 4, 8, 16):
     N = 16384
     a = torch.rand(B, N, 3, device="cuda") - 0.5; b = torch.rand(B, N, 3, device="cuda") - 0.5
     for _ in range(3): ops.chamfer_nn(a, b)

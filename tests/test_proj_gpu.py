@@ -285,7 +285,7 @@ def test_chamfer_nn_bit_exact_vs_oracle(pkg, B, N, M):
     L = pkg._lib.lib()
     pkg._lib.check(L.m355_chamfer_nn_fwd(ta.data_ptr(), tb.data_ptr(), d1.data_ptr(), i1.data_ptr(), B, N, M, pkg._lib.stream()), "chamfer")
     assert torch.equal(d1, d) and torch.equal(i1, i)
-    assert (L.m355_chamfer_nn_ws_bytes(B, N, M) > 0) == (B * ((N + 255) // 256) < 384 and M >= 2048)
+    assert (L.m355_chamfer_nn_ws_bytes(B, N, M) > 0) == (B * ((N + 255) // 256) < 2048 and M >= 2048)
 
 
 def test_chamfer_distance_gradients(pkg):
