@@ -202,8 +202,9 @@ def cpu_baseline_gan(trainer, R, seconds_budget=10.0):
                            "sample": f"{out['one'][1]} cycle(s), {out['one'][2]:.1f} s"}}
 
 
-def sample_clock_power(fn, seconds=2.5):
-    """average shader clock / socket power of GPU 0 while `fn` runs back to back (rocm-smi from a thread); None if unavailable"""
+def sample_clock_power(fn, n_steps, sample=True):
+    """average shader clock / socket power of GPU 0 while `fn` runs `n_steps` times back to back (rocm-smi from a thread on the
+    sampling rank); None if unavailable.  Every rank must call it with the SAME n_steps: the step contains collectives."""
     import re
     import subprocess
     import threading
@@ -221,13 +222,16 @@ def sample_clock_power(fn, seconds=2.5):
             time.sleep(0.1)
 
     th = threading.Thread(target=sampler, daemon=True)
-    th.start()
+    if sample:
+        th.start()
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
+    for _ in range(n_steps):
         fn()
         torch.cuda.synchronize()
+    seconds = time.perf_counter() - t0
     stop[0] = True
-    th.join(timeout=15)
+    if sample:
+        th.join(timeout=15)
     s = samples[1:] if len(samples) > 2 else samples
     if not s:
         return None
@@ -407,7 +411,8 @@ def main():
     par.reset_stats()
     pkg._lib.enable_kernel_timers(False)
 
-    sustained = sample_clock_power(step, seconds=2.5) if rank == 0 else None
+    # (the same step count on every rank -- dt is the max over ranks, identical everywhere; only rank 0 samples)
+    sustained = sample_clock_power(step, max(3, min(200, int(2.5 / max(dt / args.steps, 1e-4)))), sample=(rank == 0))
     if rank == 0:
         # the conv entry points are timed per KERNEL FAMILY they dispatched to (m355_last_kernel: k_conv_glds, k_conv_halo,
         # k_wgrad_dma, ...), i.e. under the names rocprofv3 lists
