@@ -14,6 +14,8 @@
 //   * accumulators stay in registers across the channel chunks; fp32 NCHW output (what the heads return) with
 //     bias and optional LeakyReLU.
 // Algorithmic traffic: input once (x 1.56 halo overlap) + output; LDS-read bound (1 KiB pixel fragment per MFMA).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "conv_dma.h"
@@ -490,6 +492,9 @@ struct C8Args {
     int N, H, W, Cout, Kp;
     float slope;
     unsigned xbytes, wbytes;
+#ifdef M355_DBG_STAMP_C8
+    unsigned *stamp;   // debug build (scripts/stamp_c8.py): [4 waves][64 tiles][4] shader-clock stamps of workgroup 0
+#endif
 };
 
 template <int MODE>
@@ -569,6 +574,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             bias_r[j][g] = a.bias ? *reinterpret_cast<const float4 *>(a.bias + tn * 64 + 32 * j + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef M355_DBG_STAMP_C8
+    int dbg_i = 0;
+    const bool dbg_on = a.stamp != nullptr && blockIdx.x == 0;
+#define C8_STAMP(slot) do { if (dbg_on && dbg_i < 64 && lane == 0) a.stamp[(wave * 64 + dbg_i) * 4 + (slot)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define C8_STAMP(slot) do { } while (0)
+#endif
     int tp = bp, buf = 0;
     issue_halo(tp, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // weights + first halo (the in-loop wait only covers later halos)
@@ -579,10 +591,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
         // the halo of this tile (issued one tile ago) and, first time round, the weights have landed; the 8 epilogue
         // stores of the previous tile are younger and may still be in flight
         // (vmcnt retires in order: everything but the previous tile's epilogue stores -- 8, or 10 with the bit masks)
+        C8_STAMP(0);
         if (a.bits) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        C8_STAMP(1);
         // (dgrad of a head) the mask vectors of all eight store units are requested NOW, ahead of the next tile's halo DMA:
         // they are older than it in the in-order vmcnt, and have the whole MFMA phase to arrive
         uint4 mk[2][2][2];
@@ -623,6 +637,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p1, acc[1][1], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        C8_STAMP(2);
+        __builtin_amdgcn_sched_barrier(0);
         // epilogue: acc[j][i][r] = channel 64 tn + 32 j + 8 (r>>2) + 4 half + (r&3), pixel (oy0 + 2 wave + i, ox0 + tx).
         // A lane owns ONE pixel (two lanes per pixel), so straight from the registers a store instruction touches 32
         // different 128-byte rows with 32 bytes each -- the layer is store-issue bound that way (2.8 TB/s of the 1.07 GB it
@@ -685,6 +702,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
             }
             if (a.bits) a.bits[((pix0 + tx) * (size_t)(a.Cout >> 6) + tn) * 2 + half] = wbits;
         }
+        __builtin_amdgcn_sched_barrier(0);
+        C8_STAMP(3);
+#ifdef M355_DBG_STAMP_C8
+        ++dbg_i;
+#endif
         if (tp_next >= tiles) break;
         tp = tp_next;
         buf ^= 1;
@@ -714,8 +736,16 @@ int conv_c8_launch(const m355_conv_desc *d, const void *x, const void *w_fwd, co
     a.slope = slope;
     a.xbytes = (unsigned)((size_t)d->N * d->H * d->W * 16);
     a.wbytes = (unsigned)wbytes;
+#ifdef M355_DBG_STAMP_C8
+    if (const char *sp = getenv("M355_STAMP_PTR")) a.stamp = reinterpret_cast<unsigned *>(strtoull(sp, nullptr, 0));
+#endif
     const int tiles = d->N * (d->H / 8) * (d->W / 32), nN = d->Cout / 64;
-    int per = 768 / nN;  // 3 resident workgroups per CU (50 KB of LDS each)
+    // TWO resident workgroups per CU: 50 KB of LDS would allow three, but the kernel holds 215 registers (the bias lives in 32 of
+    // them) = two waves per SIMD.  With 768 workgroups a third of them ran as a second round on a third-empty chip: the stamps
+    // (scripts/stamp_c8.py) show 10.2 k cycles per tile and wave, 43 tiles per workgroup = 194 us per round, two rounds = the
+    // measured 384 us.  512 workgroups x 64 tiles is one round.
+    static const int c8_wgs = getenv("M355_C8_WGS") ? atoi(getenv("M355_C8_WGS")) : 512;
+    int per = c8_wgs / nN;
     if (per > tiles) per = tiles;
     if (per < 1) per = 1;
     const dim3 grid(per * nN);
