@@ -526,16 +526,41 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
         dma16(rw, ldsW + j * 1024, ok ? (unsigned)(((tn * 64 + co) * a.Kp) * 2 + c * 16) : OOB, 0u);
     }
 
-    auto origin = [&](int tp, int &n, int &oy0, int &ox0) {
-        n = tp / (tpx * tpy);
-        const int r = tp - n * (tpx * tpy);
-        oy0 = (r / tpx) * TH;
-        ox0 = (r % tpx) * TW;
+    // Tile coordinates (image, tile row, tile column) are carried along and stepped by the workgroup's stride: three run-time integer
+    // divisions per tile (there is no divide instruction: ~100 cycles each, twice per tile here) were a measurable part of the
+    // ~10 k cycles a tile takes (scripts/stamp_c8.py).
+    struct TileAt {
+        int n, ty, tx;
     };
-    // halo chunk P = 64 q + lane of tile tp -> image pixel; instructions q = wave, wave + 4
-    auto issue_halo = [&](int tp, int buf) {
-        int n, oy0, ox0;
-        origin(tp, n, oy0, ox0);
+    TileAt stepv;   // the stride PS as (images, rows, columns)
+    {
+        const int per_img = tpx * tpy;
+        stepv.n = PS / per_img;
+        const int r = PS - stepv.n * per_img;
+        stepv.ty = r / tpx;
+        stepv.tx = r - stepv.ty * tpx;
+    }
+    auto at = [&](int tp) {
+        TileAt t;
+        t.n = tp / (tpx * tpy);
+        const int r = tp - t.n * (tpx * tpy);
+        t.ty = r / tpx;
+        t.tx = r - t.ty * tpx;
+        return t;
+    };
+    auto advance = [&](TileAt t) {
+        t.tx += stepv.tx;
+        const int cx = t.tx >= tpx ? 1 : 0;
+        t.tx -= cx * tpx;
+        t.ty += stepv.ty + cx;
+        const int cy = t.ty >= tpy ? 1 : 0;
+        t.ty -= cy * tpy;
+        t.n += stepv.n + cy;
+        return t;
+    };
+    // halo chunk P = 64 q + lane of a tile -> image pixel; instructions q = wave, wave + 4
+    auto issue_halo = [&](const TileAt &t, int buf) {
+        const int n = t.n, oy0 = t.ty * TH, ox0 = t.tx * TW;
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
             const int q = wave + 4 * qi;
@@ -582,11 +607,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
 #define C8_STAMP(slot) do { } while (0)
 #endif
     int tp = bp, buf = 0;
-    issue_halo(tp, 0);
+    TileAt cur = at(tp), nxt = advance(cur);
+    issue_halo(cur, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // weights + first halo (the in-loop wait only covers later halos)
     for (;;) {
-        int n, oy0, ox0;
-        origin(tp, n, oy0, ox0);
+        const int n = cur.n, oy0 = cur.ty * TH, ox0 = cur.tx * TW;
         const int tp_next = tp + PS;
         // the halo of this tile (issued one tile ago) and, first time round, the weights have landed; the 8 epilogue
         // stores of the previous tile are younger and may still be in flight
@@ -613,8 +638,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
                     }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (tp_next < tiles) issue_halo(tp_next, buf ^ 1);
-        else issue_halo(tp, buf ^ 1);  // keep the DMA count per tile constant (harmless re-load into the idle buffer)
+        if (tp_next < tiles) issue_halo(nxt, buf ^ 1);
+        else issue_halo(cur, buf ^ 1);  // keep the DMA count per tile constant (harmless re-load into the idle buffer)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -709,6 +734,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
 #endif
         if (tp_next >= tiles) break;
         tp = tp_next;
+        cur = nxt;
+        nxt = advance(nxt);
         buf ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -964,9 +991,28 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_c8(C8WgArgs a)
     // ---- DMA: every wave issues 4 dy instructions (rows 8q .. 8q+7 of the tile, q = 8k + wave, swizzled as k_wgrad_halo)
     // and 1 x instruction (halo pixels 64 wave + lane; wave 7 fills the unused tail with zeros): 5 per tile and wave
     const int csrc = (lane & 7) ^ (((lane >> 4) & 1) << 2);
-    auto issue = [&](int tile, int st) {
-        const int n = tile / (tpx * tpy), rem = tile - n * (tpx * tpy);
-        const int oy0 = (rem / tpx) * TH, ox0 = (rem % tpx) * TW;
+    // (image, tile row, tile column) of the NEXT tile to fetch, stepped by the grid stride instead of divided out per tile
+    int in_n, in_ty, in_tx, sg_n, sg_ty, sg_tx;
+    {
+        const int per_img = tpx * tpy;
+        in_n = (int)blockIdx.x / per_img;
+        int r = (int)blockIdx.x - in_n * per_img;
+        in_ty = r / tpx; in_tx = r - in_ty * tpx;
+        sg_n = G / per_img;
+        r = G - sg_n * per_img;
+        sg_ty = r / tpx; sg_tx = r - sg_ty * tpx;
+    }
+    auto issue = [&](int /*tile: the caller fetches tiles in order, blockIdx.x + k G*/, int st) {
+        const int n = in_n, oy0 = in_ty * TH, ox0 = in_tx * TW;
+        {
+            in_tx += sg_tx;
+            const int cx = in_tx >= tpx ? 1 : 0;
+            in_tx -= cx * tpx;
+            in_ty += sg_ty + cx;
+            const int cy = in_ty >= tpy ? 1 : 0;
+            in_ty -= cy * tpy;
+            in_n += sg_n + cy;
+        }
         unsigned char *dX = lds + st * STAGE, *dY = dX + XBUF;
         {
             const int P = 64 * wave + lane, hy = P / HS_X, hx = P - hy * HS_X;
