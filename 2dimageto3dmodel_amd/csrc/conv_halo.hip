@@ -832,9 +832,29 @@ __global__ __launch_bounds__(512, (TH == 4 && NCO == 1) ? 4 : 2) void k_wgrad_ha
     // DMA roles: 128-byte LDS rows (64 channels); row r of an instruction q: r = 8q + (lane>>3), slot lane&7 holds source
     // chunk (lane&7) ^ 4*((r>>1)&1) = (lane&7) ^ 4*((lane>>4)&1)  (transpose-read bank spreading, as k_wgrad_dma)
     const int csrc = (lane & 7) ^ (((lane >> 4) & 1) << 2);
-    auto issue = [&](int tile, int buf) {
-        const int n = tile / (tpx * tpy), rem = tile - n * (tpx * tpy);
-        const int oy0 = (rem / tpx) * TH, ox0 = (rem % tpx) * TW;
+    // (image, tile row, tile column) of the next tile to fetch, stepped by the grid stride (tiles are fetched in order): three
+    // run-time integer divisions per tile otherwise -- there is no divide instruction, and a tile is only 16-72 MFMAs per wave
+    int in_n, in_ty, in_tx, sg_n, sg_ty, sg_tx;
+    {
+        const int per_img = tpx * tpy, G = (int)gridDim.x;
+        in_n = (int)blockIdx.x / per_img;
+        int r = (int)blockIdx.x - in_n * per_img;
+        in_ty = r / tpx; in_tx = r - in_ty * tpx;
+        sg_n = G / per_img;
+        r = G - sg_n * per_img;
+        sg_ty = r / tpx; sg_tx = r - sg_ty * tpx;
+    }
+    auto issue = [&](int /*tile = blockIdx.x + k gridDim.x, in order*/, int buf) {
+        const int n = in_n, oy0 = in_ty * TH, ox0 = in_tx * TW;
+        {
+            in_tx += sg_tx;
+            const int cx = in_tx >= tpx ? 1 : 0;
+            in_tx -= cx * tpx;
+            in_ty += sg_ty + cx;
+            const int cy = in_ty >= tpy ? 1 : 0;
+            in_ty -= cy * tpy;
+            in_n += sg_n + cy;
+        }
         unsigned char *dX = lds + buf * STAGE, *dY = dX + XBUF;
         // plane coordinates of halo pixel (0,0); image pixel = SUB * plane + class offset - pad
         const int Y0 = UPS ? (oy0 - a.pad_h) >> 1 : (SUB == 2 ? oy0 : oy0 - a.pad_h);

@@ -147,6 +147,8 @@ __global__ __launch_bounds__(256) void k_affine_act(const short *__restrict__ x,
     short *yn = y + (size_t)n * HW * C;
     const short *rn = res ? res + (size_t)n * (res_w > 0 ? HW / 4 : HW) * C : nullptr;
     const int c0 = (int)(threadIdx.x % vecs) * 8;   // (blockIdx.x * 256 + k * gridDim.x * 256) % vecs == 0
+    const int lvecs = __builtin_ctz(vecs), lrw = res_w > 0 ? __builtin_ctz(res_w) : 0;
+    const bool rw_pow2 = res_w > 0 && (res_w & (res_w - 1)) == 0;
     float av[8], bv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -160,9 +162,11 @@ __global__ __launch_bounds__(256) void k_affine_act(const short *__restrict__ x,
         if (rn) {
             size_t ri = i;
             if (res_w > 0) {
-                const size_t p = i / vecs, v = i - p * vecs;
-                const size_t h = p / res_w, w = p - h * res_w;
-                ri = ((h >> 1) * (res_w >> 1) + (w >> 1)) * vecs + v;
+                // 32-bit shifts / one 32-bit division: the 64-bit divisions this used to be cost more than the 48 bytes moved
+                // (vecs = C / 8 divides 256: a power of two; i < HW * vecs < 2^31)
+                const unsigned iu = (unsigned)i, p = iu >> lvecs, v = iu & (unsigned)(vecs - 1);
+                const unsigned h = rw_pow2 ? p >> lrw : p / (unsigned)res_w, w = p - h * (unsigned)res_w;
+                ri = (size_t)(((h >> 1) * ((unsigned)res_w >> 1) + (w >> 1)) * (unsigned)vecs + v);
             }
             r = *reinterpret_cast<const bf16x8e *>(rn + ri * 8);
         }
