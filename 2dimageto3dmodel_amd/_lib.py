@@ -66,6 +66,8 @@ SIGNATURES = {
     "m355_weight_prep_entry_bytes": (c_size_t, []),
     "m355_weight_prep_fill_entry": (ctypes.c_longlong, [_P, _P, c_int, _P, _P, _P, _P]),
     "m355_weight_prep_batched": (c_int, [_P, c_int, ctypes.c_longlong, _P]),
+    "m355_weight_prep_entry_tiles": (c_int, [_P]),
+    "m355_weight_prep_batched_tiled": (c_int, [_P, c_int, ctypes.c_longlong, c_int, c_int, _P]),
     "m355_cproj_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "m355_cproj_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "m355_conv2d_maskbits_ok": (c_int, [_P, c_int]),

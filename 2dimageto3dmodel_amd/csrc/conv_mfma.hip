@@ -418,15 +418,81 @@ struct WeightPrepArgs {
     const float *sigma;
     int O, I, KH, KW, nparts;
     WeightPrepPart part[5];  // forward view + the dgrad view (stride 1) or its four parity classes (stride 2)
+    int tiled, OP, IP;       // k_weight_prep_tiled takes this layer: 32 x 32 (o, i) tiles over [0, OP) x [0, IP)
 };
 // one launch for all views of a layer: blockIdx.y = view
 __device__ __forceinline__ void weight_prep_body(const WeightPrepArgs &w);
 __global__ void k_weight_prep(WeightPrepArgs w) { weight_prep_body(w); }
 // ... and for all layers of a network: blockIdx.z = layer of a device-resident table (m355_weight_prep_batched)
-__global__ void k_weight_prep_batched(const WeightPrepArgs *__restrict__ tab)
+__global__ void k_weight_prep_batched(const WeightPrepArgs *__restrict__ tab, int skip_tiled)
 {
     const WeightPrepArgs &w = tab[blockIdx.z];
+    if (skip_tiled && w.tiled) return;
     if ((int)blockIdx.y < w.nparts) weight_prep_body(w);
+}
+
+// The same views through an LDS transpose.  k_weight_prep_batched gathers: a lane's eight channels of one tap sit KH*KW floats apart
+// in the [O][I][KH][KW] parameter, so a load instruction touches 64 different lines and the texture addresser, not memory, sets
+// the pace (74 us for the generator's 36 MB of weights, 1 TB/s).  Here a workgroup owns a 32 x 32 (o, i) tile with all its taps:
+// it reads 32 contiguous runs of 32*T floats (scaled by 1/sigma on the way) into LDS and writes every view's 64-byte runs from
+// there -- the forward view's rows are o with the tile's 32 i as a run per tap, the dgrad views' rows are i with its 32 o.
+// "Regular" layers only (fill_weight_prep: every view's rows and channels multiples of 32, no K tail, at most 16 taps).
+template <int TMAX>   // layers with TMAX/2 < KH*KW <= TMAX taps (two instantiations: the 37 KB tile of a 3x3 layer fits four times per CU)
+__global__ __launch_bounds__(256) void k_weight_prep_tiled(const WeightPrepArgs *__restrict__ tab)
+{
+    const WeightPrepArgs &w = tab[blockIdx.z];
+    const int T = w.KH * w.KW;
+    if (!w.tiled || T > TMAX || (TMAX == 16 && T <= 9)) return;
+    const int nti = w.IP >> 5, nto = w.OP >> 5;
+    if ((int)blockIdx.x >= nti * nto) return;
+    const int to = blockIdx.x / nti, ti = blockIdx.x - to * nti, o0 = to * 32, i0 = ti * 32;
+    __shared__ float tile[32 * (32 * TMAX + 1)];
+    const int RS = 32 * T + 1, tid = threadIdx.x, RT = 32 * T;
+    const float wscale = w.sigma ? 1.0f / w.sigma[0] : 1.0f;
+    const unsigned rcpT = 65536u / (unsigned)T + 1u, rcpRT = (1u << 24) / (unsigned)RT + 1u;   // f / T (f < 512), e / RT (e < 16384)
+    // 32 rows x RT contiguous floats each; eight independent loads in flight per thread before the first lands in LDS
+    for (int e0 = tid; e0 < 32 * RT; e0 += 8 * 256) {
+        float v[8];
+        int dst[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 256 * u;
+            v[u] = 0.0f;
+            dst[u] = -1;
+            if (e < 32 * RT) {
+                const int ol = (int)(((unsigned)e * (unsigned long long)rcpRT) >> 24), f = e - ol * RT;
+                const int o = o0 + ol, i = i0 + (int)(((unsigned)f * rcpT) >> 16);
+                dst[u] = ol * RS + f;
+                if (o < w.O && i < w.I) v[u] = w.in[((size_t)o * w.I + i0) * T + f];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (dst[u] >= 0) tile[dst[u]] = v[u] * wscale;
+    }
+    __syncthreads();
+    for (int pi = 0; pi < w.nparts; ++pi) {
+        const WeightPrepPart &p = w.part[pi];
+        const int AB = p.A * p.B;
+        // rows / channels of this view covered by the tile (whole tiles in or out: multiples of 32)
+        const int r0 = p.transpose ? i0 : o0, c0 = p.transpose ? o0 : i0;
+        if (r0 >= p.Rp || c0 >= p.Cp) continue;
+        for (int u = tid; u < 32 * AB * 4; u += 256) {
+            const int g8 = u & 3, q = u >> 2, rl = q / AB, ab = q - rl * AB;
+            const int aa = ab / p.B, b = ab - aa * p.B;
+            const int th = p.th0 + p.ths * aa, tw = p.tw0 + p.tws * b;
+            bf16x8 o8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (th >= 0 && tw >= 0 && th < w.KH && tw < w.KW) {
+                const int tap = th * w.KW + tw;
+                // forward: row = o (rl), channels i = 8 g8 ..; dgrad: row = i (rl), channels o = 8 g8 ..
+                const float *t0 = p.transpose ? tile + (8 * g8) * RS + rl * T + tap : tile + rl * RS + (8 * g8) * T + tap;
+                const int st = p.transpose ? RS : T;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o8[j] = (short)f2bf(t0[j * st]);
+            }
+            *reinterpret_cast<bf16x8 *>(p.out + (size_t)(r0 + rl) * p.Kp + (size_t)ab * p.Cp + c0 + 8 * g8) = o8;
+        }
+    }
 }
 __device__ __forceinline__ void weight_prep_body(const WeightPrepArgs &w)
 {
@@ -435,20 +501,35 @@ __device__ __forceinline__ void weight_prep_body(const WeightPrepArgs &w)
     unsigned short *__restrict__ out = p.out;
     const int O = w.O, I = w.I, KH = w.KH, KW = w.KW, transpose = p.transpose, A = p.A, B = p.B, Cp = p.Cp, Kp = p.Kp;
     const float wscale = w.sigma ? 1.0f / w.sigma[0] : 1.0f;  // spectral norm: W_sn = W_orig / sigma (gan_glue.hip)
-    // out is [Rp][Kp], a row = (A x B taps) x Cp channels then zero fill; R = transpose ? I : O, C = transpose ? O : I
-    const size_t total = (size_t)p.Rp * Kp;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int k = idx % Kp;
-        const int r = idx / Kp;
-        float v = 0.0f;
-        if (k < A * B * Cp) {
-            const int c = k % Cp, t = k / Cp;
-            const int b = t % B, aa = t / B;
-            const int o = transpose ? c : r, i = transpose ? r : c;
-            const int th = p.th0 + p.ths * aa, tw = p.tw0 + p.tws * b;
-            if (o < O && i < I && th < KH && tw < KW) v = in[(((size_t)o * I + i) * KH + th) * KW + tw];
+    // out is [Rp][Kp], a row = (A x B taps) x Cp channels then zero fill; R = transpose ? I : O, C = transpose ? O : I.
+    // A thread writes EIGHT consecutive k (one 16-byte store): Cp and Kp are multiples of 8, so the eight share a tap and the
+    // row / tap / channel split (run-time integer divisions: there is no divide instruction) is paid once per 16 bytes -- it
+    // used to be a 64-bit and three 32-bit divisions per 2-byte element, 70 us for the generator's 36 MB of weights.
+    const unsigned Kp8 = (unsigned)Kp >> 3, total8 = (unsigned)p.Rp * Kp8, AB = (unsigned)(A * B);
+    const size_t sI = (size_t)KH * KW, sO = (size_t)I * KH * KW;   // element strides of the i / o index of `in`
+    for (unsigned g = blockIdx.x * blockDim.x + threadIdx.x; g < total8; g += gridDim.x * blockDim.x) {
+        const unsigned r = g / Kp8, k = (g - r * Kp8) << 3;
+        const unsigned t = k / (unsigned)Cp, c = k - t * (unsigned)Cp;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (t < AB) {
+            const unsigned aa = t / (unsigned)B, b = t - aa * (unsigned)B;
+            const int th = p.th0 + p.ths * (int)aa, tw = p.tw0 + p.tws * (int)b;
+            if (th >= 0 && tw >= 0 && th < KH && tw < KW) {
+                // element (o, i): forward rows are o and the eight channels are i = c ..; dgrad rows are i and the channels o = c ..
+                const int nr = transpose ? I : O, nc = transpose ? O : I;
+                if ((int)r < nr) {
+                    const float *src = in + (transpose ? (size_t)r * sI : (size_t)r * sO) + (size_t)th * KW + tw;
+                    const size_t sc = transpose ? sO : sI;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if ((int)c + j < nc) v[j] = src[(size_t)(c + j) * sc] * wscale;
+                }
+            }
         }
-        out[idx] = f2bf(v * wscale);
+        bf16x8 o8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o8[j] = (short)f2bf(v[j]);
+        *reinterpret_cast<bf16x8 *>(out + (size_t)g * 8) = o8;
     }
 }
 
@@ -697,7 +778,9 @@ static int fill_weight_prep(const m355_conv_desc *d, const float *w_oihw, int ci
     w = m355::WeightPrepArgs{};
     w.in = w_oihw; w.sigma = sigma; w.O = d->Cout; w.I = cin_w; w.KH = d->kh; w.KW = d->kw;
     most = 0;
+    bool ok = true;
     auto add = [&](unsigned short *out, int transpose, int A, int B, int th0, int ths, int tw0, int tws, int Rp, int Cp, int Kp) {
+        ok = ok && Cp % 8 == 0 && Kp % 8 == 0 && (size_t)Rp * Kp < (1ull << 31);   // (the kernel writes 8 channels of one tap at a time)
         w.part[w.nparts++] = m355::WeightPrepPart{out, transpose, A, B, th0, ths, tw0, tws, Rp, Cp, Kp};
         if ((size_t)Rp * Kp > most) most = (size_t)Rp * Kp;
     };
@@ -718,6 +801,21 @@ static int fill_weight_prep(const m355_conv_desc *d, const float *w_oihw, int ci
                         cin64, cout32, Kp);
         }
     }
+    if (!ok) {
+        m355::set_error("conv2d_weight_prep: channel counts must be multiples of 8 (Cin=%d, dy channels=%d)", d->Cin, cout32);
+        return M355_ERR_BAD_ARG;
+    }
+    // k_weight_prep_tiled's layers: whole 32 x 32 tiles, no K tail, the taps fit its LDS tile
+    bool reg = d->kh * d->kw <= 16 && w.nparts > 0 && !getenv("M355_NO_WPREP_TILED");
+    int OP = 0, IP = 0;
+    for (int k = 0; k < w.nparts; ++k) {
+        const m355::WeightPrepPart &p = w.part[k];
+        reg = reg && p.Cp % 32 == 0 && p.Rp % 32 == 0 && p.Kp == p.A * p.B * p.Cp;
+        const int po = p.transpose ? p.Cp : p.Rp, pin = p.transpose ? p.Rp : p.Cp;
+        OP = po > OP ? po : OP;
+        IP = pin > IP ? pin : IP;
+    }
+    w.tiled = reg ? 1 : 0; w.OP = OP; w.IP = IP;
     return M355_OK;
 }
 
@@ -760,7 +858,39 @@ extern "C" int m355_weight_prep_batched(const void *table_dev, int L, long long 
     M355_REQUIRE(table_dev && L > 0 && L <= 65535 && max_elems > 0, "weight_prep_batched: bad argument");
     const unsigned bx = (unsigned)((max_elems + 255) / 256 > 256 ? 256 : (max_elems + 255) / 256);
     hipLaunchKernelGGL(m355::k_weight_prep_batched, dim3(bx, 5, L), dim3(256), 0, (hipStream_t)stream,
-                       (const m355::WeightPrepArgs *)table_dev);
+                       (const m355::WeightPrepArgs *)table_dev, 0);
+    return m355::check_launch("weight_prep_batched");
+}
+
+/* tiles of the LDS-transpose kernel this layer's entry needs (0: the layer stays on the gather kernel) */
+extern "C" int m355_weight_prep_entry_tiles(const void *entry_host)
+{
+    if (!entry_host) return 0;
+    m355::WeightPrepArgs w;
+    memcpy(&w, entry_host, sizeof(w));
+    return w.tiled ? (w.OP >> 5) * (w.IP >> 5) : 0;
+}
+
+/* as m355_weight_prep_batched, with the regular layers (m355_weight_prep_entry_tiles > 0) on the LDS-transpose kernel --
+ * max_tiles9 / max_tiles16 = the largest tile count among those with kh*kw <= 9 / 10..16 taps -- and the rest (max_elems = their
+ * largest view, 0 if there is none) on the gather kernel */
+extern "C" int m355_weight_prep_batched_tiled(const void *table_dev, int L, long long max_elems, int max_tiles9, int max_tiles16,
+                                              void *stream)
+{
+    M355_REQUIRE(table_dev && L > 0 && L <= 65535 && max_elems >= 0 && max_tiles9 >= 0 && max_tiles16 >= 0 &&
+                     (max_elems > 0 || max_tiles9 > 0 || max_tiles16 > 0),
+                 "weight_prep_batched_tiled: bad argument");
+    if (max_tiles9 > 0)
+        hipLaunchKernelGGL(m355::k_weight_prep_tiled<9>, dim3((unsigned)max_tiles9, 1, L), dim3(256), 0, (hipStream_t)stream,
+                           (const m355::WeightPrepArgs *)table_dev);
+    if (max_tiles16 > 0)
+        hipLaunchKernelGGL(m355::k_weight_prep_tiled<16>, dim3((unsigned)max_tiles16, 1, L), dim3(256), 0, (hipStream_t)stream,
+                           (const m355::WeightPrepArgs *)table_dev);
+    if (max_elems > 0) {
+        const unsigned bx = (unsigned)((max_elems + 255) / 256 > 256 ? 256 : (max_elems + 255) / 256);
+        hipLaunchKernelGGL(m355::k_weight_prep_batched, dim3(bx, 5, L), dim3(256), 0, (hipStream_t)stream,
+                           (const m355::WeightPrepArgs *)table_dev, 1);
+    }
     return m355::check_launch("weight_prep_batched");
 }
 

@@ -500,7 +500,7 @@ class SpectralNormGroup:
         L = lib()
         esz = L.m355_weight_prep_entry_bytes()
         raw = (ctypes.c_char * (esz * len(self.convs)))()
-        weights, most = [], 0
+        weights, most, tiles = [], 0, [0, 0]
         for i, c in enumerate(self.convs):
             cout, cw, kh, kw = c.weight_orig.shape
             stride, pad_h, pad_w, mode = c.m355
@@ -512,10 +512,14 @@ class SpectralNormGroup:
                                               ptr(wd), ctypes.byref(raw, esz * i))
             if n < 0:
                 check(1, "weight_prep_fill_entry")
-            most = max(most, n)
+            nt = L.m355_weight_prep_entry_tiles(ctypes.byref(raw, esz * i))   # > 0: the LDS-transpose kernel takes this layer
+            if nt > 0:
+                tiles[0 if kh * kw <= 9 else 1] = max(tiles[0 if kh * kw <= 9 else 1], nt)
+            else:
+                most = max(most, n)
             weights.append((wf, wd, (cx, cout, kh, kw, stride)))
         slot["wtable"] = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).to(dev)
-        slot["weights"], slot["wmost"] = weights, most
+        slot["weights"], slot["wmost"], slot["wtiles"] = weights, most, tiles
 
     def step(self, training):
         """advance (training) / evaluate sigma for every conv of the group and hand each conv its state"""
@@ -530,7 +534,7 @@ class SpectralNormGroup:
         slot["version"] += 1
         launch("sn_power_iter", ptr(slot["table"]), len(self.convs), self._max[0], self._max[1], ptr(self._norms),
                ptr(slot["sigma"]), int(bool(training)), float(self.eps), stream())
-        launch("weight_prep_batched", ptr(slot["wtable"]), len(self.convs), int(slot["wmost"]), stream())
+        launch("weight_prep_batched_tiled", ptr(slot["wtable"]), len(self.convs), int(slot["wmost"]), int(slot["wtiles"][0]), int(slot["wtiles"][1]), stream())
         for c, (sg, u, v), (wf, wd, wkey) in zip(self.convs, slot["views"], slot["weights"]):
             c._sn_state = _SnState(sg, u, v, slot, slot["version"], wf, wd, wkey)
 

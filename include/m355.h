@@ -177,6 +177,13 @@ size_t m355_weight_prep_entry_bytes(void);
 long long m355_weight_prep_fill_entry(const m355_conv_desc *d, const float *w_oihw, int cin_w, const float *sigma,
                                       void *w_fwd, void *w_dgrad, void *entry_host);
 int m355_weight_prep_batched(const void *table_dev, int n_layers, long long max_elems, void *stream);
+/* The same with the "regular" layers (every view's rows and channels multiples of 32, no K padding, <= 16 taps) on a kernel that
+ * transposes 32 x 32 (Cout, Cin) tiles through LDS instead of gathering: m355_weight_prep_entry_tiles(entry) = the tiles that
+ * layer needs there (0: it stays on the gather kernel); max_tiles9 / max_tiles16 = the largest such value among the layers with
+ * kh*kw <= 9 / 10..16 taps (two instantiations: LDS per tile), max_elems = the largest view of the layers that stay (0: none). */
+int m355_weight_prep_entry_tiles(const void *entry_host);
+int m355_weight_prep_batched_tiled(const void *table_dev, int n_layers, long long max_elems, int max_tiles9, int max_tiles16,
+                                   void *stream);
 /*      y: bf16 NHWC [N,Ho,Wo,Cout] or (y_f32_nchw) fp32 [N,Cout,Ho,Wo]; epilogue: + bias[Cout] (nullable),
  *      LeakyReLU(lrelu_slope) (1.0 = identity). */
 int m355_conv2d_fwd(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
