@@ -16,6 +16,20 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)lds_dst, 16, voff, soff, 0, 0);
 }
 
+// XCD-contiguous workgroup id: the dispatcher deals consecutive workgroups to the 8 XCDs in turn (each with its own L2), so
+// neighbours in blockIdx.x never share an L2.  This bijection of [0, n) gives XCD x the ids [start_x, start_x + count_x): what
+// is neighbouring in the result (the output-channel blocks of one pixel tile, adjacent pixel tiles with overlapping halos) meets
+// in one L2.  (k_conv_glds has had it since round 1; the persistent halo kernels fetched 1.4-1.7x their compulsory bytes.)
+#ifndef M355_HALO_XCD
+#define M355_HALO_XCD 1
+#endif
+__device__ __forceinline__ int xcd_contiguous_id(int id, int n)
+{
+    if (!M355_HALO_XCD) return id;
+    const int q = n >> 3, r8 = n & 7, xcd = id & 7, idx = id >> 3;
+    return (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+}
+
 constexpr unsigned OOB = 0x80000000u;  // beyond num_records of every descriptor (tensors are < 2 GiB, checked on the host)
 
 __device__ __forceinline__ unsigned short f2bf(float f)

@@ -185,7 +185,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
     // are visited in turn; the stream of (tile, channel chunk) pairs is continuous, so the NEXT tile's first halo is
     // prefetched by the same slice mechanism and the weight ring simply wraps around (same weights for every tile).
     const int nN = PAIR ? 1 : a.CoutP / BN;
-    const int tn = blockIdx.x % nN, bp = blockIdx.x / nN, PS = gridDim.x / nN;
+    const int vid = xcd_contiguous_id((int)blockIdx.x, (int)gridDim.x);
+    const int tn = vid % nN, bp = vid / nN, PS = gridDim.x / nN;
     const int tpx = a.Wo / TW, tpy = a.Ho / TH, tiles_p = a.N * tpx * tpy;
     const int n0 = tn * BN;
     if (bp >= tiles_p) return;
@@ -825,7 +826,8 @@ __global__ __launch_bounds__(512, (TH == 4 && NCO == 1) ? 4 : 2) void k_wgrad_ha
     const int co0 = (blockIdx.y / nci) * 64 * NCO, ci0 = (blockIdx.y % nci) * 64;
     const int cp = KS == 2 ? (int)blockIdx.z >> 1 : 0, cq = KS == 2 ? (int)blockIdx.z & 1 : 0;  // parity class
     const int tpx = a.Wo / TW, tpy = a.Ho / TH, tiles = a.N * tpx * tpy;
-    if ((int)blockIdx.x >= tiles) return;
+    const int bx = xcd_contiguous_id((int)blockIdx.x, (int)gridDim.x);   // neighbouring tile lists share an XCD's L2 (halo overlap)
+    if (bx >= tiles) return;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, ybytes, 0x00020000);
 
@@ -837,14 +839,14 @@ __global__ __launch_bounds__(512, (TH == 4 && NCO == 1) ? 4 : 2) void k_wgrad_ha
     int in_n, in_ty, in_tx, sg_n, sg_ty, sg_tx;
     {
         const int per_img = tpx * tpy, G = (int)gridDim.x;
-        in_n = (int)blockIdx.x / per_img;
-        int r = (int)blockIdx.x - in_n * per_img;
+        in_n = bx / per_img;
+        int r = bx - in_n * per_img;
         in_ty = r / tpx; in_tx = r - in_ty * tpx;
         sg_n = G / per_img;
         r = G - sg_n * per_img;
         sg_ty = r / tpx; sg_tx = r - sg_ty * tpx;
     }
-    auto issue = [&](int /*tile = blockIdx.x + k gridDim.x, in order*/, int buf) {
+    auto issue = [&](int /*tile = bx + k gridDim.x, in order*/, int buf) {
         const int n = in_n, oy0 = in_ty * TH, ox0 = in_tx * TW;
         {
             in_tx += sg_tx;
@@ -918,8 +920,8 @@ __global__ __launch_bounds__(512, (TH == 4 && NCO == 1) ? 4 : 2) void k_wgrad_ha
     float dbacc[NCO] = {};
 
     int buf = 0;
-    issue(blockIdx.x, 0);
-    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x, buf ^= 1) {
+    issue(bx, 0);
+    for (int tile = bx; tile < tiles; tile += gridDim.x, buf ^= 1) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this tile's DMAs (issued one tile ago)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
