@@ -67,3 +67,30 @@ def test_dropin_paths_resolve_to_the_hip_classes(pkg):
             "print(E.__module__)") % ROOT
     out = subprocess.check_output([sys.executable, "-c", code]).decode()
     assert "2dimageto3dmodel_amd.projection" in out
+
+
+def test_host_side_launch_rules(pkg):
+    """the launch-shaping decisions that run on the host, without a GPU: the Chamfer slicing rule (workspace > 0 <=> the sweep is
+    split: fewer than 2048 query blocks and at least two 1024-target tiles) and which layers the LDS-transpose weight-view kernel
+    takes (rows and channels of every view multiples of 32, no K padding, at most 16 taps)"""
+    import importlib
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    L = pkg._lib.lib()
+    for B, N, M in ((1, 16384, 16384), (8, 16384, 16384), (32, 16384, 16384), (64, 2048, 2048), (1, 1000, 1500), (3, 300, 3000)):
+        want = B * ((N + 255) // 256) < 2048 and M >= 2048
+        assert (L.m355_chamfer_nn_ws_bytes(B, N, M) == B * N * 8) == want and (L.m355_chamfer_nn_ws_bytes(B, N, M) > 0) == want
+    esz = L.m355_weight_prep_entry_bytes()
+    fake = ctypes.c_void_p(0x1000)   # (device pointers are only recorded here, nothing is launched)
+
+    def tiles(cin, cout, k, stride):
+        d = conv.make_desc(1, 64, 64, cin, cout, k, k, stride, k // 2, k // 2, 0, 0)
+        entry = (ctypes.c_char * esz)()
+        n = L.m355_weight_prep_fill_entry(ctypes.byref(d), fake, cin, None, fake, fake, entry)
+        assert n > 0
+        return L.m355_weight_prep_entry_tiles(entry)
+    assert tiles(64, 128, 3, 1) == (128 // 32) * (64 // 32)        # G 3x3: forward rows 128, dgrad rows 64
+    assert tiles(512, 512, 3, 1) == 16 * 16
+    assert tiles(128, 256, 4, 2) == (256 // 32) * (128 // 32)      # D 4x4 stride 2: forward + four dgrad classes, 16 taps
+    assert tiles(128, 64, 1, 1) == (64 // 32) * (128 // 32)        # 1x1 shortcut
+    assert tiles(8, 64, 5, 1) == 0                                 # D.conv1: 25 taps, 8 channels -> the gather kernel
+    assert tiles(64, 3, 5, 1) == 0                                 # a head
