@@ -9,5 +9,6 @@ their training iteration), parallel (RCCL reducers), and the SURVEY 8f widenings
 loss), reconstruction (ReconstructionNetwork), formats (on-disk caches and checkpoints).
 """
 from . import _lib, ops  # noqa: F401
+from .conv import is_deterministic, set_deterministic  # noqa: F401  (M355_DETERMINISTIC=1: bit-reproducible training cycles)
 from .projection import (CameraUtilities, EffectiveLossFunction, SupervisedLoss,  # noqa: F401
                          TrilinearInterpolation, UnsupervisedLoss, VoxelsSmooth)

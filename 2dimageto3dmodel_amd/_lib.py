@@ -51,11 +51,11 @@ SIGNATURES = {
     "m355_conv2d_dgrad_ws_bytes": (c_size_t, [_P]),
     "m355_conv2d_dgrad": (c_int, [_P, _P, _P, _P, _P, _P, c_float, _P]),
     "m355_mesh_vertices_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-    "m355_mesh_vertices_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "m355_mesh_vertices_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "m355_mesh_normals_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
-    "m355_mesh_normals_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
-    "m355_mesh_flat_fwd": (c_int, [_P, _P, _P, c_int, c_int, _P]),
-    "m355_mesh_flat_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    "m355_mesh_normals_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "m355_mesh_flat_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    "m355_mesh_flat_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "m355_dibr_ws_bytes": (c_size_t, [c_int, c_int]),
     "m355_dibr_rasterize_fwd": (c_int, [c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P, _P, _P, _P,
                                         _P, _P]),
@@ -69,7 +69,8 @@ SIGNATURES = {
     "m355_weight_prep_entry_tiles": (c_int, [_P]),
     "m355_weight_prep_batched_tiled": (c_int, [_P, c_int, ctypes.c_longlong, c_int, c_int, _P]),
     "m355_cproj_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
-    "m355_cproj_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
+    "m355_cproj_bwd_ws_floats": (c_size_t, [c_int, c_int, c_int]),
+    "m355_cproj_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "m355_conv2d_maskbits_ok": (c_int, [_P, c_int]),
     "m355_conv2d_dgrad_mask_ok": (c_int, [_P]),
     "m355_conv2d_fwd_bits": (c_int, [_P, _P, _P, _P, _P, c_float, _P, _P]),
@@ -79,6 +80,8 @@ SIGNATURES = {
     "m355_conv2d_fwd_stats": (c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "m355_conv2d_wgrad": (c_int, [_P, _P, _P, _P, _P, _P]),
     "m355_conv2d_wgrad_acc": (c_int, [_P, _P, _P, _P, _P, _P]),
+    "m355_conv2d_wgrad_det_ws_bytes": (c_size_t, [_P]),
+    "m355_conv2d_wgrad_det": (c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "m355_chan_reduce_ws_bytes": (c_size_t, [c_size_t, c_int, c_int, c_int]),
     "m355_bn_stats": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
     "m355_chan_sum": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
@@ -90,7 +93,7 @@ SIGNATURES = {
     "m355_pool_unpack_bwd": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "m355_unpack_range": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "m355_head_tail_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-    "m355_head_tail_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "m355_head_tail_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "m355_hinge_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "m355_hinge_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     "m355_affine_act_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
@@ -102,6 +105,7 @@ SIGNATURES = {
     "m355_bn_stats_partial": (c_int, [_P, _P, c_size_t, c_int, _P]),
     "m355_bn_sync_pack": (c_int, [_P, c_int, c_int, c_float, _P, _P]),
     "m355_affine_act_bwd_partial": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
+    "m355_sn_scratch_words": (c_size_t, [c_int, c_int, c_int]),
     "m355_sn_power_iter": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_float, _P]),
     "m355_sn_wgrad_finish": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "m355_sn_wgrad_finish_batched": (c_int, [_P, c_int, _P]),
@@ -126,6 +130,8 @@ class SnFinEntry(ctypes.Structure):
 
 
 SNFIN_MAX = 24
+HEAD_TAIL_WS_FLOATS = 8192   # M355_HEAD_TAIL_WS_FLOATS
+SNFIN_LDS_FLOATS = 12832   # kSnFinLds (csrc/gan_glue.hip): floats of one output channel the batched finish stages in LDS
 
 
 def lib():

@@ -3,6 +3,7 @@
 Activations are NHWC bf16 tensors ([N,H,W,C] contiguous); weights are the fp32 [Cout,Cin,kh,kw] parameter,
 turned into bf16 GEMM views by `weight_prep`.  No fallback: CPU tensors raise."""
 import ctypes
+import os
 
 import torch
 
@@ -10,6 +11,23 @@ from . import _lib
 from ._lib import ConvDesc, check, launch, lib, ptr, stream
 
 PAD_ZERO, PAD_REPLICATE, PAD_CIRCULAR = 0, 1, 2
+
+# Deterministic mode (M355_DETERMINISTIC=1 or set_deterministic(True)): the weight-gradient kernels accumulate their split-K
+# partial tiles as 64-bit fixed-point integers instead of fp32 atomics (m355_conv2d_wgrad_det) -- with the other reductions of
+# the GAN path deterministic by construction (ordered partial sums), two runs of a training cycle are then bit-identical, as the
+# reference's CPU path is.  Cost: one 8-byte memset + one conversion pass per layer.
+_DETERMINISTIC = os.environ.get("M355_DETERMINISTIC", "") == "1"
+
+
+def set_deterministic(on):
+    """-> the previous setting"""
+    global _DETERMINISTIC
+    prev, _DETERMINISTIC = _DETERMINISTIC, bool(on)
+    return prev
+
+
+def is_deterministic():
+    return _DETERMINISTIC
 
 
 def _ceil(a, b):
@@ -180,9 +198,11 @@ class WgradArena:
 
 class DbiasBlock:
     """Bias gradients the wgrad kernels accumulate with atomics need a zeroed buffer each: here they are slices of ONE block per
-    backward pass, zero-filled in one launch.  Unlike the WgradArena the block is a FRESH tensor every pass (sized from the
-    previous one) -- its slices are returned to autograd as the parameters' .grad and must outlive the pass."""
-    _state = {}   # device -> [block, used, needed, graph task id]
+    backward pass, zero-filled in one launch.  Unlike the WgradArena the block is a FRESH tensor every pass -- its slices are
+    returned to autograd as the parameters' .grad and must outlive the pass.  Its size is the LARGEST need any pass has shown
+    (the G pass of the 1 G : 2 D cycle takes nothing, the D passes do: sizing from the previous pass alone served one pass in
+    three), and it is allocated by the first take() of a pass, so a pass that takes nothing costs nothing."""
+    _state = {}   # device -> [block of this pass | None, used, largest need seen, graph task id]
 
     @classmethod
     def take(cls, numel, device):
@@ -190,9 +210,9 @@ class DbiasBlock:
         if task < 0:
             return None
         st = cls._state.setdefault(device, [None, 0, 0, None])
-        if st[3] != task:
+        if st[3] != task:   # first take of a new backward pass
             st[0] = torch.zeros(st[2], dtype=torch.float32, device=device) if st[2] else None
-            st[1], st[2], st[3] = 0, 0, task
+            st[1], st[3] = 0, task
         numel_p = (numel + 63) // 64 * 64
         off = st[1]
         st[1] += numel_p
@@ -208,6 +228,12 @@ def conv_wgrad(d, x, dy, cin_real=None, raw=False, dbias=None, arena=False, dbia
     per-pass WgradArena, valid until the next backward pass"""
     x, dy = _req(x, torch.bfloat16, "x"), _req(dy, torch.bfloat16, "dy")
     n = d.Cout * d.kh * d.kw * d.Cin
+    if _DETERMINISTIC:
+        ws = torch.empty((lib().m355_conv2d_wgrad_det_ws_bytes(ctypes.byref(d)),), dtype=torch.uint8, device=x.device)
+        dw = torch.empty((d.Cout, d.kh, d.kw, d.Cin), dtype=torch.float32, device=x.device)
+        launch("conv2d_wgrad_det", ctypes.byref(d), ptr(x), ptr(dy), ptr(ws), ptr(dw), ptr(dbias), stream(),
+               work=lambda: flops(d, cin_real), tag=lambda: tag(d))
+        return dw if raw else dw.permute(0, 3, 1, 2)
     sl = WgradArena.take(n, x.device) if (arena and raw) else None
     if sl is not None:
         dw = sl[:n].view(d.Cout, d.kh, d.kw, d.Cin)
@@ -284,7 +310,10 @@ def wgrad_finish(d, g_khwc, cin_real, w_orig=None, u=None, v=None, sigma=None, p
     `deferred_wgrad_finish()`: the work is queued, the result is accumulated into param.grad when the context exits, and
     None is returned (autograd gets no gradient for it from this call)."""
     dw = torch.empty((d.Cout, cin_real, d.kh, d.kw), dtype=torch.float32, device=g_khwc.device)
-    if _DeferredFinish.active and param is not None and param.is_leaf and param.requires_grad:
+    # (the batched kernel stages one output channel's [kh*kw][CinP + 1] block in LDS, gan_glue.hip kSnFinLds: wider layers --
+    # e.g. 1024 channels x 4x4 -- take the per-layer launch below instead of failing the whole flush after the pass)
+    fits = (d.Cin + 1) * d.kh * d.kw <= _lib.SNFIN_LDS_FLOATS
+    if fits and _DeferredFinish.active and param is not None and param.is_leaf and param.requires_grad:
         _DeferredFinish.items.append(((ptr(g_khwc), ptr(w_orig), ptr(u), ptr(v), ptr(sigma), ptr(dw), d.Cout, cin_real, d.Cin,
                                        d.kh, d.kw), (g_khwc, w_orig, u, v, sigma, dw), param))
         return None

@@ -153,6 +153,11 @@ __global__ __launch_bounds__(256) void k_chamfer_unpack(const unsigned long long
     const int i = blockIdx.x * 256 + threadIdx.x, bi = blockIdx.y;
     if (i >= N) return;
     const unsigned long long k = keys[(size_t)bi * N + i];
+    if (k == ~0ull) {   // no slice found a finite distance (NaN / overflowing input): what the one-pass form returns, no rescan
+        dist[(size_t)bi * N + i] = INFINITY;
+        idx[(size_t)bi * N + i] = -1;
+        return;
+    }
     const float d = __uint_as_float((unsigned)(k >> 32));
     const int cs = (int)(unsigned)(k & 0xffffffffull);
     const float *q = a + ((size_t)bi * N + i) * 3, *bb = b + (size_t)bi * M * 3;

@@ -99,6 +99,30 @@ struct WgradArgs {
     int Ho, Wo, Cout, Cy;
     int KH, KW, stride, pad_h, pad_w, pad_w_mode;
     int chunk;  // pixels per z-slice (multiple of WK)
+    // deterministic form (m355_conv2d_wgrad_det): the partial tiles are accumulated as 64-bit FIXED-POINT integers (integer adds
+    // are associative, so the order in which the workgroups' atomics land does not matter); fix = [flag | dw (Cout*K) | db (Cout)]
+    long long *fix;
 };
+
+// ---- split-K accumulation of the weight-gradient kernels.  Default: fp32 atomics into the zeroed dw (the result depends on
+// the order the workgroups finish in: two runs differ in the last bits).  DET: v * 2^36 rounded to int64 and added with a 64-bit
+// integer atomic -- |v| < 2^27 keeps the sum inside int64 for any realistic number of contributions, the resolution 2^-36 =
+// 1.5e-11 is below the fp32 rounding of any gradient above 1e-4 and an absolute 1.5e-11 per contribution below it; a
+// non-finite or out-of-range partial raises the flag word, and the conversion pass then writes NaN (nothing is hidden).
+constexpr float kFixScale = 68719476736.0f;          // 2^36
+constexpr double kFixInv = 1.0 / 68719476736.0;
+template <bool DET>
+__device__ __forceinline__ void wg_accum(float *dst, long long *fix, size_t idx, float v)
+{
+    if constexpr (DET) {
+        if (!(fabsf(v) < 1.0e8f)) {
+            atomicOr(reinterpret_cast<unsigned long long *>(fix), 1ull);
+            return;
+        }
+        atomicAdd(reinterpret_cast<unsigned long long *>(fix) + 1 + idx, (unsigned long long)__float2ll_rn(v * kFixScale));
+    } else {
+        atomicAdd(dst + idx, v);
+    }
+}
 
 }  // namespace m355

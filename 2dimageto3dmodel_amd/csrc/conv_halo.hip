@@ -805,7 +805,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
 //         the tile's pixels (both add their partial sums atomically).
 // TH x 32-pixel tiles; NCO = 64-channel dy blocks per workgroup sharing one x halo.  The stride-2 classes run TH 4, NCO 1
 // with two workgroups per CU (see wgrad_halo_launch).
-template <int KS, int UPS, int MODE, int TH = 8, int NCO = 1>
+template <int KS, int UPS, int MODE, int TH = 8, int NCO = 1, bool DET = false>
 __global__ __launch_bounds__(512, (TH == 4 && NCO == 1) ? 4 : 2) void k_wgrad_halo(WgradArgs a, unsigned xbytes, unsigned ybytes)
 {
     constexpr int TW = 32, T = KS * KS, NW = 8;
@@ -985,7 +985,8 @@ __global__ __launch_bounds__(512, (TH == 4 && NCO == 1) ? 4 : 2) void k_wgrad_ha
     if (do_db) {
 #pragma unroll
         for (int c = 0; c < NCO; ++c)
-            if (co0 + 64 * c + dbc < a.Cout) atomicAdd(a.db + co0 + 64 * c + dbc, dbacc[c]);
+            if (co0 + 64 * c + dbc < a.Cout)
+                wg_accum<DET>(a.db, a.fix, (DET ? (size_t)a.Cout * (a.KH * a.KW * a.Cin) : 0) + co0 + 64 * c + dbc, dbacc[c]);
     }
     // acc[t][r]: co = co0 + 32 w_co + (r&3) + 8(r>>2) + 4(lane>>5), ci = ci0 + 32 w_ci + (lane&31)
     const int K = a.KH * a.KW * a.Cin;
@@ -1000,7 +1001,7 @@ __global__ __launch_bounds__(512, (TH == 4 && NCO == 1) ? 4 : 2) void k_wgrad_ha
                 for (int r = 0; r < 16; ++r) {
                     const int co = co0 + 64 * c + 32 * w_co + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     if (co < a.Cout)
-                        atomicAdd(a.dw + (size_t)co * K + (kh * a.KW + kw) * a.Cin + ci0 + 32 * w_ci + (lane & 31), acc[c][t][r]);
+                        wg_accum<DET>(a.dw, a.fix, (size_t)co * K + (kh * a.KW + kw) * a.Cin + ci0 + 32 * w_ci + (lane & 31), acc[c][t][r]);
                 }
             }
         }
@@ -1034,17 +1035,23 @@ int wgrad_halo_launch(const WgradArgs &a, unsigned xb, unsigned yb, hipStream_t 
     if (per < 1) per = 1;
     if (per > tiles) per = tiles;
     const dim3 grid(per, ny, ncls);
-#define M355_WM(KS_, UPS_, TH_, NCO_)                                                                                         \
-    do {                                                                                                                      \
-        if (a.pad_w_mode == 0) hipLaunchKernelGGL((k_wgrad_halo<KS_, UPS_, 0, TH_, NCO_>), grid, dim3(512), 0, st, a, xb, yb);      \
-        else if (a.pad_w_mode == 1) hipLaunchKernelGGL((k_wgrad_halo<KS_, UPS_, 1, TH_, NCO_>), grid, dim3(512), 0, st, a, xb, yb); \
-        else hipLaunchKernelGGL((k_wgrad_halo<KS_, UPS_, 2, TH_, NCO_>), grid, dim3(512), 0, st, a, xb, yb);                        \
+#define M355_WD(KS_, UPS_, MD_, TH_, NCO_)                                                                                           \
+    do {                                                                                                                             \
+        if (a.fix) hipLaunchKernelGGL((k_wgrad_halo<KS_, UPS_, MD_, TH_, NCO_, true>), grid, dim3(512), 0, st, a, xb, yb);            \
+        else hipLaunchKernelGGL((k_wgrad_halo<KS_, UPS_, MD_, TH_, NCO_>), grid, dim3(512), 0, st, a, xb, yb);                        \
+    } while (0)
+#define M355_WM(KS_, UPS_, TH_, NCO_)                               \
+    do {                                                            \
+        if (a.pad_w_mode == 0) M355_WD(KS_, UPS_, 0, TH_, NCO_);    \
+        else if (a.pad_w_mode == 1) M355_WD(KS_, UPS_, 1, TH_, NCO_); \
+        else M355_WD(KS_, UPS_, 2, TH_, NCO_);                      \
     } while (0)
     if (twin) M355_WM(2, 0, 4, 1);
     else if (a.stride == 2 && wide) M355_WM(2, 0, 4, 2);
     else if (a.stride == 2) M355_WM(2, 0, 8, 1);
     else if (a.ups) M355_WM(3, 1, 8, 1);
     else M355_WM(3, 0, 8, 1);
+#undef M355_WD
 #undef M355_WM
     note_kernel("k_wgrad_halo");
     return check_launch("conv2d_wgrad (halo)");

@@ -713,9 +713,11 @@ bool dgrad_c8_replicate_eligible(const m355_conv_desc *d, int Cy);  // csrc/conv
 int dgrad_c8_replicate_launch(const m355_conv_desc *d, const void *dy, const void *w_dgrad, int Kp, size_t wbytes, void *dx,
                               hipStream_t st, const void *mask_x, float mask_slope);
 bool wgrad_c8_eligible(const m355_conv_desc *d, int Cy);  // csrc/conv_small.hip
-int wgrad_c8_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, float *db, hipStream_t st);
+int wgrad_c8_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, float *db, hipStream_t st,
+                    long long *fix = nullptr);
 bool wgrad_small_eligible(const m355_conv_desc *d, int Cy);
-int wgrad_small_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, hipStream_t st);
+int wgrad_small_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, hipStream_t st,
+                       long long *fix = nullptr);
 }  // namespace m355
 
 static int conv_out_hw(const m355_conv_desc *d, int *Ho, int *Wo)
@@ -1203,7 +1205,7 @@ __device__ __forceinline__ void transpose_store(const bf16x8 (&g)[4], unsigned s
     }
 }
 
-template <int TM>
+template <int TM, bool DET = false>
 __global__ __launch_bounds__(256) void k_wgrad_mfma(WgradArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned short At[TM * WLD];  // [co][pixel]
@@ -1299,7 +1301,7 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgradArgs a)
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wr * (TM / 2) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int col = col0 + wc * 64 + 32 * j + (lane & 31);
-                if (co < a.Cout && col < K) atomicAdd(a.dw + (size_t)co * K + col, acc[i][j][r]);
+                if (co < a.Cout && col < K) wg_accum<DET>(a.dw, a.fix, (size_t)co * K + col, acc[i][j][r]);
             }
 }
 
@@ -1334,7 +1336,7 @@ struct WgradDmaArgs {
     unsigned xbytes, ybytes;
 };
 
-template <int TM, int TN, int MODE>
+template <int TM, int TN, int MODE, bool DET = false>
 __global__ __launch_bounds__(256, 2) void k_wgrad_dma(WgradDmaArgs A)
 {
     const WgradArgs &a = A.w;
@@ -1457,9 +1459,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(WgradDmaArgs A)
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wr * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int col = col0 + wc * 64 + 32 * j + (lane & 31);
-                if (co < a.Cout && col < K) atomicAdd(a.dw + (size_t)co * K + col, acc[i][j][r]);
+                if (co < a.Cout && col < K) wg_accum<DET>(a.dw, a.fix, (size_t)co * K + col, acc[i][j][r]);
             }
-    if (do_db && co0 + dbc < a.Cout) atomicAdd(a.db + co0 + dbc, dbacc);
+    if (do_db && co0 + dbc < a.Cout) wg_accum<DET>(a.db, a.fix, (DET ? (size_t)a.Cout * K : 0) + co0 + dbc, dbacc);
 }
 
 }  // namespace m355
@@ -1483,7 +1485,50 @@ static bool wgrad_has_dbias(const m355_conv_desc *d)
 extern "C" int m355_conv2d_wgrad_fuses_dbias(const m355_conv_desc *d) { return d && wgrad_has_dbias(d) ? 1 : 0; }
 
 static int conv_wgrad_impl(const m355_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias, void *stream,
-                           bool zero);
+                           bool zero, long long *fix = nullptr);
+
+namespace m355 {
+// fix = [flag | n fixed-point sums | nb fixed-point bias sums] -> dw[n], db[nb] fp32 (one rounding per element); a raised flag
+// (some partial tile was not finite) poisons the whole result with NaN, as an fp32 accumulation would have
+__global__ __launch_bounds__(256) void k_fix_to_f32(const long long *__restrict__ fix, float *__restrict__ dw, size_t n,
+                                                    float *__restrict__ db, int nb)
+{
+    const bool bad = fix[0] != 0;
+    const size_t total = n + (db ? (size_t)nb : 0);
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const float v = bad ? __builtin_nanf("") : (float)((double)fix[1 + i] * kFixInv);
+        if (i < n) dw[i] = v;
+        else db[i - n] = v;
+    }
+}
+}  // namespace m355
+
+/* Deterministic weight gradient: same kernels, but the split-K partial tiles are accumulated as 64-bit fixed-point integers in
+ * `ws` (m355_conv2d_wgrad_det_ws_bytes(d) bytes, zeroed here) and converted to fp32 once -- bit-identical from run to run
+ * whatever order the workgroups finish in.  dw / dbias are OVERWRITTEN (no pre-zeroing needed). */
+extern "C" size_t m355_conv2d_wgrad_det_ws_bytes(const m355_conv_desc *d)
+{
+    if (!d || d->Cout <= 0 || d->Cin <= 0 || d->kh <= 0 || d->kw <= 0) return 0;
+    return sizeof(long long) * (1 + (size_t)d->Cout * d->kh * d->kw * d->Cin + (size_t)d->Cout);
+}
+
+extern "C" int m355_conv2d_wgrad_det(const m355_conv_desc *d, const void *x, const void *dy, void *ws, float *dw, float *dbias,
+                                     void *stream)
+{
+    M355_REQUIRE(ws, "conv2d_wgrad_det: null workspace");
+    if (int rc = check_desc(d, "conv2d_wgrad_det")) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, m355_conv2d_wgrad_det_ws_bytes(d), st) != hipSuccess) {
+        m355::set_error("conv2d_wgrad_det: memset failed");
+        return M355_ERR_LAUNCH;
+    }
+    if (int rc = conv_wgrad_impl(d, x, dy, dw, dbias, stream, false, (long long *)ws)) return rc;
+    const size_t n = (size_t)d->Cout * d->kh * d->kw * d->Cin;
+    const size_t blocks = (n + d->Cout + 255) / 256;
+    hipLaunchKernelGGL(m355::k_fix_to_f32, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, (const long long *)ws, dw,
+                       n, dbias, d->Cout);
+    return m355::check_launch("conv2d_wgrad_det (convert)");
+}
 
 extern "C" int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias,
                                  void *stream)
@@ -1501,7 +1546,7 @@ extern "C" int m355_conv2d_wgrad_acc(const m355_conv_desc *d, const void *x, con
 }
 
 static int conv_wgrad_impl(const m355_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias, void *stream,
-                           bool zero)
+                           bool zero, long long *fix)
 {
     if (int rc = check_desc(d, "conv2d_wgrad")) return rc;
     M355_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
@@ -1512,6 +1557,7 @@ static int conv_wgrad_impl(const m355_conv_desc *d, const void *x, const void *d
     a.dy = (const unsigned short *)dy;
     a.dw = dw;
     a.db = dbias;
+    a.fix = fix;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ups = d->upsample;
     a.Hl = d->H << d->upsample; a.Wl = d->W << d->upsample;
     conv_out_hw(d, &a.Ho, &a.Wo);
@@ -1527,8 +1573,8 @@ static int conv_wgrad_impl(const m355_conv_desc *d, const void *x, const void *d
         m355::set_error("conv2d_wgrad: memset failed");
         return M355_ERR_LAUNCH;
     }
-    if (m355::wgrad_c8_eligible(d, a.Cy)) return m355::wgrad_c8_launch(d, x, dy, a.Cy, dw, dbias, st);
-    if (m355::wgrad_small_eligible(d, a.Cy)) return m355::wgrad_small_launch(d, x, dy, a.Cy, dw, st);
+    if (m355::wgrad_c8_eligible(d, a.Cy)) return m355::wgrad_c8_launch(d, x, dy, a.Cy, dw, dbias, st, fix);
+    if (m355::wgrad_small_eligible(d, a.Cy)) return m355::wgrad_small_launch(d, x, dy, a.Cy, dw, st, fix);
     const size_t xbytes = (size_t)d->N * d->H * d->W * d->Cin * 2, ybytes = (size_t)P * a.Cy * 2;
     const int lgWo = m355::ilog2_exact(a.Wo), lgHo = m355::ilog2_exact(a.Ho);
     if (wgrad_dma_ok(d) && m355::wgrad_halo_eligible(a))
@@ -1550,14 +1596,17 @@ static int conv_wgrad_impl(const m355_conv_desc *d, const void *x, const void *d
         splits = (P + a.chunk - 1) / a.chunk;
         m355::WgradDmaArgs A = {a, lgWo, lgHo, (unsigned)xbytes, (unsigned)ybytes};
         const dim3 grid(gx, gy, splits);
-#define M355_WG(TM_, TN_)                                                                                              \
-    do {                                                                                                               \
-        if (d->pad_w_mode == 0) hipLaunchKernelGGL((m355::k_wgrad_dma<TM_, TN_, 0>), grid, dim3(256), 0, st, A);       \
-        else if (d->pad_w_mode == 1) hipLaunchKernelGGL((m355::k_wgrad_dma<TM_, TN_, 1>), grid, dim3(256), 0, st, A);  \
-        else hipLaunchKernelGGL((m355::k_wgrad_dma<TM_, TN_, 2>), grid, dim3(256), 0, st, A);                          \
+#define M355_WG(TM_, TN_, DET_)                                                                                              \
+    do {                                                                                                                     \
+        if (d->pad_w_mode == 0) hipLaunchKernelGGL((m355::k_wgrad_dma<TM_, TN_, 0, DET_>), grid, dim3(256), 0, st, A);       \
+        else if (d->pad_w_mode == 1) hipLaunchKernelGGL((m355::k_wgrad_dma<TM_, TN_, 1, DET_>), grid, dim3(256), 0, st, A);  \
+        else hipLaunchKernelGGL((m355::k_wgrad_dma<TM_, TN_, 2, DET_>), grid, dim3(256), 0, st, A);                          \
     } while (0)
-        if (TM == 128) M355_WG(128, 128);
-        else M355_WG(64, 256);
+        if (fix) {
+            if (TM == 128) M355_WG(128, 128, true);
+            else M355_WG(64, 256, true);
+        } else if (TM == 128) M355_WG(128, 128, false);
+        else M355_WG(64, 256, false);
 #undef M355_WG
         m355::note_kernel("k_wgrad_dma");
         return m355::check_launch("conv2d_wgrad (dma)");
@@ -1571,7 +1620,10 @@ static int conv_wgrad_impl(const m355_conv_desc *d, const void *x, const void *d
     if (splits < 1) splits = 1;
     a.chunk = ((P + splits - 1) / splits + m355::WK - 1) / m355::WK * m355::WK;
     splits = (P + a.chunk - 1) / a.chunk;
-    if (TM == 128) hipLaunchKernelGGL(m355::k_wgrad_mfma<128>, dim3(gx, gy, splits), dim3(256), 0, st, a);
+    if (fix) {
+        if (TM == 128) hipLaunchKernelGGL((m355::k_wgrad_mfma<128, true>), dim3(gx, gy, splits), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((m355::k_wgrad_mfma<64, true>), dim3(gx, gy, splits), dim3(256), 0, st, a);
+    } else if (TM == 128) hipLaunchKernelGGL(m355::k_wgrad_mfma<128>, dim3(gx, gy, splits), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(m355::k_wgrad_mfma<64>, dim3(gx, gy, splits), dim3(256), 0, st, a);
     m355::note_kernel("k_wgrad_mfma");
     return m355::check_launch("conv2d_wgrad");

@@ -318,6 +318,7 @@ struct SmallWgArgs {
     const unsigned short *x;   // bf16 NHWC [N,H,W,Cin]
     const unsigned short *dy;  // bf16 NHWC [N,H,W,Cy]
     float *dw;                 // fp32 [Cout][KS][KS][Cin], pre-zeroed
+    long long *fix;            // deterministic form: [flag | fixed-point dw] (conv_dma.h wg_accum), else null
     int N, H, W, Cin, Cout, Cy;
     int tiles_x, tiles_y;
     unsigned xbytes, ybytes;
@@ -336,7 +337,7 @@ __device__ __forceinline__ bf16x8 tr8(const unsigned char *p0, const unsigned ch
 // halo swizzle of the wgrad kernel: 8 pixels {x..x+3, x+8..x+11} must land on 8 distinct (parity, slot pair)
 __device__ __forceinline__ int wg_swz(int hx) { return (((hx >> 1) & 1) << 1) | (((hx >> 3) & 1) << 2); }
 
-template <int KS, int MODE>
+template <int KS, int MODE, bool DET = false>
 __global__ __launch_bounds__(256, 2) void k_wgrad_smallco(SmallWgArgs a)
 {
     constexpr int HS = ST + KS - 1, HPIX = HS * HS, HINS = (HPIX + 7) / 8, HALO_B = HINS * 1024;
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_smallco(SmallWgArgs a)
         for (int r = 0; r < 4; ++r) {
             const int co = 4 * kgp + r;
             if (co < a.Cout)
-                atomicAdd(a.dw + ((size_t)co * TAPS + t) * a.Cin + cc * 64 + 16 * wave + (lane & 15), acc[t][r]);
+                wg_accum<DET>(a.dw, a.fix, ((size_t)co * TAPS + t) * a.Cin + cc * 64 + 16 * wave + (lane & 15), acc[t][r]);
         }
 }
 
@@ -444,12 +445,13 @@ bool wgrad_small_eligible(const m355_conv_desc *d, int Cy)
            (size_t)d->N * d->H * d->W * d->Cin * 2 < (1ull << 31) && (size_t)d->N * d->H * d->W * Cy * 2 < (1ull << 31);
 }
 
-int wgrad_small_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, hipStream_t st)
+int wgrad_small_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, hipStream_t st, long long *fix)
 {
     SmallWgArgs a = {};
     a.x = (const unsigned short *)x;
     a.dy = (const unsigned short *)dy;
     a.dw = dw;
+    a.fix = fix;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cy = Cy;
     a.tiles_x = (d->W + ST - 1) / ST;
     a.tiles_y = (d->H + ST - 1) / ST;
@@ -459,14 +461,17 @@ int wgrad_small_launch(const m355_conv_desc *d, const void *x, const void *dy, i
     int gx = (512 + nchunks - 1) / nchunks;  // ~512 workgroups (2 per CU)
     if (gx > ntiles) gx = ntiles;
     const dim3 grid(gx, 1, nchunks);
-#define M355_SW(KS_)                                                                                               \
-    do {                                                                                                           \
-        if (d->pad_w_mode == 0) hipLaunchKernelGGL((k_wgrad_smallco<KS_, 0>), grid, dim3(256), 0, st, a);          \
-        else if (d->pad_w_mode == 1) hipLaunchKernelGGL((k_wgrad_smallco<KS_, 1>), grid, dim3(256), 0, st, a);     \
-        else hipLaunchKernelGGL((k_wgrad_smallco<KS_, 2>), grid, dim3(256), 0, st, a);                             \
+#define M355_SW(KS_, DET_)                                                                                               \
+    do {                                                                                                                 \
+        if (d->pad_w_mode == 0) hipLaunchKernelGGL((k_wgrad_smallco<KS_, 0, DET_>), grid, dim3(256), 0, st, a);          \
+        else if (d->pad_w_mode == 1) hipLaunchKernelGGL((k_wgrad_smallco<KS_, 1, DET_>), grid, dim3(256), 0, st, a);     \
+        else hipLaunchKernelGGL((k_wgrad_smallco<KS_, 2, DET_>), grid, dim3(256), 0, st, a);                             \
     } while (0)
-    if (d->kh == 5) M355_SW(5);
-    else M355_SW(3);
+    if (fix) {
+        if (d->kh == 5) M355_SW(5, true);
+        else M355_SW(3, true);
+    } else if (d->kh == 5) M355_SW(5, false);
+    else M355_SW(3, false);
 #undef M355_SW
     note_kernel("k_wgrad_smallco");
     return check_launch("conv2d_wgrad (small Cout)");
@@ -957,6 +962,7 @@ struct C8WgArgs {
     const unsigned short *x;   // bf16 NHWC [N,H,W,8]
     const unsigned short *dy;  // bf16 NHWC [N,H,W,Cy], Cy = 64 * k
     float *dw, *db;            // fp32 [Cout][5][5][8] (+=), [Cout] (+=) or null
+    long long *fix;            // deterministic form: [flag | fixed-point dw | fixed-point db] (conv_dma.h wg_accum), else null
     int N, H, W, Cout, Cy;
     unsigned xbytes, ybytes;
 };
@@ -973,7 +979,7 @@ __device__ __forceinline__ void sfor(F &&f)
 #ifndef M355_WGC8_NST
 #define M355_WGC8_NST 3
 #endif
-template <int MODE>
+template <int MODE, bool DET = false>
 __global__ __launch_bounds__(512, 2) void k_wgrad_c8(C8WgArgs a)
 {
     constexpr int TH = 8, TW = 32, KS = 5, HS_X = TW + KS - 1, HS_Y = TH + KS - 1, HPIX = HS_X * HS_Y;
@@ -1096,7 +1102,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_c8(C8WgArgs a)
         else tile_mma(bx, by, std::integral_constant<int, 0>{});
         st = st == NST - 1 ? 0 : st + 1;
     }
-    if (do_db && co0 + dbc < a.Cout) atomicAdd(a.db + co0 + dbc, dbacc);
+    if (do_db && co0 + dbc < a.Cout) wg_accum<DET>(a.db, a.fix, (DET ? (size_t)a.Cout * 200 : 0) + co0 + dbc, dbacc);
     // acc[t][r]: co = co0 + 32 cb + (r&3) + 8(r>>2) + 4(lane>>5); column lane&31 of block 5cg + t = (kh, kw0 + (n>>3), n&7)
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
@@ -1105,7 +1111,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_c8(C8WgArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + 32 * cb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < a.Cout) atomicAdd(a.dw + ((size_t)co * 25 + kh * 5 + kw) * 8 + ci, acc[t][r]);
+                if (co < a.Cout) wg_accum<DET>(a.dw, a.fix, ((size_t)co * 25 + kh * 5 + kw) * 8 + ci, acc[t][r]);
             }
         }
     }
@@ -1118,12 +1124,14 @@ bool wgrad_c8_eligible(const m355_conv_desc *d, int Cy)
            !getenv("M355_NO_C8");
 }
 
-int wgrad_c8_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, float *db, hipStream_t st)
+int wgrad_c8_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, float *db, hipStream_t st,
+                    long long *fix)
 {
     C8WgArgs a = {};
     a.x = (const unsigned short *)x;
     a.dy = (const unsigned short *)dy;
     a.dw = dw; a.db = db;
+    a.fix = fix;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cout = d->Cout; a.Cy = Cy;
     a.xbytes = (unsigned)((size_t)d->N * d->H * d->W * 16);
     a.ybytes = (unsigned)((size_t)d->N * d->H * d->W * Cy * 2);
@@ -1132,7 +1140,11 @@ int wgrad_c8_launch(const m355_conv_desc *d, const void *x, const void *dy, int 
     if (gx < 1) gx = 1;
     if (gx > tiles) gx = tiles;
     const dim3 grid(gx, ny);
-    if (d->pad_w_mode == 0) hipLaunchKernelGGL((k_wgrad_c8<0>), grid, dim3(512), 0, st, a);
+    if (fix) {
+        if (d->pad_w_mode == 0) hipLaunchKernelGGL((k_wgrad_c8<0, true>), grid, dim3(512), 0, st, a);
+        else if (d->pad_w_mode == 1) hipLaunchKernelGGL((k_wgrad_c8<1, true>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_wgrad_c8<2, true>), grid, dim3(512), 0, st, a);
+    } else if (d->pad_w_mode == 0) hipLaunchKernelGGL((k_wgrad_c8<0>), grid, dim3(512), 0, st, a);
     else if (d->pad_w_mode == 1) hipLaunchKernelGGL((k_wgrad_c8<1>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((k_wgrad_c8<2>), grid, dim3(512), 0, st, a);
     note_kernel("k_wgrad_c8");

@@ -24,4 +24,4 @@ void note_kernel(const char *name) { g_kernel = name; }
 extern "C" const char *m355_last_error(void) { return m355::g_err; }
 /* kernel family the calling thread's last conv2d entry point dispatched to (what rocprofv3 will list) */
 extern "C" const char *m355_last_kernel(void) { return m355::g_kernel; }
-extern "C" int m355_abi_version(void) { return 1; }
+extern "C" int m355_abi_version(void) { return 2; }

@@ -347,12 +347,14 @@ __global__ __launch_bounds__(256) void k_cproj_fwd(const short *__restrict__ fea
     if (lane == 0) o[(size_t)n * HW + p] = acc;
 }
 
-// backward: dfeat[n,p,c] = g[n,p] * emb[n,c] (bf16), demb[n,c] += sum_p g[n,p] * feat[n,p,c]   (demb zeroed by the caller).
+// backward: dfeat[n,p,c] = g[n,p] * emb[n,c] (bf16), part[n][blk][c] = the workgroup's share of demb[n,c] = sum_p g[n,p] * feat[n,p,c]
+// (one workgroup per sample: part IS demb; otherwise k_sum_partials adds the shares in workgroup order -- deterministic, where the
+// fp32 atomics this replaces depended on the order the workgroups finished in).
 // mask_slope != 1: feat is the output of a fused conv + LeakyReLU(mask_slope) whose backward is applied HERE (dfeat *= feat > 0
 // ? 1 : mask_slope) -- masking is linear, so when every consumer of that activation masks its own branch of the gradient the
 // producer needs no activation-backward pass over the summed gradient (TextureDiscriminator.conv4 -> conv5 + projection)
 __global__ __launch_bounds__(256) void k_cproj_bwd(const short *__restrict__ feat, const float *__restrict__ emb,
-                                                   const float *__restrict__ g, short *__restrict__ dfeat, float *__restrict__ demb,
+                                                   const float *__restrict__ g, short *__restrict__ dfeat, float *__restrict__ part,
                                                    int HW, int C, int ppb, float mask_slope)
 {
     __shared__ float red[256 * 8];
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(256) void k_cproj_bwd(const short *__restrict__ fea
         const int vv = c >> 3, jj = c & 7;
         float sum = 0.0f;
         for (int l = 0; l < lanes; ++l) sum += red[(l * vecs + vv) * 8 + jj];
-        atomicAdd(demb + (size_t)n * C + c, sum);
+        part[((size_t)n * gridDim.x + blockIdx.x) * C + c] = sum;
     }
 }
 
@@ -541,18 +543,24 @@ extern "C" int m355_cproj_fwd(const void *feat, const float *emb, float *out /*[
     return check_launch("cproj_fwd");
 }
 
+/* floats of scratch m355_cproj_bwd needs (0: one workgroup per sample, demb is written directly) */
+extern "C" size_t m355_cproj_bwd_ws_floats(int N, int HW, int C)
+{
+    if (N <= 0 || HW <= 0 || C <= 0) return 0;
+    const int ppb = pix_per_block((size_t)HW, C), nblk = (HW + ppb - 1) / ppb;
+    return nblk > 1 ? (size_t)N * nblk * C : 0;
+}
+
 extern "C" int m355_cproj_bwd(const void *feat, const float *emb, const float *g /*[N,HW]*/, void *dfeat, float *demb /*[N,C]*/,
-                              int N, int HW, int C, float mask_slope, void *stream)
+                              float *ws, int N, int HW, int C, float mask_slope, void *stream)
 {
     M355_REQUIRE(feat && emb && g && dfeat && demb && N > 0 && HW > 0 && N <= 65535, "cproj_bwd: bad argument");
     if (int rc = check_c(C, "cproj_bwd")) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(demb, 0, sizeof(float) * (size_t)N * C, st) != hipSuccess) {
-        set_error("cproj_bwd: memset failed");
-        return M355_ERR_LAUNCH;
-    }
-    const int ppb = pix_per_block((size_t)HW, C);
-    hipLaunchKernelGGL(k_cproj_bwd, dim3((HW + ppb - 1) / ppb, N), dim3(256), 0, st, (const short *)feat, emb, g, (short *)dfeat, demb,
+    const int ppb = pix_per_block((size_t)HW, C), nblk = (HW + ppb - 1) / ppb;
+    M355_REQUIRE(nblk == 1 || ws, "cproj_bwd: workspace required (m355_cproj_bwd_ws_floats)");
+    hipLaunchKernelGGL(k_cproj_bwd, dim3(nblk, N), dim3(256), 0, st, (const short *)feat, emb, g, (short *)dfeat, nblk == 1 ? demb : ws,
                        HW, C, ppb, mask_slope);
+    if (nblk > 1) hipLaunchKernelGGL(k_sum_partials, dim3((C + 31) / 32, N), dim3(256), 0, st, (const float *)ws, demb, nblk, C);
     return check_launch("cproj_bwd");
 }

@@ -12,9 +12,30 @@
 namespace m355 {
 
 // ------------------------------------------------------------------------------------------- spectral norm, forward
+// Two launches per training forward (one in eval mode), no atomics on floats: every cross-workgroup sum is a per-workgroup
+// partial in `scratch` added in a FIXED order, so sigma / u / v have the same bits on every run (the first version accumulated
+// the two norms with fp32 atomics: run-to-run differences in the last bit of every weight of the network).
+//   scratch = [L] int tickets (zero before the first call; the kernels leave them zero) | [L][T1] partials of |W^T u|^2 per
+//   64-column tile | [L][T2] partials per 4-row block;  T1 = ceil(max_cols / 64), T2 = ceil(max_rows / 4).
+// The last row block of a layer to finish (ticket) sums the layer's partials and does what used to be a third launch:
+// u <- s / |s|, sigma, the snapshots.
+__device__ __forceinline__ float wave_sum_fixed(float v)   // butterfly: the same additions in the same order in every wave
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float ordered_sum(const float *p, int n)   // by one full wave; identical wherever it is evaluated
+{
+    const int lane = threadIdx.x & 63;
+    float s = 0.0f;
+    for (int j = lane; j < n; j += 64) s += p[j];
+    return wave_sum_fixed(s);
+}
+
 // t = W^T u   (train only).  Block = 64 columns x 16 row groups, 4 independent loads in flight per thread (the
 // 4-group version walked 128 rows of the 512-row layers one dependent load at a time).
-__global__ __launch_bounds__(1024) void k_sn_wtu(const m355_sn_layer *__restrict__ tab, float *__restrict__ norms)
+__global__ __launch_bounds__(1024) void k_sn_wtu(const m355_sn_layer *__restrict__ tab, float *__restrict__ p1, int T1)
 {
     __shared__ float red[16][64];
     const m355_sn_layer L = tab[blockIdx.y];
@@ -35,26 +56,27 @@ __global__ __launch_bounds__(1024) void k_sn_wtu(const m355_sn_layer *__restrict
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += red[k][cl];
         if (c < L.cols) L.t[c] = t;
-        float sq = c < L.cols ? t * t : 0.0f;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-        if (cl == 0) atomicAdd(norms + 2 * blockIdx.y, sq);
+        const float sq = wave_sum_fixed(c < L.cols ? t * t : 0.0f);
+        if (cl == 0) p1[(size_t)blockIdx.y * T1 + blockIdx.x] = sq;
     }
 }
 
 // s = W vhat, one wave per row (4 rows per block).  train: vhat = t / max(||t||, eps) (and v <- vhat, written by the
-// layer's first block); eval: vhat = v.   norms[2l+1] += s_i^2 (train) or u_i * s_i (eval).
-__global__ __launch_bounds__(256) void k_sn_wv(const m355_sn_layer *__restrict__ tab, float *__restrict__ norms, int training,
-                                               float eps)
+// layer's first block); eval: vhat = v.   p2[l][block] = sum over the block's rows of s_i^2 (train) or u_i * s_i (eval);
+// the layer's last block: u <- s / max(||s||, eps), sigma = ||s||^2 / max(||s||, eps) (train) / sigma = u . s (eval).
+__global__ __launch_bounds__(256) void k_sn_wv(const m355_sn_layer *__restrict__ tab, const float *__restrict__ p1, int T1,
+                                               float *__restrict__ p2, int T2, int *__restrict__ tickets, float *__restrict__ sigma,
+                                               int training, float eps)
 {
-    const m355_sn_layer L = tab[blockIdx.y];
+    const int l = blockIdx.y;
+    const m355_sn_layer L = tab[l];
     const int r0 = blockIdx.x * 4;
     if (r0 >= L.rows) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = r0 + wave;
     float inv = 1.0f;
     const float *vv = L.v;
     if (training) {
-        inv = 1.0f / fmaxf(sqrtf(norms[2 * blockIdx.y]), eps);
+        inv = 1.0f / fmaxf(sqrtf(ordered_sum(p1 + (size_t)l * T1, (L.cols + 63) / 64)), eps);
         vv = L.t;
     }
     float acc = 0.0f;
@@ -83,12 +105,9 @@ __global__ __launch_bounds__(256) void k_sn_wv(const m355_sn_layer *__restrict__
         }
         acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    acc *= inv;
-    // one atomic per workgroup, not per row: 512 same-address atomics per layer serialise in the L2 (that, not the reads, was
-    // most of this kernel's 54 us)
+    acc = wave_sum_fixed(acc) * inv;
     __shared__ float wsum[4];
+    __shared__ int last;
     if (lane == 0) {
         float contrib = 0.0f;
         if (i < L.rows) {
@@ -97,42 +116,39 @@ __global__ __launch_bounds__(256) void k_sn_wv(const m355_sn_layer *__restrict__
         }
         wsum[wave] = contrib;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(norms + 2 * blockIdx.y + 1, (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
     if (training && blockIdx.x == 0)
         for (int j = threadIdx.x; j < L.cols; j += 256) {
             const float vn = L.t[j] * inv;
             L.v[j] = vn;
             if (L.v_snap) L.v_snap[j] = vn;
         }
-}
-
-// train: u = s / max(||s||, eps), sigma = ||s||^2 / max(||s||, eps);  eval: sigma = u . s.   Clears the norms.
-__global__ __launch_bounds__(256) void k_sn_final(const m355_sn_layer *__restrict__ tab, float *__restrict__ norms,
-                                                  float *__restrict__ sigma, int training, float eps)
-{
-    const m355_sn_layer L = tab[blockIdx.x];
-    const float n1 = norms[2 * blockIdx.x + 1];
     __syncthreads();
+    const int nblk = (L.rows + 3) / 4;
+    if (threadIdx.x == 0) {
+        p2[(size_t)l * T2 + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        __threadfence();                                   // release: this block's s rows and its partial ...
+        last = atomicAdd(tickets + l, 1) == nblk - 1;      // ... before the ticket (device scope)
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();                                       // acquire: every other block's rows and partials
+    const float n1 = ordered_sum(p2 + (size_t)l * T2, nblk);
     if (training) {
-        const float inv = 1.0f / fmaxf(sqrtf(n1), eps);
-        for (int i = threadIdx.x; i < L.rows; i += 256) {
-            const float un = L.s[i] * inv;
-            L.u[i] = un;
-            if (L.u_snap) L.u_snap[i] = un;
+        const float inv1 = 1.0f / fmaxf(sqrtf(n1), eps);
+        for (int r = threadIdx.x; r < L.rows; r += 256) {
+            const float un = __builtin_nontemporal_load(L.s + r) * inv1;
+            L.u[r] = un;
+            if (L.u_snap) L.u_snap[r] = un;
         }
-        if (threadIdx.x == 0) sigma[blockIdx.x] = n1 * inv;
+        if (threadIdx.x == 0) sigma[l] = n1 * inv1;
     } else {
         if (L.u_snap)
-            for (int i = threadIdx.x; i < L.rows; i += 256) L.u_snap[i] = L.u[i];
+            for (int r = threadIdx.x; r < L.rows; r += 256) L.u_snap[r] = L.u[r];
         if (L.v_snap)
             for (int j = threadIdx.x; j < L.cols; j += 256) L.v_snap[j] = L.v[j];
-        if (threadIdx.x == 0) sigma[blockIdx.x] = n1;
+        if (threadIdx.x == 0) sigma[l] = n1;
     }
-    if (threadIdx.x == 0) {
-        norms[2 * blockIdx.x] = 0.0f;
-        norms[2 * blockIdx.x + 1] = 0.0f;
-    }
+    if (threadIdx.x == 0) tickets[l] = 0;                  // ready for the next call (stream order)
 }
 
 // ------------------------------------------------------------------------------------------- spectral norm, backward
@@ -363,14 +379,23 @@ __global__ void k_bn_bwd_coeffs(const float *__restrict__ m, float count_h, cons
 
 using namespace m355;
 
-extern "C" int m355_sn_power_iter(const m355_sn_layer *table_dev, int L, int max_rows, int max_cols, float *norms,
+/* 4-byte words of scratch m355_sn_power_iter needs for L layers of at most max_rows x max_cols (zero them ONCE) */
+extern "C" size_t m355_sn_scratch_words(int L, int max_rows, int max_cols)
+{
+    if (L <= 0 || max_rows <= 0 || max_cols <= 0) return 0;
+    return (size_t)L * (1 + (size_t)(max_cols + 63) / 64 + (size_t)(max_rows + 3) / 4);
+}
+
+extern "C" int m355_sn_power_iter(const m355_sn_layer *table_dev, int L, int max_rows, int max_cols, float *scratch,
                                   float *sigma, int training, float eps, void *stream)
 {
-    M355_REQUIRE(table_dev && norms && sigma && L > 0 && max_rows > 0 && max_cols > 0, "sn_power_iter: bad argument");
+    M355_REQUIRE(table_dev && scratch && sigma && L > 0 && max_rows > 0 && max_cols > 0, "sn_power_iter: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    if (training) hipLaunchKernelGGL(k_sn_wtu, dim3((max_cols + 63) / 64, L), dim3(1024), 0, st, table_dev, norms);
-    hipLaunchKernelGGL(k_sn_wv, dim3((max_rows + 3) / 4, L), dim3(256), 0, st, table_dev, norms, training, eps);
-    hipLaunchKernelGGL(k_sn_final, dim3(L), dim3(256), 0, st, table_dev, norms, sigma, training, eps);
+    const int T1 = (max_cols + 63) / 64, T2 = (max_rows + 3) / 4;
+    int *tickets = reinterpret_cast<int *>(scratch);
+    float *p1 = scratch + L, *p2 = p1 + (size_t)L * T1;
+    if (training) hipLaunchKernelGGL(k_sn_wtu, dim3(T1, L), dim3(1024), 0, st, table_dev, p1, T1);
+    hipLaunchKernelGGL(k_sn_wv, dim3(T2, L), dim3(256), 0, st, table_dev, (const float *)p1, T1, p2, T2, tickets, sigma, training, eps);
     return check_launch("sn_power_iter");
 }
 

@@ -281,9 +281,10 @@ __global__ __launch_bounds__(256) void k_head_tail_fwd(const float *__restrict__
     }
 }
 
-// dout [N,C,H,Wo], out (the forward's result, for tanh') -> g [N,H,W,8] bf16 (conv's dy layout), dbias[C] += sums
+// dout [N,C,H,Wo], out (the forward's result, for tanh') -> g [N,H,W,8] bf16 (conv's dy layout), part[block][4] = the block's
+// bias-gradient sums (reduced in block order by k_head_tail_db: deterministic -- this used to be one fp32 atomic per block)
 __global__ __launch_bounds__(256) void k_head_tail_bwd(const float *__restrict__ dout, const float *__restrict__ out,
-                                                       short *__restrict__ g, float *__restrict__ dbias, int C, int H, int W,
+                                                       short *__restrict__ g, float *__restrict__ part, int C, int H, int W,
                                                        int flags, size_t total)
 {
     __shared__ float red[4][8];
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(256) void k_head_tail_bwd(const float *__restrict__
         }
         *reinterpret_cast<bf16x8i *>(g + i * 8) = pack8_i(z);
     }
-    // bias gradient: wave reduce, then one atomic per wave and channel
+    // bias gradient: wave reduce, one partial per workgroup and channel
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -329,7 +330,26 @@ __global__ __launch_bounds__(256) void k_head_tail_bwd(const float *__restrict__
         if (lane == 0) red[wave][c] = s;
     }
     __syncthreads();
-    if (threadIdx.x < C) atomicAdd(dbias + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x < 4)
+        part[(size_t)blockIdx.x * 4 + threadIdx.x] =
+            threadIdx.x < 3 ? (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]) : 0.0f;
+}
+
+// dbias[c] = part[0][c] + part[1][c] + ... : 64 lanes take every 64th block in order, lane 0 adds the 64 lane sums in order
+__global__ __launch_bounds__(256) void k_head_tail_db(const float *__restrict__ part, float *__restrict__ dbias, int nblk, int C)
+{
+    __shared__ float red[4][64];
+    const int c = threadIdx.x >> 6, l = threadIdx.x & 63;
+    float s = 0.0f;
+    if (c < C)
+        for (int b = l; b < nblk; b += 64) s += part[(size_t)b * 4 + c];
+    red[c][l] = s;
+    __syncthreads();
+    if (l == 0 && c < C) {
+        float t = 0.0f;
+        for (int k = 0; k < 64; ++k) t += red[c][k];
+        dbias[c] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------- hinge loss
@@ -343,7 +363,7 @@ struct HingeArgs {
     int mode;            // 0: generator (v = p);  1: discriminator (slot 0 = fake target, slot 1 = real target)
     float norm;          // K (unweighted) or sum of the weights
     float *loss;         // [2]
-    float *msum;         // [K,B] saved mask sums (hw_k when unmasked)
+    float *msum;         // [2,K,B]: saved mask sums (hw_k when unmasked) | the per-(discriminator, sample) loss terms (scratch)
     const float *gl;     // [2] incoming gradients of the two losses (backward)
 };
 
@@ -354,7 +374,8 @@ __device__ __forceinline__ float hinge_v(float p, int mode, bool real)
     return fminf(t, 0.0f);
 }
 
-// grid (B, K), one workgroup per (sample, discriminator):  loss[slot] += -w_k / norm / B_slot * sum(v * mask) / sum(mask)
+// grid (B, K), one workgroup per (sample, discriminator):  term[k][b] = -w_k / norm / B_slot * sum(v * mask) / sum(mask);
+// k_hinge_sum adds the terms of each slot in (k, b) order (was one fp32 atomic per workgroup: order-dependent bits)
 __global__ __launch_bounds__(256) void k_hinge_fwd(HingeArgs a)
 {
     __shared__ float red[2][4];
@@ -384,7 +405,27 @@ __global__ __launch_bounds__(256) void k_hinge_fwd(HingeArgs a)
         a.msum[(size_t)k * a.B + b] = sm;
         const int nslot = real ? a.B - a.split : a.split;
         // unmasked: torch.mean over all elements = mean over samples of per-sample means (equal sizes)
-        atomicAdd(a.loss + (real ? 1 : 0), -a.w[k] / a.norm / (float)nslot * (s / sm));
+        a.msum[(size_t)(a.K + k) * a.B + b] = -a.w[k] / a.norm / (float)nslot * (s / sm);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_hinge_sum(HingeArgs a)
+{
+    __shared__ float red[2][256];
+    const float *term = a.msum + (size_t)a.K * a.B;
+    float s0 = 0.0f, s1 = 0.0f;
+    for (int i = threadIdx.x; i < a.K * a.B; i += 256) {   // thread t: entries t, t + 256, ... in order
+        const int b = i % a.B;
+        if (b >= a.split) s1 += term[i];
+        else s0 += term[i];
+    }
+    red[0][threadIdx.x] = s0;
+    red[1][threadIdx.x] = s1;
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        float t = 0.0f;
+        for (int k = 0; k < 256; ++k) t += red[threadIdx.x][k];
+        a.loss[threadIdx.x] = t;
     }
 }
 
@@ -521,19 +562,16 @@ extern "C" int m355_head_tail_fwd(const float *y, float *out, int N, int C, int 
     return check_launch("head_tail_fwd");
 }
 
-extern "C" int m355_head_tail_bwd(const float *dout, const float *out, void *g_nhwc8, float *dbias, int N, int C, int H, int W,
-                                  int flags, void *stream)
+extern "C" int m355_head_tail_bwd(const float *dout, const float *out, void *g_nhwc8, float *dbias, float *ws, int N, int C, int H,
+                                  int W, int flags, void *stream)
 {
-    M355_REQUIRE(dout && out && g_nhwc8 && dbias && N > 0 && C >= 1 && C <= 3 && H > 0 && W > 0, "head_tail_bwd: bad argument");
+    M355_REQUIRE(dout && out && g_nhwc8 && dbias && ws && N > 0 && C >= 1 && C <= 3 && H > 0 && W > 0, "head_tail_bwd: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(dbias, 0, sizeof(float) * C, st) != hipSuccess) {
-        set_error("head_tail_bwd: memset failed");
-        return M355_ERR_LAUNCH;
-    }
     const size_t total = (size_t)N * H * W;
     const size_t gb = (total + 255) / 256;
-    hipLaunchKernelGGL(k_head_tail_bwd, dim3((unsigned)(gb > 2048 ? 2048 : gb)), dim3(256), 0, st, dout, out, (short *)g_nhwc8, dbias, C,
-                       H, W, flags, total);
+    const unsigned nblk = (unsigned)(gb > M355_HEAD_TAIL_WS_FLOATS / 4 ? M355_HEAD_TAIL_WS_FLOATS / 4 : gb);
+    hipLaunchKernelGGL(k_head_tail_bwd, dim3(nblk), dim3(256), 0, st, dout, out, (short *)g_nhwc8, ws, C, H, W, flags, total);
+    hipLaunchKernelGGL(k_head_tail_db, dim3(1), dim3(256), 0, st, (const float *)ws, dbias, (int)nblk, C);
     return check_launch("head_tail_bwd");
 }
 
@@ -561,11 +599,8 @@ extern "C" int m355_hinge_fwd(int K, const float *const *p, const float *const *
     HingeArgs a = {};
     if (int rc = fill_hinge(a, K, p, m, hw, w, B, split, mode, loss2, msum)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(loss2, 0, 2 * sizeof(float), st) != hipSuccess) {
-        set_error("hinge_fwd: memset failed");
-        return M355_ERR_LAUNCH;
-    }
     hipLaunchKernelGGL(k_hinge_fwd, dim3(B, K), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_hinge_sum, dim3(1), dim3(256), 0, st, a);
     return check_launch("hinge_fwd");
 }
 

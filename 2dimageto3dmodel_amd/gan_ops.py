@@ -11,6 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import conv as C
+from . import _lib
 from ._lib import check, launch, lib, ptr, stream
 
 
@@ -207,7 +208,8 @@ class HeadConvFn(torch.autograd.Function):
         d = ctx.d
         g = torch.empty((d.N, d.H, d.W, 8), dtype=torch.bfloat16, device=x.device)
         db = torch.empty((d.Cout,), dtype=torch.float32, device=x.device)
-        launch("head_tail_bwd", ptr(dout.contiguous()), ptr(out), ptr(g), ptr(db), d.N, d.Cout, d.H, d.W, ctx.flags, stream())
+        ws = torch.empty((_lib.HEAD_TAIL_WS_FLOATS,), dtype=torch.float32, device=x.device)
+        launch("head_tail_bwd", ptr(dout.contiguous()), ptr(out), ptr(g), ptr(db), ptr(ws), d.N, d.Cout, d.H, d.W, ctx.flags, stream())
         dx = dw = None
         if ctx.needs_input_grad[0]:
             if ctx.in_slope != 1.0 and C.dgrad_mask_ok(d):
@@ -247,7 +249,7 @@ class HingeLossFn(torch.autograd.Function):
         ha = (ctypes.c_int * 3)(*hw + [0] * (3 - K))
         wa = None if weights is None else (ctypes.c_float * 3)(*[float(v) for v in weights] + [0.0] * (3 - K))
         loss2 = torch.empty(2, dtype=torch.float32, device=dev)
-        msum = torch.empty((K, B), dtype=torch.float32, device=dev)
+        msum = torch.empty((2 * K, B), dtype=torch.float32, device=dev)   # [mask sums | loss terms (scratch of the ordered sum)]
         launch("hinge_fwd", K, pa, ma, ha, wa, B, split, mode, ptr(loss2), ptr(msum), stream())
         ctx.cfg = (mode, split, weights, K, B, hw)
         ctx.save_for_backward(msum, *preds, *[m for m in masks if m is not None])
@@ -472,7 +474,9 @@ class SpectralNormGroup:
         self._max = (max(rows), max(cols))
         nr, nc = sum(rows), sum(cols)
         self._scratch = torch.empty(nr + nc, dtype=torch.float32, device=dev)
-        self._norms = torch.zeros(2 * len(self.convs), dtype=torch.float32, device=dev)
+        # per-workgroup partial sums + tickets of the power iteration (zero once: the kernels leave the tickets zero)
+        self._norms = torch.zeros(lib().m355_sn_scratch_words(len(self.convs), self._max[0], self._max[1]), dtype=torch.float32,
+                                  device=dev)
         self._slots = []
         for _ in range(self.SLOTS):
             snap = torch.empty(nr + nc, dtype=torch.float32, device=dev)
@@ -749,8 +753,10 @@ class ClassProjection(torch.autograd.Function):
         n, h, w, c = feat.shape
         dfeat = torch.empty_like(feat)
         demb = torch.empty((n, c), dtype=torch.float32, device=feat.device)
-        launch("cproj_bwd", ptr(feat), ptr(emb), ptr(g.contiguous().float()), ptr(dfeat), ptr(demb), n, h * w, c, ctx.in_slope,
-               stream())
+        nws = lib().m355_cproj_bwd_ws_floats(n, h * w, c)
+        ws = torch.empty((nws,), dtype=torch.float32, device=feat.device) if nws else None
+        launch("cproj_bwd", ptr(feat), ptr(emb), ptr(g.contiguous().float()), ptr(dfeat), ptr(demb), ptr(ws), n, h * w, c,
+               ctx.in_slope, stream())
         return dfeat, demb, None
 
 

@@ -126,9 +126,75 @@ def _f32c(t, name):
     return t.contiguous()
 
 
+# ---- static gather tables of the backward kernels (csrc/mesh_deform.hip: every gradient element is written by one thread that
+#      sums its contributions in table order -- deterministic, no atomics).  int32 CSR, built once per template on the host.
+def _csr(keys, n, *cols):
+    """rows sorted by key (stable: ties keep the given order) -> ptr [n+1] int32 and the permuted columns"""
+    keys = np.asarray(keys, np.int64)
+    order = np.argsort(keys, kind="stable")
+    ptr_ = np.zeros(n + 1, np.int32)
+    ptr_[1:] = np.cumsum(np.bincount(keys, minlength=n))
+    return (ptr_,) + tuple(np.ascontiguousarray(np.asarray(c)[order]) for c in cols)
+
+
+def texel_table(uv, src, H, W, symmetric):
+    """per texel of the [H,W] displacement map: the (vertex, weight) pairs of the bilinear taps landing on it.  Restates
+    taps() / src_col() of csrc/mesh_deform.hip in numpy fp32, operation for operation (that file is compiled with
+    -ffp-contract=off), so the weights are the forward's bits.  uv [S,2] fp32, src [V] -> ptr [H*W+1], vtx [E], w [E]"""
+    f32 = np.float32
+    uv = np.asarray(uv, f32)
+    src = np.asarray(src, np.int64)
+    V = src.shape[0]
+    Wp = W + (2 if symmetric else 1)
+    u, v = uv[src, 0], uv[src, 1]
+    fx = (u + f32(1.0)) * f32(0.5) * f32(Wp - 1)
+    fy = (v + f32(1.0)) * f32(0.5) * f32(H - 1)
+    x0, y0 = np.floor(fx), np.floor(fy)
+    wx1, wy1 = (fx - x0).astype(f32), (fy - y0).astype(f32)
+    wx = (f32(1.0) - wx1, wx1)
+    wy = (f32(1.0) - wy1, wy1)
+    x0i, y0i = x0.astype(np.int64), y0.astype(np.int64)
+    tex, vtx, wgt = [], [], []
+    vid = np.arange(V)
+    for iy in range(2):
+        for ix in range(2):
+            xp, yc = x0i + ix, y0i + iy
+            if symmetric:   # circpad(texture, 1): padded column 0 = stored W-1, W+1 = stored 0
+                xc = np.where(xp == 0, W - 1, np.where(xp == W + 1, 0, xp - 1))
+            else:           # cat(texture, texture[..., :1])
+                xc = np.where(xp == W, 0, xp)
+            ok = (xp >= 0) & (xp < Wp) & (yc >= 0) & (yc < H)
+            tex.append((yc * W + xc)[ok])
+            vtx.append(vid[ok])
+            wgt.append((wx[ix] * wy[iy]).astype(f32)[ok])
+    tex, vtx, wgt = np.concatenate(tex), np.concatenate(vtx), np.concatenate(wgt)
+    order = np.lexsort((np.arange(tex.shape[0]), vtx))   # vertices ascending inside a texel, taps in (iy, ix) order
+    return _csr(tex[order], H * W, vtx[order].astype(np.int32), wgt[order].astype(f32))
+
+
+def vertex_corner_table(faces, V):
+    """per vertex: 4 * face + corner of its incident face corners, ascending -> ptr [V+1], fc [3F]"""
+    faces = np.asarray(faces, np.int64)
+    F = faces.shape[0]
+    fc = (4 * np.arange(F)[:, None] + np.arange(3)[None, :]).reshape(-1)
+    return _csr(faces.reshape(-1), V, fc.astype(np.int32))
+
+
+def reverse_adjacency(ff):
+    """per face f: the faces g that list f in ff[g] (one entry per occurrence), ascending -> ptr [F+1], idx [3F]"""
+    ff = np.asarray(ff, np.int64)
+    F = ff.shape[0]
+    g = np.repeat(np.arange(F), 3)
+    return _csr(ff.reshape(-1), F, g.astype(np.int32))
+
+
+def _dev_tables(arrs, device):
+    return tuple(torch.from_numpy(a).to(device) for a in arrs)
+
+
 class _Vertices(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, dmap, uv, tgm, base, src, xsign, symmetric):
+    def forward(ctx, dmap, uv, tgm, base, src, xsign, symmetric, tex_table):
         dmap = _f32c(dmap.detach(), "displacement_map")
         B, C, H, W = dmap.shape
         assert C == 3, dmap.shape
@@ -136,57 +202,60 @@ class _Vertices(torch.autograd.Function):
         pos = torch.empty((B, V, 3), dtype=torch.float32, device=dmap.device)
         _launch("mesh_vertices_fwd", ptr(dmap), ptr(uv), ptr(tgm), ptr(base), ptr(src), ptr(xsign), ptr(pos), B, V, H, W,
                 int(symmetric), stream())
-        ctx.save_for_backward(uv, tgm, src, xsign)
-        ctx.cfg = (B, V, H, W, int(symmetric))
+        ctx.save_for_backward(tgm, src, xsign, *tex_table)
+        ctx.cfg = (B, V, H, W)
         return pos
 
     @staticmethod
     def backward(ctx, dpos):
-        uv, tgm, src, xsign = ctx.saved_tensors
-        B, V, H, W, sym = ctx.cfg
+        tgm, src, xsign, tptr, tvtx, tw = ctx.saved_tensors
+        B, V, H, W = ctx.cfg
         dpos = _f32c(dpos, "grad")
         ddmap = torch.empty((B, 3, H, W), dtype=torch.float32, device=dpos.device)
-        _launch("mesh_vertices_bwd", ptr(dpos), ptr(uv), ptr(tgm), ptr(src), ptr(xsign), ptr(ddmap), B, V, H, W, sym, stream())
-        return ddmap, None, None, None, None, None, None
+        _launch("mesh_vertices_bwd", ptr(dpos), ptr(tgm), ptr(src), ptr(xsign), ptr(tptr), ptr(tvtx), ptr(tw), ptr(ddmap), B, V, H, W,
+                stream())
+        return ddmap, None, None, None, None, None, None, None
 
 
 class _Normals(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pos, faces):
+    def forward(ctx, pos, faces, vtx_table):
         pos = _f32c(pos.detach(), "vertex_positions")
         B, V, _ = pos.shape
         F = faces.shape[0]
         nrm = torch.empty((B, F, 3), dtype=torch.float32, device=pos.device)
         _launch("mesh_normals_fwd", ptr(pos), ptr(faces), ptr(nrm), B, V, F, stream())
-        ctx.save_for_backward(pos, faces)
+        ctx.save_for_backward(pos, faces, *vtx_table)
         return nrm
 
     @staticmethod
     def backward(ctx, dnrm):
-        pos, faces = ctx.saved_tensors
+        pos, faces, vptr, vfc = ctx.saved_tensors
         B, V, _ = pos.shape
         dpos = torch.empty_like(pos)
-        _launch("mesh_normals_bwd", ptr(pos), ptr(faces), ptr(_f32c(dnrm, "grad")), ptr(dpos), B, V, faces.shape[0], stream())
-        return dpos, None
+        _launch("mesh_normals_bwd", ptr(pos), ptr(faces), ptr(_f32c(dnrm, "grad")), ptr(vptr), ptr(vfc), ptr(dpos), B, V,
+                faces.shape[0], stream())
+        return dpos, None, None
 
 
 class _Flat(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, nrm, ff):
+    def forward(ctx, nrm, ff, rev_table):
         nrm = _f32c(nrm.detach(), "norms")
         B, F, _ = nrm.shape
         loss = torch.empty((1,), dtype=torch.float32, device=nrm.device)
-        _launch("mesh_flat_fwd", ptr(nrm), ptr(ff), ptr(loss), B, F, stream())
-        ctx.save_for_backward(nrm, ff)
+        ws = torch.empty((B,), dtype=torch.float32, device=nrm.device)
+        _launch("mesh_flat_fwd", ptr(nrm), ptr(ff), ptr(loss), ptr(ws), B, F, stream())
+        ctx.save_for_backward(nrm, ff, *rev_table)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, gl):
-        nrm, ff = ctx.saved_tensors
+        nrm, ff, rptr, ridx = ctx.saved_tensors
         B, F, _ = nrm.shape
         dn = torch.empty_like(nrm)
-        _launch("mesh_flat_bwd", ptr(nrm), ptr(ff), ptr(_f32c(gl.reshape(1), "grad")), ptr(dn), B, F, stream())
-        return dn, None
+        _launch("mesh_flat_bwd", ptr(nrm), ptr(ff), ptr(rptr), ptr(ridx), ptr(_f32c(gl.reshape(1), "grad")), ptr(dn), B, F, stream())
+        return dn, None, None
 
 
 def grid_sample_bilinear(input, grid):
@@ -224,9 +293,10 @@ def loss_flat(mesh, norms):
     ff32 = getattr(mesh, "_ff32", None)
     if ff32 is None or ff32.device != norms.device:
         ff32 = mesh._ff32 = mesh.ff.to(device=norms.device, dtype=torch.int32).contiguous()
+        mesh._ff_rev = _dev_tables(reverse_adjacency(mesh.ff.cpu().numpy()), norms.device)   # (one-off: the backward's gather table)
     if norms.shape[1] != ff32.shape[0]:
         raise ValueError(f"loss_flat: {norms.shape[1]} face normals for a mesh of {ff32.shape[0]} faces")
-    return _Flat.apply(norms, ff32)
+    return _Flat.apply(norms, ff32, mesh._ff_rev)
 
 
 # ------------------------------------------------------------------------------------------------ the template
@@ -314,6 +384,8 @@ class MeshTemplate:
         self._faces32 = self.mesh.faces.to(torch.int32).contiguous()
         self._tgm = (self.nonneg_tangent_map if is_symmetric else self.tangent_map).contiguous()
         self._uv_cache = {}
+        self._tex_cache = {}
+        self._vtx_table = _dev_tables(vertex_corner_table(f, V), dev)
 
     # -- the three per-step methods (HIP) -------------------------------------------------------------------------
     def _uv(self, W):
@@ -328,14 +400,23 @@ class MeshTemplate:
             uv = self._uv_cache[W] = topo.contiguous()
         return uv
 
+    def _tex_table(self, H, W):
+        """the backward's gather table for an [H,W] displacement map (one-off per map size)"""
+        t = self._tex_cache.get((H, W))
+        if t is None:
+            t = self._tex_cache[(H, W)] = _dev_tables(
+                texel_table(self._uv(W).cpu().numpy(), self._src.cpu().numpy(), H, W, self.is_symmetric), self._src.device)
+        return t
+
     def get_vertex_positions(self, displacement_map):
         """UV displacement map [B,3,H,W] -> vertex positions in object space [B,V,3] (:125-149)"""
-        return _Vertices.apply(displacement_map, self._uv(displacement_map.shape[3]), self._tgm, self.mesh.vertices,
-                               self._src, self._xsign, self.is_symmetric)
+        H, W = displacement_map.shape[2], displacement_map.shape[3]
+        return _Vertices.apply(displacement_map, self._uv(W), self._tgm, self.mesh.vertices,
+                               self._src, self._xsign, self.is_symmetric, self._tex_table(H, W))
 
     def compute_normals(self, vertex_positions):
         """face normals of the FINAL vertex positions [B,V,3] -> [B,F,3] (:113-123)"""
-        return _Normals.apply(vertex_positions, self._faces32)
+        return _Normals.apply(vertex_positions, self._faces32, self._vtx_table)
 
     def deform(self, deltas):
         """template deformation along the tangent map (:106-111); torch (the fused path is get_vertex_positions)"""

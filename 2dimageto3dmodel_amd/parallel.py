@@ -13,6 +13,8 @@ import torch
 import torch.distributed as dist
 
 
+DEFAULT_MASTER_PORT = 29533   # rendezvous port of hand-launched ranks when MASTER_PORT is unset (launchers always set it)
+
 # collective bookkeeping (bench.py reports it): how many collectives the GAN path issued and, when `time_allreduce` is
 # on, device/host time of the gradient all-reduces
 stats = {"grad_allreduces": 0, "grad_allreduce_bytes": 0, "syncbn_collectives": 0, "time_allreduce": False, "events": []}
@@ -38,15 +40,18 @@ def init_from_env(device_type="cuda", force=False):
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
-            # the launcher (torch.distributed.run, bench.py's respawn) owns the rendezvous port; only the launcher-less single-rank
-            # path (force: the 1-GPU RCCL smoke test) picks one itself -- a free one, two jobs on a host must not collide
+            # the launcher (torch.distributed.run, bench.py's respawn) owns the rendezvous port; the launcher-less single-rank
+            # path (force: the 1-GPU RCCL smoke test) picks a free one itself -- two jobs on a host must not collide
             if world > 1:
-                raise RuntimeError("parallel.init_from_env: WORLD_SIZE > 1 without MASTER_PORT (start the ranks under "
-                                   "torch.distributed.run, or through `bench.py --gpus N`)")
-            import socket
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+                # hand-launched ranks (RANK / WORLD_SIZE exported by a SLURM-style wrapper): every rank must agree on the port
+                # without talking to each other, so it is a documented constant; two such jobs on one host
+                # need MASTER_PORT set explicitly
+                os.environ["MASTER_PORT"] = str(DEFAULT_MASTER_PORT)
+            else:
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if device_type == "cuda":
             if local_rank >= torch.cuda.device_count():
                 raise RuntimeError(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible "

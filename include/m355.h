@@ -34,7 +34,7 @@ typedef enum {
 const char *m355_last_error(void);
 /* name of the kernel family the calling thread's last m355_conv2d_* call dispatched to (profiling aid) */
 const char *m355_last_kernel(void);
-int m355_abi_version(void);
+int m355_abi_version(void);   /* 2: deterministic reductions (round 4): workspaces on cproj_bwd / head_tail_bwd / mesh_flat_fwd, gather tables on the mesh backward, m355_conv2d_wgrad_det */
 
 /* flags for the projection entry points */
 #define M355_FIXED_WEIGHTS 1   /* w0 = 1-(g-floor g) instead of the literal 1-g-floor g (trilinear_interpolation.py:66) */
@@ -225,6 +225,14 @@ int m355_conv2d_wgrad_fuses_dbias(const m355_conv_desc *d);
 int m355_conv2d_wgrad(const m355_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias, void *stream);
 /*      the same with dw / dbias += (no zero fill: the caller zeroed them, e.g. one memset for all layers of a backward pass) */
 int m355_conv2d_wgrad_acc(const m355_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias, void *stream);
+/*      DETERMINISTIC form of the same: every wgrad kernel splits the pixel axis over workgroups and adds the partial tiles with
+ *      atomics -- fp32 atomics give run-to-run differences in the last bits (the reference's CPU path is bit-deterministic,
+ *      SURVEY 8c; code/main.py:691-723).  Here the SAME kernels accumulate the partials as 64-bit fixed-point integers
+ *      (value * 2^36: integer addition is associative, so the order the workgroups finish in cannot matter) in `ws`
+ *      (m355_conv2d_wgrad_det_ws_bytes(d) bytes, zeroed by the call) and one pass converts to fp32.  dw and dbias are
+ *      OVERWRITTEN.  A non-finite partial poisons the result with NaN, as fp32 accumulation would. */
+size_t m355_conv2d_wgrad_det_ws_bytes(const m355_conv_desc *d);
+int m355_conv2d_wgrad_det(const m355_conv_desc *d, const void *x, const void *dy, void *ws, float *dw, float *dbias, void *stream);
 
 /* ---- G3 / G-bwd  normalisation + conditional affine + LeakyReLU on NHWC bf16 (models/gan.py:264-286, 306-312).
  *      All reductions are two-stage and deterministic; ws >= m355_chan_reduce_ws_bytes(pixels per group, groups,
@@ -270,8 +278,10 @@ int m355_unpack_nhwc8(const void *g_nhwc8, float *dx_nchw, int N, int C, int H, 
 
 /* ---- G9  spectral normalisation (torch.nn.utils.spectral_norm, one power iteration per training forward:
  *      v = normalize(W^T u), u = normalize(W v), sigma = u.(W v); gan.py:57-65,163-177,294-302) for ALL layers of
- *      a network in three launches.  `table` is a device-resident array of L entries; norms[2L] must be zero on
- *      entry and is zero again on exit; u, v are updated in place when training, u_snap / v_snap (nullable)
+ *      a network in two launches (one in eval mode).  `table` is a device-resident array of L entries; scratch =
+ *      m355_sn_scratch_words(L, max_rows, max_cols) 4-byte words, zero before the FIRST call (the kernels leave its ticket
+ *      words zero): per-workgroup partial sums of the two norms, added in a fixed order -- sigma / u / v have the same bits on
+ *      every run (no floating-point atomics).  u, v are updated in place when training, u_snap / v_snap (nullable)
  *      receive the values this forward used (what autograd needs in the backward). */
 typedef struct {
     const float *w;          /* weight_orig viewed as [rows][cols] = [Cout][Cin*kh*kw] */
@@ -280,7 +290,8 @@ typedef struct {
     float *u_snap, *v_snap;  /* [rows], [cols] or NULL */
     int rows, cols;
 } m355_sn_layer;
-int m355_sn_power_iter(const m355_sn_layer *table, int L, int max_rows, int max_cols, float *norms, float *sigma,
+size_t m355_sn_scratch_words(int L, int max_rows, int max_cols);
+int m355_sn_power_iter(const m355_sn_layer *table, int L, int max_rows, int max_cols, float *scratch, float *sigma,
                        int training, float eps, void *stream);
 /*      weight gradient epilogue: g = dL/dW_sn as the wgrad kernel leaves it, [Cout][kh][kw][CinP] ->
  *      dw [Cout][Cin][kh][kw] = g / sigma - (<g, w_orig> / sigma^2) u v^T   (sigma NULL: plain re-layout).
@@ -342,19 +353,22 @@ int m355_unpack_range(const void *g, float *out, int M, int HW, int CP, int c0, 
 /*      Generator.forward after conv_final / conv_mesh, code/models/gan.py:407-419: flags M355_HT_TANH (tanh_),
  *      M355_HT_POLES (adjust_poles, rendering/utils.py:21-26), M355_HT_SYMM (symmetrize_texture, rendering/utils.py:15-18:
  *      out width 2W).  y [N,C<=3,H,W] -> out.  _bwd: dout, out -> g [N,H,W,8] bf16 (the layout m355_conv2d_dgrad / _wgrad
- *      expect of a 3-channel head's dy) and dbias[C]. */
+ *      expect of a 3-channel head's dy) and dbias[C] (overwritten; ws = M355_HEAD_TAIL_WS_FLOATS floats of scratch: the
+ *      workgroups' partial sums, added in workgroup order -- same bits on every run). */
 #define M355_HT_TANH 1
 #define M355_HT_POLES 2
 #define M355_HT_SYMM 4
+#define M355_HEAD_TAIL_WS_FLOATS 8192
 int m355_head_tail_fwd(const float *y, float *out, int N, int C, int H, int W, int flags, void *stream);
-int m355_head_tail_bwd(const float *dout, const float *out, void *g_nhwc8, float *dbias, int N, int C, int H, int W, int flags,
-                       void *stream);
+int m355_head_tail_bwd(const float *dout, const float *out, void *g_nhwc8, float *dbias, float *ws, int N, int C, int H, int W,
+                       int flags, void *stream);
 /*      GANLoss('hinge') over the K <= 3 discriminator outputs, code/utils/losses.py:49-120, with divide_pred
  *      (code/main.py:414-422) done by index: p[k] / m[k] (HOST arrays of K device pointers; m or m[k] NULL = unmasked)
  *      are [B,hw[k]]; samples [0,split) are the "fake" half (slot 0), [split,B) the "real" half (slot 1).
  *      mode 1 (discriminator): loss2[0] = loss vs target False on the fake half, loss2[1] = loss vs target True on the real
  *      half; mode 0 (generator, split = B): loss2[0] = -mean.  w (nullable): per-discriminator weights (main.py:486-489).
- *      msum [K,B]: per-sample mask sums kept for the backward; _bwd: gl2[2] incoming gradients -> dp[k] [B,hw[k]]. */
+ *      msum [2,K,B]: [0] per-sample mask sums kept for the backward, [1] scratch (the per-(discriminator, sample) loss terms,
+ *      which a second launch adds in (k, b) order: same bits on every run); _bwd: gl2[2] incoming gradients -> dp[k] [B,hw[k]]. */
 int m355_hinge_fwd(int K, const float *const *p, const float *const *m, const int *hw, const float *w, int B, int split, int mode,
                    float *loss2, float *msum, void *stream);
 int m355_hinge_bwd(int K, const float *const *p, const float *const *m, const int *hw, const float *w, int B, int split, int mode,
@@ -394,8 +408,9 @@ int m355_dibr_shade_bwd(const float *uvm_bxhxwx3, const float *texture_bx3xthxtw
  * mask_slope != 1: feat is a fused conv + LeakyReLU(mask_slope) output and dfeat is multiplied by that activation's derivative
  * (feat > 0 ? 1 : mask_slope), as m355_conv2d_dgrad does with mask_x for the other consumer of the same tensor. */
 int m355_cproj_fwd(const void *feat, const float *emb, float *out /*[N,HW]*/, int N, int HW, int C, void *stream);
+size_t m355_cproj_bwd_ws_floats(int N, int HW, int C);   /* scratch of _bwd (per-workgroup shares of demb, added in order); 0: none */
 int m355_cproj_bwd(const void *feat, const float *emb, const float *g /*[N,HW]*/, void *dfeat, float *demb /*[N,C]*/,
-                   int N, int HW, int C, float mask_slope, void *stream);
+                   float *ws, int N, int HW, int C, float mask_slope, void *stream);
 
 /* ---- mesh-template deformation, face normals, flat (smoothness) loss -- code/main.py:697-699 ----
  * Replaces MeshTemplate.get_vertex_positions / deform / compute_normals (code/rendering/mesh_template.py:106-149) and
@@ -407,17 +422,25 @@ int m355_cproj_bwd(const void *feat, const float *emb, const float *g /*[N,HW]*/
  *                    the symmetry plane, +1 otherwise)
  *   symmetric: 1 = circular pad by one column each side (mesh_template.py:166), 0 = one wrapped column (:169)
  *   faces [F,3] int32, ff [F,3] int32 face-face adjacency (kaolin `mesh.ff`)
- * _bwd entry points overwrite their gradient outputs. */
+ * The backward entry points are GATHERS over static CSR tables the host builds once per template (mesh.py; all int32):
+ *   tex_ptr [H*W+1], tex_vtx [E], tex_w [E]   per map texel: the (vertex, bilinear weight) pairs whose grid_sample taps land on
+ *                                              it (pad columns folded onto their source column), vertices ascending
+ *   vtx_ptr [V+1], vtx_fc [3F]                per vertex: 4 * face + corner of its incident face corners, ascending
+ *   rev_ptr [F+1], rev_idx [3F]               per face f: the faces g with f in ff[g] (the reverse of ff), ascending
+ * Every output element is written by exactly one thread, summing in table order: no atomics, no zero fill, and the same bits
+ * on every run (the reference's CPU path is deterministic).  _bwd entry points overwrite their gradient outputs;
+ * mesh_flat_fwd's ws is B floats of scratch (per-sample partial sums, added in index order). */
 int m355_mesh_vertices_fwd(const float *dmap, const float *uv, const float *tgm, const float *base, const int *src,
                            const float *xsign, float *pos /*[B,V,3]*/, int B, int V, int H, int W, int symmetric, void *stream);
-int m355_mesh_vertices_bwd(const float *dpos, const float *uv, const float *tgm, const int *src, const float *xsign,
-                           float *ddmap /*[B,3,H,W]*/, int B, int V, int H, int W, int symmetric, void *stream);
+int m355_mesh_vertices_bwd(const float *dpos, const float *tgm, const int *src, const float *xsign, const int *tex_ptr,
+                           const int *tex_vtx, const float *tex_w, float *ddmap /*[B,3,H,W]*/, int B, int V, int H, int W,
+                           void *stream);
 int m355_mesh_normals_fwd(const float *pos, const int *faces, float *normals /*[B,F,3]*/, int B, int V, int F, void *stream);
-int m355_mesh_normals_bwd(const float *pos, const int *faces, const float *dnormals, float *dpos, int B, int V, int F,
-                          void *stream);
-int m355_mesh_flat_fwd(const float *normals, const int *ff, float *loss /*[1]*/, int B, int F, void *stream);
-int m355_mesh_flat_bwd(const float *normals, const int *ff, const float *gloss /*[1]*/, float *dnormals, int B, int F,
-                       void *stream);
+int m355_mesh_normals_bwd(const float *pos, const int *faces, const float *dnormals, const int *vtx_ptr, const int *vtx_fc,
+                          float *dpos, int B, int V, int F, void *stream);
+int m355_mesh_flat_fwd(const float *normals, const int *ff, float *loss /*[1]*/, float *ws /*[B]*/, int B, int F, void *stream);
+int m355_mesh_flat_bwd(const float *normals, const int *ff, const int *rev_ptr, const int *rev_idx, const float *gloss /*[1]*/,
+                       float *dnormals, int B, int F, void *stream);
 
 #ifdef __cplusplus
 }

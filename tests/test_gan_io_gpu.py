@@ -109,7 +109,9 @@ def test_head_tail_matches_reference_ops(flags, C):
     assert (out.cpu() - t.detach()).abs().max().item() < 2e-6
     gbuf = torch.empty((N, H, W, 8), dtype=torch.bfloat16, device=DEV)
     db = torch.empty(C, device=DEV)
-    lib.launch("head_tail_bwd", lib.ptr(wt.to(DEV)), lib.ptr(out), lib.ptr(gbuf), lib.ptr(db), N, C, H, W, flags, lib.stream())
+    ws = torch.empty(lib.HEAD_TAIL_WS_FLOATS, device=DEV)
+    lib.launch("head_tail_bwd", lib.ptr(wt.to(DEV)), lib.ptr(out), lib.ptr(gbuf), lib.ptr(db), lib.ptr(ws), N, C, H, W, flags,
+               lib.stream())
     want = yr.grad.permute(0, 2, 3, 1)
     got = gbuf.float().cpu()
     assert (got[..., :C] - want).abs().max().item() < 1e-2 * want.abs().max().item()      # bf16 storage
