@@ -1117,6 +1117,268 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_c8(C8WgArgs a)
     }
 }
 
+
+// ---- k_wgrad_c8p (round 4): the same weight gradient with the x halo held CHANNEL-MAJOR ("planar") in LDS.
+// k_wgrad_c8 above reads every x pixel 25 times from LDS through transpose reads (96 ds_read_b64_tr per 40 MFMAs and wave: the LDS
+// pipe is as busy as the matrix pipe, and only 200 of the 320 MFMA columns it computes are taps) and sat at 3.0-3.2 TB/s of its
+// 1.2 GB stream at 1.4 kW.  Here:
+//   * the 12 x 36 x 8-channel halo of a tile (6.9 KB) is fetched by plain 16-byte global loads one tile ahead and written into
+//     LDS as eight planes [ci][12 rows][40 columns] of bf16 (row pitch 80 B, plane pitch 1056 B = 32 mod 256: the 16-byte window
+//     reads of a 16-lane group are conflict free);
+//   * MFMA 16x16x32 (K = one tile row of 32 pixels): a B column is (kh = 2 kp + a, ci) for a lane's a = (lane >> 3) & 1 and
+//     ci = lane & 7, and its eight k values are eight CONSECUTIVE pixels of one channel = one 16-byte run of a plane.  A lane
+//     reads a 12-pixel window of halo row (ty + kh) ONCE (ds_read_b128 + ds_read_b64) and derives the five kw taps from it in
+//     registers (kw even: a register offset; kw odd: v_alignbit_b32) -- 6 LDS reads + 24 VALU per 30 MFMAs instead of 60 reads;
+//   * column blocks: 3 kh pairs x 5 kw = 15 blocks of 16 = 240 columns for 200 taps (83 %; was 62 %); the A operand (dy^T) keeps the
+//     transpose reads of the DMA'd pixel-major dy tile; the bias gradient is one more MFMA per co block against an all-ones B;
+//   * waves = 2 co halves x 4 tile-row pairs; a wave keeps 2 x 15 (+ 2) 16 x 16 accumulators for the whole kernel; at the end the
+//     four row-pair waves of a co half are summed through LDS and leave as ONE atomic per element and workgroup;
+//   * the dy tiles (32 KB) are DMA'd four stages deep (three tiles = 96 KB in flight per CU).
+constexpr int C8P_SC = 1056, C8P_RP = 80, C8P_XB = 8 * C8P_SC;   // plane / row pitch, bytes per planar halo buffer
+constexpr int C8P_NST = 4, C8P_YB = 256 * 128;
+
+template <int MODE, bool DET = false>
+__global__ __launch_bounds__(512, 2) void k_wgrad_c8p(C8WgArgs a)
+{
+    constexpr int TH = 8, TW = 32, KS = 5, HS_X = TW + KS - 1, HS_Y = TH + KS - 1;   // 12 x 36 halo
+    constexpr int NST = C8P_NST;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NST * C8P_YB + 2 * C8P_XB];
+    unsigned char *const ldsX = lds + NST * C8P_YB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co0 = blockIdx.y * 64;
+    const int tpx = a.W / TW, tpy = a.H / TH, tiles = a.N * tpx * tpy, G = gridDim.x;
+    if ((int)blockIdx.x >= tiles) return;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, a.ybytes, 0x00020000);
+
+    // ---- tile cursors (image, tile row, tile column), stepped by the grid stride; the LAST tile is re-fetched when the list is
+    // exhausted so that every iteration issues the same number of memory instructions (constant s_waitcnt counts)
+    struct Cur { int n, ty, tx, left; };
+    int sg_n, sg_ty, sg_tx;
+    auto cur_at = [&](int tile) {
+        Cur c;
+        const int per_img = tpx * tpy;
+        c.n = tile / per_img;
+        const int r = tile - c.n * per_img;
+        c.ty = r / tpx; c.tx = r - c.ty * tpx;
+        c.left = (tiles - 1 - tile) / G;     // further tiles of this workgroup after `tile`
+        return c;
+    };
+    {
+        const int per_img = tpx * tpy;
+        sg_n = G / per_img;
+        const int r = G - sg_n * per_img;
+        sg_ty = r / tpx; sg_tx = r - sg_ty * tpx;
+    }
+    auto advance = [&](Cur &c) {
+        if (c.left <= 0) return;             // stay on the last tile
+        --c.left;
+        c.tx += sg_tx;
+        const int cx = c.tx >= tpx ? 1 : 0;
+        c.tx -= cx * tpx;
+        c.ty += sg_ty + cx;
+        const int cy = c.ty >= tpy ? 1 : 0;
+        c.ty -= cy * tpy;
+        c.n += sg_n + cy;
+    };
+    Cur cdy = cur_at((int)blockIdx.x), cx = cdy;   // next tile whose dy DMA / whose x loads are to be issued
+
+    // ---- dy DMA: instruction qi = 8 k + wave fills tile pixels 8 qi .. 8 qi + 7 (pixel = LDS row of 128 B = 64 co); slot l & 7 of
+    // row r holds source chunk (l & 7) ^ 4 ((r >> 1) & 1) ^ 2 ((r >> 3) & 1): the transpose reads of four pixel groups 8 apart
+    // then hit distinct banks
+    const int csrc = (lane & 7) ^ (((lane >> 4) & 1) << 2) ^ ((wave & 1) << 1);
+    auto issue_dy = [&](int st) {
+        const int n = cdy.n, oy0 = cdy.ty * TH, ox0 = cdy.tx * TW;
+        advance(cdy);
+        unsigned char *dY = lds + st * C8P_YB;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = 8 * (8 * k + wave) + (lane >> 3);
+            const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
+            dma16(ry, dY + (8 * k + wave) * 1024, (unsigned)((((n * a.H + oy) * a.W + ox) * a.Cy + co0) * 2 + csrc * 16), 0u);
+        }
+    };
+    // ---- x halo: thread t < 216 owns halo pixels (hy, 2 hp), (hy, 2 hp + 1), t = 18 hy + hp: two 16-byte loads, eight 4-byte
+    // plane writes
+    const bool has_x = wave < 4;                    // (wave-uniform: threads 216..255 of wave 3 idle inside)
+    const int xhy = tid / 18, xhp = tid - 18 * xhy;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    u32x4 xr0 = {0, 0, 0, 0}, xr1 = {0, 0, 0, 0};
+    auto load_x = [&]() {
+        const int n = cx.n, oy0 = cx.ty * TH, ox0 = cx.tx * TW;
+        advance(cx);
+        const int gy = oy0 - KS / 2 + xhy;
+        unsigned off[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            int gx = ox0 - KS / 2 + 2 * xhp + e;
+            bool ok = tid < 216 && (unsigned)gy < (unsigned)a.H;
+            if (MODE == 1) gx = min(max(gx, 0), a.W - 1);
+            else if (MODE == 2) gx = gx < 0 ? gx + a.W : (gx >= a.W ? gx - a.W : gx);
+            ok = ok && (unsigned)gx < (unsigned)a.W;
+            off[e] = ok ? (unsigned)(((n * a.H + gy) * a.W + gx) * 16) : OOB;
+        }
+        xr0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off[0], 0, 0));
+        xr1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off[1], 0, 0));
+    };
+    auto store_x = [&](int buf) {
+        if (tid < 216) {
+            unsigned char *dst = ldsX + buf * C8P_XB + xhy * C8P_RP + xhp * 4;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {   // word w of a pixel = channels 2w (low half), 2w + 1
+                *reinterpret_cast<unsigned *>(dst + (2 * w) * C8P_SC) = __builtin_amdgcn_perm(xr1[w], xr0[w], 0x05040100u);
+                *reinterpret_cast<unsigned *>(dst + (2 * w + 1) * C8P_SC) = __builtin_amdgcn_perm(xr1[w], xr0[w], 0x07060302u);
+            }
+        }
+    };
+
+    // ---- fragment roles
+    const int ch = wave & 1, pq = wave >> 1;                 // co half (32 channels), tile rows 2 pq, 2 pq + 1
+    const int q = lane & 15, g = lane >> 4;
+    const int swz = (((q >> 3) & 1) << 2) ^ ((g & 1) << 1);
+    int ya[2][2];                                            // [co block i][pixels 4 rd ..]: byte offset inside a dy stage, tile row 0
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd)
+            ya[i][rd] = (8 * g + 4 * rd + (q >> 2)) * 128 + (((2 * (2 * ch + i) + ((q & 3) >> 1)) ^ swz) << 4) + (q & 1) * 8;
+    const int bci = lane & 7, ba = (lane >> 3) & 1;
+    int xw[3];                                               // window base per kh pair, tile row 0: plane ci, halo row kh, column 8 g
+#pragma unroll
+    for (int kp = 0; kp < 3; ++kp) xw[kp] = bci * C8P_SC + min(2 * kp + ba, 4) * C8P_RP + 16 * g;
+
+    f32x4 acc[2][15], accb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 15; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_db = a.db != nullptr;
+    const bf16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+
+    // ---- prologue: x of tile 0 into planar buffer 0, dy of tiles 0 .. NST-2 in flight
+    if (has_x) load_x();
+#pragma unroll
+    for (int k = 0; k < NST - 1; ++k) issue_dy(k);
+    if (has_x) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NST - 1)) : "memory");
+        store_x(0);
+    }
+    int st = 0;
+    const int my_tiles = (tiles - 1 - (int)blockIdx.x) / G + 1;
+    for (int it = 0; it < my_tiles; ++it) {
+        // dy of this tile was issued NST-1 tiles ago: the DMAs of the NST-2 younger tiles may stay in flight
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (NST - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_x) load_x();                                 // x of the NEXT tile (older than the DMAs below: vmcnt(4) awaits it alone)
+        issue_dy(st == 0 ? NST - 1 : st - 1);                // into the stage consumed one tile ago
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char *by = lds + st * C8P_YB, *bx = ldsX + (it & 1) * C8P_XB;
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+            const int ty = 2 * pq + kg;
+            bf16x8 yf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const s4w y0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4w *)(by + ty * 4096 + ya[i][0]));
+                const s4w y1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4w *)(by + ty * 4096 + ya[i][1]));
+                yf[i] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            if (do_db) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], ones, accb[i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int kp = 0; kp < 3; ++kp) {
+                const unsigned char *wp = bx + ty * C8P_RP + xw[kp];
+                const u32x4 wa = *reinterpret_cast<const u32x4 *>(wp);                                     // pixels 0..7 of the window
+                const uint2 wb = *reinterpret_cast<const uint2 *>(wp + 16);                                // pixels 8..11
+                const unsigned w6[6] = {wa[0], wa[1], wa[2], wa[3], wb.x, wb.y};
+#pragma unroll
+                for (int kw = 0; kw < 5; ++kw) {
+                    u32x4 f;
+                    if (kw & 1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) f[j] = __builtin_amdgcn_alignbit(w6[kw / 2 + j + 1], w6[kw / 2 + j], 16);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) f[j] = w6[kw / 2 + j];
+                    }
+                    const bf16x8 xf = __builtin_bit_cast(bf16x8, f);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[i][kp * 5 + kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf, acc[i][kp * 5 + kw], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_x) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the next tile's x (its 4 younger dy DMAs stay in flight)
+            store_x((it + 1) & 1);                             // (that buffer was last read one tile ago, behind this tile's barrier)
+        }
+        st = st == NST - 1 ? 0 : st + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- sum the four row-pair waves of each co half through LDS (the stages are free now), one atomic per element
+    float *red = reinterpret_cast<float *>(lds);              // [co half][slot 0..1][128 values][64 lanes] = 128 KB of the free stages
+    float *const mine = red + (size_t)ch * 2 * 128 * 64 + lane;
+    auto put = [&](int s) {
+        float *o = mine + s * 128 * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int t = 0; t < 15; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[((i * 16 + t) * 4 + r) * 64] = acc[i][t][r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[((i * 16 + 15) * 4 + r) * 64] = accb[i][r];
+        }
+    };
+    auto add = [&](int s) {
+        const float *o = mine + s * 128 * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int t = 0; t < 15; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][t][r] += o[((i * 16 + t) * 4 + r) * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accb[i][r] += o[((i * 16 + 15) * 4 + r) * 64];
+        }
+    };
+    if (pq >= 2) put(pq - 2);
+    __syncthreads();
+    if (pq < 2) add(pq);
+    __syncthreads();
+    if (pq == 1) put(0);
+    __syncthreads();
+    if (pq != 0) return;
+    add(0);
+    // acc[i][kp*5+kw][r]: co = co0 + 16 (2 ch + i) + 4 g + r; column lane & 15 = (a, ci): kh = 2 kp + a
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + 16 * (2 * ch + i) + 4 * g + r;
+            if (co >= a.Cout) continue;
+            if (do_db && (lane & 15) == 0) wg_accum<DET>(a.db, a.fix, (DET ? (size_t)a.Cout * 200 : 0) + co, accb[i][r]);
+#pragma unroll
+            for (int kp = 0; kp < 3; ++kp) {
+                const int kh = 2 * kp + ba;
+                if (kh >= KS) continue;
+#pragma unroll
+                for (int kw = 0; kw < 5; ++kw) wg_accum<DET>(a.dw, a.fix, ((size_t)co * 25 + kh * 5 + kw) * 8 + bci, acc[i][kp * 5 + kw][r]);
+            }
+        }
+    }
+}
+
 bool wgrad_c8_eligible(const m355_conv_desc *d, int Cy)
 {
     return d->Cin == 8 && d->kh == 5 && d->kw == 5 && d->stride == 1 && d->upsample == 0 && d->pad_h == 2 && d->pad_w == 2 &&
@@ -1136,10 +1398,24 @@ int wgrad_c8_launch(const m355_conv_desc *d, const void *x, const void *dy, int 
     a.xbytes = (unsigned)((size_t)d->N * d->H * d->W * 16);
     a.ybytes = (unsigned)((size_t)d->N * d->H * d->W * Cy * 2);
     const int tiles = d->N * (d->H / 8) * (d->W / 32), ny = Cy / 64;
-    int gx = 256 / ny;  // one 8-wave workgroup per CU (120 KB of LDS)
+    int gx = 256 / ny;  // one 8-wave workgroup per CU (120 / 145 KB of LDS)
     if (gx < 1) gx = 1;
     if (gx > tiles) gx = tiles;
     const dim3 grid(gx, ny);
+    static const bool planar = !getenv("M355_WGC8_V1");   // (A/B: the round-2 transpose-read kernel)
+    if (planar) {
+#define M355_C8P(MD_)                                                                              \
+    do {                                                                                          \
+        if (fix) hipLaunchKernelGGL((k_wgrad_c8p<MD_, true>), grid, dim3(512), 0, st, a);          \
+        else hipLaunchKernelGGL((k_wgrad_c8p<MD_>), grid, dim3(512), 0, st, a);                    \
+    } while (0)
+        if (d->pad_w_mode == 0) M355_C8P(0);
+        else if (d->pad_w_mode == 1) M355_C8P(1);
+        else M355_C8P(2);
+#undef M355_C8P
+        note_kernel("k_wgrad_c8");
+        return check_launch("conv2d_wgrad (8 input channels, planar)");
+    }
     if (fix) {
         if (d->pad_w_mode == 0) hipLaunchKernelGGL((k_wgrad_c8<0, true>), grid, dim3(512), 0, st, a);
         else if (d->pad_w_mode == 1) hipLaunchKernelGGL((k_wgrad_c8<1, true>), grid, dim3(512), 0, st, a);

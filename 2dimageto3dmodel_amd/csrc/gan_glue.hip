@@ -12,13 +12,14 @@
 namespace m355 {
 
 // ------------------------------------------------------------------------------------------- spectral norm, forward
-// Two launches per training forward (one in eval mode), no atomics on floats: every cross-workgroup sum is a per-workgroup
-// partial in `scratch` added in a FIXED order, so sigma / u / v have the same bits on every run (the first version accumulated
-// the two norms with fp32 atomics: run-to-run differences in the last bit of every weight of the network).
-//   scratch = [L] int tickets (zero before the first call; the kernels leave them zero) | [L][T1] partials of |W^T u|^2 per
-//   64-column tile | [L][T2] partials per 4-row block;  T1 = ceil(max_cols / 64), T2 = ceil(max_rows / 4).
-// The last row block of a layer to finish (ticket) sums the layer's partials and does what used to be a third launch:
-// u <- s / |s|, sigma, the snapshots.
+// Three launches per training forward (two in eval mode), no atomics on floats: every cross-workgroup sum is a per-workgroup
+// partial in `scratch` added in a FIXED order by the next launch, so sigma / u / v have the same bits on every run (the first
+// version accumulated the two norms with fp32 atomics: run-to-run differences in the last bit of every weight of the network).
+//   scratch = [L][T1] partials of |W^T u|^2 per 64-column tile | [L][T2] partials per 4-row block;
+//   T1 = ceil(max_cols / 64), T2 = ceil(max_rows / 4).
+// (Tried in round 4: the third launch folded into the second behind a per-layer ticket -- the last row block to finish does the
+// final step.  The release / acquire fences that makes correct across the 8 XCDs' L2s are a full `buffer_wbl2` + `buffer_inv`
+// per workgroup: 65 -> 87 us per call.  Kernel boundaries are the cheaper fence.)
 __device__ __forceinline__ float wave_sum_fixed(float v)   // butterfly: the same additions in the same order in every wave
 {
 #pragma unroll
@@ -62,11 +63,9 @@ __global__ __launch_bounds__(1024) void k_sn_wtu(const m355_sn_layer *__restrict
 }
 
 // s = W vhat, one wave per row (4 rows per block).  train: vhat = t / max(||t||, eps) (and v <- vhat, written by the
-// layer's first block); eval: vhat = v.   p2[l][block] = sum over the block's rows of s_i^2 (train) or u_i * s_i (eval);
-// the layer's last block: u <- s / max(||s||, eps), sigma = ||s||^2 / max(||s||, eps) (train) / sigma = u . s (eval).
+// layer's first block); eval: vhat = v.   p2[l][block] = sum over the block's rows of s_i^2 (train) or u_i * s_i (eval).
 __global__ __launch_bounds__(256) void k_sn_wv(const m355_sn_layer *__restrict__ tab, const float *__restrict__ p1, int T1,
-                                               float *__restrict__ p2, int T2, int *__restrict__ tickets, float *__restrict__ sigma,
-                                               int training, float eps)
+                                               float *__restrict__ p2, int T2, int training, float eps)
 {
     const int l = blockIdx.y;
     const m355_sn_layer L = tab[l];
@@ -107,7 +106,6 @@ __global__ __launch_bounds__(256) void k_sn_wv(const m355_sn_layer *__restrict__
     }
     acc = wave_sum_fixed(acc) * inv;
     __shared__ float wsum[4];
-    __shared__ int last;
     if (lane == 0) {
         float contrib = 0.0f;
         if (i < L.rows) {
@@ -123,32 +121,32 @@ __global__ __launch_bounds__(256) void k_sn_wv(const m355_sn_layer *__restrict__
             if (L.v_snap) L.v_snap[j] = vn;
         }
     __syncthreads();
-    const int nblk = (L.rows + 3) / 4;
-    if (threadIdx.x == 0) {
-        p2[(size_t)l * T2 + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-        __threadfence();                                   // release: this block's s rows and its partial ...
-        last = atomicAdd(tickets + l, 1) == nblk - 1;      // ... before the ticket (device scope)
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();                                       // acquire: every other block's rows and partials
-    const float n1 = ordered_sum(p2 + (size_t)l * T2, nblk);
+    if (threadIdx.x == 0) p2[(size_t)l * T2 + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// train: u = s / max(||s||, eps), sigma = ||s||^2 / max(||s||, eps);  eval: sigma = u . s.   ||s||^2 (u . s) = the layer's
+// row-block partials added in block order.
+__global__ __launch_bounds__(256) void k_sn_final(const m355_sn_layer *__restrict__ tab, const float *__restrict__ p2, int T2,
+                                                  float *__restrict__ sigma, int training, float eps)
+{
+    const int l = blockIdx.x;
+    const m355_sn_layer L = tab[l];
+    const float n1 = ordered_sum(p2 + (size_t)l * T2, (L.rows + 3) / 4);
     if (training) {
-        const float inv1 = 1.0f / fmaxf(sqrtf(n1), eps);
-        for (int r = threadIdx.x; r < L.rows; r += 256) {
-            const float un = __builtin_nontemporal_load(L.s + r) * inv1;
-            L.u[r] = un;
-            if (L.u_snap) L.u_snap[r] = un;
+        const float inv = 1.0f / fmaxf(sqrtf(n1), eps);
+        for (int i = threadIdx.x; i < L.rows; i += 256) {
+            const float un = L.s[i] * inv;
+            L.u[i] = un;
+            if (L.u_snap) L.u_snap[i] = un;
         }
-        if (threadIdx.x == 0) sigma[l] = n1 * inv1;
+        if (threadIdx.x == 0) sigma[l] = n1 * inv;
     } else {
         if (L.u_snap)
-            for (int r = threadIdx.x; r < L.rows; r += 256) L.u_snap[r] = L.u[r];
+            for (int i = threadIdx.x; i < L.rows; i += 256) L.u_snap[i] = L.u[i];
         if (L.v_snap)
             for (int j = threadIdx.x; j < L.cols; j += 256) L.v_snap[j] = L.v[j];
         if (threadIdx.x == 0) sigma[l] = n1;
     }
-    if (threadIdx.x == 0) tickets[l] = 0;                  // ready for the next call (stream order)
 }
 
 // ------------------------------------------------------------------------------------------- spectral norm, backward
@@ -379,11 +377,11 @@ __global__ void k_bn_bwd_coeffs(const float *__restrict__ m, float count_h, cons
 
 using namespace m355;
 
-/* 4-byte words of scratch m355_sn_power_iter needs for L layers of at most max_rows x max_cols (zero them ONCE) */
+/* 4-byte words of scratch m355_sn_power_iter needs for L layers of at most max_rows x max_cols */
 extern "C" size_t m355_sn_scratch_words(int L, int max_rows, int max_cols)
 {
     if (L <= 0 || max_rows <= 0 || max_cols <= 0) return 0;
-    return (size_t)L * (1 + (size_t)(max_cols + 63) / 64 + (size_t)(max_rows + 3) / 4);
+    return (size_t)L * ((size_t)(max_cols + 63) / 64 + (size_t)(max_rows + 3) / 4);
 }
 
 extern "C" int m355_sn_power_iter(const m355_sn_layer *table_dev, int L, int max_rows, int max_cols, float *scratch,
@@ -392,10 +390,10 @@ extern "C" int m355_sn_power_iter(const m355_sn_layer *table_dev, int L, int max
     M355_REQUIRE(table_dev && scratch && sigma && L > 0 && max_rows > 0 && max_cols > 0, "sn_power_iter: bad argument");
     hipStream_t st = (hipStream_t)stream;
     const int T1 = (max_cols + 63) / 64, T2 = (max_rows + 3) / 4;
-    int *tickets = reinterpret_cast<int *>(scratch);
-    float *p1 = scratch + L, *p2 = p1 + (size_t)L * T1;
+    float *p1 = scratch, *p2 = p1 + (size_t)L * T1;
     if (training) hipLaunchKernelGGL(k_sn_wtu, dim3(T1, L), dim3(1024), 0, st, table_dev, p1, T1);
-    hipLaunchKernelGGL(k_sn_wv, dim3(T2, L), dim3(256), 0, st, table_dev, (const float *)p1, T1, p2, T2, tickets, sigma, training, eps);
+    hipLaunchKernelGGL(k_sn_wv, dim3(T2, L), dim3(256), 0, st, table_dev, (const float *)p1, T1, p2, T2, training, eps);
+    hipLaunchKernelGGL(k_sn_final, dim3(L), dim3(256), 0, st, table_dev, (const float *)p2, T2, sigma, training, eps);
     return check_launch("sn_power_iter");
 }
 

@@ -143,14 +143,17 @@ class GanTrainer(torch.nn.Module):
     def epoch(self, e):
         self._epoch, self._epoch_set = int(e), True
 
-    def capture_cycle(self, batches, epoch=None, warmup=2, noises=None):
+    def capture_cycle(self, batches, epoch=None, warmup=2, noises=None, restore_after_warmup=True):
         """One training cycle (1 G step + d_steps_per_g D steps, optimiser steps and the running-average update included) as ONE
         hipGraph: returns a CycleGraph whose replay() costs one graph launch instead of ~750 kernel launches issued from Python
         (13 ms of host time per cycle regardless of the batch: the limit below batch ~24 per GPU).  Needs
         GanTrainer(capturable=True) (Adam's step counters on the device).  `batches`: 1 + d_steps_per_g loader batches
         (X_tex, X_alpha, X_mesh, C); their storage is copied into static buffers that CycleGraph.load() refills.  noises: one
-        fixed latent batch per iteration (tests); default: fresh torch.randn noise on every replay."""
-        return CycleGraph(self, batches, epoch, warmup, noises)
+        fixed latent batch per iteration (tests); default: fresh torch.randn noise on every replay.
+        warmup: cycles run before the capture so that every allocation, lazily built table and optimiser state exists; they are
+        real training cycles on `batches`, and with restore_after_warmup (default) everything they changed is put back -- the
+        trainer is at the same step, with the same weights and the same RNG position, after capture_cycle() as before it."""
+        return CycleGraph(self, batches, epoch, warmup, noises, restore_after_warmup)
 
     def iteration(self, X_tex, X_alpha, X_mesh, C, caption=None, noise=None, epoch=None):
         """one pass of the loop body main.py:691-723 on one loader batch; returns the scalar losses.  `noise` fixes the
@@ -206,9 +209,15 @@ class CycleGraph:
     moves to another value), the batch shapes.  What stays live across replays: parameters, optimiser state, spectral-norm
     vectors, batch-norm running statistics, and the latent noise -- torch.randn inside a capture draws from the graph-safe
     Philox state, so every replay sees fresh noise.  The returned losses are tensors of the graph's memory pool, overwritten
-    by every replay."""
+    by every replay.
+    Capturing has NO training side effect: the `warmup` cycles torch's capture protocol needs (they are real optimisation steps
+    on `batches`) are undone -- weights, optimiser state, running statistics, spectral-norm vectors, the running-average
+    generator, total_it and the RNG are restored in place before the capture (restore_after_warmup=False keeps them, i.e. the
+    trainer then starts `warmup` cycles ahead).  replay(epoch=e) re-captures when the running-average ramp moves to another
+    alpha: a capture pass executes nothing."""
 
-    def __init__(self, trainer, batches, epoch=None, warmup=2, noises=None):
+    def __init__(self, trainer, batches, epoch=None, warmup=2, noises=None, restore_after_warmup=True):
+        self.restore_after_warmup = restore_after_warmup
         if not trainer.capturable:
             raise RuntimeError("capture_cycle needs GanTrainer(capturable=True): Adam's step counters must live on the device")
         n = 1 + trainer.d_steps_per_g
@@ -230,19 +239,55 @@ class CycleGraph:
             out.update(self.trainer.iteration(*b, noise=z, epoch=self.epoch))
         return out
 
+    def _snapshot(self):
+        """everything a training cycle changes on the device, cloned: parameters and buffers of the three networks (weights, batch-norm
+        running statistics, spectral-norm vectors, the running-average generator), the state of both optimisers, the RNG"""
+        tr = self.trainer
+        tensors = [t for m in (tr.generator, tr.generator_running_avg, tr.discriminator)
+                   for t in list(m.parameters()) + list(m.buffers())]
+        opt = []
+        for o in (tr.optimizer_g, tr.optimizer_d):
+            for group in o.param_groups:
+                for p in group["params"]:
+                    st = o.state.get(p)
+                    opt.append((o, p, None if not st else {k: v.clone() for k, v in st.items() if torch.is_tensor(v)}))
+        return tensors, [t.detach().clone() for t in tensors], opt, tr.total_it, torch.cuda.get_rng_state(tensors[0].device)
+
+    def _restore(self, snap):
+        """put the snapshot back IN PLACE (the addresses are what the capture records): optimiser state that did not exist before
+        the warm-up is zeroed -- Adam's initial state -- rather than deleted, so that the capture pass does not allocate it"""
+        tensors, values, opt, total_it, rng = snap
+        with torch.no_grad():
+            for t, v in zip(tensors, values):
+                t.copy_(v)
+            for o, p, saved in opt:
+                st = o.state.get(p)
+                if not st:
+                    continue
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        v.copy_(saved[k]) if saved is not None else v.zero_()
+        self.trainer.total_it = total_it
+        torch.cuda.set_rng_state(rng, tensors[0].device)
+
     def _capture(self, warmup):
         # warm-up on a side stream (torch's capture protocol): allocator pools, the weight-gradient arena, the lazily uploaded
-        # positional planes and the optimiser state all exist before the capture starts
+        # positional planes and the optimiser state all exist before the capture starts.  The warm-up cycles are REAL training
+        # cycles on the supplied batches; what they did to the weights, the optimiser state, the running statistics, total_it and
+        # the RNG is undone afterwards (restore_after_warmup), so capturing at step k leaves the trainer at step k.
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            snap = self._snapshot() if (warmup and self.restore_after_warmup) else None
             for _ in range(warmup):
                 self._run()
+            if snap is not None:
+                self._restore(snap)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = self._run()
-        self.trainer.total_it -= self.n   # (the capture pass executed nothing)
+        self.trainer.total_it -= self.n   # (the capture pass executed nothing; it only rotated the spectral-norm slots on the host)
 
     def load(self, batches):
         """copy the next cycle's loader batches into the static buffers (device-to-device, on the current stream)"""

@@ -141,6 +141,38 @@ def cpu_baseline(N, S, seconds_budget=8.0):
                           "sample": f"{n_par} clouds, one per thread on {cores} threads, {el_par:.1f} s"}}
 
 
+def parity_check(elf, crit, pc, q, sc, mask, S):
+    """AFTER the timed region (never inside it): the projection half of the benchmarked batch against the oracle
+    (oracle/p_oracle.c, the checker -- as tests/ and smoke() use it) on the first and the last cloud of the batch: silhouette per
+    pixel (contract 2e-5), the two clouds' loss term (1e-4 relative, north_star), the point gradients (1e-3).  The bench line
+    carries the result as `parity_ok`; a false value means the number above it was measured on a wrong result."""
+    from oracle import p_oracle as po
+
+    B = pc.shape[0]
+    pick = sorted({0, B - 1})
+    pcd, qd, scd = (t.detach().clone().requires_grad_() for t in (pc, q, sc))
+    proj = elf(pcd, qd, scd)
+    loss = crit(proj, mask)["full_loss"]
+    loss.backward()
+    torch.cuda.synchronize()
+    taps = po.taps(3.0, 21, True)
+    pn, qn, sn, mn = (t.detach().cpu().numpy() for t in (pc, q, sc, mask))
+    got, gp = proj.detach().cpu().numpy(), pcd.grad.cpu().numpy()
+    err_sil = err_grad = 0.0
+    ref = []
+    for i in pick:
+        p_o = po.forward(pn[i:i + 1], qn[i:i + 1], sn[i:i + 1], S, taps)
+        ref.append(p_o)
+        err_sil = max(err_sil, float(np.abs(got[i:i + 1] / p_o - 1).max()))
+        dp_o = po.backward(pn[i:i + 1], qn[i:i + 1], sn[i:i + 1], po.sup_loss_bwd(p_o, mn[i:i + 1]), S, taps)[0][0] / B
+        err_grad = max(err_grad, float(np.abs(gp[i] - dp_o).max() / np.abs(dp_o).max()))
+    sub = crit(proj[pick].detach(), mask[pick])["full_loss"].item()
+    want = po.sup_loss(np.concatenate(ref), mn[pick])
+    err_loss = abs(sub / want - 1)
+    return {"ok": bool(err_sil < 2e-5 and err_loss < 1e-4 and err_grad < 1e-3), "clouds": pick, "silhouette_rel_err": err_sil,
+            "loss_rel_err": err_loss, "grad_rel_err": err_grad, "checker": "oracle/p_oracle.c"}
+
+
 def cpu_baseline_gan(trainer, R, seconds_budget=10.0):
     """The GAN half beside the HIP path: oracle/gan_cpu.py (fp32 torch-CPU restatement of models/gan.py + utils/losses.py +
     Adam, pinned to the reference's goldens by tests/test_oracle_golden.py) running the SAME cycle (1 G step + 2 D steps incl.
@@ -474,6 +506,9 @@ def main():
                 "dominant_frac_at_sclk": (rate / (MFMA_BF16_PEAK_TF * sustained["sclk_mhz"] / 2400.0)) if is_conv else None}),
             "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(kt.items(), key=lambda kv: -kv[1][1])},
         }
+        if do_p:
+            par_chk = parity_check(elf, crit, pc, q, sc, mask, S)
+            out["parity_ok"], out["parity"] = par_chk["ok"], par_chk
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(N, S)
             if do_g:

@@ -278,10 +278,10 @@ int m355_unpack_nhwc8(const void *g_nhwc8, float *dx_nchw, int N, int C, int H, 
 
 /* ---- G9  spectral normalisation (torch.nn.utils.spectral_norm, one power iteration per training forward:
  *      v = normalize(W^T u), u = normalize(W v), sigma = u.(W v); gan.py:57-65,163-177,294-302) for ALL layers of
- *      a network in two launches (one in eval mode).  `table` is a device-resident array of L entries; scratch =
- *      m355_sn_scratch_words(L, max_rows, max_cols) 4-byte words, zero before the FIRST call (the kernels leave its ticket
- *      words zero): per-workgroup partial sums of the two norms, added in a fixed order -- sigma / u / v have the same bits on
- *      every run (no floating-point atomics).  u, v are updated in place when training, u_snap / v_snap (nullable)
+ *      a network in three launches (two in eval mode).  `table` is a device-resident array of L entries; scratch =
+ *      m355_sn_scratch_words(L, max_rows, max_cols) 4-byte words (no initialisation needed): per-workgroup partial sums of the
+ *      two norms, added in a fixed order by the next launch -- sigma / u / v have the same bits on every run (no floating-point
+ *      atomics).  u, v are updated in place when training, u_snap / v_snap (nullable)
  *      receive the values this forward used (what autograd needs in the backward). */
 typedef struct {
     const float *w;          /* weight_orig viewed as [rows][cols] = [Cout][Cin*kh*kw] */
