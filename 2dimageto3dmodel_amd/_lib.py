@@ -80,6 +80,8 @@ SIGNATURES = {
     "m355_conv2d_fwd_stats": (c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "m355_conv2d_wgrad": (c_int, [_P, _P, _P, _P, _P, _P]),
     "m355_conv2d_wgrad_acc": (c_int, [_P, _P, _P, _P, _P, _P]),
+    "m355_conv2d_wgrad_ws_bytes": (c_size_t, [_P]),
+    "m355_conv2d_wgrad_ws": (c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "m355_conv2d_wgrad_det_ws_bytes": (c_size_t, [_P]),
     "m355_conv2d_wgrad_det": (c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "m355_chan_reduce_ws_bytes": (c_size_t, [c_size_t, c_int, c_int, c_int]),

@@ -31,8 +31,6 @@ SOURCES = [
     ("conv_mfma.hip", []),
     ("conv_small.hip", []),
     ("conv_halo.hip", []),
-    ("conv_halo2.hip", []),
-    ("conv_halo3.hip", []),
     ("gan_elem.hip", []),
     ("gan_glue.hip", []),
     ("gan_io.hip", []),

@@ -162,8 +162,39 @@ def conv_dgrad(d, dy, w_dgrad, cin_real=None, mask_x=None, mask_slope=1.0, mask_
     return dx
 
 
+_WS_BYTES = {}
+
+
+def _wgrad_ws_bytes(d):
+    key = bytes(d)
+    r = _WS_BYTES.get(key)
+    if r is None:
+        r = _WS_BYTES[key] = int(lib().m355_conv2d_wgrad_ws_bytes(ctypes.byref(d)))
+    return r
+
+
 def wgrad_fuses_dbias(d):
     return bool(lib().m355_conv2d_wgrad_fuses_dbias(ctypes.byref(d)))
+
+
+def _after_fill(st, device):
+    """the zero fill of a per-pass block ran on the stream that asked first; a kernel on ANOTHER stream (gan_ops.Fork) must not
+    touch its slice before that fill has finished: the fill carries an event, other streams wait for it once per pass"""
+    if torch.device(device).type != "cuda":
+        return
+    cur = torch.cuda.current_stream(device)
+    if st["stream"] is not None and cur != st["stream"] and cur not in st["waited"]:
+        cur.wait_event(st["event"])
+        st["waited"].add(cur)
+
+
+def _mark_fill(st, device):
+    if torch.device(device).type != "cuda":
+        return
+    st["stream"] = torch.cuda.current_stream(device)
+    st["event"] = torch.cuda.Event()
+    st["event"].record(st["stream"])
+    st["waited"] = set()
 
 
 class WgradArena:
@@ -172,7 +203,7 @@ class WgradArena:
     arena is zeroed once, when the first wgrad of a backward pass (identified by autograd's graph-task id) asks for a slice;
     its size is learnt from the previous pass (a pass that outgrows it falls back to per-layer zero fills and the arena grows
     for the next one).  Slices are scratch: they are consumed by wgrad_finish inside the same backward call."""
-    _state = {}   # device -> [buffer, used, needed, graph task id]
+    _state = {}   # device -> {buf, used, needed, task, stream, event, waited}
 
     @classmethod
     def take(cls, numel, device):
@@ -180,20 +211,23 @@ class WgradArena:
         task = torch._C._current_graph_task_id() if hasattr(torch._C, "_current_graph_task_id") else -1
         if task < 0:
             return None
-        st = cls._state.setdefault(device, [None, 0, 0, None])
-        if st[3] != task:   # first wgrad of a new backward pass
-            if st[2] > (0 if st[0] is None else st[0].numel()):
-                st[0] = torch.empty(st[2], dtype=torch.float32, device=device)
-            st[1], st[2], st[3] = 0, 0, task
-            if st[0] is not None:
-                st[0].zero_()
+        st = cls._state.setdefault(device, dict(buf=None, used=0, needed=0, task=None, stream=None, event=None, waited=set()))
+        if st["task"] != task:   # first wgrad of a new backward pass
+            if st["needed"] > (0 if st["buf"] is None else st["buf"].numel()):
+                st["buf"] = torch.empty(st["needed"], dtype=torch.float32, device=device)
+            st["used"], st["needed"], st["task"] = 0, 0, task
+            if st["buf"] is not None:
+                # (every kernel of the previous pass that used a slice has been joined: flush_wgrad_finish waits for the side streams)
+                st["buf"].zero_()
+                _mark_fill(st, device)
         numel = (numel + 63) // 64 * 64
-        off = st[1]
-        st[1] += numel
-        st[2] = max(st[2], st[1])
-        if st[0] is None or off + numel > st[0].numel():
+        off = st["used"]
+        st["used"] += numel
+        st["needed"] = max(st["needed"], st["used"])
+        if st["buf"] is None or off + numel > st["buf"].numel():
             return None
-        return st[0][off:off + numel]
+        _after_fill(st, device)
+        return st["buf"][off:off + numel]
 
 
 class DbiasBlock:
@@ -202,24 +236,29 @@ class DbiasBlock:
     returned to autograd as the parameters' .grad and must outlive the pass.  Its size is the LARGEST need any pass has shown
     (the G pass of the 1 G : 2 D cycle takes nothing, the D passes do: sizing from the previous pass alone served one pass in
     three), and it is allocated by the first take() of a pass, so a pass that takes nothing costs nothing."""
-    _state = {}   # device -> [block of this pass | None, used, largest need seen, graph task id]
+    _state = {}   # device -> {buf, used, needed, task, stream, event, waited}
 
     @classmethod
     def take(cls, numel, device):
         task = torch._C._current_graph_task_id() if hasattr(torch._C, "_current_graph_task_id") else -1
         if task < 0:
             return None
-        st = cls._state.setdefault(device, [None, 0, 0, None])
-        if st[3] != task:   # first take of a new backward pass
-            st[0] = torch.zeros(st[2], dtype=torch.float32, device=device) if st[2] else None
-            st[1], st[3] = 0, task
+        st = cls._state.setdefault(device, dict(buf=None, used=0, needed=0, task=None, stream=None, event=None, waited=set()))
+        if st["task"] != task:   # first take of a new backward pass
+            st["buf"] = torch.zeros(st["needed"], dtype=torch.float32, device=device) if st["needed"] else None
+            st["used"], st["task"] = 0, task
+            if st["buf"] is not None:
+                _mark_fill(st, device)
         numel_p = (numel + 63) // 64 * 64
-        off = st[1]
-        st[1] += numel_p
-        st[2] = max(st[2], st[1])
-        if st[0] is None or off + numel_p > st[0].numel():
+        off = st["used"]
+        st["used"] += numel_p
+        st["needed"] = max(st["needed"], st["used"])
+        if st["buf"] is None or off + numel_p > st["buf"].numel():
             return None
-        return st[0][off:off + numel]
+        _after_fill(st, device)
+        if st["stream"] is not None and torch.cuda.current_stream(device) != st["stream"]:
+            st["buf"].record_stream(torch.cuda.current_stream(device))   # (slices become .grad tensors, freed on the main stream)
+        return st["buf"][off:off + numel]
 
 
 def conv_wgrad(d, x, dy, cin_real=None, raw=False, dbias=None, arena=False, dbias_zeroed=False):
@@ -228,6 +267,15 @@ def conv_wgrad(d, x, dy, cin_real=None, raw=False, dbias=None, arena=False, dbia
     per-pass WgradArena, valid until the next backward pass"""
     x, dy = _req(x, torch.bfloat16, "x"), _req(dy, torch.bfloat16, "dy")
     n = d.Cout * d.kh * d.kw * d.Cin
+    nws = _wgrad_ws_bytes(d)
+    if nws:
+        # thin layers: per-workgroup partial tiles + an ordered sum instead of atomics (deterministic in every mode; dw / dbias
+        # are overwritten, so neither the arena's zero fill nor a zeroed bias block is needed)
+        ws = torch.empty((nws,), dtype=torch.uint8, device=x.device)
+        dw = torch.empty((d.Cout, d.kh, d.kw, d.Cin), dtype=torch.float32, device=x.device)
+        launch("conv2d_wgrad_ws", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), stream(),
+               work=lambda: flops(d, cin_real), tag=lambda: tag(d))
+        return dw if raw else dw.permute(0, 3, 1, 2)
     if _DETERMINISTIC:
         ws = torch.empty((lib().m355_conv2d_wgrad_det_ws_bytes(ctypes.byref(d)),), dtype=torch.uint8, device=x.device)
         dw = torch.empty((d.Cout, d.kh, d.kw, d.Cin), dtype=torch.float32, device=x.device)
@@ -279,6 +327,10 @@ def flush_wgrad_finish(discard=False):
     items, _DeferredFinish.items = _DeferredFinish.items, []
     if discard or not items:
         return
+    # raw gradients of branches that ran on the second stream (gan_ops.Fork): join it before the batched epilogue reads them
+    from . import gan_ops
+    for sd in gan_ops.side_streams():
+        torch.cuda.current_stream(sd.device).wait_stream(sd)
     for i0 in range(0, len(items), _lib.SNFIN_MAX):
         chunk = items[i0:i0 + _lib.SNFIN_MAX]
         arr = (_lib.SnFinEntry * len(chunk))()

@@ -714,10 +714,12 @@ int dgrad_c8_replicate_launch(const m355_conv_desc *d, const void *dy, const voi
                               hipStream_t st, const void *mask_x, float mask_slope);
 bool wgrad_c8_eligible(const m355_conv_desc *d, int Cy);  // csrc/conv_small.hip
 int wgrad_c8_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, float *db, hipStream_t st,
-                    long long *fix = nullptr);
+                    long long *fix = nullptr, float *part = nullptr);
+size_t wgrad_c8_ws_floats(const m355_conv_desc *d, int Cy);
 bool wgrad_small_eligible(const m355_conv_desc *d, int Cy);
 int wgrad_small_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, hipStream_t st,
-                       long long *fix = nullptr);
+                       long long *fix = nullptr, float *part = nullptr);
+size_t wgrad_small_ws_floats(const m355_conv_desc *d);
 }  // namespace m355
 
 static int conv_out_hw(const m355_conv_desc *d, int *Ho, int *Wo)
@@ -1485,7 +1487,7 @@ static bool wgrad_has_dbias(const m355_conv_desc *d)
 extern "C" int m355_conv2d_wgrad_fuses_dbias(const m355_conv_desc *d) { return d && wgrad_has_dbias(d) ? 1 : 0; }
 
 static int conv_wgrad_impl(const m355_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias, void *stream,
-                           bool zero, long long *fix = nullptr);
+                           bool zero, long long *fix = nullptr, float *part = nullptr);
 
 namespace m355 {
 // fix = [flag | n fixed-point sums | nb fixed-point bias sums] -> dw[n], db[nb] fp32 (one rounding per element); a raised flag
@@ -1545,8 +1547,29 @@ extern "C" int m355_conv2d_wgrad_acc(const m355_conv_desc *d, const void *x, con
     return conv_wgrad_impl(d, x, dy, dw, dbias, stream, false);
 }
 
+/* The thin layers' weight gradients (8 input channels: D.conv1; <= 8 output channels: the heads) end in one fp32 atomic per
+ * element and WORKGROUP on a few thousand addresses -- ~50 us of a 340 us launch (scripts/thin_rate.py: the launch time does not
+ * go to zero with the batch).  With a workspace every workgroup instead stores its partial tile (coalesced) and a second small
+ * launch adds the rows in workgroup order: no atomics, deterministic, dw / dbias OVERWRITTEN (no pre-zeroing).
+ * m355_conv2d_wgrad_ws_bytes(d) == 0: this layer has no such form (use m355_conv2d_wgrad / _acc / _det). */
+extern "C" size_t m355_conv2d_wgrad_ws_bytes(const m355_conv_desc *d)
+{
+    if (!d || check_desc(d, "conv2d_wgrad_ws_bytes")) return 0;
+    const int cy = m355::dy_channels(d->Cout);
+    if (m355::wgrad_c8_eligible(d, cy)) return sizeof(float) * m355::wgrad_c8_ws_floats(d, cy);
+    if (m355::wgrad_small_eligible(d, cy)) return sizeof(float) * m355::wgrad_small_ws_floats(d);
+    return 0;
+}
+
+extern "C" int m355_conv2d_wgrad_ws(const m355_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias, void *ws,
+                                    void *stream)
+{
+    M355_REQUIRE(ws && m355_conv2d_wgrad_ws_bytes(d) > 0, "conv2d_wgrad_ws: this layer has no partial-sum form (m355_conv2d_wgrad_ws_bytes)");
+    return conv_wgrad_impl(d, x, dy, dw, dbias, stream, false, nullptr, (float *)ws);
+}
+
 static int conv_wgrad_impl(const m355_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias, void *stream,
-                           bool zero, long long *fix)
+                           bool zero, long long *fix, float *part)
 {
     if (int rc = check_desc(d, "conv2d_wgrad")) return rc;
     M355_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
@@ -1573,8 +1596,8 @@ static int conv_wgrad_impl(const m355_conv_desc *d, const void *x, const void *d
         m355::set_error("conv2d_wgrad: memset failed");
         return M355_ERR_LAUNCH;
     }
-    if (m355::wgrad_c8_eligible(d, a.Cy)) return m355::wgrad_c8_launch(d, x, dy, a.Cy, dw, dbias, st, fix);
-    if (m355::wgrad_small_eligible(d, a.Cy)) return m355::wgrad_small_launch(d, x, dy, a.Cy, dw, st, fix);
+    if (m355::wgrad_c8_eligible(d, a.Cy)) return m355::wgrad_c8_launch(d, x, dy, a.Cy, dw, dbias, st, fix, part);
+    if (m355::wgrad_small_eligible(d, a.Cy)) return m355::wgrad_small_launch(d, x, dy, a.Cy, dw, st, fix, part);
     const size_t xbytes = (size_t)d->N * d->H * d->W * d->Cin * 2, ybytes = (size_t)P * a.Cy * 2;
     const int lgWo = m355::ilog2_exact(a.Wo), lgHo = m355::ilog2_exact(a.Ho);
     if (wgrad_dma_ok(d) && m355::wgrad_halo_eligible(a))

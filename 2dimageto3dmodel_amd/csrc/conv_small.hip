@@ -319,6 +319,7 @@ struct SmallWgArgs {
     const unsigned short *dy;  // bf16 NHWC [N,H,W,Cy]
     float *dw;                 // fp32 [Cout][KS][KS][Cin], pre-zeroed
     long long *fix;            // deterministic form: [flag | fixed-point dw] (conv_dma.h wg_accum), else null
+    float *part;               // per-workgroup partial sums [gridDim.x][Cout*KS*KS*Cin] (summed in order by k_wgrad_part_sum), else null
     int N, H, W, Cin, Cout, Cy;
     int tiles_x, tiles_y;
     unsigned xbytes, ybytes;
@@ -433,9 +434,30 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_smallco(SmallWgArgs a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = 4 * kgp + r;
-            if (co < a.Cout)
-                wg_accum<DET>(a.dw, a.fix, ((size_t)co * TAPS + t) * a.Cin + cc * 64 + 16 * wave + (lane & 15), acc[t][r]);
+            if (co < a.Cout) {
+                const size_t e = ((size_t)co * TAPS + t) * a.Cin + cc * 64 + 16 * wave + (lane & 15);
+                if (a.part) a.part[(size_t)blockIdx.x * ((size_t)a.Cout * TAPS * a.Cin) + e] = acc[t][r];
+                else wg_accum<DET>(a.dw, a.fix, e, acc[t][r]);
+            }
         }
+}
+
+// dw[e] = part[0][e] + part[1][e] + ... (workgroup order: deterministic), e < n; optionally the same for a bias tail
+__global__ __launch_bounds__(256) void k_wgrad_part_sum(const float *__restrict__ part, int nwg, size_t stride, float *__restrict__ dw, size_t n,
+                                                        float *__restrict__ db, int nb)
+{
+    const size_t e = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (e >= n + (db ? (size_t)nb : 0)) return;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    int g = 0;
+    for (; g + 4 <= nwg; g += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[u] += part[(size_t)(g + u) * stride + e];
+    }
+    for (; g < nwg; ++g) s[0] += part[(size_t)g * stride + e];
+    const float t = (s[0] + s[1]) + (s[2] + s[3]);
+    if (e < n) dw[e] = t;
+    else db[e - n] = t;
 }
 
 bool wgrad_small_eligible(const m355_conv_desc *d, int Cy)
@@ -445,21 +467,30 @@ bool wgrad_small_eligible(const m355_conv_desc *d, int Cy)
            (size_t)d->N * d->H * d->W * d->Cin * 2 < (1ull << 31) && (size_t)d->N * d->H * d->W * Cy * 2 < (1ull << 31);
 }
 
-int wgrad_small_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, hipStream_t st, long long *fix)
+// workgroups of the small-Cout wgrad along the tile axis (each a row of the partial-sum workspace)
+static int wgrad_small_gx(const m355_conv_desc *d)
+{
+    const int ntiles = ((d->W + ST - 1) / ST) * ((d->H + ST - 1) / ST) * d->N, nchunks = d->Cin / 64;
+    int gx = (512 + nchunks - 1) / nchunks;  // ~512 workgroups (2 per CU)
+    return gx > ntiles ? ntiles : gx;
+}
+size_t wgrad_small_ws_floats(const m355_conv_desc *d) { return (size_t)wgrad_small_gx(d) * d->Cout * d->kh * d->kw * d->Cin; }
+
+int wgrad_small_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, hipStream_t st, long long *fix,
+                       float *part)
 {
     SmallWgArgs a = {};
     a.x = (const unsigned short *)x;
     a.dy = (const unsigned short *)dy;
     a.dw = dw;
     a.fix = fix;
+    a.part = part;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cy = Cy;
     a.tiles_x = (d->W + ST - 1) / ST;
     a.tiles_y = (d->H + ST - 1) / ST;
     a.xbytes = (unsigned)((size_t)d->N * d->H * d->W * d->Cin * 2);
     a.ybytes = (unsigned)((size_t)d->N * d->H * d->W * Cy * 2);
-    const int ntiles = a.tiles_x * a.tiles_y * d->N, nchunks = d->Cin / 64;
-    int gx = (512 + nchunks - 1) / nchunks;  // ~512 workgroups (2 per CU)
-    if (gx > ntiles) gx = ntiles;
+    const int nchunks = d->Cin / 64, gx = wgrad_small_gx(d);
     const dim3 grid(gx, 1, nchunks);
 #define M355_SW(KS_, DET_)                                                                                               \
     do {                                                                                                                 \
@@ -473,6 +504,11 @@ int wgrad_small_launch(const m355_conv_desc *d, const void *x, const void *dy, i
     } else if (d->kh == 5) M355_SW(5, false);
     else M355_SW(3, false);
 #undef M355_SW
+    if (part) {
+        const size_t n = (size_t)d->Cout * d->kh * d->kw * d->Cin;
+        hipLaunchKernelGGL(k_wgrad_part_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float *)part, gx, n, dw, n,
+                           (float *)nullptr, 0);
+    }
     note_kernel("k_wgrad_smallco");
     return check_launch("conv2d_wgrad (small Cout)");
 }
@@ -963,6 +999,7 @@ struct C8WgArgs {
     const unsigned short *dy;  // bf16 NHWC [N,H,W,Cy], Cy = 64 * k
     float *dw, *db;            // fp32 [Cout][5][5][8] (+=), [Cout] (+=) or null
     long long *fix;            // deterministic form: [flag | fixed-point dw | fixed-point db] (conv_dma.h wg_accum), else null
+    float *part;               // k_wgrad_c8p: per-workgroup partial sums [gridDim.x][Cout*200 + Cout] (k_wgrad_part_sum), else null
     int N, H, W, Cout, Cy;
     unsigned xbytes, ybytes;
 };
@@ -1367,13 +1404,21 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_c8p(C8WgArgs a)
         for (int r = 0; r < 4; ++r) {
             const int co = co0 + 16 * (2 * ch + i) + 4 * g + r;
             if (co >= a.Cout) continue;
-            if (do_db && (lane & 15) == 0) wg_accum<DET>(a.db, a.fix, (DET ? (size_t)a.Cout * 200 : 0) + co, accb[i][r]);
+            float *const prow = a.part ? a.part + (size_t)blockIdx.x * ((size_t)a.Cout * 201) : nullptr;
+            if (do_db && (lane & 15) == 0) {
+                if (prow) prow[(size_t)a.Cout * 200 + co] = accb[i][r];
+                else wg_accum<DET>(a.db, a.fix, (DET ? (size_t)a.Cout * 200 : 0) + co, accb[i][r]);
+            }
 #pragma unroll
             for (int kp = 0; kp < 3; ++kp) {
                 const int kh = 2 * kp + ba;
                 if (kh >= KS) continue;
 #pragma unroll
-                for (int kw = 0; kw < 5; ++kw) wg_accum<DET>(a.dw, a.fix, ((size_t)co * 25 + kh * 5 + kw) * 8 + bci, acc[i][kp * 5 + kw][r]);
+                for (int kw = 0; kw < 5; ++kw) {
+                    const size_t e = ((size_t)co * 25 + kh * 5 + kw) * 8 + bci;
+                    if (prow) prow[e] = acc[i][kp * 5 + kw][r];
+                    else wg_accum<DET>(a.dw, a.fix, e, acc[i][kp * 5 + kw][r]);
+                }
             }
         }
     }
@@ -1386,8 +1431,20 @@ bool wgrad_c8_eligible(const m355_conv_desc *d, int Cy)
            !getenv("M355_NO_C8");
 }
 
+static int wgrad_c8_gx(const m355_conv_desc *d, int Cy)
+{
+    const int tiles = d->N * (d->H / 8) * (d->W / 32), ny = Cy / 64;
+    int gx = 256 / ny;  // one 8-wave workgroup per CU (120 / 145 KB of LDS)
+    if (gx < 1) gx = 1;
+    return gx > tiles ? tiles : gx;
+}
+size_t wgrad_c8_ws_floats(const m355_conv_desc *d, int Cy)
+{
+    return getenv("M355_WGC8_V1") ? 0 : (size_t)wgrad_c8_gx(d, Cy) * ((size_t)d->Cout * 201);
+}
+
 int wgrad_c8_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, float *db, hipStream_t st,
-                    long long *fix)
+                    long long *fix, float *part)
 {
     C8WgArgs a = {};
     a.x = (const unsigned short *)x;
@@ -1397,13 +1454,11 @@ int wgrad_c8_launch(const m355_conv_desc *d, const void *x, const void *dy, int 
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cout = d->Cout; a.Cy = Cy;
     a.xbytes = (unsigned)((size_t)d->N * d->H * d->W * 16);
     a.ybytes = (unsigned)((size_t)d->N * d->H * d->W * Cy * 2);
-    const int tiles = d->N * (d->H / 8) * (d->W / 32), ny = Cy / 64;
-    int gx = 256 / ny;  // one 8-wave workgroup per CU (120 / 145 KB of LDS)
-    if (gx < 1) gx = 1;
-    if (gx > tiles) gx = tiles;
+    const int ny = Cy / 64, gx = wgrad_c8_gx(d, Cy);
     const dim3 grid(gx, ny);
     static const bool planar = !getenv("M355_WGC8_V1");   // (A/B: the round-2 transpose-read kernel)
     if (planar) {
+        a.part = part;
 #define M355_C8P(MD_)                                                                              \
     do {                                                                                          \
         if (fix) hipLaunchKernelGGL((k_wgrad_c8p<MD_, true>), grid, dim3(512), 0, st, a);          \
@@ -1413,6 +1468,12 @@ int wgrad_c8_launch(const m355_conv_desc *d, const void *x, const void *dy, int 
         else if (d->pad_w_mode == 1) M355_C8P(1);
         else M355_C8P(2);
 #undef M355_C8P
+        if (part) {
+            // every (pixel-axis workgroup) row holds the partial of ALL output channels (blockIdx.y writes its own 64): sum the rows
+            const size_t n = (size_t)d->Cout * 200;
+            hipLaunchKernelGGL(k_wgrad_part_sum, dim3((unsigned)((n + d->Cout + 255) / 256)), dim3(256), 0, st, (const float *)part, gx,
+                               (size_t)d->Cout * 201, dw, n, db, d->Cout);
+        }
         note_kernel("k_wgrad_c8");
         return check_launch("conv2d_wgrad (8 input channels, planar)");
     }

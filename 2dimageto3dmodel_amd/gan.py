@@ -220,6 +220,19 @@ class Generator(nn.Module):
         if a.conditional_text:
             att_out, attention_map = self.att(G.to_nchw_f32(x), *caption)
             x = x + G.to_nhwc_bf16(att_out)
+        # the mesh head (blk3_mesh + conv_mesh on 32 x 16 maps: small, latency-bound layers) does not depend on the texture branch
+        # below it: it runs on the second stream and fills the gaps of blk3a .. conv_final (gan_ops.Fork)
+        sym = G.HT_SYMM if self.symmetric else 0
+        x_mesh, fork = None, None
+
+        def mesh_branch():
+            m = self.blk3_mesh(x, z, upsample=1, gb=gb, out_slope=LRELU)
+            return G.head_conv(m, self.conv_mesh, G.HT_POLES | sym, in_slope=LRELU)
+
+        if self.mesh_head and G.fork_ok(x, z):
+            shared = [x, z] + ([t for pair in gb.values() for t in pair] if gb else [])
+            with G.Fork(shared) as fork:
+                x_mesh = mesh_branch()
         t = x  # every later stage starts with the x2 upsample of gan.py:391 / :395-404
         for name in ("blk3a", "blk3b", "blk3c"):
             if hasattr(self, name):
@@ -228,13 +241,12 @@ class Generator(nn.Module):
         t = self.blk5(t, z, upsample=1, gb=gb)
         # heads (gan.py:406-419): relu -> conv -> tanh_ | adjust_poles -> symmetrize.  The LeakyReLU is applied by the
         # block's last fused pass (out_slope) and differentiated by the head; the tail is one elementwise kernel.
-        sym = G.HT_SYMM if self.symmetric else 0
         t = self.blk6(t, z, upsample=1, gb=gb, out_slope=LRELU)
         x_tex = G.head_conv(t, self.conv_final, G.HT_TANH | sym, in_slope=LRELU)
-        x_mesh = None
-        if self.mesh_head:
-            m = self.blk3_mesh(x, z, upsample=1, gb=gb, out_slope=LRELU)
-            x_mesh = G.head_conv(m, self.conv_mesh, G.HT_POLES | sym, in_slope=LRELU)
+        if fork is not None:
+            fork.join([x_mesh])
+        elif self.mesh_head:
+            x_mesh = mesh_branch()
         if self.symmetric and attention_map is not None:
             attention_map = symmetrize_texture(attention_map)
         if self.training and self._nbt:
@@ -562,7 +574,20 @@ class MultiScaleDiscriminator(nn.Module):
             extra = None if self.args.texture_only else mesh_map
             if G.disc_inputs_ok(x, extra, specs):
                 hs, masks = G.disc_inputs(x, extra, specs)
-                outs = [m.trunk(h, mk, c, caption) for m, h, mk in zip(members, hs, masks)]
+                # the mesh discriminator (32 x 32 .. 8 x 8 maps: latency-bound layers that leave most of the chip idle) runs on
+                # the second stream, under the texture discriminator's big layers (gan_ops.Fork)
+                side = [k for k, m in enumerate(members) if isinstance(m, MeshDiscriminator)] if len(members) > 1 else []
+                outs = [None] * len(members)
+                fork = None
+                if side and caption is None and G.fork_ok(hs[side[0]], c):
+                    k = side[0]
+                    with G.Fork([hs[k], masks[k], c]) as fork:
+                        outs[k] = members[k].trunk(hs[k], masks[k], c, caption)
+                for k, (m, h, mk) in enumerate(zip(members, hs, masks)):
+                    if outs[k] is None:
+                        outs[k] = m.trunk(h, mk, c, caption)
+                if fork is not None:
+                    fork.join([outs[side[0]][0], outs[side[0]][1]])
                 return [o[0] for o in outs], [o[1] for o in outs]
         d1, m1 = self.d1(x, c, caption)
         if self.args.texture_only:

@@ -5,6 +5,8 @@ fallback.  The normalisation layers compute their statistics in fp32 over the NH
 all-reduces [sum, sum of squares, count] over torch.distributed (RCCL on ROCm) instead of the reference's
 master/slave pipes (code/sync_batchnorm/batchnorm.py:110-131).
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -17,6 +19,64 @@ from ._lib import check, launch, lib, ptr, stream
 
 def _ceil(a, b):
     return (a + b - 1) // b * b
+
+
+# ------------------------------------------------------------------------------------------------ second HIP stream
+# The networks have branches made of SMALL layers that leave most of the chip idle when they run alone -- the mesh discriminator
+# (32x32 .. 8x8 maps), the generator's mesh head (blk3_mesh + conv_mesh at 32x16) -- next to branches of big, power-capped
+# layers they do not depend on (the texture discriminator, blk3a .. conv_final).  `Fork` runs such a branch on a second stream:
+# its kernels fill the gaps of the main branch instead of extending the step.  Measured (profiles/r04_streams.txt): at batch 16
+# under the hipGraph 10.74 -> 10.59 ms per cycle (-1.5 %); at batch 64 26.5 -> 26.7 ms (+0.5 %, WORSE): every big kernel already
+# holds the socket at its 1400 W limit, so concurrent work only takes clock from it -- the time of a power-capped step is its
+# energy, and overlap saves none.  Hence the rule: fork only up to FORK_MAX_BATCH samples (M355_STREAMS=0 never, =1 always).
+# Autograd replays each node on the stream its forward ran on and synchronises gradients crossing streams itself; what it does
+# not know about is handled here and in conv.py: tensors shared across the streams are record_stream()ed (the caching allocator
+# must not hand their memory to the other stream's next allocation while a kernel still reads it), the per-pass zero fills of
+# conv.WgradArena / DbiasBlock carry an event the other stream waits for, and conv.flush_wgrad_finish joins the side streams.
+_SIDE = {}          # device index -> side stream
+STREAMS_ON = os.environ.get("M355_STREAMS", "auto") != "0"
+FORK_MAX_BATCH = 1 << 30 if os.environ.get("M355_STREAMS") == "1" else 32
+
+
+def side_streams():
+    return list(_SIDE.values())
+
+
+class Fork:
+    """with Fork(tensors_read_by_the_branch) as f: branch ... ; f.join(outputs) on the main stream before they are used"""
+
+    def __init__(self, shared):
+        self.shared = [t for t in shared if torch.is_tensor(t) and t.is_cuda]
+        dev = self.shared[0].device
+        self.main = torch.cuda.current_stream(dev)
+        self.side = _SIDE.get(dev.index)
+        if self.side is None:
+            self.side = _SIDE[dev.index] = torch.cuda.Stream(dev)
+        self._ctx = None
+
+    def __enter__(self):
+        self.side.wait_stream(self.main)          # everything the branch reads was produced on the main stream
+        for t in self.shared:
+            t.record_stream(self.side)
+        self._ctx = torch.cuda.stream(self.side)
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self._ctx.__exit__(*exc)
+        return False
+
+    def join(self, outputs):
+        self.main.wait_stream(self.side)
+        for t in outputs:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(self.main)
+
+
+def fork_ok(*ts):
+    """run a branch that reads `ts` on the second stream?  (CUDA tensors, and a batch small enough to leave power headroom)"""
+    return STREAMS_ON and all(t is None or (torch.is_tensor(t) and t.is_cuda) for t in ts) and ts[0] is not None and \
+        ts[0].shape[0] <= FORK_MAX_BATCH
 
 
 def to_nhwc_bf16(x_nchw, pad_to=1):

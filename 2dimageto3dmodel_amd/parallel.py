@@ -84,17 +84,33 @@ def broadcast_parameters(module, src=0):
         dist.broadcast(t.data, src=src)
 
 
+_GRAD_GROUP = [None]
+
+
+def grad_group():
+    """A process group (= an RCCL communicator with its own stream) for the gradient all-reduces alone: a collective queued on
+    the default group's stream runs behind everything queued there before it, so a flat all-reduce left in flight while the next
+    generator forward starts would hold up that forward's first SyncBN all-reduce.  Created lazily BY EVERY RANK at the same
+    point (the first reducer call); single-rank forced mode uses it too."""
+    if _GRAD_GROUP[0] is None and dist.is_available() and dist.is_initialized():
+        _GRAD_GROUP[0] = dist.new_group(ranks=list(range(dist.get_world_size())))
+    return _GRAD_GROUP[0]
+
+
 class FlatGradReducer:
-    """Averages the gradients of `params` over the ranks with one all-reduce of a persistent flat buffer."""
+    """Averages the gradients of `params` over the ranks with one all-reduce of a persistent flat buffer.
+    reducer() = start() + finish(); start() issues the collective asynchronously on the gradient group's communicator (the
+    compute stream is not blocked), finish() makes the compute stream wait for it and writes the averages back -- the trainer
+    puts the next generator forward between the two (train.GanTrainer: overlap of the discriminator's all-reduce)."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         self.flat = None
+        self._pending = None
 
-    def __call__(self):
+    def start(self):
         if not collectives_on():
-            return
-        ws = world_size()
+            return False
         ps = [p for p in self.params if p.grad is not None]
         n = sum(p.numel() for p in ps)
         if self.flat is None or self.flat.numel() != n or self.flat.device != ps[0].device:
@@ -105,21 +121,38 @@ class FlatGradReducer:
             off += p.numel()
         torch._foreach_copy_(views, [p.grad for p in ps])
         timed = stats["time_allreduce"]
+        ev = t0 = None
         if timed and self.flat.is_cuda:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
         elif timed:
             import time
             t0 = time.perf_counter()
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=grad_group(), async_op=True)
+        self._pending = (work, ps, views, ev, t0, n)
+        return True
+
+    def finish(self):
+        if self._pending is None:
+            return
+        work, ps, views, ev, t0, n = self._pending
+        self._pending = None
+        work.wait()   # (RCCL: the CURRENT STREAM waits for the collective; gloo: the host does)
+        timed = stats["time_allreduce"]
         if timed and len(stats["events"]) >= 4096:   # a measurement window, not a log: never grows without bound
             del stats["events"][:2048]
-        if timed and self.flat.is_cuda:
-            e1.record()   # the collective runs on RCCL's stream; the current stream waits for it, so e1 lands after it
-            stats["events"].append((e0, e1))
-        elif timed:
+        if ev is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()   # behind the wait: start-to-completion as the compute stream sees it (includes what overlapped)
+            stats["events"].append((ev, e1))
+        elif t0 is not None:
+            import time
             stats["events"].append((time.perf_counter() - t0) * 1e3)
         stats["grad_allreduces"] += 1
         stats["grad_allreduce_bytes"] += 4 * n
-        self.flat.mul_(1.0 / ws)
+        self.flat.mul_(1.0 / world_size())
         torch._foreach_copy_([p.grad for p in ps], views)
+
+    def __call__(self):
+        if self.start():
+            self.finish()

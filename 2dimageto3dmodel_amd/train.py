@@ -70,6 +70,12 @@ class GanTrainer(torch.nn.Module):
         self.reduce_g = P.FlatGradReducer(self.generator.parameters())
         self.reduce_d = P.FlatGradReducer(self.discriminator.parameters())
         self.total_it = 0
+        # data parallel: the discriminator's gradient all-reduce (14 MB) is issued asynchronously after its backward and awaited
+        # -- followed by optimizer_d.step() -- only where the NEXT iteration needs the discriminator: after that iteration's
+        # generator forward, which depends on no discriminator weight and overlaps the collective.  Identical results (the step is
+        # applied before anything reads the weights); finish_pending() completes it on demand (checkpoints, end of a run).
+        self.overlap_comm = True
+        self._pending_d = False
         self._epoch, self._epoch_set = 0, False   # the caller's epoch counter (main.py:668); only the running-average ramp reads it
         self.capturable = capturable
 
@@ -85,6 +91,7 @@ class GanTrainer(torch.nn.Module):
         w = self._d_weight()
         if mode == 'g':
             pred_tex, pred_mesh = self.generator(noise, C, caption)
+            self.finish_pending()                                       # (the previous D step's all-reduce + optimiser step)
             X_fake = O.mask_cat(pred_tex, X_alpha)                     # cat((pred_tex * X_alpha, X_alpha), dim=1)
             disc, mask = self.discriminator(X_fake, pred_mesh, C, caption)
             loss = self.criterion_gan(disc, True, for_discriminator=False, mask=mask, weight=w)
@@ -97,6 +104,7 @@ class GanTrainer(torch.nn.Module):
                 X_comb = O.mask_cat(pred_tex, X_alpha, X_tex)
                 C_comb = torch.cat((C, C), dim=0) if C is not None else None
                 M_comb = torch.cat((pred_mesh, X_mesh), dim=0) if pred_mesh is not None else None
+            self.finish_pending()                                       # (the previous D step's all-reduce + optimiser step)
             cap_comb = [torch.cat((t, t), dim=0) for t in caption] if caption is not None else None
             disc, mask = self.discriminator(X_comb, M_comb, C_comb, cap_comb)
             # divide_pred + the two criterion calls of main.py:516-519
@@ -104,6 +112,17 @@ class GanTrainer(torch.nn.Module):
             return loss_fake, loss_real, pred_tex, pred_mesh
         with torch.no_grad():
             return self.generator_running_avg(noise, C, caption, return_attention=True)
+
+    def finish_pending(self):
+        """complete a discriminator step whose gradient all-reduce is still in flight (see overlap_comm)"""
+        if self._pending_d:
+            self._pending_d = False
+            self.reduce_d.finish()
+            self.optimizer_d.step()
+
+    def state_dict(self, *args, **kwargs):
+        self.finish_pending()
+        return super().state_dict(*args, **kwargs)
 
     def _apply(self, fn, *args, **kwargs):
         self.__dict__.pop("_ema_lists", None)   # .to() / .cuda() replace the buffer tensors
@@ -190,13 +209,16 @@ class GanTrainer(torch.nn.Module):
             if flat is not None:
                 out["flat"] = flat.detach()
         else:
-            self.optimizer_d.zero_grad(set_to_none=True)
             loss_fake, loss_real, _, _ = self('d', X_tex, X_alpha, X_mesh, C, caption, noise)
             loss_fake, loss_real = loss_fake.mean(), loss_real.mean()
+            self.optimizer_d.zero_grad(set_to_none=True)   # (behind the forward: a pending step of the previous iteration is done)
             with CV.deferred_wgrad_finish():
                 (loss_fake + loss_real).backward()
-            self.reduce_d()
-            self.optimizer_d.step()
+            if self.overlap_comm and self.reduce_d.start():
+                self._pending_d = True                     # finished after the next iteration's generator forward
+            else:
+                self.reduce_d()
+                self.optimizer_d.step()
             out = {"d_fake": loss_fake.detach(), "d_real": loss_real.detach()}
         self.total_it += 1
         return out
@@ -237,6 +259,7 @@ class CycleGraph:
         out = {}
         for b, z in zip(self.static, self.noises):
             out.update(self.trainer.iteration(*b, noise=z, epoch=self.epoch))
+        self.trainer.finish_pending()   # a captured cycle is self-contained: the last D step's all-reduce + optimiser step inside
         return out
 
     def _snapshot(self):

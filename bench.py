@@ -414,6 +414,8 @@ def main():
         t0 = time.perf_counter()
         for _ in range(k):
             fn()
+        if do_g:
+            trainer.finish_pending()   # (a D step's all-reduce + optimiser step left in flight belongs to the timed work)
         barrier()
         t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
         if world > 1:
@@ -422,6 +424,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if do_g:
+        trainer.finish_pending()
     par.reset_stats()
     dt = timed(step, args.steps)
     coll = dict(par.stats)
@@ -430,6 +434,10 @@ def main():
     #      stream = torch's current stream); separate passes so that no marker sits inside the timed region above
     dt_p = timed(step_p, args.steps) if do_p else None
     dt_g = timed(step_g, args.steps) if do_g else None
+    # (the per-kernel pass runs every kernel ALONE: the second stream that overlaps the small branches in the timed region above
+    # -- gan_ops.Fork -- is switched off here, otherwise two concurrent kernels would each be charged the other's time)
+    gops = importlib.import_module("2dimageto3dmodel_amd.gan_ops")
+    streams_were_on, gops.STREAMS_ON = gops.STREAMS_ON, False
     pkg._lib.enable_kernel_timers(True)
     par.reset_stats(time_allreduce=True)
     for _ in range(args.steps):
@@ -437,11 +445,14 @@ def main():
             step_p()
         if do_g:
             (step_g_eager if cyc is not None else step_g)()   # (HIP events cannot be recorded into a replayed graph)
+    if do_g:
+        trainer.finish_pending()
     torch.cuda.synchronize()
     kt = pkg._lib.collect_kernel_timers()  # name -> (launches, total_ms, total algorithmic work)
     allreduce_ms = par.allreduce_ms() / args.steps
     par.reset_stats()
     pkg._lib.enable_kernel_timers(False)
+    gops.STREAMS_ON = streams_were_on
 
     # (the same step count on every rank -- dt is the max over ranks, identical everywhere; only rank 0 samples)
     sustained = sample_clock_power(step, max(3, min(200, int(2.5 / max(dt / args.steps, 1e-4)))), sample=(rank == 0))
@@ -475,6 +486,8 @@ def main():
             "config": {"workload": " + ".join(workload), "global_batch": world * B, "points": N, "grid": S,
                        "texture_resolution": R, "parallelism": f"dp{world}", "per_gpu_batch": B,
                        "gan_launch": "hipGraph replay (1 graph per cycle)" if cyc is not None else "eager (one launch per kernel)",
+                       "gan_streams": 2 if (do_g and streams_were_on) else 1,
+                       "deterministic": bool(pkg.is_deterministic()),
                        "losses": {k: float(v) for k, v in last.items()}},
             "allreduce_ms_per_step": allreduce_ms,
             "grad_allreduces_per_step": coll["grad_allreduces"] / args.steps,

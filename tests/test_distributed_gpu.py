@@ -84,6 +84,11 @@ def _worker(rank, world, port, q):
             c = torch.randint(0, 200, (B, 1), generator=g).to(dev)
             out = tr.iteration(x_tex, x_alpha, x_mesh, c)
             assert all(torch.isfinite(v).all() for v in out.values())
+        # the last D step's gradient all-reduce is still in flight (issued asynchronously, awaited after the NEXT generator
+        # forward -- train.GanTrainer.overlap_comm): its optimiser step has not been applied yet
+        assert tr._pending_d
+        tr.finish_pending()
+        assert not tr._pending_d
         for p in list(tr.generator.parameters())[:6] + list(tr.discriminator.parameters())[:6]:
             both = [torch.zeros_like(p) for _ in range(world)]
             dist.all_gather(both, p.detach())
@@ -139,6 +144,32 @@ def test_rccl_single_rank():
     assert out["max_w_diff"] <= 2.5e-4 and out["frac_w_diff"] < 0.02, out
     assert abs(out["losses_rccl"][0] - out["losses_plain"][0]) < 2e-3          # first iteration: no update in between
     assert max(abs(a - b) for a, b in zip(out["losses_rccl"], out["losses_plain"])) < 5e-2
+
+
+@pytest.mark.timeout(900)
+def test_rccl_collectives_inside_a_captured_cycle():
+    """one RCCL rank, collectives forced on, a whole training cycle captured into a hipGraph (SyncBN all-reduces,
+    the flat gradient all-reduces incl. the asynchronous one) and replayed.  If the stack can capture RCCL the replays must equal
+    the eager cycles bit for bit (deterministic mode); if it cannot, the failure mode is recorded in the assertion message and
+    `bench.py --graph` stays a single-GPU option."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    env["MASTER_PORT"] = str(_free_port())
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_single_rank.py"), "--graph"], capture_output=True,
+                           text=True, timeout=420, env=env, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        pytest.xfail("RCCL collectives inside a hipGraph capture: the probe did not finish in 420 s (hang)")
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, (r.returncode, r.stderr[-3000:])
+    g = json.loads(lines[-1])["graph"]
+    print("RCCL-in-graph probe:", g)
+    if g["error"] is not None:
+        pytest.xfail("RCCL collectives could not be captured / replayed on this stack: " + g["error"])
+    assert g["captured"] and g["replayed"] and g["bit_identical_to_eager"], g
 
 
 @pytest.mark.timeout(600)

@@ -346,13 +346,14 @@ def test_smooth_three_axes_chained_vs_oracle(pkg):
 
 
 def test_projection_is_run_to_run_deterministic(pkg):
-    """the projection half twice on the same batch: silhouette and gradients bit-identical.  The gradient path is deterministic by
-    construction (one writer per slot, csrc/proj_render21.hip); the forward splat accumulates with LDS float atomics whose order
-    is not fixed in principle -- with a handful of points per voxel two orders rarely differ, with heavy collisions (here 4096
-    points squeezed into a 10 % cube: hundreds per voxel) they can, and the clamp to [0, 1] right after the splat hides most of
-    it.  This test states what is measured: repeated runs of both shapes agree bit for bit on this hardware."""
+    """The projection half twice on the same batch.  The gradient path is deterministic by construction (one writer per slot,
+    csrc/proj_render21.hip); the forward splat accumulates with LDS float atomics whose order is not fixed.  Measured on MI355X:
+    at the benchmarked density (2048 points in a 0.7 cube, ~1 point per touched voxel) three runs agree BIT FOR BIT -- asserted;
+    with 4096 points squeezed into a 10 % cube (hundreds per voxel) the silhouettes of repeated runs differ in the last bits
+    (the sum of >= 3 floats depends on the order the atomics land in) -- there only closeness is asserted, and DESIGN.md 3 states
+    the limit (the GAN half has a deterministic mode; the projection's splat does not)."""
     rs = np.random.RandomState(7)
-    for spread, N in ((0.7, 2048), (0.1, 4096)):
+    for spread, N, exact in ((0.7, 2048, True), (0.1, 4096, False)):
         B, S = 4, 64
         pc = ((rs.rand(B, N, 3) - 0.5) * spread).astype(np.float32)
         q = rs.randn(B, 4).astype(np.float32)
@@ -368,4 +369,7 @@ def test_projection_is_run_to_run_deterministic(pkg):
             outs.append((proj.detach().clone(), tpc.grad.clone(), tq.grad.clone(), tsc.grad.clone()))
         for o in outs[1:]:
             for a, b in zip(outs[0], o):
-                assert torch.equal(a, b), (spread, N)
+                if exact:
+                    assert torch.equal(a, b), (spread, N)
+                else:
+                    assert (a - b).abs().max().item() <= 1e-4 * max(1e-12, a.abs().max().item()), (spread, N)
