@@ -5,12 +5,13 @@
 // lane); its NW waves sweep disjoint slices of every LDS-staged tile of 1024 target points.  Round 2 (the first version
 // issued 11 VALU + 3 LDS instructions per pair and ran at 6-18 % of the fp32 vector peak):
 //   * targets are staged as x[1024] | y[1024] | z[1024]: ONE ds_read_b128 broadcasts a coordinate of FOUR targets;
-//   * the distance arithmetic runs two targets at a time on the packed fp32 pipe (v_pk_add/mul_f32: each lane of a packed
-//     op rounds on its own, there is no fused op -- this file is compiled with -ffp-contract=off -- so every distance keeps
-//     the oracle's bits: ((dx*dx + dy*dy) + dz*dz));
+//   * the distance arithmetic runs two targets at a time on the packed fp32 pipe (v_pk_add / v_pk_mul / v_pk_fma_f32: each
+//     lane of a packed op rounds on its own; the file is compiled with -ffp-contract=off, the two fused operations are written
+//     out): every distance has the oracle's bits, fma(dz, dz, fma(dy, dy, dx*dx)) -- round 4: 3 + 3 packed operations per two
+//     pairs instead of 3 + 5, i.e. 3.5 instead of 4.5 VALU instructions per pair;
 //   * the sweep only tracks the running MINIMUM (one v_min3_f32 per two pairs) and, per 64-target chunk, whether it
 //     improved; the index is recovered afterwards by re-scanning that one chunk for the first target attaining the
-//     minimum (lowest j on ties, as the oracle): 4.5 VALU + 0.75 LDS instructions per pair instead of 11 + 3;
+//     minimum (lowest j on ties, as the oracle): 3.5 VALU + 0.19 LDS instructions per pair (round 1: 11 + 3);
 //   * small problems (B = 1) get 16 waves per workgroup over 64 queries instead of a quarter-filled chip.
 #include <stdlib.h>
 #include "common.h"
@@ -20,10 +21,12 @@ namespace m355 {
 constexpr int kTile = 1024;
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// squared distance, DEFINED (round 4) as the fused chain fma(dz, dz, fma(dy, dy, dx * dx)) -- what the oracle evaluates too
+// (oracle/p_oracle.c orc_chamfer_nn): 6 instead of 8 vector operations per pair, one rounding less
 __device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, float by, float bz)
 {
     const float dx = ax - bx, dy = ay - by, dz = az - bz;
-    return dx * dx + dy * dy + dz * dz;
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
 // SPLIT (round 3, small batches): gridDim.z workgroups share one block of queries, each sweeping a contiguous slice of the
@@ -84,8 +87,8 @@ __global__ __launch_bounds__(NW * 64) void k_chamfer_nn(const float *__restrict_
                         const f2 qx = {ax[k], ax[k]}, qy = {ay[k], ay[k]}, qz = {az[k], az[k]};
                         const f2 dx0 = qx - bx01, dy0 = qy - by01, dz0 = qz - bz01;
                         const f2 dx1 = qx - bx23, dy1 = qy - by23, dz1 = qz - bz23;
-                        const f2 d0 = dx0 * dx0 + dy0 * dy0 + dz0 * dz0;
-                        const f2 d1 = dx1 * dx1 + dy1 * dy1 + dz1 * dz1;
+                        const f2 d0 = __builtin_elementwise_fma(dz0, dz0, __builtin_elementwise_fma(dy0, dy0, dx0 * dx0));   // v_pk_fma_f32
+                        const f2 d1 = __builtin_elementwise_fma(dz1, dz1, __builtin_elementwise_fma(dy1, dy1, dx1 * dx1));
                         best[k] = fminf(fminf(best[k], d0.x), d0.y);
                         best[k] = fminf(fminf(best[k], d1.x), d1.y);
                     }

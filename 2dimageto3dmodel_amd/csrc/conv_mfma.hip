@@ -1547,17 +1547,17 @@ extern "C" int m355_conv2d_wgrad_acc(const m355_conv_desc *d, const void *x, con
     return conv_wgrad_impl(d, x, dy, dw, dbias, stream, false);
 }
 
-/* The thin layers' weight gradients (8 input channels: D.conv1; <= 8 output channels: the heads) end in one fp32 atomic per
- * element and WORKGROUP on a few thousand addresses -- ~50 us of a 340 us launch (scripts/thin_rate.py: the launch time does not
- * go to zero with the batch).  With a workspace every workgroup instead stores its partial tile (coalesced) and a second small
- * launch adds the rows in workgroup order: no atomics, deterministic, dw / dbias OVERWRITTEN (no pre-zeroing).
+/* The weight gradient of the 8-input-channel layer (D.conv1) ended in one fp32 atomic per element and WORKGROUP on 12.8 k
+ * addresses.  With a workspace every workgroup instead stores its partial tile and a second small launch adds the rows in
+ * workgroup order: no atomics, deterministic in every mode, dw / dbias OVERWRITTEN (no pre-zeroing); 340 -> 335 us at batch 128.
  * m355_conv2d_wgrad_ws_bytes(d) == 0: this layer has no such form (use m355_conv2d_wgrad / _acc / _det). */
 extern "C" size_t m355_conv2d_wgrad_ws_bytes(const m355_conv_desc *d)
 {
     if (!d || check_desc(d, "conv2d_wgrad_ws_bytes")) return 0;
     const int cy = m355::dy_channels(d->Cout);
     if (m355::wgrad_c8_eligible(d, cy)) return sizeof(float) * m355::wgrad_c8_ws_floats(d, cy);
-    if (m355::wgrad_small_eligible(d, cy)) return sizeof(float) * m355::wgrad_small_ws_floats(d);
+    // (the <= 8-output-channel heads keep their atomics: with up to 512 partial rows of a few thousand elements the ordered sum
+    // is the longer tail -- conv_final's wgrad 117.7 -> 155.9 us, D.conv5's 60.0 -> 65.6 us, profiles/r04_thin_rate_b.txt)
     return 0;
 }
 

@@ -117,6 +117,37 @@ __device__ __forceinline__ Corner corner_weights(float c0, float c1, float c2, f
     return k;
 }
 
+// out[k] = sum_t tap[t] * w[k + t + (kHalo - HALF)]   (FLIP: w[k - t + HALF + kHalo], the transposed convolution) for the D
+// depths of a lane from its register window, two depths per v_pk_fma_f32.  Per output the taps are accumulated in ascending
+// order with one fused multiply-add each -- the bits of the scalar loop this replaces.  The taps come from LDS (`taps`: a
+// per-lane pointer the compiler cannot prove uniform, see k_render21): one broadcast ds_read_b32 per tap.
+typedef float f2r __attribute__((ext_vector_type(2)));
+template <int NT, int D, int WIN, bool FLIP>
+__device__ __forceinline__ void depth_conv(const float (&w)[WIN], const float *taps, float (&out)[D])
+{
+    constexpr int HALF = NT / 2;
+    static_assert(D % 2 == 0, "two depths per packed operation");
+    f2r acc[D / 2];
+#pragma unroll
+    for (int m = 0; m < D / 2; ++m) acc[m] = f2r{0.0f, 0.0f};
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float tap = taps[t];
+        const f2r tp2 = {tap, tap};
+#pragma unroll
+        for (int m = 0; m < D / 2; ++m) {
+            const int j = FLIP ? 2 * m - t + HALF + kHalo : 2 * m + t + (kHalo - HALF);
+            acc[m] = __builtin_elementwise_fma(tp2, f2r{w[j], w[j + 1]}, acc[m]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < D / 2; ++m) {
+        out[2 * m] = acc[m].x;
+        out[2 * m + 1] = acc[m].y;
+    }
+}
+
 template <int NT, int LPR, int D, int TH, int TW, bool BWD>
 __global__ __launch_bounds__(kThreads21) void k_render21(Render21Args a)
 {
@@ -163,9 +194,14 @@ __global__ __launch_bounds__(kThreads21) void k_render21(Render21Args a)
         return;
     }
 
-    float tp[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) tp[t] = a.taps[t];
+    // The NT taps are uniform: left to the compiler they live in SGPRs, and the packed FMAs of the backward (two convolutions)
+    // want each as an SGPR PAIR -- 42 + the rest overflowed the scalar file: 40-81 SGPR spills into VGPR lanes and 160
+    // v_readlane_b32 (+ hazard nops) inside the per-ray loop (round 4, from the ISA).  They sit in LDS instead and each tap is
+    // read (one broadcast ds_read_b32) right where its D FMAs are issued.
+    __shared__ float taps_s[NT + 3];
+    if (tid < NT) taps_s[tid] = a.taps[tid];
+    int lz = 0;                          // a zero the compiler cannot see through: keeps the tap reads VECTOR loads (a uniform
+    asm volatile("" : "+v"(lz));         // address would be hoisted out of the ray loop and moved back into SGPRs)
 
     // ---- phase 1: zero the tile (incl. halos and the spare zero row)
     {
@@ -251,13 +287,7 @@ __global__ __launch_bounds__(kThreads21) void k_render21(Render21Args a)
                 w[4 * v + 2] = x.z;
                 w[4 * v + 3] = x.w;
             }
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc = fmaf(tp[t], w[k + t + (kHalo - HALF)], acc);
-                sm[k] = acc;
-            }
+            depth_conv<NT, D, WIN, false>(w, taps_s + lz, sm);
         }
         // -- scale/clamp (sm:80-82), occupancy clamp (elf:32), q = 1-o in fp32 (elf:34), prefix products
         float o[D], qf[D];
@@ -313,7 +343,13 @@ __global__ __launch_bounds__(kThreads21) void k_render21(Render21Args a)
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             const double suf = Ttot - (exT + Tl[k]);
-            const float d_o = (float)(g * (pex[k] - suf / (double)qf[k]));
+            // suf / q without the fp64 division (a dozen dependent fp64 instructions per depth: together they cost as much as
+            // one of the two 21-tap convolutions of this pass): fp32 reciprocal of q = float(1 - o) in [1e-5, 1] (1 ulp), one
+            // Newton step in fp64 -> relative error ~1e-14, far below the fp32 rounding of d_o
+            const double qd = (double)qf[k];
+            double rq = (double)__builtin_amdgcn_rcpf(qf[k]);
+            rq = fma(fma(-qd, rq, 1.0), rq, rq);
+            const float d_o = (float)(g * (pex[k] - suf * rq));
             float c = sm[k];
             bool pass = true;
             if (has_scale) {
@@ -344,13 +380,7 @@ __global__ __launch_bounds__(kThreads21) void k_render21(Render21Args a)
                 w[4 * v + 2] = x.z;
                 w[4 * v + 3] = x.w;
             }
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc = fmaf(tp[t], w[k - t + HALF + kHalo], acc);
-                dv[k] = acc;
-            }
+            depth_conv<NT, D, WIN, true>(w, taps_s + lz, dv);
         }
         // clamp(0,1) mask of tri:74 on the raw splat sum; park dV in the tile for phase 4
         if (valid) {

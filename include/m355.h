@@ -231,9 +231,9 @@ int m355_conv2d_wgrad_acc(const m355_conv_desc *d, const void *x, const void *dy
  *      (value * 2^36: integer addition is associative, so the order the workgroups finish in cannot matter) in `ws`
  *      (m355_conv2d_wgrad_det_ws_bytes(d) bytes, zeroed by the call) and one pass converts to fp32.  dw and dbias are
  *      OVERWRITTEN.  A non-finite partial poisons the result with NaN, as fp32 accumulation would. */
-/*      The thin layers (8 input channels: D.conv1 gan.py:163; <= 8 output channels: the heads gan.py:359,364,177,65) with a
- *      workspace: every workgroup stores its partial tile and a second launch adds them in workgroup order -- no atomics (their
- *      tail was ~50 us of a 340 us launch), deterministic; dw / dbias are OVERWRITTEN.  _ws_bytes == 0: no such form. */
+/*      The 8-input-channel layer (D.conv1, gan.py:163) with a workspace: every workgroup stores its partial tile and a second
+ *      launch adds them in workgroup order -- no atomics, deterministic in every mode; dw / dbias are OVERWRITTEN.
+ *      _ws_bytes == 0: the layer has no such form (the <= 8-output-channel heads measured slower with it). */
 size_t m355_conv2d_wgrad_ws_bytes(const m355_conv_desc *d);
 int m355_conv2d_wgrad_ws(const m355_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias, void *ws, void *stream);
 size_t m355_conv2d_wgrad_det_ws_bytes(const m355_conv_desc *d);

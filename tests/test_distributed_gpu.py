@@ -164,7 +164,11 @@ def test_rccl_collectives_inside_a_captured_cycle():
     except subprocess.TimeoutExpired:
         pytest.xfail("RCCL collectives inside a hipGraph capture: the probe did not finish in 420 s (hang)")
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert lines, (r.returncode, r.stderr[-3000:])
+    if not lines:
+        # measured on ROCm 7.2 / torch 2.10 (round 4): the process ABORTS (SIGABRT, an uncaught C++ exception out of the RCCL call
+        # issued while the stream is capturing) -- the collectives of this stack cannot be recorded into a hipGraph
+        what = [ln for ln in r.stderr.splitlines() if "what()" in ln or "Error" in ln or "error" in ln][:3]
+        pytest.xfail(f"RCCL collectives inside a hipGraph capture: the probe process died (rc {r.returncode}): {what}")
     g = json.loads(lines[-1])["graph"]
     print("RCCL-in-graph probe:", g)
     if g["error"] is not None:
