@@ -78,6 +78,9 @@ SIGNATURES = {
     "m355_conv2d_wgrad_fuses_dbias": (c_int, [_P]),
     "m355_conv2d_fwd_stats_rows": (c_int, [_P]),
     "m355_conv2d_fwd_stats": (c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "m355_conv2d_fwd_ws_bytes": (c_size_t, [_P]),
+    "m355_conv2d_fwd_ws_stats_rows": (c_int, [_P]),
+    "m355_conv2d_fwd_ws": (c_int, [_P, _P, _P, _P, _P, c_float, _P, _P, _P]),
     "m355_conv2d_wgrad": (c_int, [_P, _P, _P, _P, _P, _P]),
     "m355_conv2d_wgrad_acc": (c_int, [_P, _P, _P, _P, _P, _P]),
     "m355_conv2d_wgrad_ws_bytes": (c_size_t, [_P]),

@@ -124,6 +124,9 @@ def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0, cin_real=Non
 
 def conv_stats_rows(d):
     """rows of batch-norm partial sums conv_fwd_stats writes for this shape (0: no fused statistics)"""
+    nws, rows = _fwd_ws(d)
+    if nws:
+        return rows   # (split-K layers: the finishing pass emits them)
     return int(lib().m355_conv2d_fwd_stats_rows(ctypes.byref(d)))
 
 
@@ -134,9 +137,11 @@ def conv_fwd_stats(d, x, w_fwd, bias=None, cin_real=None, rows=None):
     assert tuple(x.shape) == (d.N, d.H, d.W, d.Cin), (tuple(x.shape), (d.N, d.H, d.W, d.Cin))
     ho, wo = out_hw(d)
     rows = conv_stats_rows(d) if rows is None else rows
+    b = None if bias is None else _req(bias.detach(), torch.float32, "bias")
+    if _fwd_ws(d)[0]:
+        return _fwd_splitk(d, x, w_fwd, b, 1.0, True)
     y = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.bfloat16, device=x.device)
     part = torch.empty((rows, 2, d.Cout), dtype=torch.float32, device=x.device)
-    b = None if bias is None else _req(bias.detach(), torch.float32, "bias")
     launch("conv2d_fwd_stats", ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(b), ptr(y), ptr(part), stream(),
            work=lambda: flops(d, cin_real), tag=lambda: tag(d))
     return y, part
@@ -160,6 +165,30 @@ def conv_dgrad(d, dy, w_dgrad, cin_real=None, mask_x=None, mask_slope=1.0, mask_
     launch("conv2d_dgrad", ctypes.byref(d), ptr(dy), ptr(w_dgrad), ptr(dx), ptr(ws), ptr(mask_x), float(mask_slope), stream(),
            work=lambda: flops(d, cin_real), tag=lambda: tag(d))
     return dx
+
+
+_FWD_WS = {}
+
+
+def _fwd_ws(d):
+    """(workspace bytes, batch-norm partial rows) of the split-K forward of a small layer, (0, 0) if it has none"""
+    key = bytes(d)
+    r = _FWD_WS.get(key)
+    if r is None:
+        L = lib()
+        r = _FWD_WS[key] = (int(L.m355_conv2d_fwd_ws_bytes(ctypes.byref(d))), int(L.m355_conv2d_fwd_ws_stats_rows(ctypes.byref(d))))
+    return r
+
+
+def _fwd_splitk(d, x, w_fwd, b, slope, want_part):
+    nws, rows = _fwd_ws(d)
+    ho, wo = out_hw(d)
+    ws = torch.empty((nws,), dtype=torch.uint8, device=x.device)
+    y = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.bfloat16, device=x.device)
+    part = torch.empty((rows, 2, d.Cout), dtype=torch.float32, device=x.device) if want_part else None
+    launch("conv2d_fwd_ws", ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(b), ptr(y), float(slope), ptr(ws), ptr(part), stream(),
+           work=lambda: flops(d), tag=lambda: tag(d))
+    return y, part
 
 
 _WS_BYTES = {}

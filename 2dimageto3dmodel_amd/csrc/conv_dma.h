@@ -87,6 +87,10 @@ struct ConvArgs {
     // k_conv_halo, plain unguarded epilogue only: [workgroups along the pixel axis][2][Cout] fp32 partial sums of the results
     // and of their squares (batch-norm statistics of the output without a pass over it), see conv_halo_stats_rows
     float *stats;
+    // k_conv_glds split-K (small layers, conv_mfma.hip splitk_plan): blockIdx.y = K slice of `sk`; the slices' fp32 accumulators go
+    // to skws[slice][M][CoutP] and a finishing pass (k_splitk_finish / k_fold_pad) adds them in slice order
+    int sk;
+    float *skws;
 };
 
 // launch description of the weight-gradient kernels (csrc/conv_mfma.hip, csrc/conv_halo.hip)

@@ -179,9 +179,19 @@ __device__ __forceinline__ void glds_wait()
 #ifndef M355_GLDS_SMALL_NST
 #define M355_GLDS_SMALL_NST 4
 #endif
-template <int BM, int BN, int NW, int WGN, bool FAST, int MODE, int NST = 2>
+// SK (round 4): split-K for problems with fewer 128 x 128 tiles than CUs (the generator's 8x4 / 16x8 stages: M = 2048 .. 8192
+// pixels against K = 2304 .. 4608).  They used to run 64 x 64 tiles -- one workgroup per CU, each pulling its own copy of the
+// operands through L2 -> LDS: 302 MB per launch for M 2048 x N 512 x K 4608, which at the ~8.4 TB/s that path gives IS the 36 us
+// the launch took.  128 x 128 tiles halve the bytes; blockIdx.y = K slice keeps every CU busy; the slices' fp32 accumulators
+// are stored raw and a finishing pass adds them in slice order (deterministic), converts to bf16 and emits the batch-norm
+// partial sums -- i.e. it REPLACES the bn_stats_partial pass these layers needed anyway.  Measured per launch incl. that pass
+// (profiles/r04_splitk.txt): blk1's convs 36 + 9 -> 33 us, blk2.conv1 43 + 9 -> 46, blk2.conv2 27 + 9 -> 34.  Where no pass is
+// replaced the extra launch costs more than the tiles save (mesh discriminator 128 -> 256 at 16x16: 27 -> 37 us; the same on the
+// padded-frame dgrads, 41 -> 43 us), so only the forward convs that feed a batch norm take this path.
+template <int BM, int BN, int NW, int WGN, bool FAST, int MODE, int NST = 2, bool SK = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void k_conv_glds(ConvArgs a, unsigned xbytes, unsigned wbytes)
 {
+    static_assert(!SK || (FAST && NST == 2), "split-K: 64-channel K steps, two stages");
     // NW waves arranged (NW / WGN) x WGN over the BM x BN tile; each wave owns a WTM x WTN sub-tile
     constexpr int WGM = NW / WGN, WTM = BM / WGM, WTN = BN / WGN, PI = WTM / 32, CJ = WTN / 32;
     constexpr int RA = BM / (8 * NW), RB = BN / (8 * NW);  // DMA instructions per wave per stage
@@ -202,7 +212,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void k_conv_glds(ConvArgs
 
     int pad_h = a.pad_h, pad_w = a.pad_w, oy_off = a.oy_off, ox_off = a.ox_off;
     const unsigned short *wv = a.w;
-    if (a.ncls > 1) {
+    if (!SK && a.ncls > 1) {
         const int cls = blockIdx.y;
         pad_h = a.cpad_h[cls]; pad_w = a.cpad_w[cls]; oy_off = a.coy[cls]; ox_off = a.cox[cls];
         wv += (size_t)cls * a.cls_w_elems;
@@ -240,9 +250,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void k_conv_glds(ConvArgs
 #pragma unroll
     for (int j = 0; j < RB; ++j) wrow[j] = (unsigned)(n0 + 8 * (NW * j + wave) + (lane >> 3)) * (unsigned)(a.Kp * 2) + csrc * 16;
 
-    const int Cin2 = a.Cin * 2, nsteps = a.Kp / 64, Ktot = a.KH * a.KW * a.Cin;
+    const int Cin2 = a.Cin * 2, Ktot = a.KH * a.KW * a.Cin;
     const int cpt = a.Cin >> 6;       // FAST: 64-channel chunks per tap
     int s_kh = 0, s_kw = 0, s_cc = 0;  // FAST: scalar tap cursor of the NEXT stage() call
+    int t_beg = 0, nsteps = a.Kp / 64; // K steps [t_beg, nsteps) of this workgroup
+    if constexpr (SK) {
+        const int per = (nsteps + a.sk - 1) / a.sk;
+        t_beg = (int)blockIdx.y * per;
+        nsteps = min(nsteps, t_beg + per);
+        const int tap = t_beg / cpt;
+        s_cc = t_beg - tap * cpt;
+        s_kh = tap / a.KW;
+        s_kw = tap - s_kh * a.KW;
+    }
 
     auto stage = [&](int t, int buf) {
         unsigned char *dstA = lds + buf * STAGE + wave * 1024, *dstB = dstA + BM * 128;
@@ -312,7 +332,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void k_conv_glds(ConvArgs
         for (int s = 0; s < NST - 1; ++s)
             if (s < nsteps) stage(s, s);
         int buf = 0, nbuf = NST - 1;   // buffer of step t / the one step t + NST - 1 goes to (= that of step t - 1)
-        for (int t = 0; t < nsteps; ++t) {
+        for (int t = 0; t < nsteps; ++t) {   // (never with SK: t_beg = 0)
             // step t's DMAs were issued NST-1 steps ago; those of the (up to) NST-2 following steps may stay in flight.
             // The barrier: every wave's part of step t has landed, and every wave is done reading the buffer refilled next
             const int younger = nsteps - 1 - t;
@@ -326,14 +346,30 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void k_conv_glds(ConvArgs
             nbuf = nbuf == NST - 1 ? 0 : nbuf + 1;
         }
     } else {
-        stage(0, 0);
+        if (t_beg < nsteps) stage(t_beg, 0);
         __syncthreads();  // (the barrier's fence drains the DMA: vmcnt(0))
-        for (int t = 0; t < nsteps; ++t) {
-            const int buf = t & 1;
+        for (int t = t_beg; t < nsteps; ++t) {
+            const int buf = (t - t_beg) & 1;
             if (t + 1 < nsteps) stage(t + 1, buf ^ 1);
             step_mma(buf);
             __syncthreads();
         }
+    }
+    if constexpr (SK) {
+        // raw fp32 accumulators of this K slice: skws[slice][m][CoutP]; lane: pixel m, 4 x 4 consecutive channels per (j, i)
+        float *wsb = a.skws + (size_t)blockIdx.y * M * a.CoutP;
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            const int m = m0 + wm * WTM + 32 * i + (lane & 31);
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4 *>(wsb + (size_t)m * a.CoutP + n0 + wn * WTN + 32 * j + 8 * g + 4 * half) =
+                        make_float4(acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+        }
+        return;
     }
 
     // ---- epilogue.  acc[j][i][r]: channel n0 + wn*WTN + 32j + 8*(r>>2) + 4*half + (r&3), pixel m0 + wm*WTM + 32i + (lane&31)
@@ -577,6 +613,58 @@ __global__ void k_fold_pad(const unsigned short *__restrict__ g, unsigned short 
     }
 }
 
+// ---- split-K finishing pass of a FORWARD conv: y[m][c] = act(bias[c] + sum_s ws[s][m][c]) as bf16 NHWC (the GEMM pixel grid IS
+// the output: no parity classes / offsets here), and -- for the convs that feed a batch norm -- the workgroup's (sum, sum of
+// squares) of the fp32 results, part[blockIdx.x][2][C]: the row layout m355_bn_finalize reduces (this pass replaces the
+// bn_stats_partial launch those layers needed anyway).  Thread = one pixel lane x 8 channels; ppb pixels per workgroup.
+__global__ __launch_bounds__(256) void k_splitk_finish(const float *__restrict__ ws, int S, size_t sstride, int M, int C, int CP,
+                                                       const float *__restrict__ bias, float slope, unsigned short *__restrict__ y,
+                                                       float *__restrict__ part, int ppb)
+{
+    __shared__ float red[256 * 8];
+    const int tid = threadIdx.x, vecs = C >> 3, lanes = 256 / vecs, v = tid % vecs, pl = tid / vecs;
+    const int p0 = blockIdx.x * ppb, p1 = min(M, p0 + ppb);
+    float bv[8], s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bv[j] = bias ? bias[v * 8 + j] : 0.0f;
+        s1[j] = s2[j] = 0.0f;
+    }
+    if (pl < lanes)
+        for (int p = p0 + pl; p < p1; p += lanes) {
+            float z[8] = {bv[0], bv[1], bv[2], bv[3], bv[4], bv[5], bv[6], bv[7]};
+            const float *src = ws + (size_t)p * CP + v * 8;
+            for (int s = 0; s < S; ++s) {   // slice order: deterministic
+                const float4 a0 = *reinterpret_cast<const float4 *>(src + s * sstride), a1 = *reinterpret_cast<const float4 *>(src + s * sstride + 4);
+                z[0] += a0.x; z[1] += a0.y; z[2] += a0.z; z[3] += a0.w;
+                z[4] += a1.x; z[5] += a1.y; z[6] += a1.z; z[7] += a1.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s1[j] += z[j];
+                s2[j] += z[j] * z[j];
+                z[j] = z[j] >= 0.0f ? z[j] : z[j] * slope;
+            }
+            uint4 o;
+            o.x = pack_bf16(z[0], z[1]); o.y = pack_bf16(z[2], z[3]); o.z = pack_bf16(z[4], z[5]); o.w = pack_bf16(z[6], z[7]);
+            *reinterpret_cast<uint4 *>(y + (size_t)p * C + v * 8) = o;
+        }
+    if (!part) return;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid * 8 + j] = k ? s2[j] : s1[j];
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            const int vv = c >> 3, jj = c & 7;
+            float t = 0.0f;
+            for (int l = 0; l < lanes; ++l) t += red[(l * vecs + vv) * 8 + jj];
+            part[((size_t)blockIdx.x * 2 + k) * C + c] = t;
+        }
+    }
+}
+
 // rows of a weight view: a multiple of the N tile the launcher will pick for that many output channels
 static inline int ilog2_exact(int v)
 {
@@ -618,6 +706,31 @@ static bool halo_takes_bits(ConvArgs a)
            !a.y_f32_nchw && !getenv("M355_NO_MASKBITS");
 }
 
+// K slices for a small problem (0: no split): plain output frame, 64-channel K steps, whole 128-channel output tiles, fewer
+// 128 x 128 tiles than CUs.  The caller (m355_conv2d_fwd_ws) owns the finishing pass.
+static int splitk_plan(const ConvArgs &a_in)
+{
+    ConvArgs a = a_in;
+    a.CoutP = rows_padded(a.Cout);
+    if (a.ncls < 1) a.ncls = 1;
+    if (getenv("M355_NO_SPLITK")) return 0;
+    if (!dma_eligible(a) || a.Cin % 64 || a.ncls != 1 || a.y_f32_nchw || a.mask_x || a.bits_in || a.bits_out || a.fold2 || a.stats)
+        return 0;
+    if (a.Cout != a.CoutP || a.CoutP % 128 || a.oy_mul != 1 || a.ox_mul != 1 || a.oy_off || a.ox_off || a.OH != a.Ho || a.OW != a.Wo)
+        return 0;
+    {
+        const char *h = getenv("M355_CONV_HALO");
+        if (!(h && h[0] == '0') && conv_halo_eligible(a)) return 0;
+    }
+    const long M = (long)a.N * a.Ho * a.Wo, tiles = ((M + 127) / 128) * (a.CoutP / 128);
+    const int nsteps = a.Kp / 64;
+    if (tiles >= 192 || nsteps < 8) return 0;
+    int S = (int)((256 + tiles - 1) / tiles);
+    if (S > nsteps / 4) S = nsteps / 4;   // at least four K steps per slice
+    if (S > 16) S = 16;
+    return S >= 2 ? S : 0;
+}
+
 static int launch_conv(ConvArgs a, hipStream_t st)
 {
     const int M = a.N * a.Ho * a.Wo;
@@ -638,6 +751,14 @@ static int launch_conv(ConvArgs a, hipStream_t st)
     if (dma_ok) {
         const bool fast = a.Cin % 64 == 0;
         const unsigned xb = (unsigned)xbytes, wb = (unsigned)wbytes;
+        if (a.sk >= 2) {   // split-K (the caller planned it and owns the finishing pass)
+            const dim3 grid((unsigned)((M + 127) / 128) * (a.CoutP / 128), a.sk);
+            if (a.pad_w_mode == 0) hipLaunchKernelGGL((k_conv_glds<128, 128, 4, 2, true, 0, 2, true>), grid, dim3(256), 0, st, a, xb, wb);
+            else if (a.pad_w_mode == 1) hipLaunchKernelGGL((k_conv_glds<128, 128, 4, 2, true, 1, 2, true>), grid, dim3(256), 0, st, a, xb, wb);
+            else hipLaunchKernelGGL((k_conv_glds<128, 128, 4, 2, true, 2, 2, true>), grid, dim3(256), 0, st, a, xb, wb);
+            note_kernel("k_conv_glds");
+            return check_launch("conv2d (dma, split K)");
+        }
         {
             const char *h = getenv("M355_CONV_HALO");  // "0": keep everything on k_conv_glds (A/B runs)
             if (!(h && h[0] == '0') && conv_halo_eligible(a)) return conv_halo_launch(a, xb, wb, st);
@@ -979,6 +1100,82 @@ extern "C" int m355_conv2d_fwd(const m355_conv_desc *d, const void *x, const voi
                                int y_f32_nchw, float lrelu_slope, void *stream)
 {
     return conv_fwd_impl(d, x, w_fwd, bias, y, y_f32_nchw, lrelu_slope, nullptr, stream, 0);
+}
+
+// ConvArgs of a plain forward (what conv_fwd_impl builds for the generic path)
+static ConvArgs fwd_args(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, float slope)
+{
+    ConvArgs a = {};
+    a.x = (const unsigned short *)x;
+    a.w = (const unsigned short *)w_fwd;
+    a.bias = bias;
+    a.y = y;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin;
+    a.ups = d->upsample;
+    a.Hl = d->H << d->upsample; a.Wl = d->W << d->upsample;
+    conv_out_hw(d, &a.Ho, &a.Wo);
+    a.Cout = d->Cout;
+    a.KH = d->kh; a.KW = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
+    a.pad_w_mode = d->pad_w_mode;
+    a.OH = a.Ho; a.OW = a.Wo; a.oy_mul = 1; a.ox_mul = 1;
+    a.Cs = d->Cout;
+    a.Kp = m355::k_padded(d->kh * d->kw * d->Cin);
+    a.slope = slope;
+    return a;
+}
+
+static int fwd_splitk(const m355_conv_desc *d)
+{
+    if (!d || check_desc(d, "conv2d_fwd_ws")) return 0;
+    if (m355::conv_small_eligible(d, 0) || m355::conv_c8_eligible(d, 0)) return 0;
+    if (d->Cout % 8 || d->Cout > 2048 || 256 % (d->Cout / 8)) return 0;   // (the finishing pass: 8-channel vectors, 256 / vecs pixel lanes)
+    return m355::splitk_plan(fwd_args(d, nullptr, nullptr, nullptr, nullptr, 1.0f));
+}
+static int fwd_splitk_ppb(const m355_conv_desc *d, int M)   // pixels per workgroup of the finishing pass: ~512 workgroups, whole lanes
+{
+    const int lanes = 256 / (d->Cout / 8);
+    int ppb = (M + 511) / 512;
+    ppb = (ppb + lanes - 1) / lanes * lanes;
+    return ppb < lanes ? lanes : ppb;
+}
+
+/* Forward of a SMALL layer as split-K (m355_conv2d_fwd_ws_bytes(d) > 0: fewer 128 x 128 output tiles than CUs -- the generator's
+ * 8x4 / 16x8 stages, gan.py:294-302 at :386-391): the K slices' fp32 accumulators go to `ws` and one finishing pass adds them in
+ * slice order, applies bias / LeakyReLU, stores bf16 NHWC and -- part != NULL -- writes the batch-norm partial sums
+ * part[m355_conv2d_fwd_ws_stats_rows(d)][2][Cout] of the fp32 results (what m355_bn_finalize reduces).  Deterministic. */
+extern "C" size_t m355_conv2d_fwd_ws_bytes(const m355_conv_desc *d)
+{
+    const int S = fwd_splitk(d);
+    if (!S) return 0;
+    int Ho, Wo;
+    conv_out_hw(d, &Ho, &Wo);
+    return sizeof(float) * (size_t)S * d->N * Ho * Wo * d->Cout;
+}
+
+extern "C" int m355_conv2d_fwd_ws_stats_rows(const m355_conv_desc *d)
+{
+    if (!fwd_splitk(d) || d->Cout > 2048 || 256 % (d->Cout / 8)) return 0;
+    int Ho, Wo;
+    conv_out_hw(d, &Ho, &Wo);
+    const int M = d->N * Ho * Wo, ppb = fwd_splitk_ppb(d, M);
+    return (M + ppb - 1) / ppb;
+}
+
+extern "C" int m355_conv2d_fwd_ws(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
+                                  float lrelu_slope, void *ws, float *stats_part, void *stream)
+{
+    M355_REQUIRE(x && w_fwd && y && ws, "conv2d_fwd_ws: null pointer");
+    const int S = fwd_splitk(d);
+    M355_REQUIRE(S >= 2 && 256 % (d->Cout / 8) == 0, "conv2d_fwd_ws: this layer has no split-K form (m355_conv2d_fwd_ws_bytes)");
+    ConvArgs a = fwd_args(d, x, w_fwd, nullptr, y, 1.0f);
+    a.sk = S;
+    a.skws = (float *)ws;
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = m355::launch_conv(a, st)) return rc;
+    const int M = d->N * a.Ho * a.Wo, ppb = fwd_splitk_ppb(d, M);
+    hipLaunchKernelGGL(m355::k_splitk_finish, dim3((M + ppb - 1) / ppb), dim3(256), 0, st, (const float *)ws, S, (size_t)M * d->Cout, M,
+                       d->Cout, d->Cout, bias, lrelu_slope, (unsigned short *)y, stats_part, ppb);
+    return m355::check_launch("conv2d_fwd_ws (finish)");
 }
 
 /* forward with a LeakyReLU epilogue that also writes the activation's sign bits (1 bit per element,

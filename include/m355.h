@@ -213,6 +213,16 @@ int m355_conv2d_fwd_bits(const m355_conv_desc *d, const void *x, const void *w_f
  *      m355_conv2d_fwd_stats_rows(d) -- the layout m355_bn_finalize reduces -- so the statistics cost no pass over y.
  *      rows == 0: this shape has no fused statistics (run m355_bn_stats_partial on y).  No activation epilogue. */
 int m355_conv2d_fwd_stats_rows(const m355_conv_desc *d);
+/*      SMALL layers (fewer 128 x 128 output tiles than CUs: the generator's 8x4 / 16x8 stages, gan.py:294-302 at :386-391) as
+ *      split-K: m355_conv2d_fwd_ws_bytes(d) > 0 -> the K slices' fp32 accumulators go to `ws`, one finishing pass adds them in
+ *      slice order, applies bias / LeakyReLU, stores bf16 NHWC and (stats_part != NULL) writes the batch-norm partial sums
+ *      part[m355_conv2d_fwd_ws_stats_rows(d)][2][Cout] -- the pass REPLACES m355_bn_stats_partial on these layers, which is
+ *      what makes the split pay (36 + 9 -> 33 us on the 512 -> 512 convs at 8x4); the Python side takes this path only for convs
+ *      that feed a batch norm. */
+size_t m355_conv2d_fwd_ws_bytes(const m355_conv_desc *d);
+int m355_conv2d_fwd_ws_stats_rows(const m355_conv_desc *d);
+int m355_conv2d_fwd_ws(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, float lrelu_slope,
+                       void *ws, float *stats_part, void *stream);
 int m355_conv2d_fwd_stats(const m355_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, float *part,
                           void *stream);
 int m355_conv2d_dgrad_bits(const m355_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, void *ws,
