@@ -30,9 +30,11 @@ __device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, f
 }
 
 // SPLIT (round 3, small batches): gridDim.z workgroups share one block of queries, each sweeping a contiguous slice of the
-// targets [z * mslice, (z+1) * mslice) (whole LDS tiles); the slices are merged by ONE 64-bit atomicMin per query on the key
-// (distance bits << 32 | index): distances are >= 0, so their float bits order like the values, and among equal distances the
-// lowest index wins -- exactly the oracle's tie rule.  keys[B*N] is pre-filled with 0xff bytes; k_chamfer_unpack splits it.
+// targets [z * mslice, (z+1) * mslice) (whole LDS tiles).  Every slice stores its key (distance bits << 32 | chunk start) for
+// every query into ITS OWN row keys[z][B*N] (all-ones when it found nothing); k_chamfer_unpack takes the minimum over the rows:
+// distances are >= 0, so their float bits order like the values, and among equal distances the lowest chunk wins -- exactly the
+// oracle's tie rule.  (Round 3 merged with a 64-bit atomicMin into one row pre-filled by a memset: one launch and B*N*slices
+// atomics more.)
 template <int QPL, int NW, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64) void k_chamfer_nn(const float *__restrict__ a, const float *__restrict__ b,
                                                        float *__restrict__ dist, int32_t *__restrict__ idx, int N, int M,
@@ -137,8 +139,8 @@ __global__ __launch_bounds__(NW * 64) void k_chamfer_nn(const float *__restrict_
             }
             if (i < N) {
                 if (SPLIT) {
-                    if (i0 >= 0)
-                        atomicMin(keys + (size_t)bi * N + i, ((unsigned long long)__float_as_uint(d0) << 32) | (unsigned)i0);
+                    keys[((size_t)blockIdx.z * gridDim.y + bi) * N + i] =
+                        i0 >= 0 ? (((unsigned long long)__float_as_uint(d0) << 32) | (unsigned)i0) : ~0ull;
                 } else {
                     dist[(size_t)bi * N + i] = d0;
                     idx[(size_t)bi * N + i] = i0;
@@ -148,14 +150,19 @@ __global__ __launch_bounds__(NW * 64) void k_chamfer_nn(const float *__restrict_
     }
 }
 
-// key = (distance bits << 32 | start of the winning 64-target chunk) -> distance, and the first target of that chunk attaining it
-__global__ __launch_bounds__(256) void k_chamfer_unpack(const unsigned long long *__restrict__ keys, const float *__restrict__ a,
+// key = (distance bits << 32 | start of the winning 64-target chunk), one row per slice -> the minimum over the rows -> distance,
+// and the first target of that chunk attaining it
+__global__ __launch_bounds__(256) void k_chamfer_unpack(const unsigned long long *__restrict__ keys, int nz, const float *__restrict__ a,
                                                         const float *__restrict__ b, float *__restrict__ dist,
                                                         int32_t *__restrict__ idx, int N, int M)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, bi = blockIdx.y;
     if (i >= N) return;
-    const unsigned long long k = keys[(size_t)bi * N + i];
+    unsigned long long k = ~0ull;
+    for (int z = 0; z < nz; ++z) {
+        const unsigned long long kz = keys[((size_t)z * gridDim.y + bi) * N + i];
+        k = kz < k ? kz : k;
+    }
     if (k == ~0ull) {   // no slice found a finite distance (NaN / overflowing input): what the one-pass form returns, no rescan
         dist[(size_t)bi * N + i] = INFINITY;
         idx[(size_t)bi * N + i] = -1;
@@ -201,7 +208,7 @@ static int chamfer_slices(int B, int N, int M)
 extern "C" size_t m355_chamfer_nn_ws_bytes(int B, int N, int M)
 {
     if (B <= 0 || N <= 0 || M <= 0) return 0;
-    return m355::chamfer_slices(B, N, M) ? (size_t)B * N * sizeof(unsigned long long) : 0;
+    return (size_t)m355::chamfer_slices(B, N, M) * B * N * sizeof(unsigned long long);   // one key row per slice
 }
 
 extern "C" int m355_chamfer_nn_fwd_ws(const float *a, const float *b, float *dist, int32_t *idx, int B, int N, int M, void *ws,
@@ -215,15 +222,11 @@ extern "C" int m355_chamfer_nn_fwd_ws(const float *a, const float *b, float *dis
     M355_REQUIRE(B <= 65535, "chamfer_nn_fwd_ws: B=%d exceeds grid.y", B);
     hipStream_t st = (hipStream_t)stream;
     unsigned long long *keys = (unsigned long long *)ws;
-    if (hipMemsetAsync(keys, 0xff, (size_t)B * N * sizeof(unsigned long long), st) != hipSuccess) {
-        m355::set_error("chamfer_nn_fwd_ws: memset failed");
-        return M355_ERR_LAUNCH;
-    }
     const int tiles = (M + m355::kTile - 1) / m355::kTile;
     const int mslice = ((tiles + ts - 1) / ts) * m355::kTile;          // whole tiles per slice
     const int nz = (M + mslice - 1) / mslice;
     hipLaunchKernelGGL((m355::k_chamfer_nn<4, 4, true>), dim3((N + 255) / 256, B, nz), dim3(256), 0, st, a, b, dist, idx, N, M, keys, mslice);
-    hipLaunchKernelGGL(m355::k_chamfer_unpack, dim3((N + 255) / 256, B), dim3(256), 0, st, keys, a, b, dist, idx, N, M);
+    hipLaunchKernelGGL(m355::k_chamfer_unpack, dim3((N + 255) / 256, B), dim3(256), 0, st, keys, nz, a, b, dist, idx, N, M);
     return m355::check_launch("chamfer_nn_fwd_ws");
 }
 

@@ -130,13 +130,14 @@ int m355_sil_loss_fwd(const float *proj, const float *mask, int Hin, int Win, in
 
 /* ---- Chamfer nearest neighbour (BASELINE configs[4]).  NEW capability: the reference contains no Chamfer code
  *      (SURVEY.md 0.3), parity is against the brute-force oracle only.
- *      a[B,N,3], b[B,M,3] -> dist[B,N] = min_j |a_i-b_j|^2, idx[B,N] = argmin (lowest j on ties). */
+ *      a[B,N,3], b[B,M,3] -> dist[B,N] = min_j |a_i-b_j|^2, idx[B,N] = argmin (lowest j on ties); the squared distance is
+ *      the fused chain fma(dz, dz, fma(dy, dy, dx * dx)) on both sides (oracle/p_oracle.c orc_chamfer_nn): bit-exact. */
 int m355_chamfer_nn_fwd(const float *a, const float *b, float *dist, int32_t *idx, int B, int N, int M,
                         void *stream);
 /*      the same with a workspace: when B * ceil(N / 256) < 256 query blocks would leave most of the chip idle (B = 1, 16384
- *      points: 64), the TARGET sweep is split over workgroups as well and merged by one 64-bit atomicMin per query on
- *      (distance bits << 32 | index) -- the lowest-index tie rule is that key's order.  ws >= m355_chamfer_nn_ws_bytes(B,N,M)
- *      (0: not needed, ws may be NULL). */
+ *      points: 64), the TARGET sweep is split over workgroups as well: every slice stores its (distance bits << 32 | chunk)
+ *      key per query into its own row of ws, a second launch takes the minimum over the rows -- the lowest-index tie rule is
+ *      that key's order; no atomics, no fill.  ws >= m355_chamfer_nn_ws_bytes(B,N,M) (0: not needed, ws may be NULL). */
 size_t m355_chamfer_nn_ws_bytes(int B, int N, int M);
 int m355_chamfer_nn_fwd_ws(const float *a, const float *b, float *dist, int32_t *idx, int B, int N, int M, void *ws,
                            void *stream);

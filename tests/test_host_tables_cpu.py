@@ -1,0 +1,99 @@
+"""CPU: the host-side tables and planning queries added in round 4 (no GPU, no kernel launches).
+
+* the static gather tables of the mesh backward (mesh.texel_table / vertex_corner_table / reverse_adjacency) against brute force
+  on the procedural UV sphere -- the backward kernels sum in table order, so a wrong table is a wrong gradient;
+* the workspace / plan queries of the C-ABI: deterministic wgrad, partial-sum wgrad, split-K forward."""
+import ctypes
+import importlib
+
+import numpy as np
+
+
+def _sphere(tmp_path):
+    m = importlib.import_module("2dimageto3dmodel_amd.mesh")
+    v, f, uvs, ft = m.load_obj(m.write_uv_sphere_obj(str(tmp_path / "uvsphere_16rings.obj")))
+    return m, v, f
+
+
+def test_vertex_corner_and_reverse_adjacency_tables(tmp_path):
+    m, v, f = _sphere(tmp_path)
+    V, F = v.shape[0], f.shape[0]
+    ptr, fc = m.vertex_corner_table(f, V)
+    assert ptr[0] == 0 and ptr[-1] == 3 * F and fc.dtype == np.int32 and ptr.dtype == np.int32
+    for vv in (0, 1, 17, 240, V - 1):
+        want = sorted(4 * i + c for i in range(F) for c in range(3) if f[i, c] == vv)
+        assert fc[ptr[vv]:ptr[vv + 1]].tolist() == want          # ascending: the summation order of the kernel
+    ff = m.face_adjacency(f)
+    rp, ri = m.reverse_adjacency(ff)
+    assert rp[-1] == 3 * F
+    for q in (0, 31, 500, F - 1):
+        assert ri[rp[q]:rp[q + 1]].tolist() == sorted(g for g in range(F) for i in range(3) if ff[g, i] == q)
+        assert sorted(ri[rp[q]:rp[q + 1]].tolist()) == sorted(ff[q].tolist())   # closed manifold: the adjacency is symmetric
+    # an asymmetric table (not a manifold adjacency) is reversed literally
+    odd = np.array([[1, 1, 2], [0, 2, 2], [0, 0, 0]])
+    p2, i2 = m.reverse_adjacency(odd)
+    assert [i2[p2[k]:p2[k + 1]].tolist() for k in range(3)] == [[1, 2, 2, 2], [0, 0], [0, 1, 1]]
+
+
+def test_texel_table_restates_the_forward_taps():
+    """every (vertex, tap) of the bilinear sampling appears exactly once under its texel, with the forward's fp32 weight; pad columns
+    fold onto their source column (circular by one when symmetric, one wrapped column otherwise)"""
+    m = importlib.import_module("2dimageto3dmodel_amd.mesh")
+    rs = np.random.RandomState(3)
+    for symmetric, H, W in ((True, 32, 16), (False, 16, 16)):
+        S, V = 300, 482
+        uv = rs.uniform(-1.02, 1.02, (S, 2)).astype(np.float32)      # a few taps fall outside the padded map: dropped
+        src = rs.randint(0, S, V)
+        ptr, vtx, w = m.texel_table(uv, src, H, W, symmetric)
+        assert ptr.shape == (H * W + 1,) and ptr[-1] == vtx.shape[0] == w.shape[0] and w.dtype == np.float32
+        Wp = W + (2 if symmetric else 1)
+        got = {}
+        for t in range(H * W):
+            seg = vtx[ptr[t]:ptr[t + 1]]
+            assert (np.diff(seg) >= 0).all()                        # vertices ascending inside a texel
+            for e in range(ptr[t], ptr[t + 1]):
+                got.setdefault((t, int(vtx[e])), []).append(float(w[e]))
+        want = {}
+        f32 = np.float32
+        for v in range(V):
+            u_, v_ = uv[src[v]]
+            fx = (u_ + f32(1.0)) * f32(0.5) * f32(Wp - 1)
+            fy = (v_ + f32(1.0)) * f32(0.5) * f32(H - 1)
+            x0, y0 = np.floor(fx), np.floor(fy)
+            wx1, wy1 = f32(fx - x0), f32(fy - y0)
+            for iy, wy in ((0, f32(1.0) - wy1), (1, wy1)):
+                for ix, wx in ((0, f32(1.0) - wx1), (1, wx1)):
+                    xp, yc = int(x0) + ix, int(y0) + iy
+                    if not (0 <= xp < Wp and 0 <= yc < H):
+                        continue
+                    xc = (W - 1 if xp == 0 else (0 if xp == W + 1 else xp - 1)) if symmetric else (0 if xp == W else xp)
+                    want.setdefault((yc * W + xc, v), []).append(float(f32(wx) * f32(wy)))
+        assert got.keys() == want.keys()
+        for k in want:
+            assert sorted(got[k]) == sorted(want[k]), k
+
+
+def test_workspace_queries(pkg):
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    L = pkg._lib.lib()
+
+    def desc(N, H, W, Cin, Cout, k, s=1, mode=1, ups=0):
+        return conv.make_desc(N, H, W, Cin, Cout, k, k, s, k // 2 if s == 1 else 1, k // 2 if s == 1 else 1, mode, ups)
+
+    d = desc(64, 8, 4, 512, 512, 3)
+    # deterministic wgrad: [flag | Cout*K fixed-point sums | Cout bias sums], 8 bytes each
+    assert L.m355_conv2d_wgrad_det_ws_bytes(ctypes.byref(d)) == 8 * (1 + 512 * 9 * 512 + 512)
+    # partial-sum wgrad: the 8-input-channel 5x5 layer only (one row of Cout * 201 floats per pixel-axis workgroup)
+    c8 = desc(128, 256, 256, 8, 64, 5, mode=2)
+    assert L.m355_conv2d_wgrad_ws_bytes(ctypes.byref(c8)) == 4 * 256 * 64 * 201
+    assert L.m355_conv2d_wgrad_ws_bytes(ctypes.byref(d)) == 0
+    assert L.m355_conv2d_wgrad_ws_bytes(ctypes.byref(desc(64, 256, 128, 64, 3, 5))) == 0        # heads keep their atomics
+    # split-K forward: fewer 128 x 128 tiles than CUs, 64-channel K steps, whole 128-channel output tiles
+    M = 64 * 8 * 4
+    assert L.m355_conv2d_fwd_ws_bytes(ctypes.byref(d)) == 4 * 4 * M * 512                         # 16 x 4 tiles -> 4 K slices of 18 steps
+    assert L.m355_conv2d_fwd_ws_stats_rows(ctypes.byref(d)) == 512
+    assert L.m355_conv2d_fwd_ws_bytes(ctypes.byref(desc(64, 32, 16, 256, 256, 3))) == 0           # 512 tiles: no split
+    assert L.m355_conv2d_fwd_ws_bytes(ctypes.byref(desc(64, 8, 4, 512, 64, 3))) == 0              # 64 output channels: 256 x 64 tiles
+    assert L.m355_conv2d_fwd_ws_bytes(ctypes.byref(desc(64, 16, 32, 128, 128, 3))) == 0           # the halo kernel's layer
+    assert L.m355_cproj_bwd_ws_floats(128, 256, 512) == 128 * 2 * 512 and L.m355_cproj_bwd_ws_floats(128, 64, 256) == 0
+    assert L.m355_sn_scratch_words(18, 512, 4608) == 18 * (72 + 128)
