@@ -191,7 +191,8 @@ static int chamfer_slices(int B, int N, int M)
     // B = 1 / 2 / 4 / 8 / 16 -- a slice's targets stay in L1 and the tail of the launch is shorter.  More than 8 slices gain
     // nothing (every slice pays a merge and 256 atomics per block, the unpack rescans one chunk per query).
     static const long target = getenv("M355_CHAMFER_WGS") ? atol(getenv("M355_CHAMFER_WGS")) : 2048;
-    static const long max_ts = getenv("M355_CHAMFER_MAXTS") ? atol(getenv("M355_CHAMFER_MAXTS")) : 8;
+    // (round 4: with per-slice key rows a slice costs a plain store per query, not an atomic: 16 slices measure 1-2 % ahead of 8)
+    static const long max_ts = getenv("M355_CHAMFER_MAXTS") ? atol(getenv("M355_CHAMFER_MAXTS")) : 16;
     const long blocks = (long)B * ((N + 255) / 256);   // 4 queries per lane: the most reuse of a broadcast target
     if (blocks >= target || M < 2 * kTile) return 0;
     long ts = (target + blocks - 1) / blocks;

@@ -467,6 +467,7 @@ extern "C" int m355_proj_render_fwd(const int32_t *tile_start, const float *tile
         r.N = N;
         r.S = S;
         r.fixed_weights = (flags & M355_FIXED_WEIGHTS) ? 1 : 0;
+        r.det_scale = (flags & M355_DET_SPLAT) ? 1.0f : 0.0f;   // (the launcher picks the actual scale)
         return m355::launch_render21<false>(r, B, (hipStream_t)stream);
     }
     m355::RenderArgs a = {};
@@ -508,6 +509,7 @@ extern "C" int m355_proj_render_bwd(const int32_t *tile_start, const float *tile
         r.N = N;
         r.S = S;
         r.fixed_weights = (flags & M355_FIXED_WEIGHTS) ? 1 : 0;
+        r.det_scale = (flags & M355_DET_SPLAT) ? 1.0f : 0.0f;
         return m355::launch_render21<true>(r, B, (hipStream_t)stream);
     }
     m355::RenderArgs a = {};

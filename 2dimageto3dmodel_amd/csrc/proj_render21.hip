@@ -148,7 +148,7 @@ __device__ __forceinline__ void depth_conv(const float (&w)[WIN], const float *t
     }
 }
 
-template <int NT, int LPR, int D, int TH, int TW, bool BWD>
+template <int NT, int LPR, int D, int TH, int TW, bool BWD, bool DETS = false>
 __global__ __launch_bounds__(kThreads21) void k_render21(Render21Args a)
 {
     static_assert(D % 4 == 0 && NT % 2 == 1 && NT / 2 <= kHalo - 2, "window layout");
@@ -160,6 +160,9 @@ __global__ __launch_bounds__(kThreads21) void k_render21(Render21Args a)
     constexpr int WIN = D + 2 * kHalo;  // window floats per lane
     // one extra all-zero row (index RAYS) yields the constant silhouette value of untouched rays
     __shared__ __attribute__((aligned(16))) float tile[(RAYS + 1) * STRIDE];
+    // DETS (deterministic mode): the splat's cells as 64-bit fixed point -- integer adds commute, so a voxel hit by many points
+    // has the same sum whatever order the LDS atomics land in; +64 KB of LDS (one workgroup per CU instead of four: the price)
+    __shared__ long long fix[DETS ? RAYS * SP : 1];
     __shared__ int rayflag[RAYS];
     __shared__ int tlist[RAYS];
     __shared__ int tcount;
@@ -209,6 +212,8 @@ __global__ __launch_bounds__(kThreads21) void k_render21(Render21Args a)
         for (int i = tid; i < (RAYS + 1) * STRIDE / 4; i += kThreads21) t4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = tid; i < RAYS; i += kThreads21) rayflag[i] = 0;
         if (tid == 0) tcount = 0;
+        if (DETS)
+            for (int i = tid; i < RAYS * SP; i += kThreads21) fix[i] = 0;
     }
     __syncthreads();
 
@@ -227,11 +232,28 @@ __global__ __launch_bounds__(kThreads21) void k_render21(Render21Args a)
                 rayflag[ray] = 1;
                 float *col = tile + ray * STRIDE + kHalo + k.f0;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) atomicAdd(col + i, k.w0[i] * k.w1[j] * k.w2[kk]);
+                for (int i = 0; i < 2; ++i) {
+                    const float wv = k.w0[i] * k.w1[j] * k.w2[kk];
+                    if (DETS) {
+                        const int z = k.f0 + i;
+                        if (z >= 0 && z < SP)
+                            atomicAdd(reinterpret_cast<unsigned long long *>(&fix[ray * SP + z]), (unsigned long long)__float2ll_rn(wv * a.det_scale));
+                    } else {
+                        atomicAdd(col + i, wv);
+                    }
+                }
             }
         }
     });
     __syncthreads();
+    if (DETS) {
+        const double inv = 1.0 / (double)a.det_scale;
+        for (int i = tid; i < RAYS * SP; i += kThreads21) {
+            const int ray = i / SP, z = i - ray * SP;
+            tile[ray * STRIDE + kHalo + z] = (float)((double)fix[i] * inv);
+        }
+        __syncthreads();
+    }
 
     // ---- phase 2.5: compact the touched rays (wave 0)
     if (wave == 0) {
@@ -459,6 +481,19 @@ int launch_render21(Render21Args a, int B, hipStream_t st)
     a.tiles_x = (a.S + c.tw - 1) / c.tw;
     a.tiles_y = (a.S + c.th - 1) / c.th;
     dim3 grid(a.tiles_x * a.tiles_y, B), block(kThreads21);
+    if (a.det_scale != 0.0f) {
+        // scale = the largest power of two that keeps N maximal weights inside 62 bits: literal weights reach (2S)^3, the
+        // "fixed" ones 1 (csrc/proj_render21.hip corner_weights); never finer than 2^-40
+        const double bound = (a.fixed_weights ? 1.0 : 8.0 * (double)a.S * a.S * a.S) * (double)(a.N > 0 ? a.N : 1);
+        int k = 62 - (int)ceil(log2(bound));
+        if (k > 40) k = 40;
+        a.det_scale = (float)ldexp(1.0, k);
+        if (a.S <= 64) hipLaunchKernelGGL((k_render21<21, 16, 4, 8, 8, BWD, true>), grid, block, 0, st, a);
+        else if (a.S <= 128) hipLaunchKernelGGL((k_render21<21, 16, 8, 8, 8, BWD, true>), grid, block, 0, st, a);
+        else if (a.S <= 256) hipLaunchKernelGGL((k_render21<21, 32, 8, 4, 8, BWD, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_render21<21, 64, 8, 4, 4, BWD, true>), grid, block, 0, st, a);
+        return check_launch(BWD ? "proj_render_bwd(21, deterministic splat)" : "proj_render_fwd(21, deterministic splat)");
+    }
     if (a.S <= 64) hipLaunchKernelGGL((k_render21<21, 16, 4, 8, 8, BWD>), grid, block, 0, st, a);
     else if (a.S <= 128) hipLaunchKernelGGL((k_render21<21, 16, 8, 8, 8, BWD>), grid, block, 0, st, a);
     else if (a.S <= 256) hipLaunchKernelGGL((k_render21<21, 32, 8, 4, 8, BWD>), grid, block, 0, st, a);

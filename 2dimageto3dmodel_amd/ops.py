@@ -10,6 +10,7 @@ from ._lib import check, lib, ptr, stream
 
 FIXED_WEIGHTS = 1
 TAPS_FROM_SIGMA = 2
+DET_SPLAT = 8        # M355_DET_SPLAT: order-independent occupancy splat (set by EffectiveLossFunction in deterministic mode)
 TRUE_GAUSSIAN = 4
 
 FOV = 1.875       # utils/effective_loss_function.py:69

@@ -94,6 +94,9 @@ class EffectiveLossFunction(nn.Module):
             f |= ops.FIXED_WEIGHTS
         if self.true_gaussian:
             f |= ops.TRUE_GAUSSIAN
+        from . import conv
+        if conv.is_deterministic() and self.kernel_size == 21:   # (the 21-tap kernels carry the order-independent splat)
+            f |= ops.DET_SPLAT
         return f
 
     def termination_probs(self, voxels, epsilon=1e-5):

@@ -40,6 +40,8 @@ int m355_abi_version(void);   /* 2: deterministic reductions (round 4): workspac
 #define M355_FIXED_WEIGHTS 1   /* w0 = 1-(g-floor g) instead of the literal 1-g-floor g (trilinear_interpolation.py:66) */
 #define M355_TAPS_FROM_SIGMA 2 /* `taps` points at the device scalar sigma; taps are built in-kernel (smooth_voxels.py:24-31) */
 #define M355_TRUE_GAUSSIAN 4   /* exp(-x^2/2s^2) instead of the literal exp(+x^2/2s^2) (smooth_voxels.py:29) */
+#define M355_DET_SPLAT 8       /* m355_proj_render_fwd/_bwd (21 explicit taps): the occupancy splat accumulates in 64-bit fixed-point
+                                  LDS cells -- bit-reproducible whatever the voxel collisions; one workgroup per CU instead of four */
 
 /* ---- P1+P2  CameraUtilities.transformation_3d_coord_to_camera_coord
  *      camera/coordinate_system_transformation.py:20-39 (+ quaternions/points_quaternions.py:41-81,

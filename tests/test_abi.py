@@ -78,8 +78,8 @@ def test_host_side_launch_rules(pkg):
     L = pkg._lib.lib()
     for B, N, M in ((1, 16384, 16384), (8, 16384, 16384), (32, 16384, 16384), (64, 2048, 2048), (1, 1000, 1500), (3, 300, 3000)):
         want = B * ((N + 255) // 256) < 2048 and M >= 2048
-        nb = L.m355_chamfer_nn_ws_bytes(B, N, M)   # one row of B * N 8-byte keys per target slice (2 .. 8 slices)
-        assert (nb > 0) == want and nb % (B * N * 8) == 0 and nb // (B * N * 8) in ((0,) if not want else (2, 4, 8))
+        nb = L.m355_chamfer_nn_ws_bytes(B, N, M)   # one row of B * N 8-byte keys per target slice (2 .. 16 slices)
+        assert (nb > 0) == want and nb % (B * N * 8) == 0 and nb // (B * N * 8) in ((0,) if not want else (2, 4, 8, 16))
     esz = L.m355_weight_prep_entry_bytes()
     fake = ctypes.c_void_p(0x1000)   # (device pointers are only recorded here, nothing is launched)
 
