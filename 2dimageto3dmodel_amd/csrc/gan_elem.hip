@@ -155,45 +155,62 @@ __global__ __launch_bounds__(256) void k_affine_act(const short *__restrict__ x,
         av[j] = a[(size_t)n * C + c0 + j];
         bv[j] = b[(size_t)n * C + c0 + j];
     }
-#pragma unroll 4
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const bf16x8e v = *reinterpret_cast<const bf16x8e *>(xn + i * 8);
-        bf16x8e r = {0, 0, 0, 0, 0, 0, 0, 0};
+    // FOUR independent 16-byte loads (eight with the residual) in flight per thread: the `#pragma unroll 4` this loop carried was
+    // refused by the compiler (-Wpass-failed), i.e. one load per thread and trip -- 5.1 TB/s where the same access mix reaches
+    // 6.2 (scripts/hbm_ceilings.py).  The stride is a multiple of C/8, so all four vectors of a thread share its coefficients.
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += 4 * stride) {
+        bf16x8e v4[4], r4[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t i = i0 + u * stride;
+            ok[u] = i < total;
+            v4[u] = ok[u] ? *reinterpret_cast<const bf16x8e *>(xn + i * 8) : bf16x8e{0, 0, 0, 0, 0, 0, 0, 0};
+        }
         if (rn) {
-            size_t ri = i;
-            if (res_w > 0) {
-                // 32-bit shifts / one 32-bit division: the 64-bit divisions this used to be cost more than the 48 bytes moved
-                // (vecs = C / 8 divides 256: a power of two; i < HW * vecs < 2^31)
-                const unsigned iu = (unsigned)i, p = iu >> lvecs, v = iu & (unsigned)(vecs - 1);
-                const unsigned h = rw_pow2 ? p >> lrw : p / (unsigned)res_w, w = p - h * (unsigned)res_w;
-                ri = (size_t)(((h >> 1) * ((unsigned)res_w >> 1) + (w >> 1)) * (unsigned)vecs + v);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t i = i0 + u * stride;
+                size_t ri = i;
+                if (res_w > 0) {
+                    // 32-bit shifts / one 32-bit division: the 64-bit divisions this used to be cost more than the 48 bytes moved
+                    // (vecs = C / 8 divides 256: a power of two; i < HW * vecs < 2^31)
+                    const unsigned iu = (unsigned)i, p = iu >> lvecs, vv = iu & (unsigned)(vecs - 1);
+                    const unsigned h = rw_pow2 ? p >> lrw : p / (unsigned)res_w, w = p - h * (unsigned)res_w;
+                    ri = (size_t)(((h >> 1) * ((unsigned)res_w >> 1) + (w >> 1)) * (unsigned)vecs + vv);
+                }
+                r4[u] = ok[u] ? *reinterpret_cast<const bf16x8e *>(rn + ri * 8) : bf16x8e{0, 0, 0, 0, 0, 0, 0, 0};
             }
-            r = *reinterpret_cast<const bf16x8e *>(rn + ri * 8);
         }
-        float zz[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float z = bf2f_e(v[j]) * av[j] + bv[j];
-            zz[j] = z >= 0.0f ? z : z * slope;
-        }
-        if (rn) {
-            // residual branch of ResBlockUp (gan.py:312): the activation is rounded to bf16 first, as the
-            // separate bf16 add it replaces did
-            const bf16x8e q = pack8_e(zz);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) zz[j] = bf2f_e(q[j]) + bf2f_e(r[j]);
-        }
-        if (out_slope != 1.0f) {
-            // the LeakyReLU the generator applies to a block's output in front of a head (gan.py:406,410), folded in:
-            // the sum is rounded to bf16 first, as the separate activation pass it replaces saw it
-            const bf16x8e q = pack8_e(zz);
+        for (int u = 0; u < 4; ++u) {
+            if (!ok[u]) continue;
+            float zz[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float t = bf2f_e(q[j]);
-                zz[j] = t >= 0.0f ? t : t * out_slope;
+                float z = bf2f_e(v4[u][j]) * av[j] + bv[j];
+                zz[j] = z >= 0.0f ? z : z * slope;
             }
+            if (rn) {
+                // residual branch of ResBlockUp (gan.py:312): the activation is rounded to bf16 first, as the
+                // separate bf16 add it replaces did
+                const bf16x8e q = pack8_e(zz);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) zz[j] = bf2f_e(q[j]) + bf2f_e(r4[u][j]);
+            }
+            if (out_slope != 1.0f) {
+                // the LeakyReLU the generator applies to a block's output in front of a head (gan.py:406,410), folded in:
+                // the sum is rounded to bf16 first, as the separate activation pass it replaces saw it
+                const bf16x8e q = pack8_e(zz);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = bf2f_e(q[j]);
+                    zz[j] = t >= 0.0f ? t : t * out_slope;
+                }
+            }
+            *reinterpret_cast<bf16x8e *>(yn + (i0 + u * stride) * 8) = pack8_e(zz);
         }
-        *reinterpret_cast<bf16x8e *>(yn + i * 8) = pack8_e(zz);
     }
 }
 
@@ -249,19 +266,30 @@ __global__ __launch_bounds__(256) void k_act_bwd_apply(const short *__restrict__
         Bv[j] = Bc[c0 + j];
         Cv[j] = Cc[c0 + j];
     }
-#pragma unroll 4
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const bf16x8e vx = *reinterpret_cast<const bf16x8e *>(x + off + i * 8);
-        const bf16x8e vd = *reinterpret_cast<const bf16x8e *>(dy + off + i * 8);
-        float oo[8];
+    const size_t stride = (size_t)gridDim.x * 256;   // (four vectors = eight independent loads per thread and trip, as k_affine_act)
+    for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += 4 * stride) {
+        bf16x8e vx4[4], vd4[4];
+        bool ok[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float xf = bf2f_e(vx[j]);
-            const float z = xf * av[j] + bv[j];
-            const float dz = bf2f_e(vd[j]) * (z >= 0.0f ? 1.0f : slope);
-            oo[j] = dz * Av[j] + xf * Bv[j] + Cv[j];
+        for (int u = 0; u < 4; ++u) {
+            const size_t i = i0 + u * stride;
+            ok[u] = i < total;
+            vx4[u] = ok[u] ? *reinterpret_cast<const bf16x8e *>(x + off + i * 8) : bf16x8e{0, 0, 0, 0, 0, 0, 0, 0};
+            vd4[u] = ok[u] ? *reinterpret_cast<const bf16x8e *>(dy + off + i * 8) : bf16x8e{0, 0, 0, 0, 0, 0, 0, 0};
         }
-        *reinterpret_cast<bf16x8e *>(dx + off + i * 8) = pack8_e(oo);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!ok[u]) continue;
+            float oo[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xf = bf2f_e(vx4[u][j]);
+                const float z = xf * av[j] + bv[j];
+                const float dz = bf2f_e(vd4[u][j]) * (z >= 0.0f ? 1.0f : slope);
+                oo[j] = dz * Av[j] + xf * Bv[j] + Cv[j];
+            }
+            *reinterpret_cast<bf16x8e *>(dx + off + (i0 + u * stride) * 8) = pack8_e(oo);
+        }
     }
 }
 
