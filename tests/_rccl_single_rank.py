@@ -55,6 +55,40 @@ def run(force):
     return losses, w, st, par.allreduce_ms()
 
 
+def overlap_probe():
+    """the asynchronous discriminator all-reduce (GanTrainer.overlap_comm: issued after D's backward on the gradient communicator,
+    awaited -- with optimizer_d.step() -- after the NEXT generator forward) against the synchronous order, deterministic mode, one
+    RCCL rank with the collectives forced on: every weight and Adam moment must be bit-identical after two cycles"""
+    pkg = importlib.import_module("2dimageto3dmodel_amd")
+    os.environ["M355_FORCE_COLLECTIVES"] = "1"
+    prev = pkg.set_deterministic(True)
+    try:
+        g = torch.Generator().manual_seed(52)
+        B, R = 2, 128
+        batches, noises = [], []
+        for _ in range(3):
+            batches.append([(torch.rand(B, 3, R, R, generator=g) * 2 - 1).to(dev), (torch.rand(B, 1, R, R, generator=g) > 0.4).float().to(dev),
+                            (0.05 * torch.randn(B, 3, 32, 32, generator=g)).to(dev), torch.randint(0, 200, (B, 1), generator=g).to(dev)])
+            noises.append(torch.randn(B, 64, generator=g).to(dev))
+        states, pend = [], []
+        for overlap in (True, False):
+            torch.manual_seed(13)
+            t = train.GanTrainer(gargs, device=dev)
+            t.overlap_comm = overlap
+            t.train()
+            for _ in range(2):
+                for b, z in zip(batches, noises):
+                    t.iteration(*b, noise=z, epoch=0)
+            pend.append(bool(t._pending_d))
+            t.finish_pending()
+            torch.cuda.synchronize()
+            states.append([v.detach().clone() for v in t.state_dict().values()] +
+                          [sv.detach().clone() for p_ in t.discriminator.parameters() for sv in t.optimizer_d.state[p_].values() if torch.is_tensor(sv)])
+        return {"pending_after_last_iteration": pend, "bit_identical": all(torch.equal(a, b) for a, b in zip(*states))}
+    finally:
+        pkg.set_deterministic(prev)
+
+
 def graph_probe():
     """RCCL collectives INSIDE a captured training cycle: capture one cycle (G, D, D) with the collectives forced
     on -- SyncBN all-reduces on the default communicator, the flat gradient all-reduces (one of them asynchronous) on the gradient
@@ -102,12 +136,13 @@ def graph_probe():
 
 l1, w1, st, ms = run(True)
 l0, w0, st0, _ = run(False)
+overlap = overlap_probe() if "--overlap" in sys.argv else None
 graph = graph_probe() if "--graph" in sys.argv else None
 try:
     dist.destroy_process_group()
 except Exception:  # noqa: BLE001  (a failed capture can leave the communicator unusable: the result line matters)
     pass
-print(json.dumps({"graph": graph,"losses_rccl": l1, "losses_plain": l0, "max_w_diff": float((w1 - w0).abs().max()),
+print(json.dumps({"graph": graph, "overlap": overlap,"losses_rccl": l1, "losses_plain": l0, "max_w_diff": float((w1 - w0).abs().max()),
                   "frac_w_diff": float(((w1 - w0).abs() > 1e-6).float().mean()),
                   "grad_allreduces": st["grad_allreduces"], "n_cbn": st["n_cbn"], "syncbn_collectives": st["syncbn_collectives"],
                   "allreduce_ms": ms, "plain_collectives": st0["grad_allreduces"] + st0["syncbn_collectives"]}))

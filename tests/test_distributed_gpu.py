@@ -129,10 +129,12 @@ def test_rccl_single_rank():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     env["MASTER_PORT"] = str(_free_port())
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_single_rank.py")], capture_output=True, text=True,
-                       timeout=850, env=env, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_single_rank.py"), "--overlap"], capture_output=True,
+                       text=True, timeout=850, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    # the asynchronous discriminator all-reduce (left in flight across the iteration boundary) against the synchronous order
+    assert out["overlap"] == {"pending_after_last_iteration": [True, False], "bit_identical": True}, out["overlap"]
     # 1 G step (every CBN layer forward + backward) + 2 D steps (forward under no_grad): 4 SyncBN collectives per layer;
     # 3 gradient all-reduces
     assert out["n_cbn"] == 12
