@@ -96,6 +96,8 @@ SIGNATURES = {
     "m355_pool_pack_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "m355_pool_pack_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, _P]),
     "m355_pool_unpack_bwd": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "m355_pool_pack_parts_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
+    "m355_pool_unpack_parts_bwd": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, _P, _P, c_int, c_int, c_int, _P]),
     "m355_unpack_range": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "m355_head_tail_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "m355_head_tail_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

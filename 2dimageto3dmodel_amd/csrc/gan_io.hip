@@ -79,11 +79,39 @@ struct PoolPackArgs {
     short *out;          // [M,Ho,Wo,CP] bf16
     float *mask;         // [M,Ho/g,Wo/g] fp32 or null
     int M, C, H, W, E, P, CP, Ho, Wo, g, mask_chan;
+    // PARTS form (x == null): the 4-channel input is never materialised -- sample m < Nf is cat(fake[m] * alpha[m], alpha[m]),
+    // sample m >= Nf is cat(real[m - Nf], alpha[m - Nf])  (k_mask_cat's definition, evaluated in the loader)
+    const float *fake, *real, *alpha;
+    int Nf;
 };
+
+// four consecutive texels of channel c of sample m, plane offset `off` (a multiple of 4).  PARTS: the product is rounded to
+// fp32 before anything is added to it (__fmul_rn: no contraction into the pooling sum), i.e. the bits k_mask_cat would have stored.
+template <bool PARTS>
+__device__ __forceinline__ float4 src4(const PoolPackArgs &a, int m, int c, size_t HW, size_t off)
+{
+    if (!PARTS) return *reinterpret_cast<const float4 *>(a.x + ((size_t)m * a.C + c) * HW + off);
+    const int n = m < a.Nf ? m : m - a.Nf;
+    const float4 al = *reinterpret_cast<const float4 *>(a.alpha + (size_t)n * HW + off);
+    if (c == 3) return al;
+    if (m >= a.Nf) return *reinterpret_cast<const float4 *>(a.real + ((size_t)n * 3 + c) * HW + off);
+    const float4 t = *reinterpret_cast<const float4 *>(a.fake + ((size_t)n * 3 + c) * HW + off);
+    return make_float4(__fmul_rn(t.x, al.x), __fmul_rn(t.y, al.y), __fmul_rn(t.z, al.z), __fmul_rn(t.w, al.w));
+}
+template <bool PARTS>
+__device__ __forceinline__ float src1(const PoolPackArgs &a, int m, int c, size_t HW, size_t off)
+{
+    if (!PARTS) return a.x[((size_t)m * a.C + c) * HW + off];
+    const int n = m < a.Nf ? m : m - a.Nf;
+    const float al = a.alpha[(size_t)n * HW + off];
+    if (c == 3) return al;
+    if (m >= a.Nf) return a.real[((size_t)n * 3 + c) * HW + off];
+    return __fmul_rn(a.fake[((size_t)n * 3 + c) * HW + off], al);
+}
 
 // One workgroup = 16 output rows x TW output columns (TW*4 threads, 4 rows each).  F = pooling factor.
 // Pooling sums the F x F window row-major and divides once, as ATen's avg_pool2d does.
-template <int F, int TW>
+template <int F, int TW, bool PARTS>
 __global__ __launch_bounds__(TW * 4) void k_pool_pack(PoolPackArgs a)
 {
     __shared__ float av[16][TW];
@@ -100,18 +128,18 @@ __global__ __launch_bounds__(TW * 4) void k_pool_pack(PoolPackArgs a)
         for (int c = 0; c < 16; ++c) {   // (c is a compile-time constant after unrolling: no dynamic register indexing)
             float v = 0.0f;
             if (c < 4 && c < a.C) {
-                const float *src = a.x + ((size_t)m * a.C + c) * HW + (size_t)(oy * F) * a.W + (size_t)ox * F;
+                const size_t src = (size_t)(oy * F) * a.W + (size_t)ox * F;
                 float s = 0.0f;
                 for (int i = 0; i < F; ++i) {
                     if (F % 4 == 0) {
 #pragma unroll
                         for (int j = 0; j < F; j += 4) {
-                            const float4 q = *reinterpret_cast<const float4 *>(src + (size_t)i * a.W + j);
+                            const float4 q = src4<PARTS>(a, m, c, HW, src + (size_t)i * a.W + j);
                             s += q.x; s += q.y; s += q.z; s += q.w;
                         }
                     } else {
 #pragma unroll
-                        for (int j = 0; j < F; ++j) s += src[(size_t)i * a.W + j];
+                        for (int j = 0; j < F; ++j) s += src1<PARTS>(a, m, c, HW, src + (size_t)i * a.W + j);
                     }
                 }
                 v = F == 1 ? s : s / (float)(F * F);
@@ -152,6 +180,7 @@ __global__ __launch_bounds__(TW * 4) void k_pool_pack(PoolPackArgs a)
 // F = 1, Wo % 64 == 0 (the full-resolution texture discriminator, the largest of the packs): one thread = one row x FOUR
 // consecutive pixels: every plane is read with 16-byte loads (8 load instructions per thread instead of 32) and the thread's
 // four packed pixels leave as 64 contiguous bytes.  Tile 16 x 64 pixels per 256 threads, as the generic kernel.
+template <bool PARTS>
 __global__ __launch_bounds__(256) void k_pack1x4(PoolPackArgs a)
 {
     __shared__ float av[16][64];
@@ -163,7 +192,7 @@ __global__ __launch_bounds__(256) void k_pack1x4(PoolPackArgs a)
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < a.C) t = *reinterpret_cast<const float4 *>(a.x + ((size_t)m * a.C + c) * HW + po);
+        if (c < a.C) t = src4<PARTS>(a, m, c, HW, po);
         else if (c - a.C < a.E) t = *reinterpret_cast<const float4 *>(a.extra + ((size_t)m * a.E + (c - a.C)) * HW + po);
         else if (c - a.C - a.E < a.P) t = *reinterpret_cast<const float4 *>(a.pos + (size_t)(c - a.C - a.E) * HW + po);
         v[c] = t;
@@ -210,6 +239,7 @@ struct PoolUnpackArgs {
     int K;
     float *dx;           // [M,C,H,W] fp32
     int M, C, H, W;
+    const float *alpha;  // non-null: the PARTS adjoint -- dx is dfake [M,3,H,W] = (the gradient of channels 0..2) * alpha[m]
 };
 
 // dx[m,c,y,x] = sum_k dh_k[m, y/f_k, x/f_k, c] / f_k^2   (C <= 4: one 8-byte read per tensor)
@@ -232,6 +262,12 @@ __global__ __launch_bounds__(256) void k_pool_unpack_bwd(PoolUnpackArgs a)
                 acc[2] += __uint_as_float(v.y << 16) * inv;
                 acc[3] += __uint_as_float(v.y & 0xffff0000u) * inv;
             }
+        }
+        if (a.alpha) {               // k_mask_cat_bwd applied in place: dfake = dX[:, :3] * alpha
+            const float al = a.alpha[i];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a.dx[(m * 3 + c) * HW + p] = acc[c] * al;
+            continue;
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -495,23 +531,22 @@ static void launch_pool_pack(const PoolPackArgs &a, hipStream_t st)
 {
     const int TW = a.Wo % 64 == 0 ? 64 : (a.Wo % 32 == 0 ? 32 : 16);
     const dim3 grid(a.Wo / TW, a.Ho / 16, a.M);
-    if (TW == 64) hipLaunchKernelGGL((k_pool_pack<F, 64>), grid, dim3(256), 0, st, a);
-    else if (TW == 32) hipLaunchKernelGGL((k_pool_pack<F, 32>), grid, dim3(128), 0, st, a);
-    else hipLaunchKernelGGL((k_pool_pack<F, 16>), grid, dim3(64), 0, st, a);
+    if (a.x) {
+        if (TW == 64) hipLaunchKernelGGL((k_pool_pack<F, 64, false>), grid, dim3(256), 0, st, a);
+        else if (TW == 32) hipLaunchKernelGGL((k_pool_pack<F, 32, false>), grid, dim3(128), 0, st, a);
+        else hipLaunchKernelGGL((k_pool_pack<F, 16, false>), grid, dim3(64), 0, st, a);
+    } else {
+        if (TW == 64) hipLaunchKernelGGL((k_pool_pack<F, 64, true>), grid, dim3(256), 0, st, a);
+        else if (TW == 32) hipLaunchKernelGGL((k_pool_pack<F, 32, true>), grid, dim3(128), 0, st, a);
+        else hipLaunchKernelGGL((k_pool_pack<F, 16, true>), grid, dim3(64), 0, st, a);
+    }
 }
 
-extern "C" int m355_pool_pack_fwd(const float *x, int M, int C, int H, int W, int f, const float *extra, int E, const float *pos,
-                                  int P, void *out, int CP, float *mask, int mask_chan, int g, void *stream)
+static int pool_pack_launch(const PoolPackArgs &a, int f, hipStream_t st)
 {
-    M355_REQUIRE(x && out && M > 0 && M <= 65535, "pool_pack_fwd: bad argument");
-    M355_REQUIRE(m355_pool_pack_ok(C, H, W, f, E, P, mask ? g : 0), "pool_pack_fwd: unsupported shape C=%d H=%d W=%d f=%d E=%d P=%d g=%d", C, H,
-                 W, f, E, P, g);
-    M355_REQUIRE((CP == 8 || CP == 16) && C + E + P <= CP && (E == 0 || extra) && (P == 0 || pos) && mask_chan >= 0 && mask_chan < C,
-                 "pool_pack_fwd: bad channel layout");
-    PoolPackArgs a = {x, extra, pos, (short *)out, mask, M, C, H, W, E, P, CP, H / f, W / f, mask ? g : 16, mask_chan};
-    hipStream_t st = (hipStream_t)stream;
-    if (f == 1 && CP == 8 && W % 64 == 0 && !getenv("M355_NO_PACK1X4")) {
-        hipLaunchKernelGGL(k_pack1x4, dim3(W / 64, H / 16, M), dim3(256), 0, st, a);
+    if (f == 1 && a.CP == 8 && a.W % 64 == 0 && !getenv("M355_NO_PACK1X4")) {
+        if (a.x) hipLaunchKernelGGL(k_pack1x4<false>, dim3(a.W / 64, a.H / 16, a.M), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_pack1x4<true>, dim3(a.W / 64, a.H / 16, a.M), dim3(256), 0, st, a);
         return check_launch("pool_pack_fwd");
     }
     switch (f) {
@@ -522,6 +557,35 @@ extern "C" int m355_pool_pack_fwd(const float *x, int M, int C, int H, int W, in
     default: launch_pool_pack<16>(a, st); break;
     }
     return check_launch("pool_pack_fwd");
+}
+
+extern "C" int m355_pool_pack_fwd(const float *x, int M, int C, int H, int W, int f, const float *extra, int E, const float *pos,
+                                  int P, void *out, int CP, float *mask, int mask_chan, int g, void *stream)
+{
+    M355_REQUIRE(x && out && M > 0 && M <= 65535, "pool_pack_fwd: bad argument");
+    M355_REQUIRE(m355_pool_pack_ok(C, H, W, f, E, P, mask ? g : 0), "pool_pack_fwd: unsupported shape C=%d H=%d W=%d f=%d E=%d P=%d g=%d", C, H,
+                 W, f, E, P, g);
+    M355_REQUIRE((CP == 8 || CP == 16) && C + E + P <= CP && (E == 0 || extra) && (P == 0 || pos) && mask_chan >= 0 && mask_chan < C,
+                 "pool_pack_fwd: bad channel layout");
+    PoolPackArgs a = {x, extra, pos, (short *)out, mask, M, C, H, W, E, P, CP, H / f, W / f, mask ? g : 16, mask_chan,
+                      nullptr, nullptr, nullptr, 0};
+    return pool_pack_launch(a, f, (hipStream_t)stream);
+}
+
+// The same assembly straight from the pieces ModelWrapper.forward concatenates (main.py:493, 503-507): x = cat(fake * alpha, alpha)
+// for samples [0, Nf), cat(real, alpha) for samples [Nf, M) (M == Nf: no real half), never written to memory.  Bit-identical to
+// m355_mask_cat_fwd followed by m355_pool_pack_fwd(C = 4, mask_chan = 3).
+extern "C" int m355_pool_pack_parts_fwd(const float *fake, const float *real, const float *alpha, int Nf, int M, int H, int W, int f,
+                                        const float *extra, int E, const float *pos, int P, void *out, int CP, float *mask, int g,
+                                        void *stream)
+{
+    M355_REQUIRE(fake && alpha && out && Nf > 0 && (M == Nf || (M == 2 * Nf && real)) && M <= 65535, "pool_pack_parts_fwd: bad argument");
+    M355_REQUIRE(m355_pool_pack_ok(4, H, W, f, E, P, mask ? g : 0) && W % 4 == 0,
+                 "pool_pack_parts_fwd: unsupported shape H=%d W=%d f=%d E=%d P=%d g=%d", H, W, f, E, P, g);
+    M355_REQUIRE((CP == 8 || CP == 16) && 4 + E + P <= CP && (E == 0 || extra) && (P == 0 || pos), "pool_pack_parts_fwd: bad channel layout");
+    PoolPackArgs a = {nullptr, extra, pos, (short *)out, mask, M, 4, H, W, E, P, CP, H / f, W / f, mask ? g : 16, 3,
+                      fake, real, alpha, Nf};
+    return pool_pack_launch(a, f, (hipStream_t)stream);
 }
 
 extern "C" int m355_pool_unpack_bwd(const void *dh0, int f0, int cp0, const void *dh1, int f1, int cp1, const void *dh2, int f2,
@@ -539,9 +603,31 @@ extern "C" int m355_pool_unpack_bwd(const void *dh0, int f0, int cp0, const void
         a.CP[k] = cp[k];
         a.K = k + 1;
     }
-    a.dx = dx; a.M = M; a.C = C; a.H = H; a.W = W;
+    a.dx = dx; a.M = M; a.C = C; a.H = H; a.W = W; a.alpha = nullptr;
     hipLaunchKernelGGL(k_pool_unpack_bwd, dim3(grid_for((size_t)M * H * W)), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("pool_unpack_bwd");
+}
+
+// adjoint of m355_pool_pack_parts_fwd with respect to `fake` (M == Nf == N; the real half never needs one): dfake [N,3,H,W] =
+// (sum_k dh_k[.., c] / f_k^2) * alpha  -- m355_pool_unpack_bwd followed by m355_mask_cat_bwd, same bits
+extern "C" int m355_pool_unpack_parts_bwd(const void *dh0, int f0, int cp0, const void *dh1, int f1, int cp1, const void *dh2, int f2,
+                                          int cp2, const float *alpha, float *dfake, int N, int H, int W, void *stream)
+{
+    M355_REQUIRE(dh0 && alpha && dfake && N > 0 && H > 0 && W > 0, "pool_unpack_parts_bwd: bad argument");
+    PoolUnpackArgs a = {};
+    const void *dh[3] = {dh0, dh1, dh2};
+    const int f[3] = {f0, f1, f2}, cp[3] = {cp0, cp1, cp2};
+    for (int k = 0; k < 3; ++k) {
+        if (!dh[k]) break;
+        M355_REQUIRE(f[k] >= 1 && H % f[k] == 0 && W % f[k] == 0 && cp[k] % 4 == 0, "pool_unpack_parts_bwd: bad factor / channel stride");
+        a.dh[k] = (const short *)dh[k];
+        a.f[k] = f[k];
+        a.CP[k] = cp[k];
+        a.K = k + 1;
+    }
+    a.dx = dfake; a.M = N; a.C = 4; a.H = H; a.W = W; a.alpha = alpha;
+    hipLaunchKernelGGL(k_pool_unpack_bwd, dim3(grid_for((size_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("pool_unpack_parts_bwd");
 }
 
 extern "C" int m355_unpack_range(const void *g, float *out, int M, int HW, int CP, int c0, int E, void *stream)

@@ -229,10 +229,14 @@ class Generator(nn.Module):
             m = self.blk3_mesh(x, z, upsample=1, gb=gb, out_slope=LRELU)
             return G.head_conv(m, self.conv_mesh, G.HT_POLES | sym, in_slope=LRELU)
 
+        # (issued BEFORE the texture branch with or without the second stream: autograd sums the trunk's three incoming gradients
+        # in reverse issue order, and that order must not depend on the stream setting -- same bits either way)
         if self.mesh_head and G.fork_ok(x, z):
             shared = [x, z] + ([t for pair in gb.values() for t in pair] if gb else [])
             with G.Fork(shared) as fork:
                 x_mesh = mesh_branch()
+        elif self.mesh_head:
+            x_mesh = mesh_branch()
         t = x  # every later stage starts with the x2 upsample of gan.py:391 / :395-404
         for name in ("blk3a", "blk3b", "blk3c"):
             if hasattr(self, name):
@@ -245,8 +249,6 @@ class Generator(nn.Module):
         x_tex = G.head_conv(t, self.conv_final, G.HT_TANH | sym, in_slope=LRELU)
         if fork is not None:
             fork.join([x_mesh])
-        elif self.mesh_head:
-            x_mesh = mesh_branch()
         if self.symmetric and attention_map is not None:
             attention_map = symmetrize_texture(attention_map)
         if self.training and self._nbt:
@@ -569,7 +571,8 @@ class MultiScaleDiscriminator(nn.Module):
         members = [self.d1, self.d2] + ([self.d3] if self.args.num_discriminators == 3 else [])
         # every member's input assembly (pooling, mesh / positional planes, masks, NHWC bf16 packing) from ONE read
         # interface: one launch per member, one backward launch for all of them (gan_ops.DiscInputsFn)
-        if torch.is_tensor(x) and x.is_cuda and (self.args.texture_only or mesh_map is not None):
+        lazy = isinstance(x, G.MaskedInput)   # (the trainer's not-yet-concatenated input: assembled by the loaders below)
+        if (lazy or (torch.is_tensor(x) and x.is_cuda)) and (self.args.texture_only or mesh_map is not None):
             specs = [m.input_spec(x, mesh_map) if isinstance(m, MeshDiscriminator) else m.input_spec(x) for m in members]
             extra = None if self.args.texture_only else mesh_map
             if G.disc_inputs_ok(x, extra, specs):
@@ -583,12 +586,16 @@ class MultiScaleDiscriminator(nn.Module):
                     k = side[0]
                     with G.Fork([hs[k], masks[k], c]) as fork:
                         outs[k] = members[k].trunk(hs[k], masks[k], c, caption)
+                elif side:   # (same issue order without the second stream)
+                    outs[side[0]] = members[side[0]].trunk(hs[side[0]], masks[side[0]], c, caption)
                 for k, (m, h, mk) in enumerate(zip(members, hs, masks)):
                     if outs[k] is None:
                         outs[k] = m.trunk(h, mk, c, caption)
                 if fork is not None:
                     fork.join([outs[side[0]][0], outs[side[0]][1]])
                 return [o[0] for o in outs], [o[1] for o in outs]
+        if lazy:
+            x = x.materialize()
         d1, m1 = self.d1(x, c, caption)
         if self.args.texture_only:
             d2, m2 = self.d2(x, c, caption)

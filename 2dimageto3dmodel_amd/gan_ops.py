@@ -162,6 +162,86 @@ def mask_cat(fake, alpha, real=None):
     return x if real is None else torch.cat((x, torch.cat((real, alpha), dim=1)), dim=0)
 
 
+class MaskedInput:
+    """The discriminator input of main.py:493 / 503-507 -- cat(fake * alpha, alpha) [stacked on cat(real, alpha)] -- NOT yet
+    assembled: MultiScaleDiscriminator.forward builds every member's packed conv1 input straight from the three pieces
+    (DiscPartsFn: the [N|2N,4,H,W] tensor is never written or re-read); anything else calls materialize()."""
+
+    def __init__(self, fake, alpha, real=None):
+        self.fake, self.alpha, self.real = fake, alpha, real
+
+    @property
+    def shape(self):
+        n, _, h, w = self.fake.shape
+        return torch.Size(((1 if self.real is None else 2) * n, 4, h, w))
+
+    @property
+    def device(self):
+        return self.fake.device
+
+    def fusable(self):
+        f, a, r = self.fake, self.alpha, self.real
+        return _plain_f32(f, a, r) and f.dim() == 4 and f.shape[1] == 3 and tuple(a.shape) == (f.shape[0], 1, f.shape[2], f.shape[3]) \
+            and f.shape[3] % 4 == 0 and (r is None or r.shape == f.shape)
+
+    def materialize(self):
+        return mask_cat(self.fake, self.alpha, self.real)
+
+
+class DiscPartsFn(torch.autograd.Function):
+    """DiscInputsFn on a MaskedInput: MaskCatFn folded into the loaders (forward) and into the unpack (backward: only `fake`
+    takes a gradient).  Same bits as the two-stage form."""
+
+    @staticmethod
+    def forward(ctx, fake, alpha, real, extra, specs):
+        fake, alpha = fake.contiguous(), alpha.contiguous()
+        real = None if real is None else real.contiguous()
+        n, _, h, w = fake.shape
+        m = n if real is None else 2 * n
+        outs, masks = [], []
+        for f, has_extra, pos, cp, g in specs:
+            ho, wo = h // f, w // f
+            e = extra.contiguous() if has_extra else None
+            out = torch.empty((m, ho, wo, cp), dtype=torch.bfloat16, device=fake.device)
+            mask = torch.empty((m, 1, ho // g, wo // g), dtype=torch.float32, device=fake.device) if g else None
+            launch("pool_pack_parts_fwd", ptr(fake), ptr(real), ptr(alpha), n, m, h, w, f, ptr(e), 0 if e is None else e.shape[1],
+                   ptr(pos), 0 if pos is None else pos.shape[0], ptr(out), cp, ptr(mask), g, stream())
+            outs.append(out)
+            masks.append(mask)
+        ctx.save_for_backward(alpha)
+        ctx.shape, ctx.specs, ctx.has_real = (n, h, w), specs, real is not None
+        ctx.eshape = None if extra is None else tuple(extra.shape)
+        res = tuple(outs) + tuple(mk for mk in masks if mk is not None)
+        ctx.mark_non_differentiable(*[mk for mk in masks if mk is not None])
+        ctx.nout = len(outs)
+        return res
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (alpha,) = ctx.saved_tensors
+        n, h, w = ctx.shape
+        dhs = grads[:ctx.nout]
+        live = [(g.contiguous(), sp[0], sp[3]) for g, sp in zip(dhs, ctx.specs) if g is not None]
+        dfake = dextra = None
+        if ctx.needs_input_grad[0] and live:
+            if ctx.has_real:   # (a gradient into the fake half of a [fake; real] batch: not a case the trainer has)
+                raise RuntimeError("DiscPartsFn: backward to `fake` with a real half stacked behind it -- materialize() the input")
+            dfake = torch.empty((n, 3, h, w), dtype=torch.float32, device=live[0][0].device)
+            a = []
+            for k in range(3):
+                a += [ptr(live[k][0]), live[k][1], live[k][2]] if k < len(live) else [None, 1, 8]
+            launch("pool_unpack_parts_bwd", *a, ptr(alpha), ptr(dfake), n, h, w, stream())
+        if ctx.eshape is not None and ctx.needs_input_grad[3]:
+            m = ctx.eshape[0]
+            for g, sp in zip(dhs, ctx.specs):
+                if sp[1] and g is not None:
+                    _, e, eh, ew = ctx.eshape
+                    part = torch.empty(ctx.eshape, dtype=torch.float32, device=g.device)
+                    launch("unpack_range", ptr(g.contiguous()), ptr(part), m, eh * ew, sp[3], 4, e, stream())
+                    dextra = part if dextra is None else dextra + part
+        return dfake, None, None, dextra, None
+
+
 class DiscInputsFn(torch.autograd.Function):
     """What the member discriminators do to their input before conv1 (gan.py:79-99, 192-211), for all members at once:
     per member k: h_k = NHWC bf16 of cat(avg_pool2d(x, f_k), extra_k, pos_k) (channels padded to 8 / 16) and, with
@@ -212,7 +292,10 @@ class DiscInputsFn(torch.autograd.Function):
 
 
 def disc_inputs_ok(x, extra, specs):
-    if not _plain_f32(x, extra) or x.dim() != 4 or x.shape[1] != 4:
+    if isinstance(x, MaskedInput):
+        if not x.fusable() or not _plain_f32(extra) or (x.real is not None and x.fake.requires_grad and torch.is_grad_enabled()):
+            return False
+    elif not _plain_f32(x, extra) or x.dim() != 4 or x.shape[1] != 4:
         return False
     _, c, h, w = x.shape
     for f, has_extra, pos, cp, g in specs:
@@ -229,7 +312,10 @@ def disc_inputs_ok(x, extra, specs):
 
 def disc_inputs(x, extra, specs):
     """-> ([h_k NHWC bf16], [mask_k or None]) for the member discriminators described by `specs`"""
-    res = DiscInputsFn.apply(x, extra, tuple(specs))
+    if isinstance(x, MaskedInput):
+        res = DiscPartsFn.apply(x.fake, x.alpha, x.real, extra, tuple(specs))
+    else:
+        res = DiscInputsFn.apply(x, extra, tuple(specs))
     n = len(specs)
     hs, rest, masks = list(res[:n]), list(res[n:]), []
     for sp in specs:

@@ -92,7 +92,7 @@ class GanTrainer(torch.nn.Module):
         if mode == 'g':
             pred_tex, pred_mesh = self.generator(noise, C, caption)
             self.finish_pending()                                       # (the previous D step's all-reduce + optimiser step)
-            X_fake = O.mask_cat(pred_tex, X_alpha)                     # cat((pred_tex * X_alpha, X_alpha), dim=1)
+            X_fake = O.MaskedInput(pred_tex, X_alpha)                  # cat((pred_tex * X_alpha, X_alpha), dim=1), built in D's loaders
             disc, mask = self.discriminator(X_fake, pred_mesh, C, caption)
             loss = self.criterion_gan(disc, True, for_discriminator=False, mask=mask, weight=w)
             return loss, pred_tex, pred_mesh
@@ -101,7 +101,7 @@ class GanTrainer(torch.nn.Module):
                 pred_tex, pred_mesh = self.generator(noise, C, caption)
                 assert (X_mesh is None) == (pred_mesh is None)
                 # cat((cat((pred_tex * X_alpha, X_alpha), 1), cat((X_tex, X_alpha), 1)), 0) in one pass
-                X_comb = O.mask_cat(pred_tex, X_alpha, X_tex)
+                X_comb = O.MaskedInput(pred_tex, X_alpha, X_tex)
                 C_comb = torch.cat((C, C), dim=0) if C is not None else None
                 M_comb = torch.cat((pred_mesh, X_mesh), dim=0) if pred_mesh is not None else None
             self.finish_pending()                                       # (the previous D step's all-reduce + optimiser step)

@@ -368,6 +368,14 @@ int m355_pool_pack_fwd(const float *x, int M, int C, int H, int W, int f, const 
 int m355_pool_unpack_bwd(const void *dh0, int f0, int cp0, const void *dh1, int f1, int cp1, const void *dh2, int f2, int cp2,
                          float *dx, int M, int C, int H, int W, void *stream);
 int m355_unpack_range(const void *g, float *out, int M, int HW, int CP, int c0, int E, void *stream);
+/*      main.py:493,503-507 and gan.py:79-99,192-211 in ONE pass: m355_pool_pack_fwd on x = m355_mask_cat_fwd(fake, real, alpha)
+ *      without x ever being written (C = 4, mask_chan = 3; samples [0,Nf) are cat(fake * alpha, alpha), samples [Nf,M) -- M is Nf
+ *      or 2 Nf -- are cat(real, alpha)); _bwd: dfake [N,3,H,W] = m355_mask_cat_bwd(m355_pool_unpack_bwd(...)).  Same bits as the
+ *      two-call forms (the product is rounded to fp32 before the pooling sum). */
+int m355_pool_pack_parts_fwd(const float *fake, const float *real, const float *alpha, int Nf, int M, int H, int W, int f,
+                             const float *extra, int E, const float *pos, int P, void *out, int CP, float *mask, int g, void *stream);
+int m355_pool_unpack_parts_bwd(const void *dh0, int f0, int cp0, const void *dh1, int f1, int cp1, const void *dh2, int f2, int cp2,
+                               const float *alpha, float *dfake, int N, int H, int W, void *stream);
 /*      Generator.forward after conv_final / conv_mesh, code/models/gan.py:407-419: flags M355_HT_TANH (tanh_),
  *      M355_HT_POLES (adjust_poles, rendering/utils.py:21-26), M355_HT_SYMM (symmetrize_texture, rendering/utils.py:15-18:
  *      out width 2W).  y [N,C<=3,H,W] -> out.  _bwd: dout, out -> g [N,H,W,8] bf16 (the layout m355_conv2d_dgrad / _wgrad

@@ -1,0 +1,57 @@
+"""diagnostic: does any kernel read memory it (or its producer) never wrote?  torch.empty / empty_like are wrapped to fill every
+new CUDA buffer with the byte 0x71 (fp32 1.2e30, bf16 4.8e30: finite, so garbage * 0 stays 0, but any real use is visible) and a
+deterministic training cycle is compared with the unpoisoned one, iteration by iteration."""
+import importlib, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+pkg = importlib.import_module("2dimageto3dmodel_amd")
+train = importlib.import_module("2dimageto3dmodel_amd.train")
+gops = importlib.import_module("2dimageto3dmodel_amd.gan_ops")
+import test_gan_modules as T
+
+_empty, _empty_like = torch.empty, torch.empty_like
+POISON = [False]
+
+
+def _poison(t):
+    if POISON[0] and t.is_cuda and t.numel() and t.is_contiguous():
+        t.view(-1).view(torch.uint8).fill_(0x71)
+    return t
+
+
+torch.empty = lambda *a, **k: _poison(_empty(*a, **k))
+torch.empty_like = lambda *a, **k: _poison(_empty_like(*a, **k))
+
+B = int(os.environ.get("DIAG_B", "4"))
+batches = T._cycle_batches(B, 128, seed0=6100)
+pkg.set_deterministic(True)
+gops.STREAMS_ON = bool(int(os.environ.get("DIAG_STREAMS", "0")))
+
+
+def run(poison, nit):
+    POISON[0] = False
+    torch.manual_seed(616)
+    tr = train.GanTrainer(T._trainer_args(), device="cuda:0", mesh_template=None)
+    tr.train()
+    POISON[0] = poison
+    losses = []
+    for i in range(nit):
+        b, z = batches[i % 3]
+        losses += [float(v) for v in tr.iteration(*b, noise=z, epoch=0).values()]
+    tr.finish_pending()
+    torch.cuda.synchronize()
+    POISON[0] = False
+    return T._state_bits(tr), losses
+
+
+for nit in (1, 2, 3, 4, 5, 6):
+    (sa, la), (sb, lb) = run(False, nit), run(True, nit)
+    bad = [k for k in sa if not torch.equal(sa[k], sb[k])]
+    print(f"== {nit} iteration(s): losses {la} vs {lb}")
+    print("   differing tensors:", len(bad), "of", len(sa))
+    for k in bad[:40]:
+        d = (sa[k].float() - sb[k].float()).abs().max().item()
+        print("     ", k, tuple(sa[k].shape), f"max diff {d:.3e}")
+    if bad:
+        break

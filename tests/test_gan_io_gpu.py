@@ -84,6 +84,50 @@ def test_disc_inputs_all_members(R, nd, stride_first):
     assert not G.disc_inputs_ok(torch.zeros(1, 4, 64, 64), None, [(1, False, None, 8, 8)])
 
 
+@pytest.mark.parametrize("R,nd,stride_first,with_real", [(256, 2, False, True), (256, 2, False, False), (128, 3, False, False),
+                                                         (512, 3, True, True), (64, 2, False, False)])
+def test_disc_inputs_from_parts_is_bit_identical_to_the_two_stage_form(R, nd, stride_first, with_real):
+    """MaskedInput (ModelWrapper.forward's cat(fake * alpha, alpha) [; cat(real, alpha)] assembled inside the discriminators'
+    loaders, never written) against mask_cat -> disc_inputs: every packed tensor, every mask and -- G step form -- dfake and the
+    mesh-map gradient carry the same bits"""
+    G, gan = _mods()
+    g = torch.Generator().manual_seed(7 * R + nd)
+    N = 3
+    fake = torch.randn(N, 3, R, R, generator=g).to(DEV)
+    real = torch.randn(N, 3, R, R, generator=g).to(DEV) if with_real else None
+    alpha = ((torch.rand(N, 1, R, R, generator=g) > 0.4).float() * (0.5 + 0.5 * torch.rand(N, 1, R, R, generator=g))).to(DEV)
+    M = 2 * N if with_real else N
+    mesh = (0.1 * torch.randn(M, 3, 32, 32, generator=g)).to(DEV)
+    pos = lambda n: torch.tensor(gan.positional_encoding(n, n), dtype=torch.float32, device=DEV)
+    specs = [(1, False, pos(R), 8, 16 if stride_first else 8), (R // 32, True, pos(32), 16, 4)]
+    if nd == 3:
+        specs.append((4, False, pos(R // 4), 8, 8))
+    grad = not with_real           # (the D step's generator output carries no graph: main.py:497-503 runs it under no_grad)
+    f1, m1 = fake.clone().requires_grad_(grad), mesh.clone().requires_grad_(grad)
+    f2, m2 = fake.clone().requires_grad_(grad), mesh.clone().requires_grad_(grad)
+    X = G.mask_cat(f1, alpha, real)
+    assert G.disc_inputs_ok(X, m1, specs)
+    hs1, mk1 = G.disc_inputs(X, m1, specs)
+    lazy = G.MaskedInput(f2, alpha, real)
+    assert tuple(lazy.shape) == tuple(X.shape) and G.disc_inputs_ok(lazy, m2, specs)
+    hs2, mk2 = G.disc_inputs(lazy, m2, specs)
+    assert hs2[0].grad_fn is None or hs2[0].grad_fn.__class__.__name__ == "DiscPartsFnBackward"
+    for a, b in zip(hs1 + mk1, hs2 + mk2):
+        assert torch.equal(a, b)
+    if grad:
+        wts = [torch.randn(h.shape, generator=g).to(DEV) for h in hs1]
+        sum((h.float() * w).sum() for h, w in zip(hs1, wts)).backward()
+        sum((h.float() * w).sum() for h, w in zip(hs2, wts)).backward()
+        assert torch.equal(f1.grad, f2.grad) and f1.grad.abs().max().item() > 0
+        assert torch.equal(m1.grad, m2.grad)
+    else:
+        # a gradient into the fake half of a [fake; real] batch is not a case the loaders take: refused, the caller materialises
+        assert not G.disc_inputs_ok(G.MaskedInput(fake.clone().requires_grad_(), alpha, real), mesh, specs)
+    # shapes the loaders do not take fall back through materialize()
+    odd = G.MaskedInput(torch.zeros(1, 3, 40, 40, device=DEV), torch.zeros(1, 1, 40, 40, device=DEV))
+    assert not G.disc_inputs_ok(odd, None, [(1, False, None, 8, 8)]) and tuple(odd.materialize().shape) == (1, 4, 40, 40)
+
+
 @pytest.mark.parametrize("flags,C", [(1 | 4, 3), (2 | 4, 3), (1, 3), (2, 3), (0, 2)])
 def test_head_tail_matches_reference_ops(flags, C):
     """tanh_ / adjust_poles / symmetrize_texture (gan.py:407-419) and their adjoint in the conv's dy layout"""
