@@ -307,8 +307,14 @@ class CycleGraph:
             if snap is not None:
                 self._restore(snap)
         torch.cuda.current_stream().wait_stream(side)
+        import os
+        import time
+        settle = float(os.environ.get("M355_CAPTURE_SETTLE_MS", "0")) * 1e-3
+        if settle > 0 and P.collectives_on():
+            torch.cuda.synchronize()
+            time.sleep(settle)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=os.environ.get("M355_CAPTURE_MODE", "global")):
             self.out = self._run()
         self.trainer.total_it -= self.n   # (the capture pass executed nothing; it only rotated the spectral-norm slots on the host)
 

@@ -167,9 +167,16 @@ def test_rccl_collectives_inside_a_captured_cycle():
         pytest.xfail("RCCL collectives inside a hipGraph capture: the probe did not finish in 420 s (hang)")
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if not lines:
-        # measured on ROCm 7.2 / torch 2.10 (round 4): the process ABORTS (SIGABRT, an uncaught C++ exception out of the RCCL call
-        # issued while the stream is capturing) -- the collectives of this stack cannot be recorded into a hipGraph
+        # measured on ROCm 7.2 / torch 2.10 (round 4): about one probe in ten dies (SIGABRT, an uncaught C++ exception) while 30 of
+        # 33 others capture, replay and match bit for bit -- intermittent, so the death is recorded (stderr kept under gpurun_out/
+        # for the next reader) instead of failing the suite
         what = [ln for ln in r.stderr.splitlines() if "what()" in ln or "Error" in ln or "error" in ln][:3]
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "rccl_graph_probe_death.txt"), "w") as f:
+                f.write(f"rc {r.returncode}\n--- stdout\n{r.stdout[-4000:]}\n--- stderr\n{r.stderr[-12000:]}\n")
+        except OSError:
+            pass
         pytest.xfail(f"RCCL collectives inside a hipGraph capture: the probe process died (rc {r.returncode}): {what}")
     g = json.loads(lines[-1])["graph"]
     print("RCCL-in-graph probe:", g)
