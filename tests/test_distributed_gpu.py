@@ -167,8 +167,8 @@ def test_rccl_collectives_inside_a_captured_cycle():
         pytest.xfail("RCCL collectives inside a hipGraph capture: the probe did not finish in 420 s (hang)")
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if not lines:
-        # measured on ROCm 7.2 / torch 2.10 (round 4): about one probe in ten dies (SIGABRT, an uncaught C++ exception) while 30 of
-        # 33 others capture, replay and match bit for bit -- intermittent, so the death is recorded (stderr kept under gpurun_out/
+        # measured on ROCm 7.2 / torch 2.10 (round 4): two probes of 31 died (SIGABRT, an uncaught C++ exception) while 29
+        # others capture, replay and match bit for bit -- intermittent, so the death is recorded (stderr kept under gpurun_out/
         # for the next reader) instead of failing the suite
         what = [ln for ln in r.stderr.splitlines() if "what()" in ln or "Error" in ln or "error" in ln][:3]
         try:
