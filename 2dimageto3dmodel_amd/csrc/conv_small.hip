@@ -1013,150 +1013,9 @@ __device__ __forceinline__ void sfor(F &&f)
     }
 }
 
-#ifndef M355_WGC8_NST
-#define M355_WGC8_NST 3
-#endif
-template <int MODE, bool DET = false>
-__global__ __launch_bounds__(512, 2) void k_wgrad_c8(C8WgArgs a)
-{
-    constexpr int TH = 8, TW = 32, KS = 5, HS_X = TW + KS - 1, HS_Y = TH + KS - 1, HPIX = HS_X * HS_Y;
-    constexpr int XBUF = 8192, YBUF = 256 * 128, STAGE = XBUF + YBUF, NST = M355_WGC8_NST;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int co0 = blockIdx.y * 64;
-    const int tpx = a.W / TW, tpy = a.H / TH, tiles = a.N * tpx * tpy, G = gridDim.x;
-    if ((int)blockIdx.x >= tiles) return;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, a.ybytes, 0x00020000);
-
-    // ---- DMA: every wave issues 4 dy instructions (rows 8q .. 8q+7 of the tile, q = 8k + wave, swizzled as k_wgrad_halo)
-    // and 1 x instruction (halo pixels 64 wave + lane; wave 7 fills the unused tail with zeros): 5 per tile and wave
-    const int csrc = (lane & 7) ^ (((lane >> 4) & 1) << 2);
-    // (image, tile row, tile column) of the NEXT tile to fetch, stepped by the grid stride instead of divided out per tile
-    int in_n, in_ty, in_tx, sg_n, sg_ty, sg_tx;
-    {
-        const int per_img = tpx * tpy;
-        in_n = (int)blockIdx.x / per_img;
-        int r = (int)blockIdx.x - in_n * per_img;
-        in_ty = r / tpx; in_tx = r - in_ty * tpx;
-        sg_n = G / per_img;
-        r = G - sg_n * per_img;
-        sg_ty = r / tpx; sg_tx = r - sg_ty * tpx;
-    }
-    auto issue = [&](int /*tile: the caller fetches tiles in order, blockIdx.x + k G*/, int st) {
-        const int n = in_n, oy0 = in_ty * TH, ox0 = in_tx * TW;
-        {
-            in_tx += sg_tx;
-            const int cx = in_tx >= tpx ? 1 : 0;
-            in_tx -= cx * tpx;
-            in_ty += sg_ty + cx;
-            const int cy = in_ty >= tpy ? 1 : 0;
-            in_ty -= cy * tpy;
-            in_n += sg_n + cy;
-        }
-        unsigned char *dX = lds + st * STAGE, *dY = dX + XBUF;
-        {
-            const int P = 64 * wave + lane, hy = P / HS_X, hx = P - hy * HS_X;
-            const int gy = oy0 - KS / 2 + hy;
-            int gx = ox0 - KS / 2 + hx;
-            bool ok = P < HPIX && (unsigned)gy < (unsigned)a.H;
-            if (MODE == 1) gx = min(max(gx, 0), a.W - 1);
-            else if (MODE == 2) gx = gx < 0 ? gx + a.W : (gx >= a.W ? gx - a.W : gx);
-            ok = ok && (unsigned)gx < (unsigned)a.W;
-            dma16(rx, dX + wave * 1024, ok ? (unsigned)(((n * a.H + gy) * a.W + gx) * 16) : OOB, 0u);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int p = 8 * (8 * k + wave) + (lane >> 3);  // tile pixel = (p >> 5, p & 31)
-            const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
-            dma16(ry, dY + (8 * k + wave) * 1024, (unsigned)((((n * a.H + oy) * a.W + ox) * a.Cy + co0) * 2 + csrc * 16), 0u);
-        }
-    };
-
-    // ---- fragment roles
-    const int ph = wave >> 2, cb = wave & 1, cg = (wave >> 1) & 1;  // pixel half (tile rows 4ph..), co block, column group
-    const int q = lane & 15, g16 = (lane >> 4) & 1, hh = lane >> 5;
-    // dy^T (A operand, rows = 32 co of block cb): as k_wgrad_halo
-    const int ybase = (((cb * 4 + g16 * 2 + ((q & 3) >> 1)) ^ (((q >> 3) & 1) << 2)) << 4) + (q & 1) * 8 + (8 * hh + (q >> 2)) * 128 +
-                      ph * 8 * 2048;
-    // x (B operand, 32 columns = taps kw0 .. kw0+3 x 8 ci): lane part of the halo address; the rest is an immediate
-    const int xbase = ((4 * ph) * HS_X + 8 * hh + (q >> 2) + 2 * g16) * 16 + (q & 3) * 8;
-
-    f32x16 acc[5];
-#pragma unroll
-    for (int t = 0; t < 5; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    const bool do_db = a.db != nullptr;
-    const int dbc = tid & 63, dbq = tid >> 6;  // channel, 32-pixel group
-    float dbacc = 0.0f;
-
-    auto tile_mma = [&](const unsigned char *bx, const unsigned char *by, auto cgc) {
-        constexpr int CG = decltype(cgc)::value;
-        sfor<0, 8>([&](auto kgc) {
-            constexpr int kg = decltype(kgc)::value;  // 16 pixels: tile row 4ph + (kg>>1), columns 16(kg&1) ..
-            const s4w y0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4w *)(by + ybase + kg * 2048));
-            const s4w y1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4w *)(by + ybase + kg * 2048 + 512));
-            const bf16x8 yf = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
-            sfor<0, 5>([&](auto tc) {
-                constexpr int blk = CG * 5 + decltype(tc)::value, kh = blk >> 1, kw0 = 4 * (blk & 1);
-                constexpr int c = ((kg >> 1) + kh) * HS_X + 16 * (kg & 1) + kw0;
-                const s4w x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4w *)(bx + xbase + c * 16));
-                const s4w x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4w *)(bx + xbase + (c + 4) * 16));
-                const bf16x8 xf = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
-                acc[decltype(tc)::value] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf, xf, acc[decltype(tc)::value], 0, 0, 0);
-            });
-        });
-    };
-
-    // ---- tiles blockIdx.x, +G, +2G, ...: three stages, two tiles in flight behind the one being consumed
-    int tile = blockIdx.x, st = 0;
-    issue(tile, 0);
-#pragma unroll
-    for (int k = 1; k < NST - 1; ++k)
-        if (tile + k * G < tiles) issue(tile + k * G, k);
-    for (; tile < tiles; tile += G) {
-        // this tile's 5 DMAs per wave were issued NST-1 tiles ago; only those of the next NST-2 tiles may still be in flight
-        if (NST >= 4 && tile + 2 * G < tiles) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
-        else if (tile + G < tiles) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        const int st2 = st == 0 ? NST - 1 : st - 1;  // the stage consumed one tile ago
-        if (tile + (NST - 1) * G < tiles) issue(tile + (NST - 1) * G, st2);
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned char *bx = lds + st * STAGE, *by = bx + XBUF;
-        if (do_db) {
-#pragma unroll 8
-            for (int pp = 0; pp < 32; ++pp) {
-                const int prow = dbq * 32 + pp;
-                dbacc += bf2f(*reinterpret_cast<const unsigned short *>(by + prow * 128 + (((dbc >> 3) ^ (((prow >> 1) & 1) << 2)) << 4) + (dbc & 7) * 2));
-            }
-        }
-        if (cg) tile_mma(bx, by, std::integral_constant<int, 1>{});
-        else tile_mma(bx, by, std::integral_constant<int, 0>{});
-        st = st == NST - 1 ? 0 : st + 1;
-    }
-    if (do_db && co0 + dbc < a.Cout) wg_accum<DET>(a.db, a.fix, (DET ? (size_t)a.Cout * 200 : 0) + co0 + dbc, dbacc);
-    // acc[t][r]: co = co0 + 32 cb + (r&3) + 8(r>>2) + 4(lane>>5); column lane&31 of block 5cg + t = (kh, kw0 + (n>>3), n&7)
-#pragma unroll
-    for (int t = 0; t < 5; ++t) {
-        const int blk = cg * 5 + t, kh = blk >> 1, kw = 4 * (blk & 1) + ((lane & 31) >> 3), ci = lane & 7;
-        if (kw < KS) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + 32 * cb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < a.Cout) wg_accum<DET>(a.dw, a.fix, ((size_t)co * 25 + kh * 5 + kw) * 8 + ci, acc[t][r]);
-            }
-        }
-    }
-}
-
-
-// ---- k_wgrad_c8p (round 4): the same weight gradient with the x halo held CHANNEL-MAJOR ("planar") in LDS.
-// k_wgrad_c8 above reads every x pixel 25 times from LDS through transpose reads (96 ds_read_b64_tr per 40 MFMAs and wave: the LDS
+// ---- k_wgrad_c8p (round 4): that weight gradient with the x halo held CHANNEL-MAJOR ("planar") in LDS.
+// Its round-2 predecessor (k_wgrad_c8, the design of the paragraph above; removed from the library in round 4, git history has it)
+// read every x pixel 25 times from LDS through transpose reads (96 ds_read_b64_tr per 40 MFMAs and wave: the LDS
 // pipe is as busy as the matrix pipe, and only 200 of the 320 MFMA columns it computes are taps) and sat at 3.0-3.2 TB/s of its
 // 1.2 GB stream at 1.4 kW.  Here:
 //   * the 12 x 36 x 8-channel halo of a tile (6.9 KB) is fetched by plain 16-byte global loads one tile ahead and written into
@@ -1440,7 +1299,7 @@ static int wgrad_c8_gx(const m355_conv_desc *d, int Cy)
 }
 size_t wgrad_c8_ws_floats(const m355_conv_desc *d, int Cy)
 {
-    return getenv("M355_WGC8_V1") ? 0 : (size_t)wgrad_c8_gx(d, Cy) * ((size_t)d->Cout * 201);
+    return (size_t)wgrad_c8_gx(d, Cy) * ((size_t)d->Cout * 201);
 }
 
 int wgrad_c8_launch(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, float *db, hipStream_t st,
@@ -1456,36 +1315,24 @@ int wgrad_c8_launch(const m355_conv_desc *d, const void *x, const void *dy, int 
     a.ybytes = (unsigned)((size_t)d->N * d->H * d->W * Cy * 2);
     const int ny = Cy / 64, gx = wgrad_c8_gx(d, Cy);
     const dim3 grid(gx, ny);
-    static const bool planar = !getenv("M355_WGC8_V1");   // (A/B: the round-2 transpose-read kernel)
-    if (planar) {
-        a.part = part;
+    a.part = part;
 #define M355_C8P(MD_)                                                                              \
     do {                                                                                          \
         if (fix) hipLaunchKernelGGL((k_wgrad_c8p<MD_, true>), grid, dim3(512), 0, st, a);          \
         else hipLaunchKernelGGL((k_wgrad_c8p<MD_>), grid, dim3(512), 0, st, a);                    \
     } while (0)
-        if (d->pad_w_mode == 0) M355_C8P(0);
-        else if (d->pad_w_mode == 1) M355_C8P(1);
-        else M355_C8P(2);
+    if (d->pad_w_mode == 0) M355_C8P(0);
+    else if (d->pad_w_mode == 1) M355_C8P(1);
+    else M355_C8P(2);
 #undef M355_C8P
-        if (part) {
-            // every (pixel-axis workgroup) row holds the partial of ALL output channels (blockIdx.y writes its own 64): sum the rows
-            const size_t n = (size_t)d->Cout * 200;
-            hipLaunchKernelGGL(k_wgrad_part_sum, dim3((unsigned)((n + d->Cout + 255) / 256)), dim3(256), 0, st, (const float *)part, gx,
-                               (size_t)d->Cout * 201, dw, n, db, d->Cout);
-        }
-        note_kernel("k_wgrad_c8");
-        return check_launch("conv2d_wgrad (8 input channels, planar)");
+    if (part) {
+        // every (pixel-axis workgroup) row holds the partial of ALL output channels (blockIdx.y writes its own 64): sum the rows
+        const size_t n = (size_t)d->Cout * 200;
+        hipLaunchKernelGGL(k_wgrad_part_sum, dim3((unsigned)((n + d->Cout + 255) / 256)), dim3(256), 0, st, (const float *)part, gx,
+                           (size_t)d->Cout * 201, dw, n, db, d->Cout);
     }
-    if (fix) {
-        if (d->pad_w_mode == 0) hipLaunchKernelGGL((k_wgrad_c8<0, true>), grid, dim3(512), 0, st, a);
-        else if (d->pad_w_mode == 1) hipLaunchKernelGGL((k_wgrad_c8<1, true>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((k_wgrad_c8<2, true>), grid, dim3(512), 0, st, a);
-    } else if (d->pad_w_mode == 0) hipLaunchKernelGGL((k_wgrad_c8<0>), grid, dim3(512), 0, st, a);
-    else if (d->pad_w_mode == 1) hipLaunchKernelGGL((k_wgrad_c8<1>), grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((k_wgrad_c8<2>), grid, dim3(512), 0, st, a);
     note_kernel("k_wgrad_c8");
-    return check_launch("conv2d_wgrad (8 input channels)");
+    return check_launch("conv2d_wgrad (8 input channels, planar)");
 }
 
 }  // namespace m355

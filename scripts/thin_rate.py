@@ -45,7 +45,6 @@ def layer(tag, B, H, W, Cin, Cout, k, mode, f32=False, legs="fdw"):
         probe(f"{tag} dgrad B{B}", lambda: conv.conv_dgrad(d, dy, wd), P * (cy * 2 + Cin * 2))
     if "w" in legs:
         probe(f"{tag} wgrad B{B}", lambda: conv.conv_wgrad(d, x, dy), P * (cy * 2 + Cin * 2))
-print("M355_WGC8_V1 =", os.environ.get("M355_WGC8_V1"))
 for B in (32, 64, 128):
     layer("D.conv1 8->64 5x5 256^2", B, 256, 256, 8, 64, 5, 2, legs="w")
 layer("D.conv1 8->64 5x5 256^2", 128, 256, 256, 8, 64, 5, 2, legs="f")
