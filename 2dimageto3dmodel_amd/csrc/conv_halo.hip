@@ -742,7 +742,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
         if (!has_next) break;
         init_acc();
         tp = tp_next;
-        fresh = RES ? 0 : (TG2 ? 1 : RB - 1 + L);
+        // Steps 0 .. RB-2 of the next tile await weights issued in steps -(RB-1) .. -1, i.e. BEFORE the epilogue above: only for
+        // those are its stores the youngest operations in flight.  (Step s awaits the weights of step s+L, issued in step
+        // s+L - (RB-1+L) = s-RB+1 -- independent of L.  Rounds 2-3 had RB-1+L here: with L = 1 the wait of step RB-1 credited
+        // stores that are OLDER than the weights it awaits, i.e. it let up to 8-10 DMAs too many stay in flight -- its own
+        // weights among them.  They had nearly always landed anyway (issued two steps earlier); about one GAN iteration in
+        // ten at 256^2 read a stale weight slot in one tile: found by round 4's run-to-run determinism checks)
+        fresh = RES ? 0 : (TG2 ? 1 : RB - 1);
     }
     wait_vm<0>();  // the trailing (unused) prefetches
 #ifdef M355_DBG_STAMP

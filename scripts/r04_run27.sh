@@ -1,0 +1,12 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+L=$GRAFT_REPO_ROOT/2dimageto3dmodel_amd/lib
+echo "--- stress test, fixed build"
+timeout 900 python -m pytest tests/test_conv_gpu.py -m gpu -q -k repeat_bit_identically 2>&1 | grep -v amdgpu.ids | tail -4 | cut -c1-400
+echo "--- stress test, rounds 2-3 credit (expected to fail now and then)"
+for i in 1 2; do
+M355_LIB=$L/libm355_oldcredit.so timeout 900 python -m pytest tests/test_conv_gpu.py -m gpu -q -k repeat_bit_identically 2>&1 | grep -v amdgpu.ids | grep "AssertionError\|passed\|failed" | cut -c1-300
+done
+echo "--- soak"
+timeout 900 python scripts/soak_determinism.py 25 32 256 2>&1 | grep -v amdgpu.ids | tail -6 | tee gpurun_out/r04_soak_256.txt | cut -c1-330
+timeout 900 python scripts/soak_determinism.py 40 16 256 2>&1 | grep -v amdgpu.ids | tail -6 | tee -a gpurun_out/r04_soak_256.txt | cut -c1-330

@@ -24,7 +24,8 @@ torch.empty = lambda *a, **k: _poison(_empty(*a, **k))
 torch.empty_like = lambda *a, **k: _poison(_empty_like(*a, **k))
 
 B = int(os.environ.get("DIAG_B", "4"))
-batches = T._cycle_batches(B, 128, seed0=6100)
+R = int(os.environ.get("DIAG_R", "128"))
+batches = T._cycle_batches(B, R, seed0=6100)
 pkg.set_deterministic(True)
 gops.STREAMS_ON = bool(int(os.environ.get("DIAG_STREAMS", "0")))
 
@@ -32,7 +33,7 @@ gops.STREAMS_ON = bool(int(os.environ.get("DIAG_STREAMS", "0")))
 def run(poison, nit):
     POISON[0] = False
     torch.manual_seed(616)
-    tr = train.GanTrainer(T._trainer_args(), device="cuda:0", mesh_template=None)
+    tr = train.GanTrainer(T._trainer_args(texture_resolution=R), device="cuda:0", mesh_template=None)
     tr.train()
     POISON[0] = poison
     losses = []

@@ -421,3 +421,63 @@ def test_conv_fwd_stats_refused_where_not_fused(pkg):
             conv.conv_fwd_stats(d, x, wf, rows=4)
 
 
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, Cout, k, stride, ph, pw, mode, ups, what
+    (16, 256, 256, 64, 128, 4, 2, 1, 1, 2, 0, "fwd_bits"),   # D.conv2 forward: 8-wave 2x2 class variant (fragment look-ahead), bit masks
+    (16, 128, 64, 128, 64, 3, 1, 1, 1, 1, 1, "fwd_stats"),   # G.blk6.conv1 forward: 4-wave variant, x2 upsample, fused statistics
+    (16, 128, 128, 128, 256, 4, 2, 1, 1, 2, 0, "fwd_bits"),  # D.conv3 forward
+    (16, 256, 256, 64, 128, 4, 2, 1, 1, 2, 0, "dgrad"),      # D.conv2 dgrad: class pairs
+    (16, 256, 128, 64, 64, 3, 1, 1, 1, 1, 0, "fwd_stats"),   # G.blk6.conv2 forward (resident weights where eligible)
+])
+def test_persistent_tile_kernels_repeat_bit_identically_under_memory_pressure(pkg, case):
+    """Every launch of a conv kernel must produce the same bits.  Round 4 found (run-to-run determinism of a training cycle at
+    256^2) that the persistent-tile variants with fragment look-ahead credited the previous tile's epilogue stores in ONE counted
+    s_waitcnt too many: the weights of the third step of every tile but a workgroup's first were not awaited, and about one launch
+    in a hundred read a stale weight slot when HBM was busy.  Here: 40 launches, each behind a 512 MB device copy that is still
+    draining when the kernel starts, against the first (launched on an idle device); the first is also compared with torch-CPU
+    on one sample."""
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    N, H, W, Cin, Cout, k, stride, ph, pw, mode, ups, what = case
+    g = torch.Generator().manual_seed(4242)
+    d = conv.make_desc(N, H, W, Cin, Cout, k, k, stride, ph, pw, mode, ups)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).bfloat16().float()
+    b = (0.1 * torch.randn(Cout, generator=g))
+    wf, wd = conv.weight_prep(d, w.to(DEV))
+    ho, wo = conv.out_hw(d)
+    x = torch.randn(N, H, W, Cin, generator=g).bfloat16().to(DEV)
+    dy = torch.randn(N, ho, wo, Cout, generator=g).bfloat16().to(DEV)
+    junk_a = torch.empty(512 << 20, dtype=torch.uint8, device=DEV)
+    junk_b = torch.empty_like(junk_a)
+
+    def once():
+        if what == "fwd_bits":
+            y, bits = conv.conv_fwd(d, x, wf, b.to(DEV), slope=0.2, emit_bits=True)
+            return [y, bits]
+        if what == "fwd_stats":
+            y, part = conv.conv_fwd_stats(d, x, wf, b.to(DEV))
+            return [y, part]
+        return [conv.conv_dgrad(d, dy, wd)]
+
+    torch.cuda.synchronize()
+    first = once()
+    assert conv.lib().m355_last_kernel().decode() == "k_conv_halo"
+    torch.cuda.synchronize()
+    for rep in range(40):
+        junk_b.copy_(junk_a)
+        out = once()
+        for t0, t in zip(first, out):
+            assert torch.equal(t0, t), f"launch {rep}: {int((t0 != t).sum())} of {t.numel()} elements differ from the first launch"
+    # ... and the first launch is right (sample 0 against torch-CPU on the same bf16 operands)
+    if what == "dgrad":
+        xr = torch.zeros(1, Cin, H, W, requires_grad=True)
+        ref_conv(xr, w, None, stride, ph, pw, mode, ups).backward(dy[:1].float().cpu().permute(0, 3, 1, 2))
+        got, want = first[0][:1].float().cpu().permute(0, 3, 1, 2), xr.grad
+    else:
+        want = ref_conv(x[:1].float().cpu().permute(0, 3, 1, 2), w, b, stride, ph, pw, mode, ups)
+        if what == "fwd_bits":
+            want = F.leaky_relu(want, 0.2)
+        got = first[0][:1].float().cpu().permute(0, 3, 1, 2)
+    assert (got - want).abs().max().item() / want.abs().max().item() < 1.2e-2
