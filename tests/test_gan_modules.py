@@ -592,3 +592,56 @@ def test_second_stream_branches_change_no_bit(monkeypatch):
         pkg.set_deterministic(prev)
     assert l_on == l_off, (l_on, l_off)
     _assert_bit_identical(s_on, s_off, "second stream on vs off")
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_deterministic_cycles_at_256_in_every_execution_mode():
+    """The benchmarked resolution (256^2; batch 16 keeps it short): eight training cycles run eagerly on one stream, eagerly with the
+    small branches on the second stream, and as hipGraph replays with either -- four trainers from one seed on the same batches,
+    deterministic mode: every weight, buffer and Adam moment bit-identical, losses equal.  The 128^2 checks above do not reach
+    the kernels of the 256^2 networks (blk6, the 256 x 256 discriminator layers): this is the configuration in which round 4's
+    soak (scripts/soak_determinism.py) exposed the stale-weight race of k_conv_halo's look-ahead variants."""
+    pkg = importlib.import_module("2dimageto3dmodel_amd")
+    train = importlib.import_module("2dimageto3dmodel_amd.train")
+    gops = importlib.import_module("2dimageto3dmodel_amd.gan_ops")
+    batches = _cycle_batches(16, 256, seed0=7300)
+    ncyc = 8
+
+    def fresh():
+        torch.manual_seed(733)
+        tr = train.GanTrainer(_trainer_args(texture_resolution=256), device="cuda:0", mesh_template=None, capturable=True)
+        tr.train()
+        return tr
+
+    def eager():
+        tr, last = fresh(), {}
+        for _ in range(ncyc):
+            for b, z in batches:
+                last.update(tr.iteration(*b, noise=z, epoch=0))
+        torch.cuda.synchronize()
+        return _state_bits(tr), {k: float(v) for k, v in last.items()}
+
+    def graph():
+        tr = fresh()
+        cyc = tr.capture_cycle([b for b, _ in batches], epoch=0, warmup=2, noises=[z for _, z in batches])
+        for _ in range(ncyc):
+            out = cyc.replay()
+        torch.cuda.synchronize()
+        return _state_bits(tr), {k: float(v) for k, v in out.items()}
+
+    prev, prev_streams = pkg.set_deterministic(True), gops.STREAMS_ON
+    try:
+        runs = {}
+        for streams in (False, True):
+            gops.STREAMS_ON = streams
+            runs[f"eager, streams {streams}"] = eager()
+            runs[f"graph, streams {streams}"] = graph()
+    finally:
+        pkg.set_deterministic(prev)
+        gops.STREAMS_ON = prev_streams
+    ref_state, ref_losses = runs["eager, streams False"]
+    assert all(np.isfinite(v) for v in ref_losses.values())
+    for name, (state, losses) in runs.items():
+        assert losses == ref_losses, (name, losses, ref_losses)
+        _assert_bit_identical(ref_state, state, f"eager on one stream vs {name}")
