@@ -425,22 +425,37 @@ def test_conv_fwd_stats_refused_where_not_fused(pkg):
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("case", [
-    # N, H, W, Cin, Cout, k, stride, ph, pw, mode, ups, what
-    (16, 256, 256, 64, 128, 4, 2, 1, 1, 2, 0, "fwd_bits"),   # D.conv2 forward: 8-wave 2x2 class variant (fragment look-ahead), bit masks
-    (16, 128, 64, 128, 64, 3, 1, 1, 1, 1, 1, "fwd_stats"),   # G.blk6.conv1 forward: 4-wave variant, x2 upsample, fused statistics
-    (16, 128, 128, 128, 256, 4, 2, 1, 1, 2, 0, "fwd_bits"),  # D.conv3 forward
-    (16, 256, 256, 64, 128, 4, 2, 1, 1, 2, 0, "dgrad"),      # D.conv2 dgrad: class pairs
-    (16, 256, 128, 64, 64, 3, 1, 1, 1, 1, 0, "fwd_stats"),   # G.blk6.conv2 forward (resident weights where eligible)
+    # N, H, W, Cin, Cout, k, stride, ph, pw, mode, ups, what, kernel family
+    (16, 256, 256, 64, 128, 4, 2, 1, 1, 2, 0, "fwd_bits", "k_conv_halo"),   # D.conv2 forward: 8-wave 2x2 class variant (fragment look-ahead), bit masks
+    (16, 128, 64, 128, 64, 3, 1, 1, 1, 1, 1, "fwd_stats", "k_conv_halo"),   # G.blk6.conv1 forward: 4-wave variant, x2 upsample, fused statistics
+    (16, 128, 128, 128, 256, 4, 2, 1, 1, 2, 0, "fwd_bits", "k_conv_halo"),  # D.conv3 forward
+    (16, 256, 256, 64, 128, 4, 2, 1, 1, 2, 0, "dgrad", "k_conv_halo"),      # D.conv2 dgrad: class pairs
+    (16, 256, 128, 64, 64, 3, 1, 1, 1, 1, 0, "fwd_stats", "k_conv_halo"),   # G.blk6.conv2 forward (resident weights where eligible)
+    (16, 64, 64, 256, 512, 4, 2, 1, 1, 2, 0, "dgrad", "k_conv_halo"),       # D.conv4 dgrad
+    (16, 64, 32, 128, 128, 3, 1, 1, 1, 1, 1, "dgrad", "k_conv_halo"),       # G.blk5.conv1 dgrad through the upsample
+    # the other pipelined families (counted waits / multi-stage LDS rings of their own)
+    (16, 256, 256, 8, 64, 5, 1, 2, 2, 2, 0, "fwd_bits", "k_conv_c8"),       # D.conv1 forward
+    (16, 256, 128, 64, 3, 5, 1, 2, 2, 1, 0, "dgrad", "k_conv_c8"),          # conv_final dgrad (+ the pad-column term)
+    (16, 256, 128, 64, 3, 5, 1, 2, 2, 1, 0, "fwd", None),                   # conv_final forward (NHWC output form)
+    (16, 128, 64, 128, 64, 1, 1, 0, 0, 0, 0, "fwd", "k_conv_glds"),         # blk6 shortcut
+    (16, 16, 8, 256, 256, 3, 1, 1, 1, 1, 1, "fwd_stats", "k_conv_glds"),    # blk3 stage: 128 x 128 tiles + split-K + finishing pass
+    (32, 32, 32, 16, 64, 5, 1, 2, 2, 2, 0, "fwd", "k_conv_glds"),           # MeshDiscriminator.conv1 (four-stage small-tile form)
+    (32, 32, 32, 512, 1, 5, 1, 2, 2, 2, 0, "fwd", None),                    # D.conv5 forward
+    (16, 256, 256, 8, 64, 5, 1, 2, 2, 2, 0, "wgrad", "k_wgrad_c8"),         # D.conv1 weight gradient (planar kernel, ordered partials)
+    (16, 128, 128, 128, 256, 4, 2, 1, 1, 2, 0, "wgrad", "k_wgrad_halo"),    # D.conv3 weight gradient (deterministic mode: fixed point)
+    (16, 256, 128, 64, 64, 3, 1, 1, 1, 1, 0, "wgrad", "k_wgrad_halo"),      # G.blk6.conv2 weight gradient
+    (32, 32, 32, 16, 64, 5, 1, 2, 2, 2, 0, "wgrad", "k_wgrad_dma"),         # MeshDiscriminator.conv1 weight gradient
+    (16, 256, 128, 64, 3, 5, 1, 2, 2, 1, 0, "wgrad", "k_wgrad_smallco"),    # conv_final weight gradient
 ])
 def test_persistent_tile_kernels_repeat_bit_identically_under_memory_pressure(pkg, case):
-    """Every launch of a conv kernel must produce the same bits.  Round 4 found (run-to-run determinism of a training cycle at
-    256^2) that the persistent-tile variants with fragment look-ahead credited the previous tile's epilogue stores in ONE counted
-    s_waitcnt too many: the weights of the third step of every tile but a workgroup's first were not awaited, and about one launch
-    in a hundred read a stale weight slot when HBM was busy.  Here: 40 launches, each behind a 512 MB device copy that is still
-    draining when the kernel starts, against the first (launched on an idle device); the first is also compared with torch-CPU
-    on one sample."""
+    """Every launch of a conv kernel must produce the same bits (the weight gradients: in deterministic mode).  Round 4 found (run-to-
+    run determinism of a training cycle at 256^2) that the persistent-tile variants of k_conv_halo with fragment look-ahead credited
+    the previous tile's epilogue stores in ONE counted s_waitcnt too many: the weights of the third step of every tile but a
+    workgroup's first were not awaited, and about one launch in a hundred read a stale weight slot when HBM was busy.  Here: 40
+    launches of every pipelined kernel family, each behind a 512 MB device copy that is still draining when the kernel starts,
+    against the first (launched on an idle device); the first is also compared with torch-CPU on one sample."""
     conv = importlib.import_module("2dimageto3dmodel_amd.conv")
-    N, H, W, Cin, Cout, k, stride, ph, pw, mode, ups, what = case
+    N, H, W, Cin, Cout, k, stride, ph, pw, mode, ups, what, family = case
     g = torch.Generator().manual_seed(4242)
     d = conv.make_desc(N, H, W, Cin, Cout, k, k, stride, ph, pw, mode, ups)
     w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).bfloat16().float()
@@ -448,32 +463,49 @@ def test_persistent_tile_kernels_repeat_bit_identically_under_memory_pressure(pk
     wf, wd = conv.weight_prep(d, w.to(DEV))
     ho, wo = conv.out_hw(d)
     x = torch.randn(N, H, W, Cin, generator=g).bfloat16().to(DEV)
-    dy = torch.randn(N, ho, wo, Cout, generator=g).bfloat16().to(DEV)
+    cy = conv.dy_channels(Cout)
+    dy = torch.zeros(N, ho, wo, cy, dtype=torch.bfloat16)
+    dy[..., :Cout] = torch.randn(N, ho, wo, Cout, generator=g).bfloat16()
+    dy = dy.to(DEV)
     junk_a = torch.empty(512 << 20, dtype=torch.uint8, device=DEV)
     junk_b = torch.empty_like(junk_a)
 
     def once():
         if what == "fwd_bits":
-            y, bits = conv.conv_fwd(d, x, wf, b.to(DEV), slope=0.2, emit_bits=True)
-            return [y, bits]
+            return list(conv.conv_fwd(d, x, wf, b.to(DEV), slope=0.2, emit_bits=True))
         if what == "fwd_stats":
-            y, part = conv.conv_fwd_stats(d, x, wf, b.to(DEV))
-            return [y, part]
+            return list(conv.conv_fwd_stats(d, x, wf, b.to(DEV)))
+        if what == "fwd":
+            return [conv.conv_fwd(d, x, wf, b.to(DEV))]
+        if what == "wgrad":
+            db = torch.zeros(Cout, dtype=torch.float32, device=DEV) if conv.wgrad_fuses_dbias(d) else None
+            return [conv.conv_wgrad(d, x, dy, raw=True, dbias=db).clone()] + ([db] if db is not None else [])
         return [conv.conv_dgrad(d, dy, wd)]
 
-    torch.cuda.synchronize()
-    first = once()
-    assert conv.lib().m355_last_kernel().decode() == "k_conv_halo"
-    torch.cuda.synchronize()
-    for rep in range(40):
-        junk_b.copy_(junk_a)
-        out = once()
-        for t0, t in zip(first, out):
-            assert torch.equal(t0, t), f"launch {rep}: {int((t0 != t).sum())} of {t.numel()} elements differ from the first launch"
-    # ... and the first launch is right (sample 0 against torch-CPU on the same bf16 operands)
-    if what == "dgrad":
+    prev = conv.set_deterministic(True)
+    try:
+        torch.cuda.synchronize()
+        first = once()
+        assert family is None or conv.lib().m355_last_kernel().decode() == family
+        torch.cuda.synchronize()
+        for rep in range(40):
+            junk_b.copy_(junk_a)
+            out = once()
+            for t0, t in zip(first, out):
+                assert torch.equal(t0, t), f"launch {rep}: {int((t0 != t).sum())} of {t.numel()} elements differ from the first launch"
+    finally:
+        conv.set_deterministic(prev)
+    # ... and the first launch is right (sample 0 against torch-CPU on the same bf16 operands; the weight gradient: all samples)
+    if what == "wgrad":
+        wr = w.clone().requires_grad_()
+        br = b.clone().requires_grad_()
+        ref_conv(x.float().cpu().permute(0, 3, 1, 2), wr, br, stride, ph, pw, mode, ups).backward(dy[..., :Cout].float().cpu().permute(0, 3, 1, 2))
+        got, want = first[0].cpu().permute(0, 3, 1, 2), wr.grad          # raw layout [Cout,kh,kw,Cin]
+        if len(first) > 1:
+            assert (first[1].cpu() - br.grad).abs().max().item() / br.grad.abs().max().item() < 1e-3
+    elif what == "dgrad":
         xr = torch.zeros(1, Cin, H, W, requires_grad=True)
-        ref_conv(xr, w, None, stride, ph, pw, mode, ups).backward(dy[:1].float().cpu().permute(0, 3, 1, 2))
+        ref_conv(xr, w, None, stride, ph, pw, mode, ups).backward(dy[:1, ..., :Cout].float().cpu().permute(0, 3, 1, 2))
         got, want = first[0][:1].float().cpu().permute(0, 3, 1, 2), xr.grad
     else:
         want = ref_conv(x[:1].float().cpu().permute(0, 3, 1, 2), w, b, stride, ph, pw, mode, ups)
