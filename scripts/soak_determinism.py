@@ -13,13 +13,14 @@ import test_gan_modules as T
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 R = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+ND = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 batches = T._cycle_batches(B, R, seed0=7300)
 pkg.set_deterministic(True)
 
 
 def fresh():
     torch.manual_seed(733)
-    tr = train.GanTrainer(T._trainer_args(texture_resolution=R), device="cuda:0", mesh_template=None, capturable=True)
+    tr = train.GanTrainer(T._trainer_args(texture_resolution=R, num_discriminators=ND), device="cuda:0", mesh_template=None, capturable=True)
     tr.train()
     return tr
 
@@ -55,6 +56,6 @@ for name, (st, losses, dt) in runs.items():
     bad = [k for k in st if not torch.equal(st[k], ref[0][k])]
     nan = [k for k in st if torch.is_floating_point(st[k]) and not bool(torch.isfinite(st[k]).all())]
     ok &= not bad and not nan and losses == ref[1]
-    print(f"{name:20s} {N} cycles (batch {B}, {R}^2) in {dt:6.2f} s  losses {losses}  differing tensors vs '{ref_name}': {len(bad)} of {len(st)}  non-finite: {len(nan)}")
+    print(f"{name:20s} {N} cycles (batch {B}, {R}^2, nd {ND}) in {dt:6.2f} s  losses {losses}  differing tensors vs '{ref_name}': {len(bad)} of {len(st)}  non-finite: {len(nan)}")
 print("SOAK", "OK" if ok else "FAILED")
 sys.exit(0 if ok else 1)
