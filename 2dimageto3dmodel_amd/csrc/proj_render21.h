@@ -17,8 +17,9 @@ struct Render21Args {
     int N, S, tiles_x, tiles_y;
     int fixed_weights;
     float empty_val;  // silhouette value of an untouched ray (render_empty_value(S))
-    // M355_DET_SPLAT: the occupancy splat accumulates round(w * det_scale) in 64-bit integer LDS cells (order-independent) and
-    // converts to fp32 once; 0 = LDS float atomics (the sum of >= 3 weights in one voxel depends on their arrival order)
+    // M355_DET_SPLAT (non-zero): the occupancy splat accumulates round(w * 2^k) in 64-bit integer LDS cells (order-independent; k
+    // chosen per tile from its record count, k_render21) and converts to fp32 once; 0 = LDS float atomics (the sum of >= 3 weights
+    // in one voxel depends on their arrival order)
     float det_scale;
 };
 

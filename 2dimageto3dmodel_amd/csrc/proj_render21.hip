@@ -201,6 +201,18 @@ __global__ __launch_bounds__(kThreads21) void k_render21(Render21Args a)
     // want each as an SGPR PAIR -- 42 + the rest overflowed the scalar file: 40-81 SGPR spills into VGPR lanes and 160
     // v_readlane_b32 (+ hazard nops) inside the per-ray loop (round 4, from the ISA).  They sit in LDS instead and each tap is
     // read (one broadcast ds_read_b32) right where its D FMAs are issued.
+    // DETS: the fixed-point scale of THIS tile = the largest power of two that keeps (its number of records) maximal weights inside
+    // 62 bits, never finer than 2^-40.  Literal weights reach (2S)^3 in magnitude with either sign (tri:66), the "fixed" ones 1.
+    // Per tile, not per launch: with the launch-wide bound (all N points in one voxel) a 512^3 grid kept only 18 fractional bits
+    // and missed the 2e-5 silhouette contract (2.4e-4); a tile holds a handful of records.  A function of (records, S) only: the
+    // same on every run.
+    float det_scale = 0.0f;
+    if (DETS) {
+        auto clog2 = [](int x) { return x > 1 ? 32 - __clz(x - 1) : 0; };
+        const int lg = clog2(end - beg) + (a.fixed_weights ? 0 : 3 + 3 * clog2(S));
+        const int kfix = min(40, 62 - lg);
+        det_scale = __int_as_float((127 + kfix) << 23);
+    }
     __shared__ float taps_s[NT + 3];
     if (tid < NT) taps_s[tid] = a.taps[tid];
     int lz = 0;                          // a zero the compiler cannot see through: keeps the tap reads VECTOR loads (a uniform
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(kThreads21) void k_render21(Render21Args a)
                     if (DETS) {
                         const int z = k.f0 + i;
                         if (z >= 0 && z < SP)
-                            atomicAdd(reinterpret_cast<unsigned long long *>(&fix[ray * SP + z]), (unsigned long long)__float2ll_rn(wv * a.det_scale));
+                            atomicAdd(reinterpret_cast<unsigned long long *>(&fix[ray * SP + z]), (unsigned long long)__float2ll_rn(wv * det_scale));
                     } else {
                         atomicAdd(col + i, wv);
                     }
@@ -247,7 +259,7 @@ __global__ __launch_bounds__(kThreads21) void k_render21(Render21Args a)
     });
     __syncthreads();
     if (DETS) {
-        const double inv = 1.0 / (double)a.det_scale;
+        const double inv = 1.0 / (double)det_scale;
         for (int i = tid; i < RAYS * SP; i += kThreads21) {
             const int ray = i / SP, z = i - ray * SP;
             tile[ray * STRIDE + kHalo + z] = (float)((double)fix[i] * inv);
@@ -482,12 +494,7 @@ int launch_render21(Render21Args a, int B, hipStream_t st)
     a.tiles_y = (a.S + c.th - 1) / c.th;
     dim3 grid(a.tiles_x * a.tiles_y, B), block(kThreads21);
     if (a.det_scale != 0.0f) {
-        // scale = the largest power of two that keeps N maximal weights inside 62 bits: literal weights reach (2S)^3, the
-        // "fixed" ones 1 (csrc/proj_render21.hip corner_weights); never finer than 2^-40
-        const double bound = (a.fixed_weights ? 1.0 : 8.0 * (double)a.S * a.S * a.S) * (double)(a.N > 0 ? a.N : 1);
-        int k = 62 - (int)ceil(log2(bound));
-        if (k > 40) k = 40;
-        a.det_scale = (float)ldexp(1.0, k);
+        // (the kernel derives the fixed-point scale per tile from the tile's record count; det_scale is only the switch here)
         if (a.S <= 64) hipLaunchKernelGGL((k_render21<21, 16, 4, 8, 8, BWD, true>), grid, block, 0, st, a);
         else if (a.S <= 128) hipLaunchKernelGGL((k_render21<21, 16, 8, 8, 8, BWD, true>), grid, block, 0, st, a);
         else if (a.S <= 256) hipLaunchKernelGGL((k_render21<21, 32, 8, 4, 8, BWD, true>), grid, block, 0, st, a);
