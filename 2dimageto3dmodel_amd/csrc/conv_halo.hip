@@ -1136,7 +1136,6 @@ bool conv_halo_eligible(const ConvArgs &a)
             if (a.ups) return false;
     // (measured, profiles/r01_conv_halo_ab.txt: with the single-instruction bf16 packing in the epilogue the 4-wave variant
     // for Cout <= 64 wins too: G.blk6.conv2 605 -> 657 TF, D.conv2 dgrad 518 -> 616 TF)
-    if (getenv("M355_HALO_8W_ONLY") && a.Cout <= 64) return false;  // A/B switch
     return true;
 }
 
