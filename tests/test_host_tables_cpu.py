@@ -97,3 +97,28 @@ def test_workspace_queries(pkg):
     assert L.m355_conv2d_fwd_ws_bytes(ctypes.byref(desc(64, 16, 32, 128, 128, 3))) == 0           # the halo kernel's layer
     assert L.m355_cproj_bwd_ws_floats(128, 256, 512) == 128 * 2 * 512 and L.m355_cproj_bwd_ws_floats(128, 64, 256) == 0
     assert L.m355_sn_scratch_words(18, 512, 4608) == 18 * (72 + 128)
+
+
+def test_masked_input_off_the_gpu():
+    """gan_ops.MaskedInput (the not-yet-concatenated discriminator input the trainer hands over): on CPU tensors -- or any layout
+    the loaders do not take -- it is not fusable, reports the shape of the tensor it stands for, and materialize() is the
+    reference's cat(fake * alpha, alpha) [; cat(real, alpha)] (main.py:493, 503-507) with autograd intact"""
+    import torch
+    G = importlib.import_module("2dimageto3dmodel_amd.gan_ops")
+    g = torch.Generator().manual_seed(3)
+    fake = torch.randn(2, 3, 16, 16, generator=g, requires_grad=True)
+    real = torch.randn(2, 3, 16, 16, generator=g)
+    alpha = (torch.rand(2, 1, 16, 16, generator=g) > 0.5).float()
+    for r in (None, real):
+        mi = G.MaskedInput(fake, alpha, r)
+        assert not mi.fusable() and not G.disc_inputs_ok(mi, None, [(1, False, None, 8, 8)])
+        want = torch.cat((fake * alpha, alpha), dim=1)
+        if r is not None:
+            want = torch.cat((want, torch.cat((r, alpha), dim=1)), dim=0)
+        x = mi.materialize()
+        assert tuple(mi.shape) == tuple(want.shape) and mi.device == fake.device and torch.equal(x, want)
+        fake.grad = None
+        x.sum().backward()
+        assert torch.equal(fake.grad, alpha.expand(-1, 3, -1, -1))
+    # a broadcast alpha is not the loaders' layout either
+    assert not G.MaskedInput(fake, torch.ones(2, 1, 1, 1), None).fusable()
