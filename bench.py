@@ -173,6 +173,41 @@ def parity_check(elf, crit, pc, q, sc, mask, S):
             "loss_rel_err": err_loss, "grad_rel_err": err_grad, "checker": "oracle/p_oracle.c"}
 
 
+def parity_check_gan(trainer, R):
+    """AFTER the timed region: the GAN half against its checker (oracle/gan_cpu.py, the fp32 torch-CPU restatement pinned to the
+    reference's goldens by tests/test_oracle_golden.py) -- the G-step forward of main.py:491-498 on 8 fresh samples FROM THE
+    TRAINER'S CURRENT WEIGHTS (i.e. after the benchmarked cycles): generated texture, every discriminator logit map, the hinge
+    loss.  Bounds: those of tests/test_gan_modules.py::test_headline_batch8_vs_cpu_oracle (bf16 activations through ~30 layers
+    against fp32) with a 1.5x margin for weights that are no longer the initial ones."""
+    from oracle import gan_cpu as gc
+    gops = importlib.import_module("2dimageto3dmodel_amd.gan_ops")
+    trainer.finish_pending()
+    args, dev = trainer.args, next(trainer.generator.parameters()).device
+    wg, wd = gc.Weights(trainer.generator.state_dict(), grad=False), gc.Weights(trainer.discriminator.state_dict(), grad=False)
+    B = 8
+    g = torch.Generator().manual_seed(77)
+    z = torch.randn(B, trainer.latent_dim, generator=g)
+    c = torch.randint(0, args.n_classes[0], (B, 1), generator=g)
+    x_alpha = (torch.rand(B, 1, R, R, generator=g) > 0.4).float()
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(32, (os.cpu_count() or 1) // 8)))
+    try:
+        with torch.no_grad():
+            loss_r, tex_r, _, disc_r, _ = gc.g_step(wg, wd, args, z, c, x_alpha)
+    finally:
+        torch.set_num_threads(nthr)
+    with torch.no_grad():
+        pred_tex, pred_mesh = trainer.generator(z.to(dev), c.to(dev))
+        disc, mask = trainer.discriminator(gops.MaskedInput(pred_tex, x_alpha.to(dev)), pred_mesh, c.to(dev))
+        loss = trainer.criterion_gan(disc, True, for_discriminator=False, mask=mask, weight=trainer._d_weight())
+    e = (pred_tex.cpu() - tex_r).abs()
+    err_logit = max(float((got.cpu() - want).abs().max() / max(1.0, float(want.abs().max()))) for got, want in zip(disc, disc_r))
+    err_loss = abs(float(loss.mean()) - float(loss_r.mean()))
+    ok = bool(e.mean().item() < 9e-3 and e.max().item() < 1.8e-1 and err_logit < 6e-2 and err_loss < 1.5e-2)
+    return {"ok": ok, "samples": B, "texture_mean_abs_err": e.mean().item(), "texture_max_abs_err": e.max().item(),
+            "logit_rel_err": err_logit, "loss_abs_err": err_loss, "checker": "oracle/gan_cpu.py"}
+
+
 def cpu_baseline_gan(trainer, R, seconds_budget=10.0):
     """The GAN half beside the HIP path: oracle/gan_cpu.py (fp32 torch-CPU restatement of models/gan.py + utils/losses.py +
     Adam, pinned to the reference's goldens by tests/test_oracle_golden.py) running the SAME cycle (1 G step + 2 D steps incl.
@@ -522,6 +557,10 @@ def main():
         if do_p:
             par_chk = parity_check(elf, crit, pc, q, sc, mask, S)
             out["parity_ok"], out["parity"] = par_chk["ok"], par_chk
+        if do_g and world == 1 and not args.graph:   # (N > 1: a rank-0-only forward would wait for the other ranks' SyncBN messages)
+            gan_chk = parity_check_gan(trainer, R)
+            out["parity_ok"] = bool(out.get("parity_ok", True) and gan_chk["ok"])
+            out["parity_gan"] = gan_chk
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(N, S)
             if do_g:
