@@ -523,7 +523,7 @@ def main():
                        "gan_launch": "hipGraph replay (1 graph per cycle)" if cyc is not None else "eager (one launch per kernel)",
                        "gan_streams": 2 if (do_g and streams_were_on) else 1,
                        "deterministic": bool(pkg.is_deterministic()),
-                       "losses": {k: float(v) for k, v in last.items()}},
+                       "losses": {k: float(v.detach() if torch.is_tensor(v) else v) for k, v in last.items()}},
             "allreduce_ms_per_step": allreduce_ms,
             "grad_allreduces_per_step": coll["grad_allreduces"] / args.steps,
             "grad_allreduce_mb_per_step": coll["grad_allreduce_bytes"] / args.steps / 1e6,
@@ -635,7 +635,7 @@ def bench_recon(args, pkg, par, dist, rank, world, dev):
             "data": "synthetic",
             "config": {"workload": f"ReconstructionNetwork(texture {R}) -> 482-vertex template -> pose (+ learnable offsets) -> 256x256 DIB-R "
                                    f"render -> MSE + flat loss, batch {B}/GPU", "per_gpu_batch": B, "parallelism": f"replicas x{world}",
-                       "losses": {k: float(v) for k, v in last.items()}},
+                       "losses": {k: float(v.detach() if torch.is_tensor(v) else v) for k, v in last.items()}},
             "kernel_ms_per_step": sum(v[1] for v in kt.values()) / args.steps,
             "all_conv_tflops": (conv_fl / (conv_ms * 1e-3) / 1e12) if conv_ms else None,
             "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(kt.items(), key=lambda kv: -kv[1][1])}}), flush=True)
