@@ -61,6 +61,11 @@ SIGNATURES = {
                                         _P, _P]),
     "m355_dibr_rasterize_bwd": (c_int, [c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P,
                                         _P, _P, _P]),
+    "m355_dibr_rasterize_bwd_det_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "m355_dibr_rasterize_bwd_det": (c_int, [c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P,
+                                            _P, _P, _P, _P]),
+    "m355_dibr_shade_bwd_det_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "m355_dibr_shade_bwd_det": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "m355_dibr_shade_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "m355_dibr_shade_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "m355_weight_prep_entry_bytes": (c_size_t, []),

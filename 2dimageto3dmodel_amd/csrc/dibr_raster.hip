@@ -26,6 +26,55 @@ namespace m355 {
 constexpr int RT = 16;          // tile side (pixels)
 constexpr int RCH = 256;        // faces scanned per round (= threads)
 
+// Deterministic mode (template parameter DET of the two backward kernels): every sum of per-pixel contributions
+// -- per tile in LDS, across tiles in memory -- is taken in INTEGERS: integer addition is associative, so neither the order in
+// which the pixels of a tile arrive nor the order in which the tiles finish can change a bit.  A contribution v is split as
+// v * 2^16 = hi + frac (hi = floor, exact in fp32) and added as the pair (hi, lo = floor(frac * 2^32)) into two 64-bit cells:
+// the value of a cell pair is (sum hi * 2^32 + sum lo) / 2^48.  Resolution 2^-48 = 3.6e-15, |v| < 1e9 per contribution (gradients
+// near an edge grow like 1 / distance: a single 64-bit cell cannot give both), and 2^16 contributions of that size -- every pixel
+// of a 256 x 256 image on one face -- stay inside int64.  fix[0] is a flag word (a non-finite or out-of-range contribution: the
+// conversion pass then writes NaN -- nothing is hidden), fix[1 + 2 i], fix[2 + 2 i] the cell pair of output element i.
+struct FixPair {
+    unsigned long long hi, lo;
+};
+__device__ __forceinline__ bool rfix_ok(float v) { return fabsf(v) < 1.0e9f; }
+__device__ __forceinline__ FixPair rfix_split(float v)
+{
+    const float t = v * 65536.0f, h = floorf(t);
+    FixPair p;
+    p.hi = (unsigned long long)(long long)h;
+    p.lo = (unsigned long long)((t - h) * 4294967296.0f);
+    return p;
+}
+template <bool DET>
+__device__ __forceinline__ void g_add(float *dst, long long *fix, size_t idx, float v)
+{
+    if constexpr (DET) {
+        if (!rfix_ok(v)) {
+            atomicOr(reinterpret_cast<unsigned long long *>(fix), 1ull);
+            return;
+        }
+        const FixPair p = rfix_split(v);
+        unsigned long long *c = reinterpret_cast<unsigned long long *>(fix) + 1 + 2 * idx;
+        atomicAdd(c, p.hi);
+        atomicAdd(c + 1, p.lo);
+    } else {
+        atomicAdd(dst + idx, v);
+    }
+}
+// fix -> the fp32 outputs: out0[0..n0) then out1[0..n1)
+__global__ __launch_bounds__(256) void k_rfix_to_f32(const long long *__restrict__ fix, float *__restrict__ out0, size_t n0,
+                                                     float *__restrict__ out1, size_t n1)
+{
+    const bool bad = fix[0] != 0;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n0 + n1; i += (size_t)gridDim.x * 256) {
+        const double hi = (double)fix[1 + 2 * i], lo = (double)(unsigned long long)fix[2 + 2 * i];
+        const float v = bad ? __builtin_nanf("") : (float)(hi * (1.0 / 65536.0) + lo * (1.0 / 281474976710656.0));
+        if (i < n0) out0[i] = v;
+        else out1[i - n0] = v;
+    }
+}
+
 struct RastArgs {
     const float *p3;     // [B,F,9]
     const float *p2;     // [B,F,6]
@@ -41,6 +90,7 @@ struct RastArgs {
     const float *dprob;  // [B,H,W]
     float *dp2;          // [B,F,6]
     float *dattr;        // [B,F,3*D]
+    long long *fix;      // deterministic backward: [flag | dp2 cells | dattr cells] (zeroed by the launcher), else null
     int B, F, H, W, D, knum;
     float delta;
 };
@@ -181,11 +231,28 @@ __global__ __launch_bounds__(256) void k_rast_fwd(RastArgs a)
 // Gradient accumulators of the faces in the tile's current scan round: pixels of one face are neighbours, so their
 // contributions are summed in LDS (ds_add_f32) and leave as ONE global atomic per (tile, face, component) -- with global
 // atomics per pixel the backward was 6x the forward (15 same-address atomics for each of ~34 pixels of a face).
+template <bool DET>
 __global__ __launch_bounds__(256) void k_rast_bwd(RastArgs a)
 {
     __shared__ FaceLds fl[RCH];
     __shared__ int wave_cnt[4];
-    __shared__ float acc[RCH][6 + 3 * 3 + 1];   // D <= 3 on the LDS path (the renderer's uv + mask); wider attributes: global atomics
+    __shared__ float acc[DET ? 1 : RCH][6 + 3 * 3 + 1];   // D <= 3 on the LDS path (the renderer's uv + mask); wider attributes: global atomics
+    __shared__ unsigned long long acch[DET ? RCH : 1][6 + 3 * 3 + 1], accl[DET ? RCH : 1][6 + 3 * 3 + 1];   // DET: the cells as (hi, lo) pairs
+    const size_t nP = (size_t)a.B * a.F * 6;   // DET: cell pair of dp2[i] = i, of dattr[i] = nP + i
+    // one LDS contribution (the two forms of "add v to cell [j][k] of this round")
+    auto lds_add = [&](int j, int k, float v) {
+        if constexpr (DET) {
+            if (!rfix_ok(v)) {
+                atomicOr(reinterpret_cast<unsigned long long *>(a.fix), 1ull);
+            } else {
+                const FixPair p = rfix_split(v);
+                atomicAdd(&acch[j][k], p.hi);
+                atomicAdd(&accl[j][k], p.lo);
+            }
+        } else {
+            atomicAdd(&acc[j][k], v);
+        }
+    };
     const int b = blockIdx.z, tid = threadIdx.x;
     const int w = blockIdx.x * RT + (tid & (RT - 1)), h = blockIdx.y * RT + (tid >> 4);
     const bool live = w < a.W && h < a.H;
@@ -218,10 +285,10 @@ __global__ __launch_bounds__(256) void k_rast_bwd(RastArgs a)
                     for (int q = 0; q < 3; ++q)
                         if (q == d) { ga[q] = w0 * g; ga[3 + q] = w1 * g; ga[6 + q] = w2 * g; }
                 } else {
-                    float *da = a.dattr + ((size_t)b * a.F + idx) * 3 * a.D;
-                    atomicAdd(da + d, w0 * g);
-                    atomicAdd(da + a.D + d, w1 * g);
-                    atomicAdd(da + 2 * a.D + d, w2 * g);
+                    const size_t da = ((size_t)b * a.F + idx) * 3 * a.D;
+                    g_add<DET>(a.dattr, a.fix, (DET ? nP : 0) + da + d, w0 * g);
+                    g_add<DET>(a.dattr, a.fix, (DET ? nP : 0) + da + a.D + d, w1 * g);
+                    g_add<DET>(a.dattr, a.fix, (DET ? nP : 0) + da + 2 * a.D + d, w2 * g);
                 }
             }
         }
@@ -238,8 +305,7 @@ __global__ __launch_bounds__(256) void k_rast_bwd(RastArgs a)
             gv[4] = dN0 * (-(by - py)) + dN1 * (ay - py) + dA * (-(by - ay));
             gv[5] = dN0 * (bx - px) + dN1 * (-(ax - px)) + dA * (bx - ax);
             if (!lds_path) {
-                float *dp = a.dp2 + ((size_t)b * a.F + idx) * 6;
-                for (int k = 0; k < 6; ++k) atomicAdd(dp + k, gv[k]);
+                for (int k = 0; k < 6; ++k) g_add<DET>(a.dp2, a.fix, ((size_t)b * a.F + idx) * 6 + k, gv[k]);
             }
         }
     }
@@ -250,7 +316,10 @@ __global__ __launch_bounds__(256) void k_rast_bwd(RastArgs a)
     int kcount = 0;
     for (int base = 0; base < a.F; base += RCH) {
         const int n = scan_faces(a, b, base, tx0, tx1, ty0, ty1, fl, wave_cnt);
-        for (int t = tid; t < n * 16; t += 256) acc[t >> 4][t & 15] = 0.0f;
+        for (int t = tid; t < n * 16; t += 256) {
+            if constexpr (DET) acch[t >> 4][t & 15] = accl[t >> 4][t & 15] = 0;
+            else acc[t >> 4][t & 15] = 0.0f;
+        }
         __syncthreads();
         // covered pixel: its face is in exactly one round's list (a face covering a pixel of the tile overlaps the tile)
         if (has && lds_path && idx >= base && idx < base + RCH) {
@@ -260,13 +329,13 @@ __global__ __launch_bounds__(256) void k_rast_bwd(RastArgs a)
             if (jf >= 0) {
 #pragma unroll
                 for (int k = 0; k < 6; ++k)
-                    if (gv[k] != 0.0f) atomicAdd(&acc[jf][k], gv[k]);
+                    if (gv[k] != 0.0f) lds_add(jf, k, gv[k]);
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
                     if (d < a.D) {
-                        if (ga[d] != 0.0f) atomicAdd(&acc[jf][6 + d], ga[d]);
-                        if (ga[3 + d] != 0.0f) atomicAdd(&acc[jf][6 + a.D + d], ga[3 + d]);
-                        if (ga[6 + d] != 0.0f) atomicAdd(&acc[jf][6 + 2 * a.D + d], ga[6 + d]);
+                        if (ga[d] != 0.0f) lds_add(jf, 6 + d, ga[d]);
+                        if (ga[3 + d] != 0.0f) lds_add(jf, 6 + a.D + d, ga[3 + d]);
+                        if (ga[6 + d] != 0.0f) lds_add(jf, 6 + 2 * a.D + d, ga[6 + d]);
                     }
                 }
             }
@@ -296,20 +365,26 @@ __global__ __launch_bounds__(256) void k_rast_bwd(RastArgs a)
             const float rx = px - (sx + t * (ex_ - sx)), ry = py - (sy + t * (ey_ - sy));
             // d d^2 / d start = -2 (1 - t) r,  d d^2 / d end = -2 t r
             const int is = 2 * e, ie = 2 * ((e + 1) % 3);
-            atomicAdd(&acc[j][is], gd2 * -2.0f * (1.0f - t) * rx);
-            atomicAdd(&acc[j][is + 1], gd2 * -2.0f * (1.0f - t) * ry);
-            atomicAdd(&acc[j][ie], gd2 * -2.0f * t * rx);
-            atomicAdd(&acc[j][ie + 1], gd2 * -2.0f * t * ry);
+            lds_add(j, is, gd2 * -2.0f * (1.0f - t) * rx);
+            lds_add(j, is + 1, gd2 * -2.0f * (1.0f - t) * ry);
+            lds_add(j, ie, gd2 * -2.0f * t * rx);
+            lds_add(j, ie + 1, gd2 * -2.0f * t * ry);
         }
         __syncthreads();
         // flush: one global atomic per (face of the round, component) that received something
         for (int t = tid; t < n * 16; t += 256) {
             const int jj = t >> 4, k = t & 15;
-            const float v = acc[jj][k];
-            if (k < NA && v != 0.0f) {
-                const int f = fl[jj].id;
-                if (k < 6) atomicAdd(a.dp2 + ((size_t)b * a.F + f) * 6 + k, v);
-                else atomicAdd(a.dattr + ((size_t)b * a.F + f) * 3 * a.D + (k - 6), v);
+            if (k >= NA) continue;
+            const int f = fl[jj].id;
+            const size_t cell = k < 6 ? ((size_t)b * a.F + f) * 6 + k : ((size_t)b * a.F + f) * 3 * a.D + (k - 6);
+            if constexpr (DET) {
+                const unsigned long long vh = acch[jj][k], vl = accl[jj][k];
+                unsigned long long *c = reinterpret_cast<unsigned long long *>(a.fix) + 1 + 2 * ((k < 6 ? 0 : nP) + cell);
+                if (vh != 0) atomicAdd(c, vh);
+                if (vl != 0) atomicAdd(c + 1, vl);
+            } else {
+                const float v = acc[jj][k];
+                if (v != 0.0f) atomicAdd((k < 6 ? a.dp2 : a.dattr) + cell, v);
             }
         }
         __syncthreads();
@@ -326,6 +401,7 @@ struct ShadeArgs {
     float *color;
     const float *dcolor;
     float *duvm, *dtex, *dbg;
+    long long *fix;   // deterministic backward: [flag | dtex cells] (zeroed by the launcher), else null
     int B, H, W, TH, TW;
 };
 
@@ -338,7 +414,7 @@ __device__ __forceinline__ void shade_coords(const ShadeArgs &a, float u, float 
     y0 = (int)floorf(fy);
 }
 
-template <bool BWD>
+template <bool BWD, bool DET = false>
 __global__ __launch_bounds__(256) void k_shade(ShadeArgs a)
 {
     const size_t HW = (size_t)a.H * a.W, total = (size_t)a.B * HW, THW = (size_t)a.TH * a.TW;
@@ -389,14 +465,14 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a)
             a.duvm[i * 3 + 1] = -dfy * (float)(a.TH - 1);
             a.duvm[i * 3 + 2] = dhard;
             if (a.dtex) {
-                float *db = a.dtex + b * 3 * THW;
+                const size_t db = b * 3 * THW;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const bool in = (unsigned)xs[k] < (unsigned)a.TW && (unsigned)ys[k] < (unsigned)a.TH;
                     if (in && wgt[k] != 0.0f) {
 #pragma unroll
                         for (int c = 0; c < 3; ++c)
-                            if (dt[c] != 0.0f) atomicAdd(db + c * THW + (size_t)ys[k] * a.TW + xs[k], dt[c] * wgt[k]);
+                            if (dt[c] != 0.0f) g_add<DET>(a.dtex, a.fix, db + c * THW + (size_t)ys[k] * a.TW + xs[k], dt[c] * wgt[k]);
                     }
                 }
             }
@@ -421,24 +497,52 @@ extern "C" int m355_dibr_shade_fwd(const float *uvm_bxhxwx3, const float *textur
     return check_launch("dibr_shade_fwd");
 }
 
-extern "C" int m355_dibr_shade_bwd(const float *uvm_bxhxwx3, const float *texture_bx3xthxtw, const float *background_bxhxwx3,
-                                   const float *dcolor_bxhxwx3, float *duvm_bxhxwx3, float *dtexture_bx3xthxtw,
-                                   float *dbackground_bxhxwx3, int B, int H, int W, int TH, int TW, void *stream)
+static int shade_bwd_impl(const float *uvm, const float *tex, const float *bg, const float *dcolor, float *duvm, float *dtex,
+                          float *dbg, int B, int H, int W, int TH, int TW, void *fix_ws, hipStream_t st)
 {
-    M355_REQUIRE(uvm_bxhxwx3 && texture_bx3xthxtw && dcolor_bxhxwx3 && duvm_bxhxwx3 && B > 0 && H > 0 && W > 0 && TH > 0 && TW > 0,
-                 "dibr_shade_bwd: bad argument");
-    hipStream_t st = (hipStream_t)stream;
-    if (dtexture_bx3xthxtw && hipMemsetAsync(dtexture_bx3xthxtw, 0, sizeof(float) * (size_t)B * 3 * TH * TW, st) != hipSuccess) {
+    M355_REQUIRE(uvm && tex && dcolor && duvm && B > 0 && H > 0 && W > 0 && TH > 0 && TW > 0, "dibr_shade_bwd: bad argument");
+    const size_t nT = (size_t)B * 3 * TH * TW;
+    const bool det = fix_ws != nullptr && dtex != nullptr;
+    if (dtex && hipMemsetAsync(det ? fix_ws : (void *)dtex, 0, det ? sizeof(long long) * (1 + 2 * nT) : sizeof(float) * nT, st) != hipSuccess) {
         set_error("dibr_shade_bwd: memset failed");
         return M355_ERR_LAUNCH;
     }
     ShadeArgs a = {};
-    a.uvm = uvm_bxhxwx3; a.tex = texture_bx3xthxtw; a.bg = background_bxhxwx3; a.dcolor = dcolor_bxhxwx3;
-    a.duvm = duvm_bxhxwx3; a.dtex = dtexture_bx3xthxtw; a.dbg = dbackground_bxhxwx3;
+    a.uvm = uvm; a.tex = tex; a.bg = bg; a.dcolor = dcolor;
+    a.duvm = duvm; a.dtex = dtex; a.dbg = dbg; a.fix = det ? (long long *)fix_ws : nullptr;
     a.B = B; a.H = H; a.W = W; a.TH = TH; a.TW = TW;
     const size_t g = ((size_t)B * H * W + 255) / 256;
-    hipLaunchKernelGGL(k_shade<true>, dim3((unsigned)(g > 16384 ? 16384 : g)), dim3(256), 0, st, a);
+    const dim3 grid((unsigned)(g > 16384 ? 16384 : g));
+    if (det) {
+        hipLaunchKernelGGL((k_shade<true, true>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_rfix_to_f32, dim3((unsigned)((nT + 255) / 256 > 2048 ? 2048 : (nT + 255) / 256)), dim3(256), 0, st,
+                           (const long long *)fix_ws, dtex, nT, (float *)nullptr, (size_t)0);
+    } else {
+        hipLaunchKernelGGL((k_shade<true, false>), grid, dim3(256), 0, st, a);
+    }
     return check_launch("dibr_shade_bwd");
+}
+
+extern "C" int m355_dibr_shade_bwd(const float *uvm_bxhxwx3, const float *texture_bx3xthxtw, const float *background_bxhxwx3,
+                                   const float *dcolor_bxhxwx3, float *duvm_bxhxwx3, float *dtexture_bx3xthxtw,
+                                   float *dbackground_bxhxwx3, int B, int H, int W, int TH, int TW, void *stream)
+{
+    return shade_bwd_impl(uvm_bxhxwx3, texture_bx3xthxtw, background_bxhxwx3, dcolor_bxhxwx3, duvm_bxhxwx3, dtexture_bx3xthxtw,
+                          dbackground_bxhxwx3, B, H, W, TH, TW, nullptr, (hipStream_t)stream);
+}
+
+extern "C" size_t m355_dibr_shade_bwd_det_ws_bytes(int B, int TH, int TW)
+{
+    return (B > 0 && TH > 0 && TW > 0) ? sizeof(long long) * (1 + 2 * (size_t)B * 3 * TH * TW) : 0;
+}
+
+extern "C" int m355_dibr_shade_bwd_det(const float *uvm_bxhxwx3, const float *texture_bx3xthxtw, const float *background_bxhxwx3,
+                                       const float *dcolor_bxhxwx3, void *fix_ws, float *duvm_bxhxwx3, float *dtexture_bx3xthxtw,
+                                       float *dbackground_bxhxwx3, int B, int H, int W, int TH, int TW, void *stream)
+{
+    M355_REQUIRE(fix_ws || !dtexture_bx3xthxtw, "dibr_shade_bwd_det: no workspace");
+    return shade_bwd_impl(uvm_bxhxwx3, texture_bx3xthxtw, background_bxhxwx3, dcolor_bxhxwx3, duvm_bxhxwx3, dtexture_bx3xthxtw,
+                          dbackground_bxhxwx3, B, H, W, TH, TW, fix_ws, (hipStream_t)stream);
 }
 
 extern "C" size_t m355_dibr_ws_bytes(int B, int F) { return (size_t)(B > 0 ? B : 0) * (size_t)(F > 0 ? F : 0) * sizeof(float4); }
@@ -469,26 +573,62 @@ extern "C" int m355_dibr_rasterize_fwd(int height, int width, const float *point
     return check_launch("dibr_rasterize_fwd");
 }
 
-extern "C" int m355_dibr_rasterize_bwd(int height, int width, const float *points3d_bxfx9, const float *points2d_bxfx6,
-                                       const float *attr_bxfx3d, int B, int F, int D, int knum, float delta, const void *ws,
-                                       const float *improb, const int32_t *imidx, const float *imwei, const float *dimfeat,
-                                       const float *dimprob, float *dpoints2d_bxfx6, float *dattr_bxfx3d, void *stream)
+static int rasterize_bwd_impl(int height, int width, const float *points3d_bxfx9, const float *points2d_bxfx6,
+                              const float *attr_bxfx3d, int B, int F, int D, int knum, float delta, const void *ws,
+                              const float *improb, const int32_t *imidx, const float *imwei, const float *dimfeat,
+                              const float *dimprob, float *dpoints2d_bxfx6, float *dattr_bxfx3d, void *fix_ws, hipStream_t st)
 {
     if (int rc = rast_check("dibr_rasterize_bwd", B, F, height, width, D, knum)) return rc;
     M355_REQUIRE(points3d_bxfx9 && points2d_bxfx6 && attr_bxfx3d && ws && improb && imidx && imwei && dimfeat && dimprob &&
                      dpoints2d_bxfx6 && dattr_bxfx3d,
                  "dibr_rasterize_bwd: null pointer");
-    hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(dpoints2d_bxfx6, 0, sizeof(float) * (size_t)B * F * 6, st) != hipSuccess ||
-        hipMemsetAsync(dattr_bxfx3d, 0, sizeof(float) * (size_t)B * F * 3 * D, st) != hipSuccess) {
+    const size_t nP = (size_t)B * F * 6, nA = (size_t)B * F * 3 * D;
+    bool fail;
+    if (fix_ws) fail = hipMemsetAsync(fix_ws, 0, sizeof(long long) * (1 + 2 * (nP + nA)), st) != hipSuccess;
+    else fail = hipMemsetAsync(dpoints2d_bxfx6, 0, sizeof(float) * nP, st) != hipSuccess ||
+                hipMemsetAsync(dattr_bxfx3d, 0, sizeof(float) * nA, st) != hipSuccess;
+    if (fail) {
         set_error("dibr_rasterize_bwd: memset failed");
         return M355_ERR_LAUNCH;
     }
     RastArgs a = {};
     a.p3 = points3d_bxfx9; a.p2 = points2d_bxfx6; a.attr = attr_bxfx3d; a.bbox = (const float4 *)ws;
     a.improb = (float *)improb; a.imidx = (int *)imidx; a.imwei = (float *)imwei;
-    a.dfeat = dimfeat; a.dprob = dimprob; a.dp2 = dpoints2d_bxfx6; a.dattr = dattr_bxfx3d;
+    a.dfeat = dimfeat; a.dprob = dimprob; a.dp2 = dpoints2d_bxfx6; a.dattr = dattr_bxfx3d; a.fix = (long long *)fix_ws;
     a.B = B; a.F = F; a.H = height; a.W = width; a.D = D; a.knum = knum; a.delta = delta;
-    hipLaunchKernelGGL(k_rast_bwd, dim3((width + RT - 1) / RT, (height + RT - 1) / RT, B), dim3(256), 0, st, a);
+    const dim3 grid((width + RT - 1) / RT, (height + RT - 1) / RT, B);
+    if (fix_ws) {
+        hipLaunchKernelGGL(k_rast_bwd<true>, grid, dim3(256), 0, st, a);
+        const size_t blocks = (nP + nA + 255) / 256;
+        hipLaunchKernelGGL(k_rfix_to_f32, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, (const long long *)fix_ws,
+                           dpoints2d_bxfx6, nP, dattr_bxfx3d, nA);
+    } else {
+        hipLaunchKernelGGL(k_rast_bwd<false>, grid, dim3(256), 0, st, a);
+    }
     return check_launch("dibr_rasterize_bwd");
+}
+
+extern "C" int m355_dibr_rasterize_bwd(int height, int width, const float *points3d_bxfx9, const float *points2d_bxfx6,
+                                       const float *attr_bxfx3d, int B, int F, int D, int knum, float delta, const void *ws,
+                                       const float *improb, const int32_t *imidx, const float *imwei, const float *dimfeat,
+                                       const float *dimprob, float *dpoints2d_bxfx6, float *dattr_bxfx3d, void *stream)
+{
+    return rasterize_bwd_impl(height, width, points3d_bxfx9, points2d_bxfx6, attr_bxfx3d, B, F, D, knum, delta, ws, improb, imidx,
+                              imwei, dimfeat, dimprob, dpoints2d_bxfx6, dattr_bxfx3d, nullptr, (hipStream_t)stream);
+}
+
+extern "C" size_t m355_dibr_rasterize_bwd_det_ws_bytes(int B, int F, int D)
+{
+    return (B > 0 && F > 0 && D > 0) ? sizeof(long long) * (1 + 2 * (size_t)B * F * (6 + 3 * (size_t)D)) : 0;
+}
+
+extern "C" int m355_dibr_rasterize_bwd_det(int height, int width, const float *points3d_bxfx9, const float *points2d_bxfx6,
+                                           const float *attr_bxfx3d, int B, int F, int D, int knum, float delta, const void *ws,
+                                           const float *improb, const int32_t *imidx, const float *imwei, const float *dimfeat,
+                                           const float *dimprob, void *fix_ws, float *dpoints2d_bxfx6, float *dattr_bxfx3d,
+                                           void *stream)
+{
+    M355_REQUIRE(fix_ws, "dibr_rasterize_bwd_det: no workspace");
+    return rasterize_bwd_impl(height, width, points3d_bxfx9, points2d_bxfx6, attr_bxfx3d, B, F, D, knum, delta, ws, improb, imidx,
+                              imwei, dimfeat, dimprob, dpoints2d_bxfx6, dattr_bxfx3d, fix_ws, (hipStream_t)stream);
 }

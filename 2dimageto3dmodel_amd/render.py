@@ -11,6 +11,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import launch, lib, ptr, stream
+from .conv import is_deterministic
 
 EXPAND, KNUM, MULTIPLIER, DELTA = 0.02, 30, 1000, 7000.0   # kaolin.graphics.dib_renderer.rasterizer defaults
 
@@ -54,6 +55,11 @@ class LinearRasterizerFn(torch.autograd.Function):
         dprob = torch.zeros((B, height, width, 1), device=dev) if dprob is None else _f32c(dprob, "grad")
         dp2 = torch.empty_like(points2d)
         dattr = torch.empty_like(attr)
+        if is_deterministic():   # sums over pixels in 64-bit fixed point: the same bits on every run
+            fix = torch.empty((lib().m355_dibr_rasterize_bwd_det_ws_bytes(B, F, D),), dtype=torch.uint8, device=dev)
+            launch("dibr_rasterize_bwd_det", height, width, ptr(points3d), ptr(points2d), ptr(attr), B, F, D, knum, delta, ptr(ws),
+                   ptr(improb), ptr(imidx), ptr(imwei), ptr(dfeat), ptr(dprob), ptr(fix), ptr(dp2), ptr(dattr), stream())
+            return None, None, None, dp2, None, dattr, None, None, None
         launch("dibr_rasterize_bwd", height, width, ptr(points3d), ptr(points2d), ptr(attr), B, F, D, knum, delta, ptr(ws),
                ptr(improb), ptr(imidx), ptr(imwei), ptr(dfeat), ptr(dprob), ptr(dp2), ptr(dattr), stream())
         return None, None, None, dp2, None, dattr, None, None, None
@@ -104,6 +110,12 @@ class ShadeFn(torch.autograd.Function):
         duvm = torch.empty_like(uvm)
         dtex = torch.empty_like(texture) if ctx.needs_input_grad[1] else None
         dbg = torch.empty_like(bg) if (bg is not None and ctx.needs_input_grad[2]) else None
+        if is_deterministic() and dtex is not None:
+            fix = torch.empty((lib().m355_dibr_shade_bwd_det_ws_bytes(B, texture.shape[2], texture.shape[3]),), dtype=torch.uint8,
+                              device=uvm.device)
+            launch("dibr_shade_bwd_det", ptr(uvm), ptr(texture), ptr(bg), ptr(_f32c(dcolor, "grad")), ptr(fix), ptr(duvm), ptr(dtex),
+                   ptr(dbg), B, H, W, texture.shape[2], texture.shape[3], stream())
+            return duvm, dtex, dbg
         launch("dibr_shade_bwd", ptr(uvm), ptr(texture), ptr(bg), ptr(_f32c(dcolor, "grad")), ptr(duvm), ptr(dtex), ptr(dbg), B, H, W,
                texture.shape[2], texture.shape[3], stream())
         return duvm, dtex, dbg

@@ -419,6 +419,15 @@ int m355_dibr_rasterize_bwd(int height, int width, const float *points3d_bxfx9, 
                             const float *attr_bxfx3d, int B, int F, int D, int knum, float delta, const void *ws,
                             const float *improb, const int32_t *imidx, const float *imwei, const float *dimfeat,
                             const float *dimprob, float *dpoints2d_bxfx6, float *dattr_bxfx3d, void *stream);
+/*      _bwd_det (deterministic mode): the same gradients, but every sum over pixels -- per tile in LDS, across tiles in memory -- is
+ *      taken in integers (a contribution as a pair of 64-bit cells, resolution 2^-48; fix_ws = m355_dibr_rasterize_bwd_det_ws_bytes(B, F,
+ *      D) bytes, zeroed here) and converted once: bit-identical from run to run.  A non-finite or >= 1e9 contribution turns the
+ *      outputs into NaN. */
+size_t m355_dibr_rasterize_bwd_det_ws_bytes(int B, int F, int D);
+int m355_dibr_rasterize_bwd_det(int height, int width, const float *points3d_bxfx9, const float *points2d_bxfx6,
+                                const float *attr_bxfx3d, int B, int F, int D, int knum, float delta, const void *ws,
+                                const float *improb, const int32_t *imidx, const float *imwei, const float *dimfeat,
+                                const float *dimprob, void *fix_ws, float *dpoints2d_bxfx6, float *dattr_bxfx3d, void *stream);
 /*      fragmentshader(imtexcoord, texture, improb, filtering='bilinear', background_image) of fragment_shader.py:22-37:
  *      uvm [B,H,W,3] = (u, v, hard mask) as the rasteriser writes them; color = grid_sample(texture, (uv*2-1)*(1,-1),
  *      bilinear, align_corners=True) * hard, or lerp(background, that, hard).  _bwd: d color -> d uvm, d texture (nullable),
@@ -428,6 +437,12 @@ int m355_dibr_shade_fwd(const float *uvm_bxhxwx3, const float *texture_bx3xthxtw
 int m355_dibr_shade_bwd(const float *uvm_bxhxwx3, const float *texture_bx3xthxtw, const float *background_bxhxwx3,
                         const float *dcolor_bxhxwx3, float *duvm_bxhxwx3, float *dtexture_bx3xthxtw, float *dbackground_bxhxwx3,
                         int B, int H, int W, int TH, int TW, void *stream);
+/*      _bwd_det: the texel gradient (many pixels per texel) summed in integers as above; fix_ws =
+ *      m355_dibr_shade_bwd_det_ws_bytes(B, TH, TW) bytes (only read when d texture is requested) */
+size_t m355_dibr_shade_bwd_det_ws_bytes(int B, int TH, int TW);
+int m355_dibr_shade_bwd_det(const float *uvm_bxhxwx3, const float *texture_bx3xthxtw, const float *background_bxhxwx3,
+                            const float *dcolor_bxhxwx3, void *fix_ws, float *duvm_bxhxwx3, float *dtexture_bx3xthxtw,
+                            float *dbackground_bxhxwx3, int B, int H, int W, int TH, int TW, void *stream);
 
 /* Projection discriminator (code/models/gan.py:104-116, 216-228): out[n,p] = sum_c feat[n,p,c] * emb[n,c] on the NHWC bf16
  * feature map (C a power of two in 8..2048); backward: dfeat = g * emb (bf16, overwritten), demb[n,c] = sum_p g * feat.

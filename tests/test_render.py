@@ -170,6 +170,40 @@ def test_renderer_forward_backward_matches_oracle():
 
 
 @pytest.mark.gpu
+def test_renderer_backward_is_bit_reproducible_in_deterministic_mode():
+    """Deterministic mode (pkg.set_deterministic): the rasteriser's and the shader's backward sum their per-pixel contributions as
+    pairs of 64-bit integer cells instead of float atomics (csrc/dibr_raster.hip, DET): five runs of Renderer forward + backward
+    on a scene whose faces span many tiles give the SAME bits, equal the default mode's gradients to fp32 rounding, and the range
+    guard turns an absurd contribution into NaN instead of a wrapped sum."""
+    R = _mods()
+    pkg = importlib.import_module("2dimageto3dmodel_amd")
+    B, H, W = 3, 128, 128
+    pts, faces, uv, tex = scene(B, 5)
+    g = torch.Generator().manual_seed(3)
+    w_img, w_sil = torch.randn(B, H, W, 3, generator=g).cuda(), torch.randn(B, H, W, 1, generator=g).cuda()
+    ren = R.Renderer(H, W)
+
+    def run(scale=1.0):
+        pd, td = pts.cuda().requires_grad_(), tex.cuda().requires_grad_()
+        img, sil, _ = ren([pd, faces.cuda()], uv.cuda(), td)
+        (((img * w_img).sum() + (sil * w_sil).sum()) * scale).backward()
+        return pd.grad.clone(), td.grad.clone()
+
+    ref = run()
+    prev = pkg.set_deterministic(True)
+    try:
+        det = [run() for _ in range(5)]
+        huge = run(1e12)
+    finally:
+        pkg.set_deterministic(prev)
+    for gp, gt in det[1:]:
+        assert torch.equal(gp, det[0][0]) and torch.equal(gt, det[0][1])
+    for a, b in zip(det[0], ref):
+        assert float(b.abs().max()) > 0 and (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+    assert bool(torch.isnan(huge[0]).any())   # >= 1e9 per contribution: flagged, not wrapped
+
+
+@pytest.mark.gpu
 def test_mesh_template_forward_renderer(tmp_path):
     """MeshTemplate.forward_renderer (rendering/mesh_template.py:172-186) on the procedural UV sphere: an image and an alpha"""
     R = _mods()
