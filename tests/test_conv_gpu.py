@@ -514,3 +514,40 @@ def test_persistent_tile_kernels_repeat_bit_identically_under_memory_pressure(pk
             want = F.leaky_relu(want, 0.2)
         got = first[0][:1].float().cpu().permute(0, 3, 1, 2)
     assert (got - want).abs().max().item() / want.abs().max().item() < 1.2e-2
+
+
+@pytest.mark.timeout(900)
+def test_every_shape_class_repeats_bit_identically_under_memory_pressure(pkg):
+    """the shape classes of CASES (every dispatch path: generic MFMA, LDS-DMA, halo, 8-channel, small-Cout, heads, odd-kernel
+    stride-2 folds): forward, dgrad and the deterministic weight gradient eight times each behind a draining 256 MB copy -- the
+    same bits every time (correctness of the first launch is test_conv_fwd_and_dgrad's business)"""
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    junk_a = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
+    junk_b = torch.empty_like(junk_a)
+    prev = conv.set_deterministic(True)
+    try:
+        for case in CASES:
+            N, H, W, Cin, Cout, k, stride, ph, pw, mode, ups = case
+            g = torch.Generator().manual_seed(hash(case) % 1000)
+            d = conv.make_desc(N, H, W, Cin, Cout, k, k, stride, ph, pw, mode, ups)
+            w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).bfloat16().float()
+            wf, wd = conv.weight_prep(d, w.to(DEV))
+            b = torch.randn(Cout, generator=g).to(DEV)
+            x = torch.randn(N, H, W, Cin, generator=g).bfloat16().to(DEV)
+            ho, wo = conv.out_hw(d)
+            dy = torch.zeros(N, ho, wo, conv.dy_channels(Cout), dtype=torch.bfloat16)
+            dy[..., :Cout] = torch.randn(N, ho, wo, Cout, generator=g).bfloat16()
+            dy = dy.to(DEV)
+
+            def once():
+                return [conv.conv_fwd(d, x, wf, b, slope=0.2), conv.conv_dgrad(d, dy, wd), conv.conv_wgrad(d, x, dy, raw=True).clone()]
+
+            torch.cuda.synchronize()
+            first = once()
+            torch.cuda.synchronize()
+            for rep in range(8):
+                junk_b.copy_(junk_a)
+                for name, t0, t in zip(("fwd", "dgrad", "wgrad"), first, once()):
+                    assert torch.equal(t0, t), (case, name, rep, int((t0 != t).sum()))
+    finally:
+        conv.set_deterministic(prev)
