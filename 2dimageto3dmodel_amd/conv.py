@@ -90,30 +90,65 @@ def weight_prep(d, w_oihw, want_dgrad=True, sigma=None):
     return wf, wd
 
 
+# Tensors of 2 GiB and more.  The specialised kernels address bytes with 32 bits (buffer descriptors, LDS-DMA offsets), so their
+# eligibility checks hand such layers to the generic 64-bit-addressed kernels -- correct, and 3-4x slower (D.conv2 forward at N =
+# 256: 300 TF instead of 1000).  No conv kernel couples the samples of a batch -- batch-norm partial rows and weight gradients
+# are SUMS over samples -- so the same layer is run on each half of the batch instead (recursively), every half on the fast path;
+# outputs are slices of one tensor, the weight-gradient halves are added.
+_HALVES = {}
+
+
+def _halves(d):
+    """None, or (descriptor of half the batch, N/2) when a tensor of this layer reaches 2 GiB"""
+    key = bytes(d)
+    r = _HALVES.get(key, 0)
+    if r == 0:
+        r = None
+        if d.N >= 2 and d.N % 2 == 0:
+            ho, wo = out_hw(d)
+            big = max(d.N * d.H * d.W * d.Cin * 2, d.N * ho * wo * max(d.Cout, dy_channels(d.Cout)) * 2)
+            if big >= (1 << 31):
+                r = (make_desc(d.N // 2, d.H, d.W, d.Cin, d.Cout, d.kh, d.kw, d.stride, d.pad_h, d.pad_w, d.pad_w_mode, d.upsample), d.N // 2)
+        _HALVES[key] = r
+    return r
+
+
 def maskbits_ok(d, role):
     """role 0: the forward of this layer can write bit-packed activation masks; role 1: its dgrad can read them"""
-    return bool(lib().m355_conv2d_maskbits_ok(ctypes.byref(d), int(role)))
+    hv = _halves(d)
+    return maskbits_ok(hv[0], role) if hv else bool(lib().m355_conv2d_maskbits_ok(ctypes.byref(d), int(role)))
 
 
 def dgrad_mask_ok(d):
     """can conv_dgrad(mask_x=...) apply the producer's LeakyReLU backward in its epilogue on this layer?"""
-    return bool(lib().m355_conv2d_dgrad_mask_ok(ctypes.byref(d)))
+    hv = _halves(d)
+    return dgrad_mask_ok(hv[0]) if hv else bool(lib().m355_conv2d_dgrad_mask_ok(ctypes.byref(d)))
 
 
-def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0, cin_real=None, emit_bits=False):
+def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0, cin_real=None, emit_bits=False, _out=None):
     """emit_bits: also return the sign bits of the pre-activation ([N,Ho,Wo,Cout/64,2] int32, opaque layout) for
-    the consumer's conv_dgrad(mask_bits=...); requires maskbits_ok(d, 0)"""
+    the consumer's conv_dgrad(mask_bits=...); requires maskbits_ok(d, 0).  (_out: the output views of a half-batch launch)"""
     x = _req(x, torch.bfloat16, "x")
     assert tuple(x.shape) == (d.N, d.H, d.W, d.Cin), (tuple(x.shape), (d.N, d.H, d.W, d.Cin))
     ho, wo = out_hw(d)
-    if out_f32_nchw:
-        y = torch.empty((d.N, d.Cout, ho, wo), dtype=torch.float32, device=x.device)
+    if _out is not None:
+        y, bits = _out
     else:
-        y = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.bfloat16, device=x.device)
+        bits = torch.empty((d.N, ho, wo, d.Cout // 64, 2), dtype=torch.int32, device=x.device) if emit_bits else None
+        if out_f32_nchw:
+            y = torch.empty((d.N, d.Cout, ho, wo), dtype=torch.float32, device=x.device)
+        else:
+            y = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.bfloat16, device=x.device)
+    hv = _halves(d)
+    if hv:
+        dh, h = hv
+        for i in (0, 1):
+            conv_fwd(dh, x[i * h:(i + 1) * h], w_fwd, bias, out_f32_nchw, slope, cin_real, emit_bits,
+                     _out=(y[i * h:(i + 1) * h], None if bits is None else bits[i * h:(i + 1) * h]))
+        return (y, bits) if emit_bits else y
     b = None if bias is None else _req(bias.detach(), torch.float32, "bias")
     if emit_bits:
         assert not out_f32_nchw
-        bits = torch.empty((d.N, ho, wo, d.Cout // 64, 2), dtype=torch.int32, device=x.device)
         launch("conv2d_fwd_bits", ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(b), ptr(y), float(slope), ptr(bits), stream(),
                work=lambda: flops(d, cin_real), tag=lambda: tag(d))
         return y, bits
@@ -124,37 +159,58 @@ def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0, cin_real=Non
 
 def conv_stats_rows(d):
     """rows of batch-norm partial sums conv_fwd_stats writes for this shape (0: no fused statistics)"""
+    hv = _halves(d)
+    if hv:
+        return 2 * conv_stats_rows(hv[0])   # (the halves' partial rows, one after the other)
     nws, rows = _fwd_ws(d)
     if nws:
         return rows   # (split-K layers: the finishing pass emits them)
     return int(lib().m355_conv2d_fwd_stats_rows(ctypes.byref(d)))
 
 
-def conv_fwd_stats(d, x, w_fwd, bias=None, cin_real=None, rows=None):
+def conv_fwd_stats(d, x, w_fwd, bias=None, cin_real=None, rows=None, _out=None):
     """-> y, part: the forward (no activation) and part [rows,2,Cout] fp32 = per-workgroup (sum, sum of squares) of the fp32
     results over the workgroup's pixels -- what bn_finalize reduces; requires conv_stats_rows(d) > 0"""
     x = _req(x, torch.bfloat16, "x")
     assert tuple(x.shape) == (d.N, d.H, d.W, d.Cin), (tuple(x.shape), (d.N, d.H, d.W, d.Cin))
     ho, wo = out_hw(d)
     rows = conv_stats_rows(d) if rows is None else rows
+    hv = _halves(d)
+    if hv:
+        dh, h = hv
+        y, part = _out if _out is not None else (torch.empty((d.N, ho, wo, d.Cout), dtype=torch.bfloat16, device=x.device),
+                                                 torch.empty((rows, 2, d.Cout), dtype=torch.float32, device=x.device))
+        r = rows // 2
+        for i in (0, 1):
+            conv_fwd_stats(dh, x[i * h:(i + 1) * h], w_fwd, bias, cin_real, r, _out=(y[i * h:(i + 1) * h], part[i * r:(i + 1) * r]))
+        return y, part
     b = None if bias is None else _req(bias.detach(), torch.float32, "bias")
     if _fwd_ws(d)[0]:
+        assert _out is None
         return _fwd_splitk(d, x, w_fwd, b, 1.0, True)
-    y = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.bfloat16, device=x.device)
-    part = torch.empty((rows, 2, d.Cout), dtype=torch.float32, device=x.device)
+    y, part = _out if _out is not None else (torch.empty((d.N, ho, wo, d.Cout), dtype=torch.bfloat16, device=x.device),
+                                             torch.empty((rows, 2, d.Cout), dtype=torch.float32, device=x.device))
     launch("conv2d_fwd_stats", ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(b), ptr(y), ptr(part), stream(),
            work=lambda: flops(d, cin_real), tag=lambda: tag(d))
     return y, part
 
 
-def conv_dgrad(d, dy, w_dgrad, cin_real=None, mask_x=None, mask_slope=1.0, mask_bits=None):
+def conv_dgrad(d, dy, w_dgrad, cin_real=None, mask_x=None, mask_slope=1.0, mask_bits=None, _out=None):
     """mask_x: this conv's input x when it is the output of a fused conv+LeakyReLU(mask_slope): the returned gradient
     is then already multiplied by that activation's derivative; mask_bits: the same from the producer's bit masks
     (conv_fwd(emit_bits=True)), 1/16 of the bytes"""
     dy = _req(dy, torch.bfloat16, "dy")
     ho, wo = out_hw(d)
     assert tuple(dy.shape) == (d.N, ho, wo, dy_channels(d.Cout)), tuple(dy.shape)
-    dx = torch.empty((d.N, d.H, d.W, d.Cin), dtype=torch.bfloat16, device=dy.device)
+    dx = _out if _out is not None else torch.empty((d.N, d.H, d.W, d.Cin), dtype=torch.bfloat16, device=dy.device)
+    hv = _halves(d)
+    if hv:
+        dh, h = hv
+        for i in (0, 1):
+            sl = slice(i * h, (i + 1) * h)
+            conv_dgrad(dh, dy[sl], w_dgrad, cin_real, None if mask_x is None else mask_x[sl], mask_slope,
+                       None if mask_bits is None else mask_bits[sl], _out=dx[sl])
+        return dx
     nws = lib().m355_conv2d_dgrad_ws_bytes(ctypes.byref(d))
     ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device)
     if mask_bits is not None:
@@ -203,7 +259,8 @@ def _wgrad_ws_bytes(d):
 
 
 def wgrad_fuses_dbias(d):
-    return bool(lib().m355_conv2d_wgrad_fuses_dbias(ctypes.byref(d)))
+    hv = _halves(d)
+    return wgrad_fuses_dbias(hv[0]) if hv else bool(lib().m355_conv2d_wgrad_fuses_dbias(ctypes.byref(d)))
 
 
 def _after_fill(st, device):
@@ -296,6 +353,17 @@ def conv_wgrad(d, x, dy, cin_real=None, raw=False, dbias=None, arena=False, dbia
     per-pass WgradArena, valid until the next backward pass"""
     x, dy = _req(x, torch.bfloat16, "x"), _req(dy, torch.bfloat16, "dy")
     n = d.Cout * d.kh * d.kw * d.Cin
+    hv = _halves(d)
+    if hv:
+        # a sum over samples: the first half as usual (arena slice, zeroing rules and all), the second half into fresh buffers, added
+        # in this fixed order (deterministic when the halves are)
+        dh, h = hv
+        dw = conv_wgrad(dh, x[:h], dy[:h], cin_real, True, dbias, arena, dbias_zeroed)
+        db2 = None if dbias is None else torch.empty_like(dbias)
+        dw.add_(conv_wgrad(dh, x[h:], dy[h:], cin_real, True, db2))
+        if dbias is not None:
+            dbias.add_(db2)
+        return dw if raw else dw.permute(0, 3, 1, 2)
     nws = _wgrad_ws_bytes(d)
     if nws:
         # thin layers: per-workgroup partial tiles + an ordered sum instead of atomics (deterministic in every mode; dw / dbias

@@ -351,6 +351,24 @@ class _DiscBase(nn.Module):
             dev = self.__dict__["_pos_dev"] = self.pos_emb.to(device)
         return dev[0]
 
+    @staticmethod
+    def _out_shape(conv, s):
+        """NHWC shape of conv's output for an input of NHWC shape s"""
+        st, ph, pw, _ = conv.m355
+        kh, kw = conv.kernel_size
+        return (s[0], (s[1] + 2 * ph - kh) // st + 1, (s[2] + 2 * pw - kw) // st + 1, conv.out_channels)
+
+    @staticmethod
+    def _masks_its_input(conv, s):
+        """can conv's dgrad, at input shape s, apply the LeakyReLU backward of the layer below in its epilogue?  (Not for every
+        size: the direct-form dgrad it rides on ends at 2 GiB tensors -- a batch of 256 at 256^2 is past that, and the pair then
+        runs unfused: the producer keeps its activation and differentiates it itself.)"""
+        st, ph, pw, mode = conv.m355
+        if mode == C.PAD_REPLICATE:
+            return False
+        kh, kw = conv.kernel_size
+        return C.dgrad_mask_ok(C.make_desc(s[0], s[1], s[2], s[3], conv.out_channels, kh, kw, st, ph, pw, mode, 0))
+
     def _act(self, conv, norm, x, in_act=False, sole_consumer_masks=False):
         """conv -> [InstanceNorm] -> LeakyReLU on NHWC bf16.  With the activation in the conv epilogue (no norm):
         in_act = x is the previous layer's fused conv+LeakyReLU output and this conv is its only consumer -> this
@@ -459,9 +477,12 @@ class MeshDiscriminator(_DiscBase):
         # conv1 -> conv2 -> conv3 are single-consumer chains when norm_d == 'none': each dgrad carries the LeakyReLU
         # backward of the layer below (conv3's output also feeds the projection term, so it keeps its own)
         n2, n3 = getattr(self, "bn2", None), getattr(self, "bn3", None)
-        h = self._act(self.conv1, None, h, False, n2 is None)
-        h = self._act(self.conv2, n2, h, True, n3 is None)
-        return self._tail(self.conv3, n3, self.conv4, h, n2 is None, c, caption), mask
+        s2 = self._out_shape(self.conv1, h.shape)
+        p12 = n2 is None and h.is_cuda and self._masks_its_input(self.conv2, s2)
+        p23 = n2 is None and n3 is None and h.is_cuda and self._masks_its_input(self.conv3, self._out_shape(self.conv2, s2))
+        h = self._act(self.conv1, None, h, False, p12)
+        h = self._act(self.conv2, n2, h, p12, p23)
+        return self._tail(self.conv3, n3, self.conv4, h, p23, c, caption), mask
 
 
 class TextureDiscriminator(_DiscBase):
@@ -529,10 +550,15 @@ class TextureDiscriminator(_DiscBase):
     def trunk(self, h, mask, c=None, caption=None):
         """conv1 .. conv5 + projection on the packed NHWC bf16 input (gan.py:212-233)"""
         n2, n3, n4 = getattr(self, "bn2", None), getattr(self, "bn3", None), getattr(self, "bn4", None)
-        h = self._act(self.conv1, None, h, False, n2 is None)
-        h = self._act(self.conv2, n2, h, True, n3 is None)
-        h = self._act(self.conv3, n3, h, n2 is None, n4 is None)
-        return self._tail(self.conv4, n4, self.conv5, h, n3 is None, c, caption), mask
+        s2 = self._out_shape(self.conv1, h.shape)
+        s3 = self._out_shape(self.conv2, s2)
+        p12 = n2 is None and h.is_cuda and self._masks_its_input(self.conv2, s2)
+        p23 = n2 is None and n3 is None and h.is_cuda and self._masks_its_input(self.conv3, s3)
+        p34 = n3 is None and n4 is None and h.is_cuda and self._masks_its_input(self.conv4, self._out_shape(self.conv3, s3))
+        h = self._act(self.conv1, None, h, False, p12)
+        h = self._act(self.conv2, n2, h, p12, p23)
+        h = self._act(self.conv3, n3, h, p23, p34)
+        return self._tail(self.conv4, n4, self.conv5, h, p34, c, caption), mask
 
 
 class MultiScaleDiscriminator(nn.Module):

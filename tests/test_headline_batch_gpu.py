@@ -157,3 +157,38 @@ def test_generator_blocks_batch64_sampled_vs_torch_cpu(pkg):
     assert (dx[pick].float().cpu().permute(0, 3, 1, 2) - xs.grad).abs().max().item() / xs.grad.abs().max().item() < 1.2e-2
     dw = conv.conv_wgrad(d, x, dy).cpu()
     assert (dw - wr.grad).abs().max().item() / wr.grad.abs().max().item() < 2e-4
+
+
+@pytest.mark.timeout(900)
+def test_two_gib_layers_run_as_half_batches_on_the_fast_kernels(pkg):
+    """A D step at batch 128 per GPU (N = 256): D.conv1's output / D.conv2's input reach 2 GiB, past the 32-bit byte offsets of the
+    specialised kernels.  conv.py then runs the layer on each half of the batch (outputs = slices of one tensor, bit masks and
+    batch-norm partial rows likewise, the weight-gradient halves added): same parity bar as at batch 64 -- first image (first
+    half), last image (second half), an untouched image's gradient exactly zero -- and on the FAST kernel families."""
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    N = 256
+    y1, b1 = _layer(conv, N, 256, 256, 8, 64, 5, 1, 2, 2, 2, 0, 31, LRELU, want_dgrad=False)
+    assert y1.numel() * 2 == (1 << 31) and b1 is not None
+    assert conv.lib().m355_last_kernel().decode() in ("k_wgrad_c8", "k_wgrad_part_sum")
+    d2 = conv.make_desc(N, 256, 256, 64, 128, 4, 4, 2, 1, 1, 2, 0)
+    assert conv._halves(d2) is not None and conv.maskbits_ok(d2, 0) and conv.maskbits_ok(d2, 1) and conv.dgrad_mask_ok(d2)
+    y2, b2 = _layer(conv, N, 256, 256, 64, 128, 4, 2, 1, 1, 2, 0, 32, LRELU, bits_in=b1, x=y1)
+    assert conv.lib().m355_last_kernel().decode() == "k_wgrad_halo" and b2 is not None
+    del y1, b1, y2, b2
+    torch.cuda.empty_cache()
+    # fused batch-norm statistics across the halves: G.blk6.conv2's shape at N = 512 (2 GiB in, 2 GiB out)
+    d = conv.make_desc(512, 256, 128, 64, 64, 3, 3, 1, 1, 1, 1, 0)
+    dh = conv._halves(d)[0]
+    assert conv.conv_stats_rows(d) == 2 * conv.conv_stats_rows(dh) > 0
+    g = torch.Generator(device=DEV).manual_seed(33)
+    x = torch.randn((512, 256, 128, 64), generator=g, device=DEV).bfloat16()
+    w = (torch.randn((64, 64, 3, 3), generator=g, device=DEV) / 24.0).bfloat16().float()
+    wf, _ = conv.weight_prep(d, w, want_dgrad=False)
+    y, part = conv.conv_fwd_stats(d, x, wf, None)
+    assert conv.lib().m355_last_kernel().decode() == "k_conv_halo" and tuple(part.shape) == (conv.conv_stats_rows(d), 2, 64)
+    yh, parth = conv.conv_fwd_stats(dh, x[256:], wf, None)
+    assert torch.equal(y[256:], yh) and torch.equal(part[part.shape[0] // 2:], parth)          # the second half IS the half-batch launch
+    s = part.double().sum(0).cpu()
+    yf = y[::64].double()                                                                      # every 64th image: 8 of 512
+    assert abs(float(s[0].sum()) / 512 - float(yf.sum()) / 8) < 0.05 * float(yf.abs().sum()) / 8 + 1.0
+    assert abs(float(s[1].sum()) / 512 / (float((yf * yf).sum()) / 8) - 1) < 0.02
