@@ -309,12 +309,21 @@ class CycleGraph:
         torch.cuda.current_stream().wait_stream(side)
         import os
         import time
-        settle = float(os.environ.get("M355_CAPTURE_SETTLE_MS", "0")) * 1e-3
+        # (... and a pause first: synchronize, then let the watchdog -- it wakes every 100 ms -- retire the warm-up's work objects, so
+        # that its list is empty while the capture is open; a death with "event last recorded in a capturing stream" was seen once
+        # in 16 thread-local probes without it)
+        settle = float(os.environ.get("M355_CAPTURE_SETTLE_MS", "400")) * 1e-3
         if settle > 0 and P.collectives_on():
             torch.cuda.synchronize()
             time.sleep(settle)
+        # With collectives in the cycle the capture is THREAD-LOCAL: ProcessGroupNCCL's watchdog thread polls the events of the
+        # warm-up's collectives (hipEventQuery) whenever it wakes up, and in the default global mode such a call from ANY thread
+        # while a capture is open is an error -- the watchdog then throws and the process aborts (seen in 3 of ~40 probe runs:
+        # "operation not permitted when stream is capturing", gpurun_out/rccl_graph_probe_death.txt).  Thread-local mode only
+        # polices the capturing thread.
+        mode = os.environ.get("M355_CAPTURE_MODE") or ("thread_local" if P.collectives_on() else "global")
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode=os.environ.get("M355_CAPTURE_MODE", "global")):
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.out = self._run()
         self.trainer.total_it -= self.n   # (the capture pass executed nothing; it only rotated the spectral-norm slots on the host)
 

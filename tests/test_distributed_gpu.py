@@ -167,9 +167,10 @@ def test_rccl_collectives_inside_a_captured_cycle():
         pytest.xfail("RCCL collectives inside a hipGraph capture: the probe did not finish in 420 s (hang)")
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if not lines:
-        # measured on ROCm 7.2 / torch 2.10 (round 4): two probes of 31 died (SIGABRT, an uncaught C++ exception) while 29
-        # others capture, replay and match bit for bit -- intermittent, so the death is recorded (stderr kept under gpurun_out/
-        # for the next reader) instead of failing the suite
+        # measured on ROCm 7.2 / torch 2.10 (round 4): with a GLOBAL-mode capture about one probe in fifteen died -- ProcessGroupNCCL's
+        # watchdog thread queried an event while the capture was open and turned the error into terminate().  CycleGraph now
+        # captures thread-locally after a pause (16 of 16 since); should the process still die, the death is recorded (stderr
+        # kept under gpurun_out/ for the next reader) instead of failing the suite
         what = [ln for ln in r.stderr.splitlines() if "what()" in ln or "Error" in ln or "error" in ln][:3]
         try:
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
