@@ -122,3 +122,23 @@ def test_masked_input_off_the_gpu():
         assert torch.equal(fake.grad, alpha.expand(-1, 3, -1, -1))
     # a broadcast alpha is not the loaders' layout either
     assert not G.MaskedInput(fake, torch.ones(2, 1, 1, 1), None).fusable()
+
+
+def test_two_gib_layers_are_halved_on_the_host():
+    """conv._halves: a layer whose input or output reaches 2 GiB runs as two half-batch launches (the specialised kernels address
+    bytes with 32 bits); pure geometry, no GPU"""
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    mk = lambda n, h=256, w=256, ci=8, co=64, k=5, s=1, p=2: conv.make_desc(n, h, w, ci, co, k, k, s, p, p, 2, 0)
+    assert conv._halves(mk(128)) is None                      # D.conv1 at the benchmarked D step: 1 GiB out
+    d, h = conv._halves(mk(256))                              # 2 GiB out
+    assert (d.N, h) == (128, 128) and (d.H, d.W, d.Cin, d.Cout, d.kh, d.stride, d.pad_w_mode) == (256, 256, 8, 64, 5, 1, 2)
+    assert conv._halves(d) is None
+    d4, _ = conv._halves(mk(512))                             # 4 GiB: halves of halves
+    assert d4.N == 256 and conv._halves(d4)[0].N == 128
+    assert conv._halves(mk(257)) is None                      # an odd batch cannot be halved: the generic kernels take it
+    assert conv._halves(mk(256, ci=64, co=128, k=4, s=2, p=1)) is not None     # D.conv2: 2 GiB IN
+    assert conv._halves(mk(254, ci=64, co=128, k=4, s=2, p=1)) is None
+    # the eligibility questions of a halved layer are its halves' (no GPU needed: they are table lookups in the library)
+    big, half = mk(256, ci=64, co=128, k=4, s=2, p=1), mk(128, ci=64, co=128, k=4, s=2, p=1)
+    assert conv.dgrad_mask_ok(big) == conv.dgrad_mask_ok(half) and conv.wgrad_fuses_dbias(big) == conv.wgrad_fuses_dbias(half)
+    assert conv.conv_stats_rows(mk(512, 256, 128, 64, 64, 3, 1, 1)) == 2 * conv.conv_stats_rows(mk(256, 256, 128, 64, 64, 3, 1, 1))
