@@ -103,3 +103,43 @@ def test_the_source_carries_the_rule_the_model_proves():
     assert "constexpr int cnt_b = (RB - 2) * NBW + halo_dmas_behind<T, NAW, NAS, RB - 1>(tap);" in src
     assert "constexpr int cnt_a = (T - 1 - L - TL) * NBW;" in src
     assert "constexpr int cnt = (tap == (T - L) % T && cnt_a < cnt_b) ? cnt_a : cnt_b;" in src
+
+
+# ---- the two other counted-wait pipelines, same in-order model -------------------------------------------------------------------
+def test_glds_four_stage_ring_waits_for_its_own_step():
+    """k_conv_glds, NST = 4 (conv_mfma.hip): steps 0 .. NST-2 are staged up front; step t waits with vmcnt(min(2, steps after t) *
+    PER), meets the other waves, stages step t + NST-1 into the buffer read in step t-1, then multiplies buffer t % NST"""
+    NST = 4
+    for PER, nsteps in itertools.product((2, 3, 6), range(1, 12)):
+        issued = [(s, i) for s in range(min(NST - 1, nsteps)) for i in range(PER)]
+        for t in range(nsteps):
+            allowed = min(2, nsteps - 1 - t) * PER
+            landed = set(issued[:len(issued) - allowed])
+            assert all((t, i) in landed for i in range(PER)), (PER, nsteps, t)
+            if t + NST - 1 < nsteps:
+                # the buffer it overwrites, (t + NST-1) % NST == (t-1) % NST, was last read in step t-1: behind this step's barrier
+                assert (t + NST - 1) % NST == (t - 1) % NST
+                issued += [(t + NST - 1, i) for i in range(PER)]
+
+
+def test_wgrad_c8p_waits_cover_x_and_dy():
+    """k_wgrad_c8p (conv_small.hip), waves that also fetch x: prologue = x of tile 0 (2 loads), dy of tiles 0 .. NST-2 (4 DMAs each),
+    vmcnt(4 (NST-1)) -> x0.  Per tile: vmcnt(4 (NST-2)) -> this tile's dy; then x of the next tile (2 loads) and the dy of tile
+    it + NST-1 (4 DMAs) are issued; at the end vmcnt(4) -> the next tile's x.  Waves without x loads: the same minus the x parts."""
+    NST = 4
+    for has_x, tiles in itertools.product((True, False), range(1, 9)):
+        issued = []
+        if has_x:
+            issued += [("x", 0, i) for i in range(2)]
+        for k in range(NST - 1):
+            issued += [("dy", k, i) for i in range(4)]
+        done = lambda allowed: set(issued[:len(issued) - allowed])
+        if has_x:
+            assert all(("x", 0, i) in done(4 * (NST - 1)) for i in range(2))
+        for it in range(tiles):
+            assert all(("dy", it, i) in done(4 * (NST - 2)) for i in range(4)), (has_x, tiles, it)
+            if has_x:
+                issued += [("x", it + 1, i) for i in range(2)]
+            issued += [("dy", it + NST - 1, i) for i in range(4)]       # (past the last tile the kernel re-fetches the last one)
+            if has_x:
+                assert all(("x", it + 1, i) in done(4) for i in range(2)), (tiles, it)
