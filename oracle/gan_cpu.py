@@ -313,3 +313,93 @@ def adam_step(params, grads, state, lr, step, b1=0.0, b2=0.9, eps=1e-8):
             v.mul_(b2).addcmul_(g, g, value=1 - b2)
             denom = (v.sqrt() / math.sqrt(1 - b2 ** step)).add_(eps)
             p.addcdiv_(m, denom, value=-lr / (1 - b1 ** step))
+
+
+# ------------------------------------------------------------------------------------------------ bf16-faithful generator forward
+# TEST INFRASTRUCTURE like the rest of this file.  The HIP path keeps activations and GEMM weight views in bf16 (fp32 accumulation,
+# fp32 statistics, fp32 master weights): against the fp32 restatement above its outputs agree to a few 1e-3 -- bf16 noise through
+# ~30 layers, which hides any logic error smaller than that.  This variant rounds WHERE THE HIP PATH ROUNDS (2dimageto3dmodel_amd/
+# gan.py ResBlockUp.forward, csrc/gan_elem.hip k_affine_act, csrc/gan_glue.hip k_bn_finalize, conv.weight_prep), so that only the
+# summation order inside the convolutions and reductions is left between the two: module-level agreement an order of magnitude
+# tighter (tests/test_gan_modules.py::test_generator_forward_vs_bf16_faithful_oracle).
+def _r(t):
+    return t.bfloat16().float()
+
+
+def _fma(x, a, b):
+    """x * a + b rounded once (the kernels' fused multiply-add), via fp64"""
+    return (x.double() * a.double() + b.double()).float()
+
+
+def _conv_bf16(w, name, x, k, mode, training):
+    """bf16 operands, fp32 accumulation: -> the fp32 results (the caller rounds them where the kernel's epilogue does)"""
+    c = w.sub(name)
+    ph = k // 2
+    return F.conv2d(pad_w(x, ph, mode), _r(sn_weight(c, "weight", training)), c["bias"] if c.has("bias") else None, padding=(ph, 0))
+
+
+def _cbn_act_bf16(w, name, y32, z, res=None, out_slope=1.0):
+    """k_bn_finalize + k_affine_act on a conv's fp32 results y32: batch statistics of the fp32 values (the conv epilogue's partial
+    sums), a = rstd (1 + gamma), b = beta - mean a; then on the bf16-rounded tensor: lrelu(fma(x, a, b)) -> bf16 [+ res -> bf16]
+    [-> lrelu(out_slope) -> bf16]"""
+    c = w.sub(name)
+    mean = y32.mean(dim=(0, 2, 3))
+    var = ((y32 * y32).mean(dim=(0, 2, 3)) - mean * mean).clamp_min(0.0)
+    rstd = torch.rsqrt(var + 1e-5)
+    gamma = F.linear(z, c["fc_gamma.weight"], c["fc_gamma.bias"])
+    beta = F.linear(z, c["fc_beta.weight"], c["fc_beta.bias"])
+    a = rstd[None, :] * (1.0 + gamma)
+    b = beta - mean[None, :] * a
+    t = _r(F.leaky_relu(_fma(_r(y32), a[:, :, None, None], b[:, :, None, None]), SLOPE))
+    if res is not None:
+        t = t + res
+        if out_slope != 1.0:
+            t = F.leaky_relu(_r(t), out_slope)
+        t = _r(t)
+    elif out_slope != 1.0:
+        t = _r(F.leaky_relu(t, out_slope))
+    return t
+
+
+def _res_block_up_bf16(w, name, x, sc_in, z, mode, training, out_slope=1.0):
+    """x: the block input at the block's resolution (already upsampled), sc_in: the same tensor BEFORE the upsample (the shortcut
+    conv runs there and is read through the upsample: identical values, one rounding)"""
+    b = w.sub(name)
+    up = (lambda t: F.interpolate(t, scale_factor=2, mode="nearest")) if sc_in.shape[2] != x.shape[2] else (lambda t: t)
+    sc = up(_r(_conv_bf16(b, "shortcut", sc_in, 1, "zero", training))) if b.has("shortcut.weight_orig") else up(sc_in)
+    h = _cbn_act_bf16(b, "norm1", _conv_bf16(b, "conv1", x, 3, mode, training), z)
+    return _cbn_act_bf16(b, "norm2", _conv_bf16(b, "conv2", h, 3, mode, training), z, sc, out_slope)
+
+
+@torch.no_grad()
+def generator_bf16(w, args, z, c=None, symmetric=True, training=True):
+    """Generator.forward with the HIP path's storage precision (class-conditional or unconditional, batch / syncbatch norm, no
+    text conditioning) -> (x_tex, x_mesh or None)"""
+    assert args.norm_g in ("batch", "syncbatch") and not args.conditional_text and training
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")
+    mode = "replicate" if symmetric else "circular"
+    if args.conditional_class:
+        parts = [z, F.embedding(c[:, 0], w["emb_class.weight"])]
+        if args.conditional_color:
+            parts.append(F.embedding(c[:, 1], w["emb_color.weight"]))
+        z = torch.cat(parts, dim=1)
+    x = _r(F.linear(z, w["fc.weight"], w["fc.bias"]).view(z.shape[0], -1, 8, 4 if symmetric else 8))
+    x = _res_block_up_bf16(w, "blk1", x, x, z, mode, training)
+    x = _res_block_up_bf16(w, "blk2", up(x), x, z, mode, training)
+    t = x
+    for name, res in (("blk3a", 256), ("blk3b", 512), ("blk3c", 1024)):
+        if args.texture_resolution >= res:
+            t = _res_block_up_bf16(w, name, up(t), t, z, mode, training)
+    t = _res_block_up_bf16(w, "blk4", up(t), t, z, mode, training)
+    t = _res_block_up_bf16(w, "blk5", up(t), t, z, mode, training)
+    t = _res_block_up_bf16(w, "blk6", up(t), t, z, mode, training, out_slope=SLOPE)
+    x_tex = torch.tanh(F.conv2d(pad_w(t, 2, mode), _r(w["conv_final.weight"]), w["conv_final.bias"], padding=(2, 0)))
+    x_mesh = None
+    if w.has("conv_mesh.weight"):
+        m = _res_block_up_bf16(w, "blk3_mesh", up(x), x, z, mode, training, out_slope=SLOPE)
+        x_mesh = poles(F.conv2d(pad_w(m, 2, mode), _r(w["conv_mesh.weight"]), w["conv_mesh.bias"], padding=(2, 0)))
+    if symmetric:
+        x_tex = symmetrize(x_tex)
+        if x_mesh is not None:
+            x_mesh = symmetrize(x_mesh)
+    return x_tex, x_mesh
