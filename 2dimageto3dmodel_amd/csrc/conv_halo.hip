@@ -146,7 +146,7 @@ __device__ __forceinline__ float lane_reduce32(const float (&v)[32], bool b1, bo
 template <int BN, int NW, int KS, int UPS, int MODE, int SUB = 1, int RES = 0, int PAIR = 0, int STATS = 0>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs a, unsigned xbytes, unsigned wbytes)
 {
-    static_assert(!STATS || (KS == 3 && SUB == 1 && !PAIR), "fused statistics: 3x3 forward");
+    static_assert(!STATS || SUB == 1, "fused statistics: 3x3 forward, 2x2 classes of the sub-pixel upsample conv");
     static_assert(SUB == 1 || (KS == 2 && !UPS), "stride-2 forward = 2x2 classes");
     static_assert(!PAIR || (BN == 128 && NW == 8 && KS == 2 && !UPS && SUB == 1 && !RES), "class pairs: 8-wave 2x2 class convs");
     constexpr int NC = SUB == 2 ? 4 : 1;  // classes accumulated into one output tile
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
         for (int j = 0; j < CJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int co = n0 + wn * 64 + 32 * j + 8 * g + 4 * half;
+                const int co = (PAIR ? 0 : n0 + wn * 64) + 32 * j + 8 * g + 4 * half;
                 bias_r[NW == 4 ? j : 0][g] = (a.bias && co < a.Cout) ? *reinterpret_cast<const float4 *>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
     }
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
             for (int j = 0; j < CJ; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int co = n0 + wn * 64 + 32 * j + 8 * g + 4 * half;
+                    const int co = (PAIR ? 0 : n0 + wn * 64) + 32 * j + 8 * g + 4 * half;   // (PAIR: both wave columns = channels 0..63)
                     const float4 b = NW == 4 ? bias_r[NW == 4 ? j : 0][g]
                                              : (co < a.Cout ? *reinterpret_cast<const float4 *>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f));
 #pragma unroll
@@ -787,8 +787,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                 float t = 0.0f;
 #pragma unroll
                 for (int m = 0; m < NW / WGN; ++m) t += red[((m * WGN + wave) * CJ + j) * 64 + lane];
-                const int ch = n0 + wave * 64 + 32 * j + 8 * (r >> 2) + 4 * half + (r & 3);
-                st_ptr[((size_t)bp * 2 + kind) * a.Cout + ch] = t;
+                // (classes: one block of PS rows per class; PAIR: the two wave columns are the two classes' SAME 64 channels)
+                const int ch = n0 + (PAIR ? 0 : wave * 64) + 32 * j + 8 * (r >> 2) + 4 * half + (r & 3);
+                const int row = bp + PS * (PAIR ? 2 * (int)blockIdx.y + wave : (a.ncls > 1 ? (int)blockIdx.y : 0));
+                st_ptr[((size_t)row * 2 + kind) * a.Cout + ch] = t;
             }
         }
     }
@@ -811,13 +813,18 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
 //         the tile's pixels (both add their partial sums atomically).
 // TH x 32-pixel tiles; NCO = 64-channel dy blocks per workgroup sharing one x halo.  The stride-2 classes run TH 4, NCO 1
 // with two workgroups per CU (see wgrad_halo_launch).
-template <int KS, int UPS, int MODE, int TH = 8, int NCO = 1, bool DET = false>
+// UPC: one output-parity class (blockIdx.z = 2p+q) of "nearest x2 upsample -> 3x3 conv" in its sub-pixel form (conv_mfma.hip
+//         `subpixel`): dE[co][2a+p][2b+q][ci] = sum_o dy[2o + (p,q)][co] * xpad[o + (a,b) - (1-p, 1-q)][ci] -- the same 2x2 all-taps
+//         problem with the roles of the strides swapped: the x halo is a plain window of the STORED tensor (W pad by MODE), the
+//         dy tile is addressed with pixel stride 2.  dw = the 16-entry effective gradient (KH = KW = 4), folded by k_up16_to_9.
+template <int KS, int UPS, int MODE, int TH = 8, int NCO = 1, bool DET = false, bool UPC = false>
 __global__ __launch_bounds__(512, (TH == 4 && NCO == 1) ? 4 : 2) void k_wgrad_halo(WgradArgs a, unsigned xbytes, unsigned ybytes)
 {
     constexpr int TW = 32, T = KS * KS, NW = 8;
     static_assert(TH == 8 || (TH == 4 && KS == 2), "4-row tiles: class kernels only");
+    static_assert(!UPC || (KS == 2 && !UPS), "sub-pixel classes: 2x2");
     constexpr int NT = KS == 3 ? 5 : 4;                  // accumulators per wave
-    constexpr int SUB = KS == 2 ? 2 : 1;                 // input pixel stride of the plane
+    constexpr int SUB = (KS == 2 && !UPC) ? 2 : 1;       // input pixel stride of the plane
     constexpr int HH = UPS ? TH / 2 + 2 : TH + KS - 1, HWD = UPS ? TW / 2 + 2 : TW + KS - 1, HR = HH * HWD;
     constexpr int NAX = ((HR + 7) / 8 + NW - 1) / NW;   // x-halo DMA slots per wave
     constexpr int NAY = TH / 2;                          // dy block: TH*4 instructions / 8 waves
@@ -865,8 +872,8 @@ __global__ __launch_bounds__(512, (TH == 4 && NCO == 1) ? 4 : 2) void k_wgrad_ha
         }
         unsigned char *dX = lds + buf * STAGE, *dY = dX + XBUF;
         // plane coordinates of halo pixel (0,0); image pixel = SUB * plane + class offset - pad
-        const int Y0 = UPS ? (oy0 - a.pad_h) >> 1 : (SUB == 2 ? oy0 : oy0 - a.pad_h);
-        const int X0 = UPS ? (ox0 - a.pad_w) >> 1 : (SUB == 2 ? ox0 : ox0 - a.pad_w);
+        const int Y0 = UPS ? (oy0 - a.pad_h) >> 1 : (SUB == 2 ? oy0 : (UPC ? oy0 - (1 - cp) : oy0 - a.pad_h));
+        const int X0 = UPS ? (ox0 - a.pad_w) >> 1 : (SUB == 2 ? ox0 : (UPC ? ox0 - (1 - cq) : ox0 - a.pad_w));
 #pragma unroll
         for (int k = 0; k < NAX; ++k) {
             const int rho = 8 * (NW * k + wave) + (lane >> 3);
@@ -885,8 +892,8 @@ __global__ __launch_bounds__(512, (TH == 4 && NCO == 1) ? 4 : 2) void k_wgrad_ha
             for (int k = 0; k < NAY; ++k) {
                 const int p = 8 * (NW * k + wave) + (lane >> 3);  // tile pixel = (p >> 5, p & 31)
                 const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
-                dma16(ry, dY + c * YB1 + (NW * k + wave) * 1024,
-                      (unsigned)((((n * a.Ho + oy) * a.Wo + ox) * a.Cy + co0 + 64 * c) * 2 + csrc * 16), 0u);
+                const unsigned pix = UPC ? (unsigned)((n * 2 * a.Ho + 2 * oy + cp) * 2 * a.Wo + 2 * ox + cq) : (unsigned)((n * a.Ho + oy) * a.Wo + ox);
+                dma16(ry, dY + c * YB1 + (NW * k + wave) * 1024, (pix * a.Cy + co0 + 64 * c) * 2 + csrc * 16, 0u);
             }
     };
 
@@ -921,7 +928,8 @@ __global__ __launch_bounds__(512, (TH == 4 && NCO == 1) ? 4 : 2) void k_wgrad_ha
 
     // bias gradient (column sums of dy) by the workgroups of the first ci tile / class: thread -> channel tid % 64 (of
     // every co block), pixels (TH*4) (tid / 64) .. of every tile
-    const bool do_db = a.db != nullptr && (blockIdx.y % nci) == 0 && blockIdx.z == 0;
+    // (UPC: every class sees its own quarter of the dy pixels)
+    const bool do_db = a.db != nullptr && (blockIdx.y % nci) == 0 && (UPC || blockIdx.z == 0);
     const int dbc = tid & 63, dbq = tid >> 6;
     float dbacc[NCO] = {};
 
@@ -1063,6 +1071,33 @@ int wgrad_halo_launch(const WgradArgs &a, unsigned xb, unsigned yb, hipStream_t 
     return check_launch("conv2d_wgrad (halo)");
 }
 
+// the four sub-pixel classes of an upsample + 3x3 layer (a.H x a.W = the stored extent = the class grid; dy is [N, 2H, 2W, Cy];
+// a.dw / a.fix = the 16-entry effective gradient): 4 x 32-pixel tiles, two workgroups per CU, as the stride-2 classes
+int wgrad_halo_up_launch(const WgradArgs &a, unsigned xb, unsigned yb, hipStream_t st)
+{
+    if (a.Cin % 64 || a.Cy % 64 || a.Wo % 32 || a.Ho % 4 || a.KH != 4 || a.KW != 4) {
+        set_error("conv2d_wgrad (sub-pixel classes): shape not eligible");
+        return M355_ERR_BAD_ARG;
+    }
+    const int tiles = a.N * (a.Ho / 4) * (a.Wo / 32);
+    const int ny = ((a.Cout + 63) / 64) * (a.Cin / 64);
+    int per = 512 / (ny * 4);
+    if (per < 1) per = 1;
+    if (per > tiles) per = tiles;
+    const dim3 grid(per, ny, 4);
+#define M355_WU(MD_)                                                                                                   \
+    do {                                                                                                               \
+        if (a.fix) hipLaunchKernelGGL((k_wgrad_halo<2, 0, MD_, 4, 1, true, true>), grid, dim3(512), 0, st, a, xb, yb);  \
+        else hipLaunchKernelGGL((k_wgrad_halo<2, 0, MD_, 4, 1, false, true>), grid, dim3(512), 0, st, a, xb, yb);       \
+    } while (0)
+    if (a.pad_w_mode == 0) M355_WU(0);
+    else if (a.pad_w_mode == 1) M355_WU(1);
+    else M355_WU(2);
+#undef M355_WU
+    note_kernel("k_wgrad_halo");
+    return check_launch("conv2d_wgrad (halo, sub-pixel classes)");
+}
+
 // =====================================================================================================
 // Replicate-pad adjoint for the DIRECT dgrad of the generator's 3x3 convs (F.pad(mode='replicate') on W, gan.py:329).
 //   xp = replicate_pad_W(up(x)),  y = conv3x3_valid_W(xp):   dL/d up(x) = conv_zero_same(dy, flipped w) + E,
@@ -1120,6 +1155,62 @@ __global__ __launch_bounds__(256) void k_dgrad_edge(const unsigned short *__rest
     }
 }
 
+// The same edge term for the SUB-PIXEL form of upsample + 3x3 (conv_mfma.hip `subpixel`), from the adjoint 4x4 view
+// w4[ci][kh][kw][co] = W4[3-kh][3-kw]: the pad column left of stored column 0 is read by output column 0 only, with the W-axis weight
+// w0 = W4[.][0] (kw = 3); the one right of column W-1 by output column 2W-1 with w2 = W4[.][3] (kw = 0):
+//   E[h][0]   = sum_{kh, co} dy[2h-1+kh][0]    * w4[ci][kh][3][co],     E[h][W-1] = sum_{kh, co} dy[2h-1+kh][2W-1] * w4[ci][kh][0][co]
+// Four row taps instead of the six of the 9-tap form; same GEMM shape and lane roles as k_dgrad_edge.
+__global__ __launch_bounds__(256) void k_dgrad_edge_up4(const unsigned short *__restrict__ dy, const unsigned short *__restrict__ w4,
+                                                        unsigned short *__restrict__ dx, int N, int H, int W, int Cy, int Cin, int Kp)
+{
+    const int Hl = 2 * H, Wl = 2 * W;
+    const int edge = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    const int m = blockIdx.x * 32 + (lane & 31);
+    const bool mok = m < N * H;
+    const int n = mok ? m / H : 0, h = mok ? m - n * H : 0;
+    const int col = edge ? Wl - 1 : 0, kw4 = edge ? 0 : 3;
+    const bf16x8 zero = {};
+    for (int ct = wave; ct * 32 < Cin; ct += 4) {
+        const unsigned short *wrow = w4 + (size_t)(ct * 32 + (lane & 31)) * Kp + kw4 * Cy + 8 * half;  // rows padded to 64
+        f32x16 acc = {};
+        for (int kh = 0; kh < 4; ++kh) {
+            const int hl = 2 * h - 1 + kh;
+            const bool ok = mok && (unsigned)hl < (unsigned)Hl;
+            const unsigned short *src = dy + (((size_t)n * Hl + (ok ? hl : 0)) * Wl + col) * Cy + 8 * half;
+            const unsigned short *wk = wrow + kh * 4 * Cy;
+#pragma unroll 4
+            for (int c = 0; c < Cy; c += 16) {
+                const bf16x8 pf = ok ? *reinterpret_cast<const bf16x8 *>(src + c) : zero;
+                const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(wk + c);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, pf, acc, 0, 0, 0);
+            }
+        }
+        // acc[r] = channel 32ct + 8(r>>2) + 4half + (r&3) of pixel lane&31
+        if (mok) {
+            unsigned short *o = dx + (((size_t)n * H + h) * W + (edge ? W - 1 : 0)) * Cin;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ci = ct * 32 + 8 * g + 4 * half;
+                if (ci < Cin) {
+                    uint2 *p = reinterpret_cast<uint2 *>(o + ci);
+                    const uint2 old = *p;
+                    uint2 nw;
+                    nw.x = pack_bf16(__uint_as_float(old.x << 16) + acc[4 * g], __uint_as_float(old.x & 0xffff0000u) + acc[4 * g + 1]);
+                    nw.y = pack_bf16(__uint_as_float(old.y << 16) + acc[4 * g + 2], __uint_as_float(old.y & 0xffff0000u) + acc[4 * g + 3]);
+                    *p = nw;
+                }
+            }
+        }
+    }
+}
+
+int dgrad_edge_up4_launch(const m355_conv_desc *d, const void *dy, int Cy, const void *w4, int Kp, void *dx, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_dgrad_edge_up4, dim3((d->N * d->H + 31) / 32, 2), dim3(256), 0, st, (const unsigned short *)dy,
+                       (const unsigned short *)w4, (unsigned short *)dx, d->N, d->H, d->W, Cy, d->Cin, Kp);
+    return check_launch("conv2d_dgrad (sub-pixel edge term)");
+}
+
 // host side (called from launch_conv, conv_mfma.hip)
 bool conv_halo_eligible(const ConvArgs &a)
 {
@@ -1160,14 +1251,40 @@ static int halo_grid_per(const ConvArgs &a)
 
 // rows of partial sums a forward with fused batch-norm statistics writes (0: this problem has none -- the kernel that runs it
 // must be k_conv_halo with the plain unguarded epilogue, one class, whole 64-channel groups)
+// class pairs (see k_conv_halo PAIR): 2x2 class convs with 64 output channels -- the classes of a stride-2 dgrad with 64 input
+// channels (D.conv2), of a sub-pixel upsample conv with 64 output channels (G.blk6.conv1)
+static bool halo_pair(const ConvArgs &a)
+{
+    return a.ncls == 4 && a.CoutP == 64 && a.Cout == 64 && a.stride == 1 && a.KH == 2 && a.KW == 2 && !a.ups && !a.fold2 &&
+           a.cpad_h[0] == a.cpad_h[1] && a.cpad_h[2] == a.cpad_h[3] && a.coy[0] == a.coy[1] && a.coy[2] == a.coy[3] &&
+           !getenv("M355_NO_HALO_PAIR");
+}
+static int halo_pair_per(const ConvArgs &a)   // workgroups along the pixel-tile axis of the PAIR launch (x 2 row parities)
+{
+    const int tiles = a.N * (a.Ho / 8) * (a.Wo / 32);
+    const char *wgs = getenv("M355_HALO_WGS");
+    int pp = (wgs ? atoi(wgs) : 256) / 2;
+    if (pp < 1) pp = 1;
+    if (pp > tiles) pp = tiles;
+    return (tiles + (tiles + pp - 1) / pp - 1) / ((tiles + pp - 1) / pp);
+}
+
 int conv_halo_stats_rows(const ConvArgs &a)
 {
-    if (!conv_halo_eligible(a) || a.KH != 3 || a.ncls != 1 || a.stride != 1 || a.fold2 || a.Cout != a.CoutP || a.slope != 1.0f || a.mask_x ||
+    if (!conv_halo_eligible(a) || a.stride != 1 || a.fold2 || a.Cout != a.CoutP || a.slope != 1.0f || a.mask_x ||
         a.bits_in || a.bits_out || a.y_f32_nchw || getenv("M355_NO_CONV_STATS"))
         return 0;
     ConvArgs b = a;
     b.stats = reinterpret_cast<float *>(1);
-    return halo_grid_per(b);
+    if (a.KH == 3 && a.ncls == 1) return halo_grid_per(b);
+    // the four 2x2 classes of a sub-pixel upsample conv: one block of rows per class (8-wave variants only: 64 output channels run
+    // as class pairs; the 4-wave / resident-panel class kernels carry no statistics code)
+    if (a.KH == 2 && a.ncls == 4 && !a.ups && !getenv("M355_NO_CLASS_STATS")) {
+        if (halo_pair(a)) return 4 * halo_pair_per(a);
+        if (a.CoutP == 64) return 0;
+        return 4 * halo_grid_per(b);
+    }
+    return 0;
 }
 
 // (Two alternative kernels for the 8-wave 2x2 class families were built in round 3 -- pairs of pixel tiles on one weight ring,
@@ -1192,6 +1309,8 @@ int conv_halo_launch(const ConvArgs &a_in, unsigned xb, unsigned wb, hipStream_t
     do {                                                                                                                       \
         if (KS_ == 3 && a.stats)                                                                                               \
             hipLaunchKernelGGL((k_conv_halo<BN_, NW_, 3, UPS_, MD_, 1, 0, 0, 1>), grid, dim3(NW_ * 64), 0, st, a, xb, wb);      \
+        else if (KS_ == 2 && NW_ == 8 && a.stats)   /* sub-pixel classes with >= 128 output channels (conv_halo_stats_rows) */  \
+            hipLaunchKernelGGL((k_conv_halo<128, 8, 2, 0, MD_, 1, 0, 0, 1>), grid, dim3(512), 0, st, a, xb, wb);               \
         else hipLaunchKernelGGL((k_conv_halo<BN_, NW_, KS_, UPS_, MD_>), grid, dim3(NW_ * 64), 0, st, a, xb, wb);              \
     } while (0)
 #define M355_HM(BN_, NW_, KS_, UPS_)                                   \
@@ -1214,19 +1333,18 @@ int conv_halo_launch(const ConvArgs &a_in, unsigned xb, unsigned wb, hipStream_t
         else M355_HM(BN_, NW_, 3, 0);                                  \
     } while (0)
     // class pairs (see k_conv_halo PAIR): the 2x2 class convs of a stride-2 dgrad with 64 input channels
-    const bool pair = a.ncls == 4 && a.CoutP == 64 && a.Cout == 64 && a.stride == 1 && a.KH == 2 && a.KW == 2 && !a.ups && !a.fold2 &&
-                      !a.bias && a.cpad_h[0] == a.cpad_h[1] && a.cpad_h[2] == a.cpad_h[3] && a.coy[0] == a.coy[1] &&
-                      a.coy[2] == a.coy[3] && !getenv("M355_NO_HALO_PAIR");
-    if (pair) {
-        int pp = (wgs ? atoi(wgs) : 256) / 2;
-        if (pp < 1) pp = 1;
-        if (pp > tiles) pp = tiles;
-        pp = (tiles + (tiles + pp - 1) / pp - 1) / ((tiles + pp - 1) / pp);
-        const dim3 gridp((unsigned)pp, 2);
+    if (halo_pair(a)) {
+        const dim3 gridp((unsigned)halo_pair_per(a), 2);
         const unsigned wb2 = 2u * a.cls_w_elems * 2u;   // the resource spans the two classes of a pair
-        if (a.pad_w_mode == 0) hipLaunchKernelGGL((k_conv_halo<128, 8, 2, 0, 0, 1, 0, 1>), gridp, dim3(512), 0, st, a, xb, wb2);
-        else if (a.pad_w_mode == 1) hipLaunchKernelGGL((k_conv_halo<128, 8, 2, 0, 1, 1, 0, 1>), gridp, dim3(512), 0, st, a, xb, wb2);
-        else hipLaunchKernelGGL((k_conv_halo<128, 8, 2, 0, 2, 1, 0, 1>), gridp, dim3(512), 0, st, a, xb, wb2);
+#define M355_HP(MD_)                                                                                                              \
+    do {                                                                                                                          \
+        if (a.stats) hipLaunchKernelGGL((k_conv_halo<128, 8, 2, 0, MD_, 1, 0, 1, 1>), gridp, dim3(512), 0, st, a, xb, wb2);         \
+        else hipLaunchKernelGGL((k_conv_halo<128, 8, 2, 0, MD_, 1, 0, 1>), gridp, dim3(512), 0, st, a, xb, wb2);                    \
+    } while (0)
+        if (a.pad_w_mode == 0) M355_HP(0);
+        else if (a.pad_w_mode == 1) M355_HP(1);
+        else M355_HP(2);
+#undef M355_HP
         note_kernel("k_conv_halo");
         return check_launch("conv2d (halo, class pairs)");
     }

@@ -445,15 +445,21 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void k_conv_glds(ConvArgs
 //   transpose == 0:  out[o][a][b][i] = in[o][i][th0+ths*a][tw0+tws*b]        (forward)
 //   transpose == 1:  out[i][a][b][o] = in[o][i][th0+ths*a][tw0+tws*b]        (dgrad: flipped taps, swapped roles)
 // rows/channels beyond the real extents are zero filled.
+//   eff == 1: (th, tw) index the EFFECTIVE 4x4 kernel of "nearest x2 upsample -> 3x3 conv" on the low-res tensor,
+//             W4[eh][ew] = sum of in[..][kh][kw] over kh in {eh-1, eh}, kw in {ew-1, ew} (inside the 3x3), summed in fp32 (after the
+//             1/sigma scaling) and rounded to bf16 once: the sub-pixel form's four 2x2 class kernels are W4[2a+p][2b+q], the
+//             adjoint stride-2 conv's kernel is W4[3-kh][3-kw] (conv_fwd_impl / conv_dgrad_impl, `subpixel`)
 struct WeightPrepPart {
     unsigned short *out;
-    int transpose, A, B, th0, ths, tw0, tws, Rp, Cp, Kp;
+    int transpose, A, B, th0, ths, tw0, tws, Rp, Cp, Kp, eff;
 };
 struct WeightPrepArgs {
     const float *in;
     const float *sigma;
     int O, I, KH, KW, nparts;
-    WeightPrepPart part[5];  // forward view + the dgrad view (stride 1) or its four parity classes (stride 2)
+    WeightPrepPart part[8];  // forward view + the dgrad view (stride 1) or its four parity classes (stride 2); upsample + 3x3 layers:
+                             // + the four sub-pixel class views and the 4x4 adjoint view
+
     int tiled, OP, IP;       // k_weight_prep_tiled takes this layer: 32 x 32 (o, i) tiles over [0, OP) x [0, IP)
 };
 // one launch for all views of a layer: blockIdx.y = view
@@ -518,11 +524,21 @@ __global__ __launch_bounds__(256) void k_weight_prep_tiled(const WeightPrepArgs 
             const int aa = ab / p.B, b = ab - aa * p.B;
             const int th = p.th0 + p.ths * aa, tw = p.tw0 + p.tws * b;
             bf16x8 o8 = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (th >= 0 && tw >= 0 && th < w.KH && tw < w.KW) {
-                const int tap = th * w.KW + tw;
-                // forward: row = o (rl), channels i = 8 g8 ..; dgrad: row = i (rl), channels o = 8 g8 ..
-                const float *t0 = p.transpose ? tile + (8 * g8) * RS + rl * T + tap : tile + rl * RS + (8 * g8) * T + tap;
-                const int st = p.transpose ? RS : T;
+            // forward: row = o (rl), channels i = 8 g8 ..; dgrad: row = i (rl), channels o = 8 g8 ..
+            const float *tb = p.transpose ? tile + (8 * g8) * RS + rl * T : tile + rl * RS + (8 * g8) * T;
+            const int st = p.transpose ? RS : T;
+            if (p.eff) {   // effective 4x4 kernel of upsample + 3x3: up to four source taps per entry, summed in fp32
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int kh = max(th - 1, 0); kh <= min(th, w.KH - 1); ++kh)
+                    for (int kw = max(tw - 1, 0); kw <= min(tw, w.KW - 1); ++kw) {
+                        const float *t0 = tb + kh * w.KW + kw;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += t0[j * st];
+                    }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o8[j] = (short)f2bf(v[j]);
+            } else if (th >= 0 && tw >= 0 && th < w.KH && tw < w.KW) {
+                const float *t0 = tb + th * w.KW + tw;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o8[j] = (short)f2bf(t0[j * st]);
             }
@@ -550,12 +566,21 @@ __device__ __forceinline__ void weight_prep_body(const WeightPrepArgs &w)
         if (t < AB) {
             const unsigned aa = t / (unsigned)B, b = t - aa * (unsigned)B;
             const int th = p.th0 + p.ths * (int)aa, tw = p.tw0 + p.tws * (int)b;
-            if (th >= 0 && tw >= 0 && th < KH && tw < KW) {
-                // element (o, i): forward rows are o and the eight channels are i = c ..; dgrad rows are i and the channels o = c ..
-                const int nr = transpose ? I : O, nc = transpose ? O : I;
+            // element (o, i): forward rows are o and the eight channels are i = c ..; dgrad rows are i and the channels o = c ..
+            const int nr = transpose ? I : O, nc = transpose ? O : I;
+            const size_t sc = transpose ? sO : sI;
+            if (p.eff) {   // effective 4x4 kernel of upsample + 3x3 (see WeightPrepPart): same fp32 sum order as the tiled kernel
+                if ((int)r < nr)
+                    for (int kh = max(th - 1, 0); kh <= min(th, KH - 1); ++kh)
+                        for (int kw = max(tw - 1, 0); kw <= min(tw, KW - 1); ++kw) {
+                            const float *src = in + (transpose ? (size_t)r * sI : (size_t)r * sO) + (size_t)kh * KW + kw;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if ((int)c + j < nc) v[j] += src[(size_t)(c + j) * sc] * wscale;
+                        }
+            } else if (th >= 0 && tw >= 0 && th < KH && tw < KW) {
                 if ((int)r < nr) {
                     const float *src = in + (transpose ? (size_t)r * sI : (size_t)r * sO) + (size_t)th * KW + tw;
-                    const size_t sc = transpose ? sO : sI;
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
                         if ((int)c + j < nc) v[j] = src[(size_t)(c + j) * sc] * wscale;
@@ -688,6 +713,8 @@ int dgrad_direct_replicate_launch(const m355_conv_desc *d, const void *dy, int C
                                   void *dx, hipStream_t st);
 bool wgrad_halo_eligible(const WgradArgs &a);  // csrc/conv_halo.hip
 int wgrad_halo_launch(const WgradArgs &a, unsigned xb, unsigned yb, hipStream_t st);
+int wgrad_halo_up_launch(const WgradArgs &a, unsigned xb, unsigned yb, hipStream_t st);   // sub-pixel classes of upsample + 3x3
+int dgrad_edge_up4_launch(const m355_conv_desc *d, const void *dy, int Cy, const void *w4, int Kp, void *dx, hipStream_t st);
 
 static bool dma_eligible(const ConvArgs &a)
 {
@@ -883,6 +910,33 @@ extern "C" int m355_fold2x2(const void *g, void *dx, int N, int H, int W, int C,
 
 extern "C" int m355_conv2d_dy_channels(int cout) { return m355::dy_channels(cout); }
 
+// ---- "nearest x2 upsample -> 3x3 stride-1 conv" (models/gan.py:319,386-404 `self.up` in front of ResBlockUp.conv1 :294,309) in its
+// SUB-PIXEL form.  Output pixel (2i+p, 2j+q) reads the upsampled rows 2i+p-1 .. 2i+p+1 = the stored rows {i-1, i, i} (p = 0) or
+// {i, i, i+1} (p = 1): per output parity class the conv is a 2x2 stride-1 conv of the STORED tensor with pre-summed weights
+// (w0, w1+w2) / (w0+w1, w2) per axis -- 4 taps instead of 9, exactly (the zero H pad and the replicate / circular W pad of the
+// upsampled tensor are the same pads of the stored one).  Forward = four class convs (the launch shape of a stride-2 dgrad),
+// dgrad = the adjoint 4x4 stride-2 conv of dy (+ the replicate pad columns' edge term), wgrad = per class the 2x2 all-taps problem
+// into a 16-entry effective gradient, folded onto the 3x3 taps by the adjoint of the pre-sum.  `up3`: the layers whose weight
+// buffers carry the extra views (a property of the layer, not of the image size: the views are prepared once per network);
+// `subpixel`: ... and whose shape runs on the halo kernels in that form.
+static bool up3(const m355_conv_desc *d)
+{
+    return d->upsample == 1 && d->stride == 1 && d->kh == 3 && d->kw == 3 && d->pad_h == 1 && d->pad_w == 1;
+}
+static bool subpixel(const m355_conv_desc *d)
+{
+    if (!up3(d) || d->Cin % 64 || d->Cout % 64 || d->W % 32 || d->H % 8) return false;
+    const size_t xb = (size_t)d->N * d->H * d->W * d->Cin * 2, yb = (size_t)d->N * d->H * d->W * 4 * d->Cout * 2;
+    static const bool off = getenv("M355_NO_SUBPIXEL") != nullptr;   // A/B runs: the 9-tap kernels with the upsample in the halo load
+    return xb < (1ull << 31) && yb < (1ull << 31) && !off;
+}
+// element offsets of the sub-pixel views inside the forward / dgrad weight buffers of an up3 layer (behind the 3x3 views)
+static size_t up3_fwd_off(const m355_conv_desc *d) { return (size_t)m355::rows_padded(d->Cout) * m355::k_padded(9 * d->Cin); }
+static size_t up3_dgrad_off(const m355_conv_desc *d)
+{
+    return (size_t)m355::rows_padded(d->Cin) * m355::k_padded(9 * m355::dy_channels(d->Cout));
+}
+
 extern "C" size_t m355_conv2d_weight_elems(const m355_conv_desc *d, int which)
 {
     // which 0: forward view [rows_padded(Cout)][ceil64(kh*kw*Cin)]; 1: dgrad views (stride 1: one
@@ -890,6 +944,10 @@ extern "C" size_t m355_conv2d_weight_elems(const m355_conv_desc *d, int which)
     if (!d) return 0;
     const size_t rows_f = m355::rows_padded(d->Cout), rows_d = m355::rows_padded(d->Cin);
     const size_t cout32 = (size_t)m355::dy_channels(d->Cout);
+    if (up3(d)) {   // + the four sub-pixel class views [rows_f][ceil64(4 Cin)] / the adjoint 4x4 view [rows_d][ceil64(16 Cout_p32)]
+        if (which == 0) return up3_fwd_off(d) + 4 * rows_f * (size_t)m355::k_padded(4 * d->Cin);
+        return up3_dgrad_off(d) + rows_d * (size_t)m355::k_padded(16 * (int)cout32);
+    }
     if (which == 0) return rows_f * (size_t)m355::k_padded(d->kh * d->kw * d->Cin);
     if (d->stride == 1) return rows_d * (size_t)m355::k_padded(d->kh * d->kw * (int)cout32);
     return 4 * rows_d * (size_t)m355::k_padded(((d->kh + 1) / 2) * ((d->kw + 1) / 2) * (int)cout32);  // four parity-class views
@@ -904,9 +962,10 @@ static int fill_weight_prep(const m355_conv_desc *d, const float *w_oihw, int ci
     w.in = w_oihw; w.sigma = sigma; w.O = d->Cout; w.I = cin_w; w.KH = d->kh; w.KW = d->kw;
     most = 0;
     bool ok = true;
-    auto add = [&](unsigned short *out, int transpose, int A, int B, int th0, int ths, int tw0, int tws, int Rp, int Cp, int Kp) {
+    auto add = [&](unsigned short *out, int transpose, int A, int B, int th0, int ths, int tw0, int tws, int Rp, int Cp, int Kp,
+                   int eff = 0) {
         ok = ok && Cp % 8 == 0 && Kp % 8 == 0 && (size_t)Rp * Kp < (1ull << 31);   // (the kernel writes 8 channels of one tap at a time)
-        w.part[w.nparts++] = m355::WeightPrepPart{out, transpose, A, B, th0, ths, tw0, tws, Rp, Cp, Kp};
+        w.part[w.nparts++] = m355::WeightPrepPart{out, transpose, A, B, th0, ths, tw0, tws, Rp, Cp, Kp, eff};
         if ((size_t)Rp * Kp > most) most = (size_t)Rp * Kp;
     };
     if (w_fwd) add((unsigned short *)w_fwd, 0, d->kh, d->kw, 0, 1, 0, 1, cout64, d->Cin, m355::k_padded(d->kh * d->kw * d->Cin));
@@ -925,6 +984,15 @@ static int fill_weight_prep(const m355_conv_desc *d, const float *w_oihw, int ci
                     add((unsigned short *)w_dgrad + (size_t)(py * 2 + px) * each, 1, A, B, py + 2 * (A - 1), -2, px + 2 * (B - 1), -2,
                         cin64, cout32, Kp);
         }
+    }
+    if (up3(d)) {   // sub-pixel views (see `subpixel`): class (p, q) tap (a, b) = W4[2a+p][2b+q]; adjoint tap (kh, kw) = W4[3-kh][3-kw]
+        if (w_fwd) {
+            const int Kp = m355::k_padded(4 * d->Cin);
+            for (int c = 0; c < 4; ++c)
+                add((unsigned short *)w_fwd + up3_fwd_off(d) + (size_t)c * cout64 * Kp, 0, 2, 2, c >> 1, 2, c & 1, 2, cout64, d->Cin, Kp, 1);
+        }
+        if (w_dgrad)
+            add((unsigned short *)w_dgrad + up3_dgrad_off(d), 1, 4, 4, 3, -1, 3, -1, cin64, cout32, m355::k_padded(16 * cout32), 1);
     }
     if (!ok) {
         m355::set_error("conv2d_weight_prep: channel counts must be multiples of 8 (Cin=%d, dy channels=%d)", d->Cin, cout32);
@@ -982,7 +1050,7 @@ extern "C" int m355_weight_prep_batched(const void *table_dev, int L, long long 
 {
     M355_REQUIRE(table_dev && L > 0 && L <= 65535 && max_elems > 0, "weight_prep_batched: bad argument");
     const unsigned bx = (unsigned)((max_elems + 255) / 256 > 256 ? 256 : (max_elems + 255) / 256);
-    hipLaunchKernelGGL(m355::k_weight_prep_batched, dim3(bx, 5, L), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(m355::k_weight_prep_batched, dim3(bx, 8, L), dim3(256), 0, (hipStream_t)stream,
                        (const m355::WeightPrepArgs *)table_dev, 0);
     return m355::check_launch("weight_prep_batched");
 }
@@ -1013,7 +1081,7 @@ extern "C" int m355_weight_prep_batched_tiled(const void *table_dev, int L, long
                            (const m355::WeightPrepArgs *)table_dev);
     if (max_elems > 0) {
         const unsigned bx = (unsigned)((max_elems + 255) / 256 > 256 ? 256 : (max_elems + 255) / 256);
-        hipLaunchKernelGGL(m355::k_weight_prep_batched, dim3(bx, 5, L), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(m355::k_weight_prep_batched, dim3(bx, 8, L), dim3(256), 0, (hipStream_t)stream,
                            (const m355::WeightPrepArgs *)table_dev, 1);
     }
     return m355::check_launch("weight_prep_batched");
@@ -1063,10 +1131,24 @@ static int conv_fwd_impl(const m355_conv_desc *d, const void *x, const void *w_f
     a.Kp = m355::k_padded(d->kh * d->kw * d->Cin);
     a.slope = lrelu_slope;
     a.bits_out = bits_out;
+    if (!y_f32_nchw && !bits_out && probe != 1 && subpixel(d)) {
+        // sub-pixel form: four 2x2 class convs of the STORED tensor, class (p, q) writing the output pixels (2i+p, 2j+q)
+        a.w = w_fwd ? (const unsigned short *)w_fwd + up3_fwd_off(d) : nullptr;
+        a.ups = 0; a.Hl = d->H; a.Wl = d->W;
+        a.Ho = d->H; a.Wo = d->W; a.OH = 2 * d->H; a.OW = 2 * d->W; a.oy_mul = a.ox_mul = 2;
+        a.KH = a.KW = 2; a.pad_h = a.pad_w = 1;
+        a.Kp = m355::k_padded(4 * d->Cin);
+        a.ncls = 4;
+        a.cls_w_elems = (unsigned)((size_t)m355::rows_padded(d->Cout) * a.Kp);
+        for (int c = 0; c < 4; ++c) {
+            a.cpad_h[c] = 1 - (c >> 1); a.cpad_w[c] = 1 - (c & 1);
+            a.coy[c] = c >> 1; a.cox[c] = c & 1;
+        }
+    }
     if (probe == 2 || stats) {
         ConvArgs b = a;
         b.CoutP = m355::rows_padded(b.Cout);
-        b.ncls = 1;
+        if (b.ncls < 1) b.ncls = 1;
         const char *h = getenv("M355_CONV_HALO");
         const int rows = (m355::dma_eligible(b) && !(h && h[0] == '0')) ? m355::conv_halo_stats_rows(b) : 0;
         if (probe) return rows;
@@ -1194,6 +1276,7 @@ static bool dgrad_direct(const m355_conv_desc *d)
 {
     int Ho, Wo;
     if (conv_out_hw(d, &Ho, &Wo) != 0) return false;
+    if (subpixel(d)) return true;
     const int cy = m355::dy_channels(d->Cout);
     ConvArgs a = {};
     a.N = d->N; a.H = Ho; a.W = Wo; a.Cin = cy; a.Cout = d->Cin; a.Cs = d->Cin;
@@ -1231,6 +1314,24 @@ static int conv_dgrad_impl(const m355_conv_desc *d, const void *dy, const void *
     // the padding is an index map on dy -- a circularly padded conv's dgrad is a circular conv of dy.
     a.Kp = m355::k_padded((d->stride == 1 ? d->kh * d->kw : ((d->kh + 1) / 2) * ((d->kw + 1) / 2)) * cout32);
     const bool direct = dgrad_direct(d);
+    if (subpixel(d)) {
+        // upsample + 3x3 in the sub-pixel form: dx = the adjoint 4x4 stride-2 conv of dy (kernel W4[3-kh][3-kw], pad 1) on the
+        // stride-2 forward variant of k_conv_halo; a circular W pad of x is a circular pad of dy, a replicate pad adds the
+        // gradient of the two pad columns to the first / last column of dx (k_dgrad_edge)
+        if (probe) return 0;
+        M355_REQUIRE(!mask_x && !mask_bits, "conv2d_dgrad: no fused activation backward on the sub-pixel form");
+        a.x = (const unsigned short *)dy;
+        a.w = (const unsigned short *)w_dgrad + up3_dgrad_off(d);
+        a.y = dx;
+        a.H = Ho; a.W = Wo; a.Hl = Ho; a.Wl = Wo;
+        a.Ho = d->H; a.Wo = d->W; a.OH = d->H; a.OW = d->W; a.oy_mul = a.ox_mul = 1;
+        a.KH = a.KW = 4; a.stride = 2; a.pad_h = a.pad_w = 1;
+        a.pad_w_mode = d->pad_w_mode == 2 ? 2 : 0;
+        a.Kp = m355::k_padded(16 * cout32);
+        if (int rc = m355::launch_conv(a, st)) return rc;
+        if (d->pad_w_mode == 1) return m355::dgrad_edge_up4_launch(d, dy, cout32, a.w, a.Kp, dx, st);
+        return M355_OK;
+    }
     if (probe && (!direct || d->pad_w_mode == 1)) return 0;
     const bool c8rep = !mask_bits && m355::dgrad_c8_replicate_eligible(d, cout32);   // 5x5 heads of the symmetric generator
     M355_REQUIRE((!mask_x && !mask_bits) || direct || c8rep,
@@ -1356,7 +1457,7 @@ extern "C" int m355_conv2d_dgrad_mask_ok(const m355_conv_desc *d)
 {
     if (!d || check_desc(d, "conv2d_dgrad_mask_ok")) return 0;
     if (m355::dgrad_c8_replicate_eligible(d, m355::dy_channels(d->Cout))) return 1;
-    return dgrad_direct(d) && d->pad_w_mode != 1;
+    return dgrad_direct(d) && d->pad_w_mode != 1 && !subpixel(d);
 }
 
 /* role 0: can the forward of this layer (bf16 NHWC output, activation epilogue) write bit masks?
@@ -1702,12 +1803,75 @@ __global__ __launch_bounds__(256) void k_fix_to_f32(const long long *__restrict_
 }
 }  // namespace m355
 
+namespace m355 {
+// sub-pixel weight gradient (see `subpixel`): src = the 16-entry effective gradient dE[co][eh][ew][ci] (+ Cout bias sums behind it),
+// fp32 or -- DET -- the fixed-point cells behind the flag word; dw[co][kh][kw][ci] = sum of dE over eh in {kh, kh+1}, ew in
+// {kw, kw+1}: the adjoint of the weights' pre-sum W4[e] = w[e-1] + w[e].  DET adds the integers and rounds once.
+template <bool DET>
+__global__ __launch_bounds__(256) void k_up16_to_9(const void *__restrict__ src, float *__restrict__ dw, float *__restrict__ db,
+                                                   int Cout, int Cin)
+{
+    const float *sf = reinterpret_cast<const float *>(src);
+    const long long *sx = reinterpret_cast<const long long *>(src);
+    const bool bad = DET && sx[0] != 0;
+    const size_t n9 = (size_t)Cout * 9 * Cin, n16 = (size_t)Cout * 16 * Cin, total = n9 + (db ? (size_t)Cout : 0);
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        if (i >= n9) {
+            db[i - n9] = DET ? (bad ? __builtin_nanf("") : (float)((double)sx[1 + n16 + (i - n9)] * kFixInv)) : sf[n16 + (i - n9)];
+            continue;
+        }
+        const int ci = (int)(i % Cin);
+        const size_t t = i / Cin;
+        const int tap = (int)(t % 9), co = (int)(t / 9), kh = tap / 3, kw = tap - 3 * kh;
+        const size_t b = (((size_t)co * 4 + kh) * 4 + kw) * Cin + ci;   // entry (kh, kw); (kh+1, .) is 4 Cin further, (., kw+1) Cin
+        if (DET) {
+            const long long v = sx[1 + b] + sx[1 + b + Cin] + sx[1 + b + 4 * (size_t)Cin] + sx[1 + b + 5 * (size_t)Cin];
+            dw[i] = bad ? __builtin_nanf("") : (float)((double)v * kFixInv);
+        } else {
+            dw[i] = (sf[b] + sf[b + Cin]) + (sf[b + 4 * (size_t)Cin] + sf[b + 5 * (size_t)Cin]);
+        }
+    }
+}
+}  // namespace m355
+
+// ws of the sub-pixel weight gradient: fp32 (m355_conv2d_wgrad_ws) or fixed-point (m355_conv2d_wgrad_det) cells
+static size_t subpixel_ws_cells(const m355_conv_desc *d) { return (size_t)d->Cout * 16 * d->Cin + (size_t)d->Cout; }
+
+static int subpixel_wgrad(const m355_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias, void *ws, bool det,
+                          hipStream_t st)
+{
+    const size_t cells = subpixel_ws_cells(d), n16 = (size_t)d->Cout * 16 * d->Cin;
+    const size_t bytes = det ? sizeof(long long) * (1 + cells) : sizeof(float) * cells;
+    if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) {
+        m355::set_error("conv2d_wgrad (sub-pixel): memset failed");
+        return M355_ERR_LAUNCH;
+    }
+    m355::WgradArgs a = {};
+    a.x = (const unsigned short *)x;
+    a.dy = (const unsigned short *)dy;
+    a.dw = det ? nullptr : (float *)ws;
+    a.db = dbias ? (det ? (float *)ws /* non-null marker */ : (float *)ws + n16) : nullptr;
+    a.fix = det ? (long long *)ws : nullptr;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Hl = d->H; a.Wl = d->W; a.ups = 0;
+    a.Ho = d->H; a.Wo = d->W;   // the class grid = the stored extent; dy is [N, 2 Ho, 2 Wo, Cy]
+    a.Cout = d->Cout; a.Cy = m355::dy_channels(d->Cout);
+    a.KH = a.KW = 4; a.stride = 1; a.pad_h = a.pad_w = 1; a.pad_w_mode = d->pad_w_mode;
+    const size_t xbytes = (size_t)d->N * d->H * d->W * d->Cin * 2, ybytes = (size_t)d->N * d->H * d->W * 4 * a.Cy * 2;
+    if (int rc = m355::wgrad_halo_up_launch(a, (unsigned)xbytes, (unsigned)ybytes, st)) return rc;
+    const size_t blocks = ((size_t)d->Cout * 9 * d->Cin + d->Cout + 255) / 256;
+    const dim3 grid((unsigned)(blocks > 2048 ? 2048 : blocks));
+    if (det) hipLaunchKernelGGL(m355::k_up16_to_9<true>, grid, dim3(256), 0, st, (const void *)ws, dw, dbias, d->Cout, d->Cin);
+    else hipLaunchKernelGGL(m355::k_up16_to_9<false>, grid, dim3(256), 0, st, (const void *)ws, dw, dbias, d->Cout, d->Cin);
+    return m355::check_launch("conv2d_wgrad (sub-pixel fold)");
+}
+
 /* Deterministic weight gradient: same kernels, but the split-K partial tiles are accumulated as 64-bit fixed-point integers in
  * `ws` (m355_conv2d_wgrad_det_ws_bytes(d) bytes, zeroed here) and converted to fp32 once -- bit-identical from run to run
  * whatever order the workgroups finish in.  dw / dbias are OVERWRITTEN (no pre-zeroing needed). */
 extern "C" size_t m355_conv2d_wgrad_det_ws_bytes(const m355_conv_desc *d)
 {
     if (!d || d->Cout <= 0 || d->Cin <= 0 || d->kh <= 0 || d->kw <= 0) return 0;
+    if (subpixel(d)) return sizeof(long long) * (1 + subpixel_ws_cells(d));   // the 16-entry effective gradient
     return sizeof(long long) * (1 + (size_t)d->Cout * d->kh * d->kw * d->Cin + (size_t)d->Cout);
 }
 
@@ -1717,6 +1881,10 @@ extern "C" int m355_conv2d_wgrad_det(const m355_conv_desc *d, const void *x, con
     M355_REQUIRE(ws, "conv2d_wgrad_det: null workspace");
     if (int rc = check_desc(d, "conv2d_wgrad_det")) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (subpixel(d)) {
+        M355_REQUIRE(x && dy && dw, "conv2d_wgrad_det: null pointer");
+        return subpixel_wgrad(d, x, dy, dw, dbias, ws, true, st);
+    }
     if (hipMemsetAsync(ws, 0, m355_conv2d_wgrad_det_ws_bytes(d), st) != hipSuccess) {
         m355::set_error("conv2d_wgrad_det: memset failed");
         return M355_ERR_LAUNCH;
@@ -1753,6 +1921,9 @@ extern "C" size_t m355_conv2d_wgrad_ws_bytes(const m355_conv_desc *d)
     if (!d || check_desc(d, "conv2d_wgrad_ws_bytes")) return 0;
     const int cy = m355::dy_channels(d->Cout);
     if (m355::wgrad_c8_eligible(d, cy)) return sizeof(float) * m355::wgrad_c8_ws_floats(d, cy);
+    // upsample + 3x3 in the sub-pixel form: the 16-entry effective gradient (zeroed here, accumulated with fp32 atomics -- NOT the
+    // ordered sum of the thin layers: m355_conv2d_wgrad_det is the run-to-run reproducible form of these layers)
+    if (subpixel(d)) return sizeof(float) * subpixel_ws_cells(d);
     // (the <= 8-output-channel heads keep their atomics: with up to 512 partial rows of a few thousand elements the ordered sum
     // is the longer tail -- conv_final's wgrad 117.7 -> 155.9 us, D.conv5's 60.0 -> 65.6 us, profiles/r04_thin_rate_b.txt)
     return 0;
@@ -1762,6 +1933,10 @@ extern "C" int m355_conv2d_wgrad_ws(const m355_conv_desc *d, const void *x, cons
                                     void *stream)
 {
     M355_REQUIRE(ws && m355_conv2d_wgrad_ws_bytes(d) > 0, "conv2d_wgrad_ws: this layer has no partial-sum form (m355_conv2d_wgrad_ws_bytes)");
+    if (subpixel(d)) {
+        M355_REQUIRE(x && dy && dw, "conv2d_wgrad_ws: null pointer");
+        return subpixel_wgrad(d, x, dy, dw, dbias, ws, false, (hipStream_t)stream);
+    }
     return conv_wgrad_impl(d, x, dy, dw, dbias, stream, false, nullptr, (float *)ws);
 }
 

@@ -60,11 +60,16 @@ class Conv2d(nn.Conv2d):
     def __init__(self, cin, cout, k, stride=1, pad_h=0, pad_w=0, pad_w_mode=C.PAD_ZERO, bias=True):
         super().__init__(cin, cout, k, stride=stride, padding=(pad_h, 0), bias=bias)
         self.m355 = (stride, pad_h, pad_w, pad_w_mode)
+        # is this conv called with the nearest x2 upsample folded in?  (its bf16 weight buffers then also carry the sub-pixel views,
+        # csrc/conv_mfma.hip `up3`; the owning SpectralNormGroup prepares them with the whole network's.)  Learnt from the calls:
+        # a group whose views were built for the other setting serves one forward through the per-call weight_prep and rebuilds.
+        self.m355_ups = 0
         self._sn_state = None
         self._sn_own = None
 
     def forward(self, x, upsample=0, slope=1.0, out_f32_nchw=False, in_slope=1.0, premasked=False, want_stats=False):
         stride, pad_h, pad_w, mode = self.m355
+        self.m355_ups = int(upsample)
         sn, weight = None, None
         if "weight_orig" in self._parameters:
             sn, self._sn_state = self._sn_state, None
@@ -201,6 +206,10 @@ class Generator(nn.Module):
             self.conv_mesh = Conv2d(64, 3, 5, pad_h=2, pad_w=2, pad_w_mode=self.pad)
             self.conv_mesh.weight.data[:] = 0  # zero-initialised for smoothness (gan.py:366-368)
             self.conv_mesh.bias.data[:] = 0
+        # every block but blk1 sits behind the nearest x2 upsample of gan.py:386-404, folded into its conv1 (forward below)
+        for name, blk in self.named_children():
+            if isinstance(blk, ResBlockUp) and name != "blk1":
+                blk.conv1.m355_ups = 1
 
     def forward(self, z, c=None, caption=None, return_attention=False):
         a = self.args

@@ -467,7 +467,7 @@ class Conv2dFn(torch.autograd.Function):
         d = C.make_desc(n, h, w, cx, cout, kh, kw, stride, pad_h, pad_w, mode, ups)
         need_dx = ctx.needs_input_grad[0]
         sigma = None if sn is None else sn.sigma
-        if sn is not None and sn.wkey == (cx, cout, kh, kw, stride) and (sn.wd is not None or not need_dx):
+        if sn is not None and sn.wkey == (cx, cout, kh, kw, stride, int(ups)) and (sn.wd is not None or not need_dx):
             wf, wd = sn.wf, (sn.wd if need_dx else None)   # prepared with the whole network's views (SpectralNormGroup.step)
         else:
             wf, wd = C.weight_prep(d, weight, want_dgrad=need_dx, sigma=sigma)
@@ -655,7 +655,8 @@ class SpectralNormGroup:
             cout, cw, kh, kw = c.weight_orig.shape
             stride, pad_h, pad_w, mode = c.m355
             cx = (cw + 7) // 8 * 8
-            d = C.make_desc(1, 64, 64, cx, cout, kh, kw, stride, pad_h, pad_w, mode, 0)
+            ups = int(getattr(c, "m355_ups", 0))   # (layers called with the upsample folded in carry the sub-pixel views too)
+            d = C.make_desc(1, 64, 64, cx, cout, kh, kw, stride, pad_h, pad_w, mode, ups)
             wf = torch.empty((L.m355_conv2d_weight_elems(ctypes.byref(d), 0),), dtype=torch.bfloat16, device=dev)
             wd = torch.empty((L.m355_conv2d_weight_elems(ctypes.byref(d), 1),), dtype=torch.bfloat16, device=dev)
             n = L.m355_weight_prep_fill_entry(ctypes.byref(d), ptr(c.weight_orig), int(cw), ptr(slot["sigma"][i:i + 1]), ptr(wf),
@@ -667,7 +668,7 @@ class SpectralNormGroup:
                 tiles[0 if kh * kw <= 9 else 1] = max(tiles[0 if kh * kw <= 9 else 1], nt)
             else:
                 most = max(most, n)
-            weights.append((wf, wd, (cx, cout, kh, kw, stride)))
+            weights.append((wf, wd, (cx, cout, kh, kw, stride, ups)))
         slot["wtable"] = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).to(dev)
         slot["weights"], slot["wmost"], slot["wtiles"] = weights, most, tiles
 
@@ -675,7 +676,8 @@ class SpectralNormGroup:
         """advance (training) / evaluate sigma for every conv of the group and hand each conv its state"""
         if not self.convs:
             return
-        key = tuple(t.data_ptr() for c in self.convs for t in (c.weight_orig, c.weight_u, c.weight_v))
+        key = tuple(t.data_ptr() for c in self.convs for t in (c.weight_orig, c.weight_u, c.weight_v)) + \
+            tuple(int(getattr(c, "m355_ups", 0)) for c in self.convs)
         if key != self._key:
             self._build(self.convs[0].weight_orig.device)
             self._key = key

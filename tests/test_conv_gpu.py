@@ -55,6 +55,14 @@ CASES = [
     (2, 32, 64, 128, 256, 4, 2, 1, 1, 2, 0),  # stride-2 dgrad: four 2x2 classes of dy on the halo kernel, circular
     (2, 32, 64, 64, 128, 4, 2, 1, 1, 0, 0),   # stride-2 dgrad with zero W pad, dx has 64 channels (4-wave variant)
     (1, 16, 32, 64, 64, 3, 1, 1, 1, 2, 0),    # 3x3 circular
+    # ---- upsample + 3x3 in the SUB-PIXEL form (csrc/conv_mfma.hip `subpixel`: stored W % 32 == 0, H % 8 == 0, channels % 64 == 0):
+    # forward = four 2x2 class convs with pre-summed weights, dgrad = the adjoint 4x4 stride-2 conv (+ replicate edge term),
+    # wgrad = class kernels into the 16-entry effective gradient + fold.  The reference is built from the ORIGINAL 3x3 weights.
+    (2, 16, 32, 128, 64, 3, 1, 1, 1, 1, 1),   # G.blk6.conv1 shape class: 64 output channels = class PAIRS, replicate
+    (2, 8, 32, 128, 128, 3, 1, 1, 1, 1, 1),   # G.blk5.conv1 shape class: 8-wave class kernels, replicate, two chunks
+    (1, 16, 64, 64, 128, 3, 1, 1, 1, 2, 1),   # circular W pad, two pixel tiles across W, one chunk
+    (2, 8, 32, 64, 64, 3, 1, 1, 1, 0, 1),     # zero W pad, class pairs
+    (1, 24, 32, 192, 256, 3, 1, 1, 1, 1, 1),  # three chunks, two 128-channel output tiles
     # ---- odd kernels with stride 2 (the encoder of models/reconstruction.py:53-63): dgrad through the padded even kernel
     (2, 32, 32, 8, 64, 5, 2, 2, 2, 0, 0),     # conv1e: 5x5 s2 p2 on (4 -> 8) channels
     (2, 16, 16, 64, 128, 3, 2, 1, 1, 0, 0),   # conv2e: 3x3 s2 p1
@@ -159,7 +167,9 @@ def test_conv_tile_variants(pkg, case, tile, monkeypatch):
 
 @pytest.mark.parametrize("wgs", ["3", "8"])
 @pytest.mark.parametrize("case", [(3, 16, 64, 128, 128, 3, 1, 1, 1, 1, 0), (2, 16, 16, 128, 64, 3, 1, 1, 1, 1, 1),
-                                  (2, 32, 64, 128, 256, 4, 2, 1, 1, 2, 0), (3, 24, 32, 64, 64, 3, 1, 1, 1, 2, 0)])
+                                  (2, 32, 64, 128, 256, 4, 2, 1, 1, 2, 0), (3, 24, 32, 64, 64, 3, 1, 1, 1, 2, 0),
+                                  (3, 16, 32, 128, 64, 3, 1, 1, 1, 1, 1),     # sub-pixel upsample conv: class pairs
+                                  (2, 16, 64, 64, 128, 3, 1, 1, 1, 1, 1)])    # ... 8-wave classes; dgrad = stride-2 forward variant
 def test_conv_halo_persistent_tiles(pkg, case, wgs, monkeypatch):
     """k_conv_halo with few persistent workgroups: each walks several pixel tiles (cross-tile halo prefetch, weight
     ring wrap-around, uneven tile counts per workgroup)"""
@@ -358,7 +368,9 @@ def test_wgrad_arena_accumulates_inside_backward(pkg, case, monkeypatch):
                                   (2, 16, 32, 256, 256, 3, 1, 1, 1, 2, 1),    # 8 waves, two 128-channel tiles, upsample, circular
                                   (2, 16, 16, 128, 64, 3, 1, 1, 1, 1, 1),     # 4 waves, upsample (two workgroups per CU)
                                   (3, 24, 32, 64, 64, 3, 1, 1, 1, 1, 0),      # 4 waves, resident weights
-                                  (2, 16, 64, 128, 64, 3, 1, 1, 1, 0, 0)])    # 4 waves, streamed weights, zero pad, bias
+                                  (2, 16, 64, 128, 64, 3, 1, 1, 1, 0, 0),     # 4 waves, streamed weights, zero pad, bias
+                                  (3, 16, 32, 128, 64, 3, 1, 1, 1, 1, 1),     # sub-pixel upsample conv: class pairs (rows per class)
+                                  (2, 16, 32, 64, 128, 3, 1, 1, 1, 0, 1)])    # sub-pixel, 8-wave classes, zero pad, bias
 def test_conv_fwd_fused_bn_statistics(pkg, case, wgs, monkeypatch):
     """m355_conv2d_fwd_stats: y is bit-identical to m355_conv2d_fwd and the per-workgroup partial rows add up to the per-channel
     sum / sum of squares of the conv's fp32 results (fp32 reference conv on the same bf16 operands: only the summation order
@@ -376,6 +388,10 @@ def test_conv_fwd_fused_bn_statistics(pkg, case, wgs, monkeypatch):
     # channel-dependent scale and offset: every channel has its own statistics
     w = w * (0.5 + torch.arange(Cout).float().view(-1, 1, 1, 1) / Cout)
     w = w.bfloat16().float()
+    if ups and W % 32 == 0 and H % 8 == 0:
+        # the sub-pixel form rounds PRE-SUMMED weights (w0+w1, ...) to bf16: small-integer weights (x a power of two, x 1..3 per
+        # channel) keep every sum of up to four taps exact, so the fp32 reference below still describes the same operator
+        w = torch.randint(-15, 16, (Cout, Cin, k, k), generator=g).float() * (1 + torch.arange(Cout) % 3).float().view(-1, 1, 1, 1) / 512
     y_ref = ref_conv(x, w, b, stride, ph, pw, mode, ups)
     d = conv.make_desc(N, H, W, Cin, Cout, k, k, stride, ph, pw, mode, ups)
     rows = conv.conv_stats_rows(d)
@@ -447,6 +463,12 @@ def test_conv_fwd_stats_refused_where_not_fused(pkg):
     (16, 256, 128, 64, 64, 3, 1, 1, 1, 1, 0, "wgrad", "k_wgrad_halo"),      # G.blk6.conv2 weight gradient
     (32, 32, 32, 16, 64, 5, 1, 2, 2, 2, 0, "wgrad", "k_wgrad_dma"),         # MeshDiscriminator.conv1 weight gradient
     (16, 256, 128, 64, 3, 5, 1, 2, 2, 1, 0, "wgrad", "k_wgrad_smallco"),    # conv_final weight gradient
+    # the sub-pixel form of upsample + 3x3 (round 5): forward on the class kernels with fused statistics, weight gradient on the
+    # class variant of k_wgrad_halo (dy addressed with stride 2) + the 16 -> 9 fold, fixed point in deterministic mode
+    (16, 64, 32, 128, 128, 3, 1, 1, 1, 1, 1, "fwd_stats", "k_conv_halo"),   # G.blk5.conv1 forward: 8-wave 2x2 classes
+    (16, 128, 64, 128, 64, 3, 1, 1, 1, 1, 1, "dgrad", "k_conv_halo"),       # G.blk6.conv1 dgrad: stride-2 forward variant on dy
+    (16, 128, 64, 128, 64, 3, 1, 1, 1, 1, 1, "wgrad", "k_wgrad_halo"),      # G.blk6.conv1 weight gradient
+    (16, 64, 32, 128, 128, 3, 1, 1, 1, 1, 1, "wgrad", "k_wgrad_halo"),      # G.blk5.conv1 weight gradient
 ])
 def test_persistent_tile_kernels_repeat_bit_identically_under_memory_pressure(pkg, case):
     """Every launch of a conv kernel must produce the same bits (the weight gradients: in deterministic mode).  Round 4 found (run-to-

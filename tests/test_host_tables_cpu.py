@@ -95,6 +95,22 @@ def test_workspace_queries(pkg):
     assert L.m355_conv2d_fwd_ws_bytes(ctypes.byref(desc(64, 32, 16, 256, 256, 3))) == 0           # 512 tiles: no split
     assert L.m355_conv2d_fwd_ws_bytes(ctypes.byref(desc(64, 8, 4, 512, 64, 3))) == 0              # 64 output channels: 256 x 64 tiles
     assert L.m355_conv2d_fwd_ws_bytes(ctypes.byref(desc(64, 16, 32, 128, 128, 3))) == 0           # the halo kernel's layer
+    # upsample + 3x3 layers (round 5): the weight buffers carry the sub-pixel views behind the 3x3 ones whatever the image size ...
+    up = desc(64, 128, 64, 128, 64, 3, ups=1)      # G.blk6.conv1: runs in the sub-pixel form
+    small = desc(64, 32, 16, 256, 128, 3, ups=1)   # G.blk4.conv1: stored width 16 -> the 9-tap kernels
+    for dd, cin, cout in ((up, 128, 64), (small, 256, 128)):
+        rows_f, rows_d = (64 if cout <= 64 else 128), (64 if cin <= 64 else (cin + 127) // 128 * 128)
+        assert L.m355_conv2d_weight_elems(ctypes.byref(dd), 0) == rows_f * 9 * cin + 4 * rows_f * 4 * cin
+        assert L.m355_conv2d_weight_elems(ctypes.byref(dd), 1) == rows_d * 9 * cout + rows_d * 16 * cout
+    assert L.m355_conv2d_weight_elems(ctypes.byref(desc(64, 128, 64, 128, 64, 3)), 0) == 64 * 9 * 128
+    # ... the 16-entry effective weight gradient (+ bias sums) only where the shape takes that form; its dgrad needs no frame
+    assert L.m355_conv2d_wgrad_ws_bytes(ctypes.byref(up)) == 4 * (64 * 16 * 128 + 64)
+    assert L.m355_conv2d_wgrad_det_ws_bytes(ctypes.byref(up)) == 8 * (1 + 64 * 16 * 128 + 64)
+    assert L.m355_conv2d_wgrad_ws_bytes(ctypes.byref(small)) == 0
+    assert L.m355_conv2d_wgrad_det_ws_bytes(ctypes.byref(small)) == 8 * (1 + 128 * 9 * 256 + 128)
+    assert L.m355_conv2d_dgrad_ws_bytes(ctypes.byref(up)) == 0
+    assert L.m355_conv2d_fwd_stats_rows(ctypes.byref(up)) == 4 * 128     # class pairs: 128 workgroups x 2 row parities, a row block per class
+    assert L.m355_conv2d_fwd_stats_rows(ctypes.byref(desc(64, 64, 32, 128, 128, 3, ups=1))) == 4 * 64
     assert L.m355_cproj_bwd_ws_floats(128, 256, 512) == 128 * 2 * 512 and L.m355_cproj_bwd_ws_floats(128, 64, 256) == 0
     assert L.m355_sn_scratch_words(18, 512, 4608) == 18 * (72 + 128)
 
