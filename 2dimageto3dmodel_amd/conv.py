@@ -98,15 +98,16 @@ def weight_prep(d, w_oihw, want_dgrad=True, sigma=None):
 _HALVES = {}
 
 
-def _halves(d):
-    """None, or (descriptor of half the batch, N/2) when a tensor of this layer reaches 2 GiB"""
-    key = bytes(d)
+def _halves(d, out_bytes=2):
+    """None, or (descriptor of half the batch, N/2) when a tensor of this layer reaches 2 GiB (out_bytes = 4: the fp32 NCHW
+    output form of conv_fwd)"""
+    key = bytes(d) + bytes([out_bytes])
     r = _HALVES.get(key, 0)
     if r == 0:
         r = None
         if d.N >= 2 and d.N % 2 == 0:
             ho, wo = out_hw(d)
-            big = max(d.N * d.H * d.W * d.Cin * 2, d.N * ho * wo * max(d.Cout, dy_channels(d.Cout)) * 2)
+            big = max(d.N * d.H * d.W * d.Cin * 2, d.N * ho * wo * max(d.Cout, dy_channels(d.Cout)) * out_bytes)
             if big >= (1 << 31):
                 r = (make_desc(d.N // 2, d.H, d.W, d.Cin, d.Cout, d.kh, d.kw, d.stride, d.pad_h, d.pad_w, d.pad_w_mode, d.upsample), d.N // 2)
         _HALVES[key] = r
@@ -139,7 +140,7 @@ def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0, cin_real=Non
             y = torch.empty((d.N, d.Cout, ho, wo), dtype=torch.float32, device=x.device)
         else:
             y = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.bfloat16, device=x.device)
-    hv = _halves(d)
+    hv = _halves(d, 4 if out_f32_nchw else 2)
     if hv:
         dh, h = hv
         for i in (0, 1):
@@ -428,7 +429,7 @@ def flush_wgrad_finish(discard=False):
         return
     # raw gradients of branches that ran on the second stream (gan_ops.Fork): join it before the batched epilogue reads them
     from . import gan_ops
-    for sd in gan_ops.side_streams():
+    for sd in gan_ops.side_streams_to_join():
         torch.cuda.current_stream(sd.device).wait_stream(sd)
     for i0 in range(0, len(items), _lib.SNFIN_MAX):
         chunk = items[i0:i0 + _lib.SNFIN_MAX]

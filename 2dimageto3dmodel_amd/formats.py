@@ -65,6 +65,11 @@ def load_poses_metadata(cache_dir):
 def save_checkpoint(path, trainer, epoch, g_curve=(), d_fake_curve=(), d_real_curve=(), flat_curve=(), args=None):
     """main.py:749-770 from a train.GanTrainer; `args` defaults to the trainer's namespace"""
     a = args if args is not None else trainer.args
+    # data parallel with overlap_comm: the last discriminator step's all-reduce + optimizer_d.step() may still be pending (it is
+    # normally completed inside the next forward, train.GanTrainer); the optimiser / discriminator state read below must be the
+    # state AFTER step total_it, as the reference's checkpoint is (main.py:749-770)
+    if hasattr(trainer, "finish_pending"):
+        trainer.finish_pending()
     out = {
         "optimizer_g": trainer.optimizer_g.state_dict(),
         "optimizer_d": trainer.optimizer_d.state_dict(),
@@ -90,6 +95,10 @@ def load_checkpoint(path, trainer, map_location="cpu", strict=True):
     missing = [k for k in ("generator", "generator_running_avg", "discriminator") if k not in ck]
     if missing:
         raise KeyError(f"{path}: not a GAN checkpoint (missing {missing})")
+    # a discriminator step still pending here would be applied -- with the OLD run's averaged gradients -- to the loaded weights by
+    # the next forward: complete it first (its result is overwritten below)
+    if hasattr(trainer, "finish_pending"):
+        trainer.finish_pending()
     trainer.generator.load_state_dict(ck["generator"], strict=strict)
     trainer.generator_running_avg.load_state_dict(ck["generator_running_avg"], strict=strict)
     trainer.discriminator.load_state_dict(ck["discriminator"], strict=strict)

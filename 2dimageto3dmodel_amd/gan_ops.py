@@ -38,8 +38,27 @@ STREAMS_ON = os.environ.get("M355_STREAMS", "auto") != "0"
 FORK_MAX_BATCH = 1 << 30 if os.environ.get("M355_STREAMS") == "1" else 32
 
 
+_FORKED = set()     # device indices whose side stream has run a branch since conv.flush_wgrad_finish last joined it
+
+
 def side_streams():
     return list(_SIDE.values())
+
+
+def side_streams_to_join():
+    """the side streams a backward pass may have put weight-gradient kernels on since the last join (Fork.__enter__ marks them),
+    minus -- while the current stream is being captured into a hipGraph -- those that are not part of that capture: waiting on
+    their (uncaptured) work from a capturing stream is a capture-isolation error, and nothing of this pass ran there"""
+    out = []
+    for idx in sorted(_FORKED):
+        sd = _SIDE[idx]
+        if torch.cuda.is_current_stream_capturing():
+            with torch.cuda.stream(sd):
+                if not torch.cuda.is_current_stream_capturing():
+                    continue
+        out.append(sd)
+    _FORKED.clear()
+    return out
 
 
 class Fork:
@@ -56,6 +75,7 @@ class Fork:
 
     def __enter__(self):
         self.side.wait_stream(self.main)          # everything the branch reads was produced on the main stream
+        _FORKED.add(self.side.device.index)       # (its backward runs there too: conv.flush_wgrad_finish joins it)
         for t in self.shared:
             t.record_stream(self.side)
         self._ctx = torch.cuda.stream(self.side)

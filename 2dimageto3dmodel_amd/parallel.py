@@ -156,3 +156,56 @@ class FlatGradReducer:
     def __call__(self):
         if self.start():
             self.finish()
+
+
+# ------------------------------------------------------------------------------------------------ projection path
+class ImageShard:
+    """what rank `rank` of `world` owns of a batch of `n_images` source images with `group` candidate clouds each"""
+    __slots__ = ("img_lo", "img_hi", "cloud_lo", "cloud_hi", "group", "weight")
+
+    def __init__(self, img_lo, img_hi, group, weight):
+        self.img_lo, self.img_hi, self.group, self.weight = img_lo, img_hi, group, weight
+        self.cloud_lo, self.cloud_hi = img_lo * group, img_hi * group
+
+    @property
+    def n_images(self):
+        return self.img_hi - self.img_lo
+
+    def images(self, t):
+        """the rank's rows of a per-image tensor ([n_images, ...]: masks, student poses)"""
+        return t[self.img_lo:self.img_hi]
+
+    def clouds(self, t):
+        """the rank's rows of a per-cloud tensor ([n_images * group, ...], candidate index fastest: point clouds, projections,
+        ensemble poses -- the layout `projection_loss.view(-1, K)` of unsupervised_part.py:117 assumes)"""
+        if t.shape[0] % self.group:
+            raise ValueError(f"per-cloud tensor has {t.shape[0]} rows, not a multiple of the {self.group} candidates per image")
+        return t[self.cloud_lo:self.cloud_hi]
+
+
+def shard_by_image(n_images, group=1, rank=None, world=None):
+    """the projection path shards by SOURCE IMAGE, never by cloud -- the `group` = K (x V views) candidate clouds of one
+    image must meet on one rank, because UnsupervisedLoss takes the argmin of their silhouette losses per image
+    (/root/reference/code/models/unsupervised_part.py:117-126: `.view(-1, K)`, `argmin(dim=-1)`); a cloud-granular split would
+    put candidates of one image on two ranks and silently turn the argmin over K into two argmins over fewer.  Contiguous image
+    blocks, the first n_images % world ranks one image larger.  The path has no parameters and no collective of its own: the
+    encoder / pose-decoder gradients that flow out of it are averaged by the caller's FlatGradReducer.  `weight` scales a loss
+    that is a MEAN over the rank's images (every loss of the path is, unsup:120,134 / sup:72) so that the all-reduce MEAN of the
+    ranks' gradients is the gradient of the global-batch mean even when the blocks are uneven: weight = n_local * world / n."""
+    if rank is None:
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    if world is None:
+        world = world_size()
+    if n_images < 0 or group < 1 or not (0 <= rank < world):
+        raise ValueError(f"shard_by_image: n_images={n_images}, group={group}, rank={rank}, world={world}")
+    q, r = divmod(n_images, world)
+    lo = rank * q + min(rank, r)
+    hi = lo + q + (1 if rank < r else 0)
+    return ImageShard(lo, hi, group, (hi - lo) * world / n_images if n_images else 0.0)
+
+
+def check_image_groups(n_clouds, n_images, group):
+    """raise unless a rank's local batch holds WHOLE candidate groups (what a loader that shards by cloud would violate)"""
+    if n_clouds != n_images * group:
+        raise ValueError(f"projection shard holds {n_clouds} clouds for {n_images} images x {group} candidates: the candidates of "
+                         "an image must stay on one rank (parallel.shard_by_image)")

@@ -208,6 +208,10 @@ class UnsupervisedLoss(nn.Module):
             total, _ = ops.silhouette_sse(projection, masks)
             return dict(projection_loss=total.reshape(()) / projection.size(0))
         ensemble_poses, student_poses = poses
+        # (data parallel: a rank's batch must hold whole candidate groups -- parallel.shard_by_image; a cloud-granular shard would
+        # silently take the argmin over a mixed group, so the shapes are checked here)
+        from .parallel import check_image_groups
+        check_image_groups(projection.size(0), masks.size(0), K)
         # masks are repeated K times per element (unsup:113); the kernel indexes mask row b // K instead
         _, sse = ops.silhouette_sse(projection, masks, mask_repeat=K)
         projection_loss = sse.view(-1, K)

@@ -298,6 +298,10 @@ class CycleGraph:
         # positional planes and the optimiser state all exist before the capture starts.  The warm-up cycles are REAL training
         # cycles on the supplied batches; what they did to the weights, the optimiser state, the running statistics, total_it and
         # the RNG is undone afterwards (restore_after_warmup), so capturing at step k leaves the trainer at step k.
+        # a discriminator step left pending by eager iterations before this capture (overlap_comm) is completed NOW, once and for
+        # real: inside the warm-up it would be rolled back with the snapshot (one update silently lost), and on the re-capture
+        # path (warmup = 0) its finish() / step() would be recorded into the graph instead of executed
+        self.trainer.finish_pending()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

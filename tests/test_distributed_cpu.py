@@ -70,6 +70,37 @@ def _worker(rank, world, port, q):
         assert torch.allclose(sbn.running_mean, bn.running_mean, atol=1e-6)
         assert torch.allclose(sbn.running_var, bn.running_var, atol=1e-6)
         assert torch.allclose(xs.grad, xf.grad[sl], atol=2e-2, rtol=2e-2)
+        # ---- projection path: shard by SOURCE IMAGE.  Per-cloud silhouette losses stand in for the HIP kernel's
+        # output (the kernel needs a GPU; tests/test_proj_gpu.py runs the real loss on shards): the per-image argmin over the K
+        # candidates of the ranks' blocks is the global one, and the weighted local means reduce to the global mean
+        n_img, K = 7, 4
+        torch.manual_seed(99)
+        sse = torch.rand(n_img * K)                                   # identical on every rank: the "global batch"
+        pose_w = torch.nn.Linear(3, 1)
+        par.broadcast_parameters(pose_w, src=0)
+        feats = torch.randn(n_img, 3)
+        want_idx = sse.view(-1, K).argmin(-1)
+        sh = par.shard_by_image(n_img, K)
+        assert (sh.img_hi - sh.img_lo) == (4 if rank == 0 else 3) and sh.cloud_lo == sh.img_lo * K
+        loc = sh.clouds(sse).view(-1, K)
+        li = loc.argmin(-1)
+        both = [torch.zeros(4, dtype=torch.long) for _ in range(world)]
+        pad = torch.full((4,), -1, dtype=torch.long)
+        pad[:li.numel()] = li
+        dist.all_gather(both, pad)
+        got = torch.cat([b[b >= 0] for b in both])
+        assert torch.equal(got, want_idx)
+        # loss = mean over the rank's images (as unsup:120,134), scaled by the shard weight, gradients averaged over ranks
+        best = loc[torch.arange(li.numel()), li]
+        (sh.weight * (best * pose_w(sh.images(feats)).squeeze(-1)).mean()).backward()
+        par.FlatGradReducer(pose_w.parameters())()
+        ref_lin = torch.nn.Linear(3, 1)
+        ref_lin.load_state_dict(pose_w.state_dict())
+        gbest = sse.view(-1, K)[torch.arange(n_img), want_idx]
+        (gbest * ref_lin(feats).squeeze(-1)).mean().backward()
+        assert torch.allclose(pose_w.weight.grad, ref_lin.weight.grad, atol=1e-6)
+        with pytest.raises(ValueError):
+            par.check_image_groups(K * 3 + 1, 3, K)
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         import traceback

@@ -23,10 +23,11 @@ LRELU = 0.2
 
 
 @pytest.mark.timeout(900)
-def test_projection_batch64_sampled_vs_oracle(pkg):
+@pytest.mark.parametrize("B,N,S,pick", [(64, 2048, 128, [0, 21, 42, 63]),     # the headline batch
+                                        (16, 4096, 128, [0, 5, 10, 15])])      # BASELINE configs[3] per-GPU shape: 16 clouds x 4096 points
+def test_projection_batch64_sampled_vs_oracle(pkg, B, N, S, pick):
     from oracle import p_oracle as po
-    B, N, S = 64, 2048, 128
-    rs = np.random.RandomState(64)
+    rs = np.random.RandomState(B)
     pc = ((rs.rand(B, N, 3) - 0.5) * 0.8).astype(np.float32)
     q = rs.randn(B, 4).astype(np.float32)
     sc = (1 / (1 + np.exp(-rs.randn(B, 1)))).astype(np.float32)
@@ -39,13 +40,12 @@ def test_projection_batch64_sampled_vs_oracle(pkg):
     loss.backward()
     torch.cuda.synchronize()
     taps = po.taps(3.0, 21, True)
-    pick = [0, 21, 42, 63]
     got = proj.detach().cpu().numpy()
     for i in pick:
         p_o = po.forward(pc[i:i + 1], q[i:i + 1], sc[i:i + 1], S, taps)
         assert np.abs(got[i:i + 1] / p_o - 1).max() < 2e-5, i                                    # silhouette, per pixel
         # per-cloud gradient: full_loss = sum_i SSE_i / (2B) (models/supervised_part.py:68-72), so cloud i's gradient in the batch
-        # of 64 is its single-cloud gradient (B = 1) times 1 / 64
+        # of B is its single-cloud gradient (B = 1) times 1 / B
         dproj_o = po.sup_loss_bwd(p_o, mask[i:i + 1])
         dp_o, dq_o, ds_o, _ = po.backward(pc[i:i + 1], q[i:i + 1], sc[i:i + 1], dproj_o, S, taps)
         scale = 1.0 / B

@@ -218,6 +218,45 @@ def test_unsupervised_loss_matches_reference(pkg, tag):
     assert rel(stu.grad.cpu().numpy(), g[f"{tag}:dstu"]) < 1e-5
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_unsupervised_loss_sharded_by_image_equals_unsharded(pkg, world):
+    """the projection path shards by SOURCE IMAGE (parallel.shard_by_image): the ranks' UnsupervisedLoss runs on their
+    image blocks -- emulated one after the other on the one GPU -- reproduce the unsharded run of the reference-executed golden
+    (unsupervised_part.py:117-126): argmin indices exact, the weighted mean of the ranks' losses and the weighted sum of their
+    gradients equal to the global ones; a cloud-granular shard is refused"""
+    import importlib
+    par = importlib.import_module("2dimageto3dmodel_amd.parallel")
+    g = load_golden("p8_unsup")
+    B, K = int(g["a:B"]), int(g["a:K"])
+    proj, masks = t(g["a:proj"]), t(g["a:masks"].astype(np.float32))
+    ens, stu = t(g["a:ens"]), t(g["a:stu"])
+    lossm = pkg.UnsupervisedLoss(number_of_pose_predictor_candidates=K)
+    pj, st = proj.clone().requires_grad_(), stu.clone().requires_grad_()
+    full = lossm((pj, ens, st), masks, training=True)
+    full["total_loss"].backward()
+    want_idx = lossm.minimum_indexes.clone()
+    idx, tot, gp, gs = [], 0.0, torch.zeros_like(proj), torch.zeros_like(stu)
+    for rank in range(world):
+        sh = par.shard_by_image(B, K, rank, world)
+        assert sh.cloud_hi - sh.cloud_lo == K * sh.n_images
+        if sh.n_images == 0:
+            continue
+        pr, sr = sh.clouds(proj).clone().requires_grad_(), sh.images(stu).clone().requires_grad_()
+        out = lossm((pr, sh.clouds(ens), sr), sh.images(masks), training=True)
+        (out["total_loss"] * sh.weight).backward()          # what the rank back-propagates
+        idx.append(lossm.minimum_indexes.clone())
+        tot += out["total_loss"].item() * sh.weight / world   # all-reduce MEAN over ranks
+        gp[sh.cloud_lo:sh.cloud_hi] = pr.grad / world
+        gs[sh.img_lo:sh.img_hi] = sr.grad / world
+    assert torch.equal(torch.cat(idx), want_idx)
+    assert abs(tot / full["total_loss"].item() - 1) < 1e-5
+    assert (gp - pj.grad).abs().max().item() < 1e-6 * max(1.0, pj.grad.abs().max().item())
+    assert (gs - st.grad).abs().max().item() < 1e-5 * max(1.0, st.grad.abs().max().item())
+    # a shard that cuts a candidate group: refused, not mis-reduced
+    with pytest.raises(ValueError):
+        lossm((proj[:K + 1], ens[:K + 1], stu[:1]), masks[:1], training=True)
+
+
 @pytest.mark.timeout(900)
 def test_config5_s512_vs_oracle(pkg):
     """BASELINE configs[4] geometry (N = 16384 points -> 512^3 grid, 512 x 512 silhouette; m355_proj_ntiles(512) = 16384 tiles,
