@@ -4,7 +4,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", os.environ.get("M355_LIB", "libm355.so"))  # M355_LIB: A/B builds of the same ABI (build.py)
+# M355_LIB: A/B builds of the same ABI (build.py); M355_EXACT=1: the fp32 EXACT build (lib/libm355_exact.so, csrc/conv_exact.hip)
+EXACT_LIB = "libm355_exact.so"
+LIB_PATH = os.path.join(_HERE, "lib", os.environ.get("M355_LIB", EXACT_LIB if os.environ.get("M355_EXACT") == "1" else "libm355.so"))
 
 c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 
@@ -21,6 +23,7 @@ SIGNATURES = {
     "m355_last_error": (ctypes.c_char_p, []),
     "m355_last_kernel": (ctypes.c_char_p, []),
     "m355_abi_version": (c_int, []),
+    "m355_act_bytes": (c_int, []),
     "m355_proj_transform_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, _P]),
     "m355_quat_rotate_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "m355_quat_rotate_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
@@ -160,6 +163,38 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+_ACT_DTYPE = None
+_RESET_HOOKS = []   # caches of library answers (conv.py) cleared when the loaded library changes
+
+
+def act_dtype():
+    """torch dtype of the GAN path's activation tensors in the loaded build: bfloat16 (product) or float32 (EXACT build)"""
+    global _ACT_DTYPE
+    if _ACT_DTYPE is None:
+        import torch
+        _ACT_DTYPE = torch.float32 if lib().m355_act_bytes() == 4 else torch.bfloat16
+    return _ACT_DTYPE
+
+
+def is_exact():
+    return lib().m355_act_bytes() == 4
+
+
+def set_exact(on):
+    """Switch this process between the product library and the EXACT build (fp32 activations, fp32 convs with fp64 accumulation:
+    SURVEY.md 8c's exact mode) -> the previous setting.  Tensors and modules created under one setting must not be used under the
+    other: networks keep no activation state between forwards, but build them (and their SpectralNormGroup views) AFTER switching."""
+    global _lib, LIB_PATH, _ACT_DTYPE
+    prev = _lib is not None and is_exact()
+    want = os.path.join(_HERE, "lib", EXACT_LIB if on else "libm355.so")
+    if want != LIB_PATH or _lib is None:
+        LIB_PATH, _lib, _ACT_DTYPE = want, None, None
+        for h in _RESET_HOOKS:
+            h()
+        lib()
+    return prev
 
 
 def check(rc, what):

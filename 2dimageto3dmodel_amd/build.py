@@ -31,6 +31,7 @@ SOURCES = [
     ("conv_mfma.hip", []),
     ("conv_small.hip", []),
     ("conv_halo.hip", []),
+    ("conv_exact.hip", []),
     ("gan_elem.hip", []),
     ("gan_glue.hip", []),
     ("gan_io.hip", []),
@@ -53,7 +54,17 @@ def _newer(src, dst, extra=()):
     return any(os.path.getmtime(p) > t for p in (src,) + tuple(extra))
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, exact=False):
+    """exact=True: lib/libm355_exact.so -- the same sources with -DM355_EXACT (fp32 activations, fp32 convs with fp64
+    accumulation, csrc/conv_exact.hip; include/m355.h m355_act_bytes): the library behind M355_EXACT=1 / _lib.set_exact(True)"""
+    global OBJ, LIB, COMMON
+    if exact:
+        saved = (OBJ, LIB, COMMON)
+        OBJ, LIB, COMMON = os.path.join(HERE, "build_exact"), os.path.join(LIBDIR, "libm355_exact.so"), COMMON + ["-DM355_EXACT"]
+        try:
+            return build(force, verbose)
+        finally:
+            OBJ, LIB, COMMON = saved
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     headers = tuple(os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")) + (
@@ -84,4 +95,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, exact="--exact" in sys.argv))

@@ -41,6 +41,15 @@ def make_desc(N, H, W, Cin, Cout, kh, kw, stride=1, pad_h=0, pad_w=0, pad_w_mode
 _OUT_HW, _DY_CH = {}, {}   # pure geometry (no environment switches behind them): memoised, the hot loop calls them per launch
 
 
+def _reset_caches():
+    """the memoised answers below belong to ONE build of the library (_lib.set_exact switches it)"""
+    for c in (_OUT_HW, _DY_CH, _HALVES, _FWD_WS, _WS_BYTES):
+        c.clear()
+
+
+_lib._RESET_HOOKS.append(_reset_caches)
+
+
 def out_hw(d):
     key = bytes(d)
     r = _OUT_HW.get(key)
@@ -82,7 +91,7 @@ def weight_prep(d, w_oihw, want_dgrad=True, sigma=None):
     """bf16 GEMM views of the fp32 parameter; `sigma` (1-element device tensor) divides it (spectral norm)"""
     w = _req(w_oihw.detach(), torch.float32, "weight")
     L = lib()
-    wf = torch.empty((L.m355_conv2d_weight_elems(ctypes.byref(d), 0),), dtype=torch.bfloat16, device=w.device)
+    wf = torch.empty((L.m355_conv2d_weight_elems(ctypes.byref(d), 0),), dtype=torch.bfloat16, device=w.device)   # (2-byte elements)
     wd = None
     if want_dgrad:
         wd = torch.empty((L.m355_conv2d_weight_elems(ctypes.byref(d), 1),), dtype=torch.bfloat16, device=w.device)
@@ -129,7 +138,7 @@ def dgrad_mask_ok(d):
 def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0, cin_real=None, emit_bits=False, _out=None):
     """emit_bits: also return the sign bits of the pre-activation ([N,Ho,Wo,Cout/64,2] int32, opaque layout) for
     the consumer's conv_dgrad(mask_bits=...); requires maskbits_ok(d, 0).  (_out: the output views of a half-batch launch)"""
-    x = _req(x, torch.bfloat16, "x")
+    x = _req(x, _lib.act_dtype(), "x")
     assert tuple(x.shape) == (d.N, d.H, d.W, d.Cin), (tuple(x.shape), (d.N, d.H, d.W, d.Cin))
     ho, wo = out_hw(d)
     if _out is not None:
@@ -139,7 +148,7 @@ def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0, cin_real=Non
         if out_f32_nchw:
             y = torch.empty((d.N, d.Cout, ho, wo), dtype=torch.float32, device=x.device)
         else:
-            y = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.bfloat16, device=x.device)
+            y = torch.empty((d.N, ho, wo, d.Cout), dtype=_lib.act_dtype(), device=x.device)
     hv = _halves(d, 4 if out_f32_nchw else 2)
     if hv:
         dh, h = hv
@@ -172,14 +181,14 @@ def conv_stats_rows(d):
 def conv_fwd_stats(d, x, w_fwd, bias=None, cin_real=None, rows=None, _out=None):
     """-> y, part: the forward (no activation) and part [rows,2,Cout] fp32 = per-workgroup (sum, sum of squares) of the fp32
     results over the workgroup's pixels -- what bn_finalize reduces; requires conv_stats_rows(d) > 0"""
-    x = _req(x, torch.bfloat16, "x")
+    x = _req(x, _lib.act_dtype(), "x")
     assert tuple(x.shape) == (d.N, d.H, d.W, d.Cin), (tuple(x.shape), (d.N, d.H, d.W, d.Cin))
     ho, wo = out_hw(d)
     rows = conv_stats_rows(d) if rows is None else rows
     hv = _halves(d)
     if hv:
         dh, h = hv
-        y, part = _out if _out is not None else (torch.empty((d.N, ho, wo, d.Cout), dtype=torch.bfloat16, device=x.device),
+        y, part = _out if _out is not None else (torch.empty((d.N, ho, wo, d.Cout), dtype=_lib.act_dtype(), device=x.device),
                                                  torch.empty((rows, 2, d.Cout), dtype=torch.float32, device=x.device))
         r = rows // 2
         for i in (0, 1):
@@ -189,7 +198,7 @@ def conv_fwd_stats(d, x, w_fwd, bias=None, cin_real=None, rows=None, _out=None):
     if _fwd_ws(d)[0]:
         assert _out is None
         return _fwd_splitk(d, x, w_fwd, b, 1.0, True)
-    y, part = _out if _out is not None else (torch.empty((d.N, ho, wo, d.Cout), dtype=torch.bfloat16, device=x.device),
+    y, part = _out if _out is not None else (torch.empty((d.N, ho, wo, d.Cout), dtype=_lib.act_dtype(), device=x.device),
                                              torch.empty((rows, 2, d.Cout), dtype=torch.float32, device=x.device))
     launch("conv2d_fwd_stats", ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(b), ptr(y), ptr(part), stream(),
            work=lambda: flops(d, cin_real), tag=lambda: tag(d))
@@ -200,10 +209,10 @@ def conv_dgrad(d, dy, w_dgrad, cin_real=None, mask_x=None, mask_slope=1.0, mask_
     """mask_x: this conv's input x when it is the output of a fused conv+LeakyReLU(mask_slope): the returned gradient
     is then already multiplied by that activation's derivative; mask_bits: the same from the producer's bit masks
     (conv_fwd(emit_bits=True)), 1/16 of the bytes"""
-    dy = _req(dy, torch.bfloat16, "dy")
+    dy = _req(dy, _lib.act_dtype(), "dy")
     ho, wo = out_hw(d)
     assert tuple(dy.shape) == (d.N, ho, wo, dy_channels(d.Cout)), tuple(dy.shape)
-    dx = _out if _out is not None else torch.empty((d.N, d.H, d.W, d.Cin), dtype=torch.bfloat16, device=dy.device)
+    dx = _out if _out is not None else torch.empty((d.N, d.H, d.W, d.Cin), dtype=_lib.act_dtype(), device=dy.device)
     hv = _halves(d)
     if hv:
         dh, h = hv
@@ -241,7 +250,7 @@ def _fwd_splitk(d, x, w_fwd, b, slope, want_part):
     nws, rows = _fwd_ws(d)
     ho, wo = out_hw(d)
     ws = torch.empty((nws,), dtype=torch.uint8, device=x.device)
-    y = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.bfloat16, device=x.device)
+    y = torch.empty((d.N, ho, wo, d.Cout), dtype=_lib.act_dtype(), device=x.device)
     part = torch.empty((rows, 2, d.Cout), dtype=torch.float32, device=x.device) if want_part else None
     launch("conv2d_fwd_ws", ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(b), ptr(y), float(slope), ptr(ws), ptr(part), stream(),
            work=lambda: flops(d), tag=lambda: tag(d))
@@ -352,7 +361,7 @@ def conv_wgrad(d, x, dy, cin_real=None, raw=False, dbias=None, arena=False, dbia
     """-> dw fp32 in the parameter's layout [Cout,Cin,kh,kw] (a permuted view), or with raw=True the kernel's own
     [Cout,kh,kw,Cin] buffer.  arena=True (with raw=True, from inside a backward pass): the buffer is a slice of the
     per-pass WgradArena, valid until the next backward pass"""
-    x, dy = _req(x, torch.bfloat16, "x"), _req(dy, torch.bfloat16, "dy")
+    x, dy = _req(x, _lib.act_dtype(), "x"), _req(dy, _lib.act_dtype(), "dy")
     n = d.Cout * d.kh * d.kw * d.Cin
     hv = _halves(d)
     if hv:

@@ -587,10 +587,16 @@ __device__ __forceinline__ void weight_prep_body(const WeightPrepArgs &w)
                 }
             }
         }
+#ifdef M355_EXACT
+        float *outf = reinterpret_cast<float *>(out) + (size_t)g * 8;   // (no rounding: W / sigma in fp32)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) outf[j] = v[j];
+#else
         bf16x8 o8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o8[j] = (short)f2bf(v[j]);
         *reinterpret_cast<bf16x8 *>(out + (size_t)g * 8) = o8;
+#endif
     }
 }
 
@@ -870,6 +876,15 @@ int wgrad_small_launch(const m355_conv_desc *d, const void *x, const void *dy, i
 size_t wgrad_small_ws_floats(const m355_conv_desc *d);
 }  // namespace m355
 
+#ifdef M355_EXACT
+namespace m355 { namespace exact {   // csrc/conv_exact.hip: the fp32 kernels every conv entry point dispatches to in the EXACT build
+int conv_fwd(const m355_conv_desc *d, const void *x, const void *w, const float *bias, void *y, int nchw, float slope, hipStream_t st);
+int conv_dgrad(const m355_conv_desc *d, const void *dy, int Cy, const void *w, void *dx, const void *mask_x, float mask_slope, hipStream_t st);
+int conv_wgrad(const m355_conv_desc *d, const void *x, const void *dy, int Cy, float *dw, float *dbias, int accumulate, hipStream_t st);
+int fold2x2(const void *gr, void *dx, int N, int H, int W, int C, hipStream_t st);
+} }
+#endif
+
 static int conv_out_hw(const m355_conv_desc *d, int *Ho, int *Wo)
 {
     const int Hl = d->H << d->upsample, Wl = d->W << d->upsample;
@@ -902,6 +917,9 @@ extern "C" int m355_conv2d_out_hw(const m355_conv_desc *d, int *Ho, int *Wo)
 extern "C" int m355_fold2x2(const void *g, void *dx, int N, int H, int W, int C, void *stream)
 {
     M355_REQUIRE(g && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "fold2x2: bad argument");
+#ifdef M355_EXACT
+    return m355::exact::fold2x2(g, dx, N, H, W, C, (hipStream_t)stream);
+#endif
     const size_t total = (size_t)N * H * W * (C / 8);
     hipLaunchKernelGGL(m355::k_fold_pad, dim3((unsigned)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, (const unsigned short *)g, (unsigned short *)dx, N, H, W, C, 1, 0, 0, 2 * H, 0);
@@ -925,6 +943,9 @@ static bool up3(const m355_conv_desc *d)
 }
 static bool subpixel(const m355_conv_desc *d)
 {
+#ifdef M355_EXACT
+    return false;
+#endif
     if (!up3(d) || d->Cin % 64 || d->Cout % 64 || d->W % 32 || d->H % 8) return false;
     const size_t xb = (size_t)d->N * d->H * d->W * d->Cin * 2, yb = (size_t)d->N * d->H * d->W * 4 * d->Cout * 2;
     static const bool off = getenv("M355_NO_SUBPIXEL") != nullptr;   // A/B runs: the 9-tap kernels with the upsample in the halo load
@@ -942,6 +963,10 @@ extern "C" size_t m355_conv2d_weight_elems(const m355_conv_desc *d, int which)
     // which 0: forward view [rows_padded(Cout)][ceil64(kh*kw*Cin)]; 1: dgrad views (stride 1: one
     // [rows_padded(Cin)][ceil64(kh*kw*Cout_p32)]; stride 2: four [rows_padded(Cin)][ceil64(kh/2*kw/2*Cout_p32)])
     if (!d) return 0;
+#ifdef M355_EXACT
+    // fp32 [Cout][kh][kw][Cin] for both views (counted in 2-byte elements: the caller allocates a bf16 buffer of that many)
+    return 2 * (size_t)d->Cout * d->kh * d->kw * d->Cin;
+#endif
     const size_t rows_f = m355::rows_padded(d->Cout), rows_d = m355::rows_padded(d->Cin);
     const size_t cout32 = (size_t)m355::dy_channels(d->Cout);
     if (up3(d)) {   // + the four sub-pixel class views [rows_f][ceil64(4 Cin)] / the adjoint 4x4 view [rows_d][ceil64(16 Cout_p32)]
@@ -968,6 +993,17 @@ static int fill_weight_prep(const m355_conv_desc *d, const float *w_oihw, int ci
         w.part[w.nparts++] = m355::WeightPrepPart{out, transpose, A, B, th0, ths, tw0, tws, Rp, Cp, Kp, eff};
         if ((size_t)Rp * Kp > most) most = (size_t)Rp * Kp;
     };
+#ifdef M355_EXACT
+    // EXACT build: both "views" are the fp32 array [Cout][kh][kw][Cin] (conv_exact.hip), written by the gather kernel
+    if (w_fwd) add((unsigned short *)w_fwd, 0, d->kh, d->kw, 0, 1, 0, 1, d->Cout, d->Cin, d->kh * d->kw * d->Cin);
+    if (w_dgrad) add((unsigned short *)w_dgrad, 0, d->kh, d->kw, 0, 1, 0, 1, d->Cout, d->Cin, d->kh * d->kw * d->Cin);
+    if (!ok) {
+        m355::set_error("conv2d_weight_prep: channel counts must be multiples of 8 (Cin=%d)", d->Cin);
+        return M355_ERR_BAD_ARG;
+    }
+    w.tiled = 0; w.OP = 0; w.IP = 0;
+    return M355_OK;
+#endif
     if (w_fwd) add((unsigned short *)w_fwd, 0, d->kh, d->kw, 0, 1, 0, 1, cout64, d->Cin, m355::k_padded(d->kh * d->kw * d->Cin));
     if (w_dgrad) {
         if (d->stride == 1) {
@@ -1094,6 +1130,11 @@ static int conv_fwd_impl(const m355_conv_desc *d, const void *x, const void *w_f
 {
     if (int rc = check_desc(d, "conv2d_fwd")) return probe ? 0 : rc;
     if (!probe) M355_REQUIRE(x && w_fwd && y, "conv2d_fwd: null pointer");
+#ifdef M355_EXACT
+    if (probe) return 0;   // no bit masks, no fused statistics: the callers take their generic paths
+    M355_REQUIRE(!bits_out && !stats, "conv2d_fwd: the EXACT build has no bit-mask / fused-statistics forward");
+    return m355::exact::conv_fwd(d, x, w_fwd, bias, y, y_f32_nchw, lrelu_slope, (hipStream_t)stream);
+#endif
     if (probe == 2 || stats) {
         if (m355::conv_small_eligible(d, y_f32_nchw) || (m355::conv_c8_eligible(d, y_f32_nchw) && !getenv("M355_NO_C8"))) {
             if (probe) return 0;
@@ -1208,6 +1249,9 @@ static ConvArgs fwd_args(const m355_conv_desc *d, const void *x, const void *w_f
 
 static int fwd_splitk(const m355_conv_desc *d)
 {
+#ifdef M355_EXACT
+    return 0;
+#endif
     if (!d || check_desc(d, "conv2d_fwd_ws")) return 0;
     if (m355::conv_small_eligible(d, 0) || m355::conv_c8_eligible(d, 0)) return 0;
     if (d->Cout % 8 || d->Cout > 2048 || 256 % (d->Cout / 8)) return 0;   // (the finishing pass: 8-channel vectors, 256 / vecs pixel lanes)
@@ -1274,6 +1318,9 @@ extern "C" int m355_conv2d_fwd_bits(const m355_conv_desc *d, const void *x, cons
 // does the dgrad of this layer run in the direct form (writes dx itself: no padded frame, no fold pass)?
 static bool dgrad_direct(const m355_conv_desc *d)
 {
+#ifdef M355_EXACT
+    return true;   // (the gather kernel writes dx itself)
+#endif
     int Ho, Wo;
     if (conv_out_hw(d, &Ho, &Wo) != 0) return false;
     if (subpixel(d)) return true;
@@ -1300,6 +1347,11 @@ static int conv_dgrad_impl(const m355_conv_desc *d, const void *dy, const void *
     if (int rc = check_desc(d, "conv2d_dgrad")) return probe ? 0 : rc;
     if (!probe) M355_REQUIRE(dy && w_dgrad && dx, "conv2d_dgrad: null pointer");
     hipStream_t st = (hipStream_t)stream;
+#ifdef M355_EXACT
+    if (probe) return 0;
+    M355_REQUIRE(!mask_bits, "conv2d_dgrad: the EXACT build reads no bit masks");
+    return m355::exact::conv_dgrad(d, dy, m355::dy_channels(d->Cout), w_dgrad, dx, mask_x, mask_slope, st);
+#endif
     int Ho, Wo;
     conv_out_hw(d, &Ho, &Wo);
     const int Hl = d->H << d->upsample, Wl = d->W << d->upsample;
@@ -1456,6 +1508,9 @@ extern "C" int m355_conv2d_dgrad_bits(const m355_conv_desc *d, const void *dy, c
 extern "C" int m355_conv2d_dgrad_mask_ok(const m355_conv_desc *d)
 {
     if (!d || check_desc(d, "conv2d_dgrad_mask_ok")) return 0;
+#ifdef M355_EXACT
+    return 1;
+#endif
     if (m355::dgrad_c8_replicate_eligible(d, m355::dy_channels(d->Cout))) return 1;
     return dgrad_direct(d) && d->pad_w_mode != 1 && !subpixel(d);
 }
@@ -1780,6 +1835,9 @@ static bool wgrad_dma_ok(const m355_conv_desc *d)
 /* 1 when m355_conv2d_wgrad can also produce the bias gradient (column sums of dy) for this layer */
 static bool wgrad_has_dbias(const m355_conv_desc *d)
 {
+#ifdef M355_EXACT
+    return true;
+#endif
     return wgrad_dma_ok(d) || m355::wgrad_c8_eligible(d, m355::dy_channels(d->Cout));
 }
 extern "C" int m355_conv2d_wgrad_fuses_dbias(const m355_conv_desc *d) { return d && wgrad_has_dbias(d) ? 1 : 0; }
@@ -1881,6 +1939,9 @@ extern "C" int m355_conv2d_wgrad_det(const m355_conv_desc *d, const void *x, con
     M355_REQUIRE(ws, "conv2d_wgrad_det: null workspace");
     if (int rc = check_desc(d, "conv2d_wgrad_det")) return rc;
     hipStream_t st = (hipStream_t)stream;
+#ifdef M355_EXACT
+    return conv_wgrad_impl(d, x, dy, dw, dbias, stream, true);   // (already a sequential fp64 sum per element)
+#endif
     if (subpixel(d)) {
         M355_REQUIRE(x && dy && dw, "conv2d_wgrad_det: null pointer");
         return subpixel_wgrad(d, x, dy, dw, dbias, ws, true, st);
@@ -1919,6 +1980,9 @@ extern "C" int m355_conv2d_wgrad_acc(const m355_conv_desc *d, const void *x, con
 extern "C" size_t m355_conv2d_wgrad_ws_bytes(const m355_conv_desc *d)
 {
     if (!d || check_desc(d, "conv2d_wgrad_ws_bytes")) return 0;
+#ifdef M355_EXACT
+    return 0;
+#endif
     const int cy = m355::dy_channels(d->Cout);
     if (m355::wgrad_c8_eligible(d, cy)) return sizeof(float) * m355::wgrad_c8_ws_floats(d, cy);
     // upsample + 3x3 in the sub-pixel form: the 16-entry effective gradient (zeroed here, accumulated with fp32 atomics -- NOT the
@@ -1945,6 +2009,11 @@ static int conv_wgrad_impl(const m355_conv_desc *d, const void *x, const void *d
 {
     if (int rc = check_desc(d, "conv2d_wgrad")) return rc;
     M355_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
+#ifdef M355_EXACT
+    // (zero = overwrite; the accumulating entry point adds to what the caller zeroed; the deterministic one overwrites -- every
+    // exact kernel is a sequential fp64 sum, so it is its own deterministic form)
+    return m355::exact::conv_wgrad(d, x, dy, m355::dy_channels(d->Cout), dw, dbias, (zero || fix) ? 0 : 1, (hipStream_t)stream);
+#endif
     M355_REQUIRE(!dbias || wgrad_has_dbias(d), "conv2d_wgrad: dbias is only fused on the DMA paths (m355_conv2d_wgrad_fuses_dbias)");
     hipStream_t st = (hipStream_t)stream;
     m355::WgradArgs a = {};

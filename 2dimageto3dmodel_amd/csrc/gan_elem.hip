@@ -10,6 +10,28 @@
 
 namespace m355 {
 
+// The ACTIVATION element type of this translation unit.  Product build: bf16 (`act_t` = short, eight of them = one 16-byte vector).
+// EXACT build (-DM355_EXACT, csrc/conv_exact.hip): fp32 -- the same kernels with `act_t` = float, the eight-element vector a
+// 32-byte aggregate, and every "round to the storage type" helper the identity, so the formulas (statistics, affine, activation
+// backward, projection) are the ones the product runs, minus the bf16 roundings.
+#ifdef M355_EXACT
+typedef float act_t;
+struct __attribute__((aligned(16))) bf16x8e {
+    float v[8];
+    __device__ __forceinline__ float operator[](int j) const { return v[j]; }
+    __device__ __forceinline__ float &operator[](int j) { return v[j]; }
+};
+__device__ __forceinline__ float bf2f_e(float h) { return h; }
+__device__ __forceinline__ bf16x8e pack8_e(const float (&z)[8])
+{
+    bf16x8e r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.v[j] = z[j];
+    return r;
+}
+__device__ __forceinline__ float f2bf_e(float f) { return f; }
+#else
+typedef short act_t;
 typedef __attribute__((ext_vector_type(8))) short bf16x8e;
 
 __device__ __forceinline__ float bf2f_e(short h) { return __uint_as_float(((unsigned int)(unsigned short)h) << 16); }
@@ -32,6 +54,7 @@ __device__ __forceinline__ short f2bf_e(float f)
     u += 0x7fffu + ((u >> 16) & 1u);
     return (short)(u >> 16);
 }
+#endif
 
 constexpr int kMinElemsPerBlock = 65536;  // elements a workgroup reduces (more when that keeps the partial count <= 1024)
 
@@ -81,7 +104,7 @@ __device__ __forceinline__ void pixel_reduce(int C, size_t pix0, int npix, float
 }
 
 // x[P][C] -> part[blk][2][C] = (sum, sum of squares)
-__global__ __launch_bounds__(256) void k_chan_stats(const short *__restrict__ x, float *__restrict__ part, size_t P, int C,
+__global__ __launch_bounds__(256) void k_chan_stats(const act_t *__restrict__ x, float *__restrict__ part, size_t P, int C,
                                                     int ppb)
 {
     const size_t pix0 = (size_t)blockIdx.x * ppb;
@@ -98,7 +121,7 @@ __global__ __launch_bounds__(256) void k_chan_stats(const short *__restrict__ x,
 }
 
 // x[P][C] -> part[blk][1][C] = sum over pixels (bias gradient of a conv whose incoming gradient is already masked)
-__global__ __launch_bounds__(256) void k_chan_sum(const short *__restrict__ x, float *__restrict__ part, size_t P, int C, int ppb)
+__global__ __launch_bounds__(256) void k_chan_sum(const act_t *__restrict__ x, float *__restrict__ part, size_t P, int C, int ppb)
 {
     const size_t pix0 = (size_t)blockIdx.x * ppb;
     const int npix = (int)min((size_t)ppb, P - pix0);
@@ -133,9 +156,9 @@ __global__ __launch_bounds__(256) void k_sum_partials(const float *__restrict__ 
 // y = lrelu(x * a[n,c] + b[n,c]) [+ res];  x,y [N][HW][C].  A thread keeps ONE 8-channel group for its whole loop
 // (the grid stride is a multiple of C/8), so its 16 coefficients live in registers: the kernel is pure 16-byte
 // streaming (the first version re-read a/b per element and ran at a third of the HBM rate).
-__global__ __launch_bounds__(256) void k_affine_act(const short *__restrict__ x, const float *__restrict__ a,
-                                                    const float *__restrict__ b, const short *__restrict__ res,
-                                                    short *__restrict__ y, int HW, int C, float slope, int res_w,
+__global__ __launch_bounds__(256) void k_affine_act(const act_t *__restrict__ x, const float *__restrict__ a,
+                                                    const float *__restrict__ b, const act_t *__restrict__ res,
+                                                    act_t *__restrict__ y, int HW, int C, float slope, int res_w,
                                                     float out_slope)
 {
     // res_w > 0: the residual is stored at HALF resolution ([N][H/2][res_w/2][C]) and read through the nearest x2
@@ -143,9 +166,9 @@ __global__ __launch_bounds__(256) void k_affine_act(const short *__restrict__ x,
     const int n = blockIdx.y;
     const int vecs = C >> 3;
     const size_t total = (size_t)HW * vecs;
-    const short *xn = x + (size_t)n * HW * C;
-    short *yn = y + (size_t)n * HW * C;
-    const short *rn = res ? res + (size_t)n * (res_w > 0 ? HW / 4 : HW) * C : nullptr;
+    const act_t *xn = x + (size_t)n * HW * C;
+    act_t *yn = y + (size_t)n * HW * C;
+    const act_t *rn = res ? res + (size_t)n * (res_w > 0 ? HW / 4 : HW) * C : nullptr;
     const int c0 = (int)(threadIdx.x % vecs) * 8;   // (blockIdx.x * 256 + k * gridDim.x * 256) % vecs == 0
     const int lvecs = __builtin_ctz(vecs), lrw = res_w > 0 ? __builtin_ctz(res_w) : 0;
     const bool rw_pow2 = res_w > 0 && (res_w & (res_w - 1)) == 0;
@@ -215,7 +238,7 @@ __global__ __launch_bounds__(256) void k_affine_act(const short *__restrict__ x,
 }
 
 // dz = dy * lrelu'(x*a+b);  part[n][blk][2][C] = (sum dz, sum dz*x) over the workgroup's pixels of sample n
-__global__ __launch_bounds__(256) void k_act_bwd_reduce(const short *__restrict__ dy, const short *__restrict__ x,
+__global__ __launch_bounds__(256) void k_act_bwd_reduce(const act_t *__restrict__ dy, const act_t *__restrict__ x,
                                                         const float *__restrict__ a, const float *__restrict__ b,
                                                         float *__restrict__ part, int HW, int C, float slope, int ppb)
 {
@@ -246,10 +269,10 @@ __global__ __launch_bounds__(256) void k_act_bwd_reduce(const short *__restrict_
 }
 
 // dx = dz * A[n,c] + x * B[c] + Cc[c]   (coefficients of the thread's 8-channel group in registers, as above)
-__global__ __launch_bounds__(256) void k_act_bwd_apply(const short *__restrict__ dy, const short *__restrict__ x,
+__global__ __launch_bounds__(256) void k_act_bwd_apply(const act_t *__restrict__ dy, const act_t *__restrict__ x,
                                                        const float *__restrict__ a, const float *__restrict__ b,
                                                        const float *__restrict__ A, const float *__restrict__ Bc,
-                                                       const float *__restrict__ Cc, short *__restrict__ dx, int HW,
+                                                       const float *__restrict__ Cc, act_t *__restrict__ dx, int HW,
                                                        int C, float slope)
 {
     const int n = blockIdx.y;
@@ -294,8 +317,8 @@ __global__ __launch_bounds__(256) void k_act_bwd_apply(const short *__restrict__
 }
 
 // g[P][Cp] = dy[P][C] * (y > 0 ? 1 : slope), channels C..Cp-1 zero;  part[blk][1][C] = sum over pixels of g
-__global__ __launch_bounds__(256) void k_lrelu_bwd(const short *__restrict__ dy, const short *__restrict__ y,
-                                                   short *__restrict__ g, float *__restrict__ part, size_t P, int C,
+__global__ __launch_bounds__(256) void k_lrelu_bwd(const act_t *__restrict__ dy, const act_t *__restrict__ y,
+                                                   act_t *__restrict__ g, float *__restrict__ part, size_t P, int C,
                                                    float slope, int ppb)
 {
     const size_t pix0 = (size_t)blockIdx.x * ppb;
@@ -317,7 +340,7 @@ __global__ __launch_bounds__(256) void k_lrelu_bwd(const short *__restrict__ dy,
 // NCHW fp32 image (C <= 8 planes) [+ P constant planes, e.g. the positional encoding of gan.py:9-20] -> NHWC bf16 with
 // exactly 8 channels (zero filled beyond C + P): what TextureDiscriminator.forward builds with cat + permute + cast
 // (gan.py:204-209) in one pass.  One thread per pixel: plane reads are coalesced along W, the store is 16 bytes.
-__global__ __launch_bounds__(256) void k_pack_nhwc8(const float *__restrict__ x, const float *__restrict__ pos, short *__restrict__ out,
+__global__ __launch_bounds__(256) void k_pack_nhwc8(const float *__restrict__ x, const float *__restrict__ pos, act_t *__restrict__ out,
                                                     int C, int P, size_t HW, size_t total)
 {
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -335,7 +358,7 @@ __global__ __launch_bounds__(256) void k_pack_nhwc8(const float *__restrict__ x,
 }
 
 // backward of the above w.r.t. the image: d out [.., 8] bf16 -> dx NCHW fp32 (first C channels)
-__global__ __launch_bounds__(256) void k_unpack_nhwc8(const short *__restrict__ g, float *__restrict__ dx, int C, size_t HW, size_t total)
+__global__ __launch_bounds__(256) void k_unpack_nhwc8(const act_t *__restrict__ g, float *__restrict__ dx, int C, size_t HW, size_t total)
 {
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t n = i / HW, p = i - n * HW;
@@ -357,12 +380,12 @@ static int check_c(int C, const char *who)
 
 // ---- projection discriminator (gan.py:104-116, 216-228): o[n,p] = sum_c feat[n,p,c] * emb[n,c] on the bf16 NHWC feature
 // map (the torch path converted it to fp32 -- 67 M elements at batch 128 -- for an einsum).  One wave per pixel.
-__global__ __launch_bounds__(256) void k_cproj_fwd(const short *__restrict__ feat, const float *__restrict__ emb, float *__restrict__ o,
+__global__ __launch_bounds__(256) void k_cproj_fwd(const act_t *__restrict__ feat, const float *__restrict__ emb, float *__restrict__ o,
                                                    int HW, int C)
 {
     const int n = blockIdx.y, p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (p >= HW) return;
-    const short *f = feat + ((size_t)n * HW + p) * C;
+    const act_t *f = feat + ((size_t)n * HW + p) * C;
     const float *e = emb + (size_t)n * C;
     float acc = 0.0f;
     for (int v = lane; v < (C >> 3); v += 64) {
@@ -381,8 +404,8 @@ __global__ __launch_bounds__(256) void k_cproj_fwd(const short *__restrict__ fea
 // mask_slope != 1: feat is the output of a fused conv + LeakyReLU(mask_slope) whose backward is applied HERE (dfeat *= feat > 0
 // ? 1 : mask_slope) -- masking is linear, so when every consumer of that activation masks its own branch of the gradient the
 // producer needs no activation-backward pass over the summed gradient (TextureDiscriminator.conv4 -> conv5 + projection)
-__global__ __launch_bounds__(256) void k_cproj_bwd(const short *__restrict__ feat, const float *__restrict__ emb,
-                                                   const float *__restrict__ g, short *__restrict__ dfeat, float *__restrict__ part,
+__global__ __launch_bounds__(256) void k_cproj_bwd(const act_t *__restrict__ feat, const float *__restrict__ emb,
+                                                   const float *__restrict__ g, act_t *__restrict__ dfeat, float *__restrict__ part,
                                                    int HW, int C, int ppb, float mask_slope)
 {
     __shared__ float red[256 * 8];
@@ -444,7 +467,7 @@ extern "C" int m355_bn_stats_partial(const void *x, float *part, size_t P, int C
     if (int rc = check_c(C, "bn_stats_partial")) return rc;
     const int ppb = pix_per_block(P, C);
     const int nblk = (int)((P + ppb - 1) / ppb);
-    hipLaunchKernelGGL(k_chan_stats, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const short *)x, part, P, C, ppb);
+    hipLaunchKernelGGL(k_chan_stats, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const act_t *)x, part, P, C, ppb);
     return check_launch("bn_stats_partial");
 }
 
@@ -456,7 +479,7 @@ extern "C" int m355_affine_act_bwd_partial(const void *dy, const void *x, const 
     if (int rc = check_c(C, "affine_act_bwd_partial")) return rc;
     const int ppb = pix_per_block((size_t)HW, C);
     const int nblk = (HW + ppb - 1) / ppb;
-    hipLaunchKernelGGL(k_act_bwd_reduce, dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, (const short *)dy, (const short *)x,
+    hipLaunchKernelGGL(k_act_bwd_reduce, dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, (const act_t *)dy, (const act_t *)x,
                        a, b, part, HW, C, slope, ppb);
     return check_launch("affine_act_bwd_partial");
 }
@@ -468,7 +491,7 @@ extern "C" int m355_chan_sum(const void *x, float *sums /*[C]*/, void *ws, size_
     const int ppb = pix_per_block(P, C);
     const int nblk = (int)((P + ppb - 1) / ppb);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_chan_sum, dim3(nblk), dim3(256), 0, st, (const short *)x, (float *)ws, P, C, ppb);
+    hipLaunchKernelGGL(k_chan_sum, dim3(nblk), dim3(256), 0, st, (const act_t *)x, (float *)ws, P, C, ppb);
     hipLaunchKernelGGL(k_sum_partials, dim3((C + 31) / 32, 1), dim3(256), 0, st, (const float *)ws, sums, nblk, C);
     return check_launch("chan_sum");
 }
@@ -480,7 +503,7 @@ extern "C" int m355_bn_stats(const void *x, float *sums /*[2][C]*/, void *ws, si
     const int ppb = pix_per_block(P, C);
     const int nblk = (int)((P + ppb - 1) / ppb);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_chan_stats, dim3(nblk), dim3(256), 0, st, (const short *)x, (float *)ws, P, C, ppb);
+    hipLaunchKernelGGL(k_chan_stats, dim3(nblk), dim3(256), 0, st, (const act_t *)x, (float *)ws, P, C, ppb);
     hipLaunchKernelGGL(k_sum_partials, dim3((2 * C + 31) / 32, 1), dim3(256), 0, st, (const float *)ws, sums, nblk, 2 * C);
     return check_launch("bn_stats");
 }
@@ -495,8 +518,8 @@ extern "C" int m355_affine_act_fwd(const void *x, const float *a, const float *b
     const size_t total = (size_t)HW * (C / 8);
     // ~8 vectors per thread (its coefficients are loaded once), still thousands of workgroups with N in grid.y
     const unsigned gx = (unsigned)min((size_t)4096, (total + 2047) / 2048);
-    hipLaunchKernelGGL(k_affine_act, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, (const short *)x, a, b,
-                       (const short *)res, (short *)y, HW, C, slope, res ? res_w : 0, out_slope);
+    hipLaunchKernelGGL(k_affine_act, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, (const act_t *)x, a, b,
+                       (const act_t *)res, (act_t *)y, HW, C, slope, res ? res_w : 0, out_slope);
     return check_launch("affine_act_fwd");
 }
 
@@ -509,7 +532,7 @@ extern "C" int m355_affine_act_bwd_reduce(const void *dy, const void *x, const f
     const int ppb = pix_per_block((size_t)HW, C);
     const int nblk = (HW + ppb - 1) / ppb;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_act_bwd_reduce, dim3(nblk, N), dim3(256), 0, st, (const short *)dy, (const short *)x, a, b,
+    hipLaunchKernelGGL(k_act_bwd_reduce, dim3(nblk, N), dim3(256), 0, st, (const act_t *)dy, (const act_t *)x, a, b,
                        (float *)ws, HW, C, slope, ppb);
     hipLaunchKernelGGL(k_sum_partials, dim3((2 * C + 31) / 32, N), dim3(256), 0, st, (const float *)ws, sums, nblk, 2 * C);
     return check_launch("affine_act_bwd_reduce");
@@ -524,8 +547,8 @@ extern "C" int m355_affine_act_bwd_apply(const void *dy, const void *x, const fl
     const size_t total = (size_t)HW * (C / 8);
     // ~8 vectors per thread (its coefficients are loaded once), still thousands of workgroups with N in grid.y
     const unsigned gx = (unsigned)min((size_t)4096, (total + 2047) / 2048);
-    hipLaunchKernelGGL(k_act_bwd_apply, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, (const short *)dy, (const short *)x,
-                       a, b, A, Bc, Cc, (short *)dx, HW, C, slope);
+    hipLaunchKernelGGL(k_act_bwd_apply, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, (const act_t *)dy, (const act_t *)x,
+                       a, b, A, Bc, Cc, (act_t *)dx, HW, C, slope);
     return check_launch("affine_act_bwd_apply");
 }
 
@@ -537,7 +560,7 @@ extern "C" int m355_lrelu_bwd(const void *dy, const void *y, void *g, float *dbi
     const int ppb = pix_per_block(P, C);
     const int nblk = (int)((P + ppb - 1) / ppb);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_lrelu_bwd, dim3(nblk), dim3(256), 0, st, (const short *)dy, (const short *)y, (short *)g,
+    hipLaunchKernelGGL(k_lrelu_bwd, dim3(nblk), dim3(256), 0, st, (const act_t *)dy, (const act_t *)y, (act_t *)g,
                        (float *)ws, P, C, slope, ppb);
     hipLaunchKernelGGL(k_sum_partials, dim3((C + 31) / 32, 1), dim3(256), 0, st, (const float *)ws, dbias, nblk, C);
     return check_launch("lrelu_bwd");
@@ -550,7 +573,7 @@ extern "C" int m355_pack_nhwc8(const float *x_nchw, const float *pos, void *out_
                  "pack_nhwc8: bad argument");
     const size_t HW = (size_t)H * W, total = (size_t)N * HW;
     const unsigned g = (unsigned)min((size_t)65535, (total + 255) / 256);
-    hipLaunchKernelGGL(k_pack_nhwc8, dim3(g), dim3(256), 0, (hipStream_t)stream, x_nchw, pos, (short *)out_nhwc8, C, P, HW, total);
+    hipLaunchKernelGGL(k_pack_nhwc8, dim3(g), dim3(256), 0, (hipStream_t)stream, x_nchw, pos, (act_t *)out_nhwc8, C, P, HW, total);
     return check_launch("pack_nhwc8");
 }
 
@@ -559,7 +582,7 @@ extern "C" int m355_unpack_nhwc8(const void *g_nhwc8, float *dx_nchw, int N, int
     M355_REQUIRE(g_nhwc8 && dx_nchw && N > 0 && C >= 1 && C <= 8 && H > 0 && W > 0, "unpack_nhwc8: bad argument");
     const size_t HW = (size_t)H * W, total = (size_t)N * HW;
     const unsigned g = (unsigned)min((size_t)65535, (total + 255) / 256);
-    hipLaunchKernelGGL(k_unpack_nhwc8, dim3(g), dim3(256), 0, (hipStream_t)stream, (const short *)g_nhwc8, dx_nchw, C, HW, total);
+    hipLaunchKernelGGL(k_unpack_nhwc8, dim3(g), dim3(256), 0, (hipStream_t)stream, (const act_t *)g_nhwc8, dx_nchw, C, HW, total);
     return check_launch("unpack_nhwc8");
 }
 
@@ -567,7 +590,7 @@ extern "C" int m355_cproj_fwd(const void *feat, const float *emb, float *out /*[
 {
     M355_REQUIRE(feat && emb && out && N > 0 && HW > 0 && N <= 65535, "cproj_fwd: bad argument");
     if (int rc = check_c(C, "cproj_fwd")) return rc;
-    hipLaunchKernelGGL(k_cproj_fwd, dim3((HW + 3) / 4, N), dim3(256), 0, (hipStream_t)stream, (const short *)feat, emb, out, HW, C);
+    hipLaunchKernelGGL(k_cproj_fwd, dim3((HW + 3) / 4, N), dim3(256), 0, (hipStream_t)stream, (const act_t *)feat, emb, out, HW, C);
     return check_launch("cproj_fwd");
 }
 
@@ -587,7 +610,7 @@ extern "C" int m355_cproj_bwd(const void *feat, const float *emb, const float *g
     hipStream_t st = (hipStream_t)stream;
     const int ppb = pix_per_block((size_t)HW, C), nblk = (HW + ppb - 1) / ppb;
     M355_REQUIRE(nblk == 1 || ws, "cproj_bwd: workspace required (m355_cproj_bwd_ws_floats)");
-    hipLaunchKernelGGL(k_cproj_bwd, dim3(nblk, N), dim3(256), 0, st, (const short *)feat, emb, g, (short *)dfeat, nblk == 1 ? demb : ws,
+    hipLaunchKernelGGL(k_cproj_bwd, dim3(nblk, N), dim3(256), 0, st, (const act_t *)feat, emb, g, (act_t *)dfeat, nblk == 1 ? demb : ws,
                        HW, C, ppb, mask_slope);
     if (nblk > 1) hipLaunchKernelGGL(k_sum_partials, dim3((C + 31) / 32, N), dim3(256), 0, st, (const float *)ws, demb, nblk, C);
     return check_launch("cproj_bwd");

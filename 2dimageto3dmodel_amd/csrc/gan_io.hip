@@ -19,6 +19,28 @@
 
 namespace m355 {
 
+// activation element type: bf16 in the product build, fp32 in the EXACT build (see csrc/gan_elem.hip / conv_exact.hip)
+#ifdef M355_EXACT
+typedef float act_t;
+struct __attribute__((aligned(16))) bf16x8i {
+    float v[8];
+};
+__device__ __forceinline__ float bf2f_i(float h) { return h; }
+__device__ __forceinline__ bf16x8i pack8_i(const float *z)
+{
+    bf16x8i r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.v[j] = z[j];
+    return r;
+}
+// the first four channels of a packed pixel as floats
+__device__ __forceinline__ void load4_i(const float *s, float (&f)[4])
+{
+    const float4 v = *reinterpret_cast<const float4 *>(s);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+}
+#else
+typedef short act_t;
 typedef __attribute__((ext_vector_type(8))) short bf16x8i;
 
 __device__ __forceinline__ float bf2f_i(short h) { return __uint_as_float(((unsigned int)(unsigned short)h) << 16); }
@@ -34,6 +56,13 @@ __device__ __forceinline__ bf16x8i pack8_i(const float *z)
     u4 w = {pack2_i(z[0], z[1]), pack2_i(z[2], z[3]), pack2_i(z[4], z[5]), pack2_i(z[6], z[7])};
     return __builtin_bit_cast(bf16x8i, w);
 }
+__device__ __forceinline__ void load4_i(const short *s, float (&f)[4])
+{
+    const uint2 v = *reinterpret_cast<const uint2 *>(s);
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------- mask + cat
 // X[m,c,:]: m < N: c < 3 ? fake[m,c,:] * alpha[m,:] : alpha[m,:];   m >= N (only with `real`): real / alpha of sample m - N
@@ -76,7 +105,7 @@ struct PoolPackArgs {
     const float *x;      // [M,C,H,W] fp32
     const float *extra;  // [M,E,Ho,Wo] fp32 or null
     const float *pos;    // [P,Ho,Wo] fp32 or null
-    short *out;          // [M,Ho,Wo,CP] bf16
+    act_t *out;          // [M,Ho,Wo,CP] bf16
     float *mask;         // [M,Ho/g,Wo/g] fp32 or null
     int M, C, H, W, E, P, CP, Ho, Wo, g, mask_chan;
     // PARTS form (x == null): the 4-channel input is never materialised -- sample m < Nf is cat(fake[m] * alpha[m], alpha[m]),
@@ -151,7 +180,7 @@ __global__ __launch_bounds__(TW * 4) void k_pool_pack(PoolPackArgs a)
             }
             z[c] = v;
         }
-        short *o = a.out + ((size_t)m * HWo + po) * a.CP;
+        act_t *o = a.out + ((size_t)m * HWo + po) * a.CP;
         *reinterpret_cast<bf16x8i *>(o) = pack8_i(z);
         if (a.CP == 16) *reinterpret_cast<bf16x8i *>(o + 8) = pack8_i(z + 8);
         av[ty * 4 + r][tx] = mval;
@@ -197,7 +226,7 @@ __global__ __launch_bounds__(256) void k_pack1x4(PoolPackArgs a)
         else if (c - a.C - a.E < a.P) t = *reinterpret_cast<const float4 *>(a.pos + (size_t)(c - a.C - a.E) * HW + po);
         v[c] = t;
     }
-    short *o = a.out + ((size_t)m * HW + po) * 8;
+    act_t *o = a.out + ((size_t)m * HW + po) * 8;
     {
         const float z0[8] = {v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x};
         const float z1[8] = {v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y};
@@ -234,7 +263,7 @@ __global__ __launch_bounds__(256) void k_pack1x4(PoolPackArgs a)
 }
 
 struct PoolUnpackArgs {
-    const short *dh[3];  // [M,H/f,W/f,CP] bf16 gradients of the packed tensors
+    const act_t *dh[3];  // [M,H/f,W/f,CP] bf16 gradients of the packed tensors
     int f[3], CP[3];
     int K;
     float *dx;           // [M,C,H,W] fp32
@@ -254,13 +283,14 @@ __global__ __launch_bounds__(256) void k_pool_unpack_bwd(PoolUnpackArgs a)
         for (int k = 0; k < 3; ++k) {
             if (k < a.K) {
                 const int f = a.f[k], Wk = a.W / f, Hk = a.H / f;
-                const short *s = a.dh[k] + ((m * Hk + (size_t)(y / f)) * Wk + (size_t)(x / f)) * a.CP[k];
-                const uint2 v = *reinterpret_cast<const uint2 *>(s);
+                const act_t *s = a.dh[k] + ((m * Hk + (size_t)(y / f)) * Wk + (size_t)(x / f)) * a.CP[k];
+                float v4[4];
+                load4_i(s, v4);
                 const float inv = 1.0f / (float)(f * f);
-                acc[0] += __uint_as_float(v.x << 16) * inv;
-                acc[1] += __uint_as_float(v.x & 0xffff0000u) * inv;
-                acc[2] += __uint_as_float(v.y << 16) * inv;
-                acc[3] += __uint_as_float(v.y & 0xffff0000u) * inv;
+                acc[0] += v4[0] * inv;
+                acc[1] += v4[1] * inv;
+                acc[2] += v4[2] * inv;
+                acc[3] += v4[3] * inv;
             }
         }
         if (a.alpha) {               // k_mask_cat_bwd applied in place: dfake = dX[:, :3] * alpha
@@ -276,7 +306,7 @@ __global__ __launch_bounds__(256) void k_pool_unpack_bwd(PoolUnpackArgs a)
 }
 
 // g [M,HW,CP] bf16, channels c0 .. c0+E-1 -> out [M,E,HW] fp32
-__global__ __launch_bounds__(256) void k_unpack_range(const short *__restrict__ g, float *__restrict__ out, int CP, int c0, int E,
+__global__ __launch_bounds__(256) void k_unpack_range(const act_t *__restrict__ g, float *__restrict__ out, int CP, int c0, int E,
                                                       size_t HW, size_t total)
 {
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -320,7 +350,7 @@ __global__ __launch_bounds__(256) void k_head_tail_fwd(const float *__restrict__
 // dout [N,C,H,Wo], out (the forward's result, for tanh') -> g [N,H,W,8] bf16 (conv's dy layout), part[block][4] = the block's
 // bias-gradient sums (reduced in block order by k_head_tail_db: deterministic -- this used to be one fp32 atomic per block)
 __global__ __launch_bounds__(256) void k_head_tail_bwd(const float *__restrict__ dout, const float *__restrict__ out,
-                                                       short *__restrict__ g, float *__restrict__ part, int C, int H, int W,
+                                                       act_t *__restrict__ g, float *__restrict__ part, int C, int H, int W,
                                                        int flags, size_t total)
 {
     __shared__ float red[4][8];
@@ -567,7 +597,7 @@ extern "C" int m355_pool_pack_fwd(const float *x, int M, int C, int H, int W, in
                  W, f, E, P, g);
     M355_REQUIRE((CP == 8 || CP == 16) && C + E + P <= CP && (E == 0 || extra) && (P == 0 || pos) && mask_chan >= 0 && mask_chan < C,
                  "pool_pack_fwd: bad channel layout");
-    PoolPackArgs a = {x, extra, pos, (short *)out, mask, M, C, H, W, E, P, CP, H / f, W / f, mask ? g : 16, mask_chan,
+    PoolPackArgs a = {x, extra, pos, (act_t *)out, mask, M, C, H, W, E, P, CP, H / f, W / f, mask ? g : 16, mask_chan,
                       nullptr, nullptr, nullptr, 0};
     return pool_pack_launch(a, f, (hipStream_t)stream);
 }
@@ -583,7 +613,7 @@ extern "C" int m355_pool_pack_parts_fwd(const float *fake, const float *real, co
     M355_REQUIRE(m355_pool_pack_ok(4, H, W, f, E, P, mask ? g : 0) && W % 4 == 0,
                  "pool_pack_parts_fwd: unsupported shape H=%d W=%d f=%d E=%d P=%d g=%d", H, W, f, E, P, g);
     M355_REQUIRE((CP == 8 || CP == 16) && 4 + E + P <= CP && (E == 0 || extra) && (P == 0 || pos), "pool_pack_parts_fwd: bad channel layout");
-    PoolPackArgs a = {nullptr, extra, pos, (short *)out, mask, M, 4, H, W, E, P, CP, H / f, W / f, mask ? g : 16, 3,
+    PoolPackArgs a = {nullptr, extra, pos, (act_t *)out, mask, M, 4, H, W, E, P, CP, H / f, W / f, mask ? g : 16, 3,
                       fake, real, alpha, Nf};
     return pool_pack_launch(a, f, (hipStream_t)stream);
 }
@@ -598,7 +628,7 @@ extern "C" int m355_pool_unpack_bwd(const void *dh0, int f0, int cp0, const void
     for (int k = 0; k < 3; ++k) {
         if (!dh[k]) break;
         M355_REQUIRE(f[k] >= 1 && H % f[k] == 0 && W % f[k] == 0 && cp[k] % 4 == 0, "pool_unpack_bwd: bad factor / channel stride");
-        a.dh[k] = (const short *)dh[k];
+        a.dh[k] = (const act_t *)dh[k];
         a.f[k] = f[k];
         a.CP[k] = cp[k];
         a.K = k + 1;
@@ -620,7 +650,7 @@ extern "C" int m355_pool_unpack_parts_bwd(const void *dh0, int f0, int cp0, cons
     for (int k = 0; k < 3; ++k) {
         if (!dh[k]) break;
         M355_REQUIRE(f[k] >= 1 && H % f[k] == 0 && W % f[k] == 0 && cp[k] % 4 == 0, "pool_unpack_parts_bwd: bad factor / channel stride");
-        a.dh[k] = (const short *)dh[k];
+        a.dh[k] = (const act_t *)dh[k];
         a.f[k] = f[k];
         a.CP[k] = cp[k];
         a.K = k + 1;
@@ -634,7 +664,7 @@ extern "C" int m355_unpack_range(const void *g, float *out, int M, int HW, int C
 {
     M355_REQUIRE(g && out && M > 0 && HW > 0 && c0 >= 0 && E >= 1 && c0 + E <= CP, "unpack_range: bad argument");
     const size_t total = (size_t)M * HW;
-    hipLaunchKernelGGL(k_unpack_range, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const short *)g, out, CP, c0, E,
+    hipLaunchKernelGGL(k_unpack_range, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const act_t *)g, out, CP, c0, E,
                        (size_t)HW, total);
     return check_launch("unpack_range");
 }
@@ -656,7 +686,7 @@ extern "C" int m355_head_tail_bwd(const float *dout, const float *out, void *g_n
     const size_t total = (size_t)N * H * W;
     const size_t gb = (total + 255) / 256;
     const unsigned nblk = (unsigned)(gb > M355_HEAD_TAIL_WS_FLOATS / 4 ? M355_HEAD_TAIL_WS_FLOATS / 4 : gb);
-    hipLaunchKernelGGL(k_head_tail_bwd, dim3(nblk), dim3(256), 0, st, dout, out, (short *)g_nhwc8, ws, C, H, W, flags, total);
+    hipLaunchKernelGGL(k_head_tail_bwd, dim3(nblk), dim3(256), 0, st, dout, out, (act_t *)g_nhwc8, ws, C, H, W, flags, total);
     hipLaunchKernelGGL(k_head_tail_db, dim3(1), dim3(256), 0, st, (const float *)ws, dbias, (int)nblk, C);
     return check_launch("head_tail_bwd");
 }

@@ -17,6 +17,12 @@ from . import _lib
 from ._lib import check, launch, lib, ptr, stream
 
 
+def _act():
+    """dtype of the activation tensors: bfloat16, or float32 when the EXACT build of the library is loaded (_lib.set_exact)"""
+    from . import _lib
+    return _lib.act_dtype()
+
+
 def _ceil(a, b):
     return (a + b - 1) // b * b
 
@@ -106,7 +112,7 @@ def to_nhwc_bf16(x_nchw, pad_to=1):
     cp = _ceil(c, pad_to)
     if cp != c:
         x = F.pad(x, (0, cp - c))
-    return x.contiguous().to(torch.bfloat16)
+    return x.contiguous().to(_act())
 
 
 class PackNHWC8(torch.autograd.Function):
@@ -118,7 +124,7 @@ class PackNHWC8(torch.autograd.Function):
         x = x.contiguous()
         n, c, h, w = x.shape
         p = 0 if pos is None else pos.shape[0]
-        out = torch.empty((n, h, w, 8), dtype=torch.bfloat16, device=x.device)
+        out = torch.empty((n, h, w, 8), dtype=_act(), device=x.device)
         launch("pack_nhwc8", ptr(x), ptr(pos), ptr(out), n, c, p, h, w, stream())
         ctx.shape = (n, c, h, w)
         return out
@@ -222,7 +228,7 @@ class DiscPartsFn(torch.autograd.Function):
         for f, has_extra, pos, cp, g in specs:
             ho, wo = h // f, w // f
             e = extra.contiguous() if has_extra else None
-            out = torch.empty((m, ho, wo, cp), dtype=torch.bfloat16, device=fake.device)
+            out = torch.empty((m, ho, wo, cp), dtype=_act(), device=fake.device)
             mask = torch.empty((m, 1, ho // g, wo // g), dtype=torch.float32, device=fake.device) if g else None
             launch("pool_pack_parts_fwd", ptr(fake), ptr(real), ptr(alpha), n, m, h, w, f, ptr(e), 0 if e is None else e.shape[1],
                    ptr(pos), 0 if pos is None else pos.shape[0], ptr(out), cp, ptr(mask), g, stream())
@@ -276,7 +282,7 @@ class DiscInputsFn(torch.autograd.Function):
         for f, has_extra, pos, cp, g in specs:
             ho, wo = h // f, w // f
             e = extra.contiguous() if has_extra else None
-            out = torch.empty((m, ho, wo, cp), dtype=torch.bfloat16, device=x.device)
+            out = torch.empty((m, ho, wo, cp), dtype=_act(), device=x.device)
             mask = torch.empty((m, 1, ho // g, wo // g), dtype=torch.float32, device=x.device) if g else None
             launch("pool_pack_fwd", ptr(x), m, c, h, w, f, ptr(e), 0 if e is None else e.shape[1], ptr(pos),
                    0 if pos is None else pos.shape[0], ptr(out), cp, ptr(mask), 3, g, stream())
@@ -372,7 +378,7 @@ class HeadConvFn(torch.autograd.Function):
     def backward(ctx, dout):
         x, wd, out = ctx.saved_tensors
         d = ctx.d
-        g = torch.empty((d.N, d.H, d.W, 8), dtype=torch.bfloat16, device=x.device)
+        g = torch.empty((d.N, d.H, d.W, 8), dtype=_act(), device=x.device)
         db = torch.empty((d.Cout,), dtype=torch.float32, device=x.device)
         ws = torch.empty((_lib.HEAD_TAIL_WS_FLOATS,), dtype=torch.float32, device=x.device)
         launch("head_tail_bwd", ptr(dout.contiguous()), ptr(out), ptr(g), ptr(db), ptr(ws), d.N, d.Cout, d.H, d.W, ctx.flags, stream())
@@ -553,7 +559,7 @@ class Conv2dFn(torch.autograd.Function):
             # instead of permute / pad (fill + copy) / cast
             dyc = dy.contiguous()
             db = dyc.sum((0, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[2] else None
-            g = torch.empty((d.N, dyc.shape[2], dyc.shape[3], 8), dtype=torch.bfloat16, device=dy.device)
+            g = torch.empty((d.N, dyc.shape[2], dyc.shape[3], 8), dtype=_act(), device=dy.device)
             launch("pack_nhwc8", ptr(dyc), ptr(None), ptr(g), d.N, d.Cout, 0, dyc.shape[2], dyc.shape[3], stream())
         else:
             g = dy.permute(0, 2, 3, 1) if ctx.f32 else dy       # -> NHWC view
@@ -563,7 +569,7 @@ class Conv2dFn(torch.autograd.Function):
             db = g.float().sum((0, 1, 2)) if ctx.has_bias and ctx.needs_input_grad[2] else None
             if c32 != d.Cout:
                 g = F.pad(g, (0, c32 - d.Cout))
-            g = g.contiguous().to(torch.bfloat16)
+            g = g.contiguous().to(_act())
         dx = None
         if ctx.needs_input_grad[0]:
             if ctx.in_slope != 1.0 and in_bits is not None:
@@ -697,7 +703,7 @@ class SpectralNormGroup:
         if not self.convs:
             return
         key = tuple(t.data_ptr() for c in self.convs for t in (c.weight_orig, c.weight_u, c.weight_v)) + \
-            tuple(int(getattr(c, "m355_ups", 0)) for c in self.convs)
+            tuple(int(getattr(c, "m355_ups", 0)) for c in self.convs) + (_act(),)   # (views belong to one build of the library)
         if key != self._key:
             self._build(self.convs[0].weight_orig.device)
             self._key = key
@@ -898,7 +904,7 @@ def _match_res(res, x):
 
 def _fused_ok(x):
     c = x.shape[-1]
-    return x.is_cuda and x.dtype == torch.bfloat16 and c % 8 == 0 and c <= 2048 and 256 % (c // 8) == 0
+    return x.is_cuda and x.dtype == _act() and c % 8 == 0 and c <= 2048 and 256 % (c // 8) == 0
 
 
 class ClassProjection(torch.autograd.Function):
@@ -948,7 +954,7 @@ def _affine_act(xhat, scale, shift, slope):
     y = xhat * scale[:, None, None, :].float() + shift[:, None, None, :].float()
     if slope != 1.0:
         y = F.leaky_relu(y, slope)
-    return y.to(torch.bfloat16)
+    return y.to(_act())
 
 
 class _SyncMoments(torch.autograd.Function):

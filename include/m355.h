@@ -34,7 +34,13 @@ typedef enum {
 const char *m355_last_error(void);
 /* name of the kernel family the calling thread's last m355_conv2d_* call dispatched to (profiling aid) */
 const char *m355_last_kernel(void);
-int m355_abi_version(void);   /* 2: deterministic reductions (round 4): workspaces on cproj_bwd / head_tail_bwd / mesh_flat_fwd, gather tables on the mesh backward, m355_conv2d_wgrad_det */
+int m355_abi_version(void);   /* 2: deterministic reductions (round 4): workspaces on cproj_bwd / head_tail_bwd / mesh_flat_fwd, gather tables on the mesh backward, m355_conv2d_wgrad_det; 3 (round 5): m355_act_bytes */
+/* Bytes of an ACTIVATION element ("bf16" in the comments below) in this build of the library: 2 = bf16, the product; 4 = fp32, the
+ * EXACT build (lib/libm355_exact.so, compiled from the same sources with -DM355_EXACT; SURVEY.md 8c "an fp32-accumulate exact mode
+ * for 1e-4 checks").  Same entry points, same argument meaning; the GAN path's activation tensors, conv operands and weight views
+ * are then fp32 and the convolutions run on plain fp32 kernels with fp64 accumulation (csrc/conv_exact.hip) -- what the module-level
+ * parity tests hold against the reference's fp32 CPU results (models/gan.py, utils/losses.py, main.py:431-447,588-589,691-723). */
+int m355_act_bytes(void);
 
 /* flags for the projection entry points */
 #define M355_FIXED_WEIGHTS 1   /* w0 = 1-(g-floor g) instead of the literal 1-g-floor g (trilinear_interpolation.py:66) */

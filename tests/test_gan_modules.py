@@ -19,6 +19,29 @@ G_CASES = ["g_class128", "g_class256_nobn", "g_uncond_circ",
            "g_class256_sync", "g_class512_nd3", "g_class512_nd2w", "g_inst_color128", "g_text128", "g_nomask128"]
 
 
+class Tol:
+    """bounds of the module-level comparisons.  BF16: the product build (bf16 activations through ~30 layers against the reference's
+    fp32; DESIGN.md 8.6 shows 2-3e-3 is the floor between any two bf16 implementations).  EXACT: the fp32 EXACT build of the same
+    sources (lib/libm355_exact.so, _lib.set_exact; tests/test_exact_mode_gpu.py) -- what remains is fp32 summation order, and the
+    goldens' own storage precision (generated textures and full gradient tensors are kept as fp16: 2^-11 relative)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+BF16 = Tol(name="bf16", tex_mean=6e-3, tex_q999=5e-2, tex_max=1.2e-1, eval_mean=1.5e-2, eval_frac=1.5e-2, att_mean=2e-2, logit=4e-2,
+           loss=2e-2, gn_med=3e-2, gn_max=0.25, gn_max_inst=0.40, cos=0.975, l2=0.25, cos_inst=0.95, l2_inst=0.35, bn_mean=2e-2,
+           tr_cos0=0.85, tr_cos=0.90, tr_cos_avg=0.87, tr_mag=5e-2, tr_sq=0.10, tr_sqsum=5e-2, tr_loss0=1e-2, tr_loss=8e-2)
+EXACT = Tol(name="exact", tex_mean=2e-4, tex_q999=6e-4, tex_max=1.5e-3, eval_mean=3e-4, eval_frac=1e-3, att_mean=1e-4, logit=1e-4,
+            loss=1e-4, gn_med=1e-4, gn_max=1e-3, gn_max_inst=1e-3, cos=0.99999, l2=1e-3, cos_inst=0.99999, l2_inst=1e-3, bn_mean=1e-5,
+            tr_cos0=0.9999, tr_cos=0.9999, tr_cos_avg=0.9999, tr_mag=1e-3, tr_sq=1e-3, tr_sqsum=1e-3, tr_loss0=1e-4, tr_loss=1e-3)
+REPORT = {}   # measured values of the last run, per check (the exact-mode test writes them to gpurun_out/)
+
+
+def _note(key, *vals):
+    REPORT.setdefault(key, []).append(tuple(float(v) for v in vals))
+
+
 def build(g):
     gan = importlib.import_module("2dimageto3dmodel_amd.gan")
     args = argparse.Namespace(**ast.literal_eval(str(g["args"])))
@@ -53,13 +76,14 @@ def d_weight(args):
     return [2, 1] if args.num_discriminators == 2 and args.texture_resolution >= 512 else None
 
 
-def check_full_grads(module, g, prefix, instance_norm=False):
+def check_full_grads(module, g, prefix, instance_norm=False, tol=None):
     """elementwise: the full gradient tensors the golden keeps (fp16) -- a transposed / permuted / sign-flipped gradient
     passes a norm check, not this one (it gives cosine ~ 0 or -1).  Thresholds: the goldens are fp32 runs at batch 2, this
     path keeps bf16 activations through ~30 layers whose batch / instance statistics are taken over 2 samples; measured
     on MI355X (round 2): cosine 0.984-0.9995 and relative L2 0.03-0.18 with batch / no normalisation, 0.97 / 0.25 with
     instance norms.  test_headline_batch8_vs_cpu_oracle shows the same quantities tighten as the batch grows."""
-    cos_min, l2_max = (0.95, 0.35) if instance_norm else (0.975, 0.25)
+    tol = tol or BF16
+    cos_min, l2_max = (tol.cos_inst, tol.l2_inst) if instance_norm else (tol.cos, tol.l2)
     named = dict(module.named_parameters())
     n = 0
     for k in g:
@@ -72,6 +96,7 @@ def check_full_grads(module, g, prefix, instance_norm=False):
             continue
         cos = float(torch.dot(got, want) / (got.norm() * want.norm()))
         l2 = float((got - want).norm() / want.norm())
+        _note("grad " + k, cos, l2)
         assert cos >= cos_min and l2 <= l2_max, (k, cos, l2)
         n += 1
     assert n >= 4, (prefix, n)
@@ -90,6 +115,10 @@ def test_state_dict_keys_and_shapes_match_reference(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", G_CASES)
 def test_g_step_and_d_step_match_reference(name):
+    run_g_step_and_d_step(name, BF16)
+
+
+def run_g_step_and_d_step(name, tol):
     g = load_golden(name)
     gan, args, G, D = build(g)
     dev = "cuda:0"
@@ -118,13 +147,15 @@ def test_g_step_and_d_step_match_reference(name):
         # pre-activation is in the hundreds and tanh saturates: where it crosses zero a bf16 rounding flips +-1.  Robust
         # comparison: mean error and the share of such pixels; measured 0.6-0.8 % mean, < 0.5 % flipped)
         e = (te.cpu() - torch.from_numpy(g["eval_tex"].astype(np.float32))).abs()
-        assert e.mean().item() < 1.5e-2 and (e > 0.1).float().mean().item() < 1.5e-2, (e.mean().item(), (e > 0.1).float().mean().item())
+        _note("eval_tex", e.mean().item(), (e > 0.1).float().mean().item())
+        assert e.mean().item() < tol.eval_mean and (e > 0.1).float().mean().item() < tol.eval_frac, (e.mean().item(), (e > 0.1).float().mean().item())
         assert (me.cpu() - torch.from_numpy(g["eval_mesh"])).abs().max().item() < 1e-6
         if "eval_att" in g:
             assert tuple(att.shape) == g["eval_att"].shape
             # (softmax over the un-normalised eval-mode activations is near one-hot: a bf16 rounding can move the argmax of
             # single pixels; the map as a whole must agree)
-            assert (att.cpu() - torch.from_numpy(g["eval_att"])).abs().mean().item() < 2e-2
+            _note("eval_att", (att.cpu() - torch.from_numpy(g["eval_att"])).abs().mean().item())
+            assert (att.cpu() - torch.from_numpy(g["eval_att"])).abs().mean().item() < tol.att_mean
         else:
             assert att is None
     # ---- G step
@@ -137,7 +168,8 @@ def test_g_step_and_d_step_match_reference(name):
     # (round 3: the text-conditioned case measured q999 = 0.0422 on one box, 0.039 on another -- sigma of the spectral norm is
     # accumulated with fp32 atomics, so the bf16 weight views differ in the last bit between runs; bound 5e-2)
     q999 = torch.quantile(e.flatten()[:1 << 24], 0.999).item()
-    assert e.mean().item() < 6e-3 and q999 < 5e-2 and e.max().item() < 1.2e-1, (e.mean().item(), q999, e.max().item())
+    _note("pred_tex", e.mean().item(), q999, e.max().item())
+    assert e.mean().item() < tol.tex_mean and q999 < tol.tex_q999 and e.max().item() < tol.tex_max, (e.mean().item(), q999, e.max().item())
     assert (pred_mesh.detach().cpu() - torch.from_numpy(g["pred_mesh"])).abs().max().item() < 1e-6  # zero-init head
     x_fake = torch.cat((pred_tex * x_alpha, x_alpha), dim=1)
     disc, mask = D(x_fake, pred_mesh, c, caption)
@@ -148,9 +180,11 @@ def test_g_step_and_d_step_match_reference(name):
     else:
         assert all(m is None for m in mask)
     for got, want in zip(disc, [g[f"d{i + 1}"] for i in range(nd)]):
-        assert np.abs(got.detach().cpu().numpy() - want).max() < 4e-2 * max(1.0, np.abs(want).max())
+        _note("logits G step", np.abs(got.detach().cpu().numpy() - want).max() / max(1.0, np.abs(want).max()))
+        assert np.abs(got.detach().cpu().numpy() - want).max() < tol.logit * max(1.0, np.abs(want).max())
     loss_g = crit(disc, True, for_discriminator=False, mask=mask if args.mask_output else None, weight=w)
-    assert np.abs(loss_g.detach().cpu().numpy() - g["loss_g"]).max() < 2e-2 * max(1.0, np.abs(g["loss_g"]).max())
+    _note("loss_g", np.abs(loss_g.detach().cpu().numpy() - g["loss_g"]).max() / max(1.0, np.abs(g["loss_g"]).max()))
+    assert np.abs(loss_g.detach().cpu().numpy() - g["loss_g"]).max() < tol.loss * max(1.0, np.abs(g["loss_g"]).max())
     loss_g.mean().backward()
     gn = {k: float(p.grad.norm()) for k, p in G.named_parameters() if p.grad is not None}
     assert list(gn.keys()) == list(g["gnorm_G_keys"])
@@ -160,8 +194,9 @@ def test_g_step_and_d_step_match_reference(name):
     inst = "instance" in (args.norm_g, args.norm_d)
     # (instance norms at batch 2: measured 0.21-0.27 on the worst parameter from run to run -- the split-K atomics of the
     # weight gradients make the last bits, and with them this maximum, vary)
-    assert np.median(rel) < 3e-2 and rel.max() < (0.40 if inst else 0.25), (np.median(rel), rel.max())
-    check_full_grads(G, g, "gradG:", inst)
+    _note("gnorm G", np.median(rel), rel.max())
+    assert np.median(rel) < tol.gn_med and rel.max() < (tol.gn_max_inst if inst else tol.gn_max), (np.median(rel), rel.max())
+    check_full_grads(G, g, "gradG:", inst, tol)
     G.zero_grad()
     D.zero_grad()
     # ---- D step
@@ -173,24 +208,29 @@ def test_g_step_and_d_step_match_reference(name):
         mc = torch.cat((fm, x_mesh), 0)
     disc2, mask2 = D(xc, mc, cc, capc)
     for got, want in zip(disc2, [g[f"dd{i + 1}"] for i in range(nd)]):
-        assert np.abs(got.detach().cpu().numpy() - want).max() < 4e-2 * max(1.0, np.abs(want).max())
+        _note("logits D step", np.abs(got.detach().cpu().numpy() - want).max() / max(1.0, np.abs(want).max()))
+        assert np.abs(got.detach().cpu().numpy() - want).max() < tol.logit * max(1.0, np.abs(want).max())
     fake, real = [t[:B] for t in disc2], [t[B:] for t in disc2]
     mfake = [t[:B] for t in mask2] if args.mask_output else None
     mreal = [t[B:] for t in mask2] if args.mask_output else None
     loss_fake = crit(fake, False, for_discriminator=True, mask=mfake, weight=w)
     loss_real = crit(real, True, for_discriminator=True, mask=mreal, weight=w)
-    assert np.abs(loss_fake.detach().cpu().numpy() - g["loss_fake"]).max() < 2e-2 * max(1.0, np.abs(g["loss_fake"]).max())
-    assert np.abs(loss_real.detach().cpu().numpy() - g["loss_real"]).max() < 2e-2 * max(1.0, np.abs(g["loss_real"]).max())
+    _note("loss_d", np.abs(loss_fake.detach().cpu().numpy() - g["loss_fake"]).max() / max(1.0, np.abs(g["loss_fake"]).max()),
+          np.abs(loss_real.detach().cpu().numpy() - g["loss_real"]).max() / max(1.0, np.abs(g["loss_real"]).max()))
+    assert np.abs(loss_fake.detach().cpu().numpy() - g["loss_fake"]).max() < tol.loss * max(1.0, np.abs(g["loss_fake"]).max())
+    assert np.abs(loss_real.detach().cpu().numpy() - g["loss_real"]).max() < tol.loss * max(1.0, np.abs(g["loss_real"]).max())
     (loss_fake + loss_real).mean().backward()
     gd = {k: float(p.grad.norm()) for k, p in D.named_parameters() if p.grad is not None}
     assert list(gd.keys()) == list(g["gnorm_D_keys"])
     got, want = np.array(list(gd.values())), g["gnorm_D"]
     big = want > 1e-3 * want.max()
     rel = np.abs(got[big] / want[big] - 1)
-    assert np.median(rel) < 3e-2 and rel.max() < (0.40 if inst else 0.25), (np.median(rel), rel.max())
-    check_full_grads(D, g, "gradD:", inst)
+    _note("gnorm D", np.median(rel), rel.max())
+    assert np.median(rel) < tol.gn_med and rel.max() < (tol.gn_max_inst if inst else tol.gn_max), (np.median(rel), rel.max())
+    check_full_grads(D, g, "gradD:", inst, tol)
     if "running_mean" in dict(G.blk6.norm2.norm.named_buffers()):
-        assert np.abs(G.blk6.norm2.norm.running_mean.cpu().numpy() - g["bn_mean_blk6"]).max() < 2e-2
+        _note("bn running_mean", np.abs(G.blk6.norm2.norm.running_mean.cpu().numpy() - g["bn_mean_blk6"]).max())
+        assert np.abs(G.blk6.norm2.norm.running_mean.cpu().numpy() - g["bn_mean_blk6"]).max() < tol.bn_mean
 
 
 # ------------------------------------------------------------------------------------------------ GANLoss, all four modes
@@ -283,6 +323,10 @@ def test_ema_alpha_ramp():
 
 @pytest.mark.gpu
 def test_trainer_four_iterations_match_reference():
+    run_trainer_four_iterations(BF16)
+
+
+def run_trainer_four_iterations(tol):
     """GanTrainer.iteration x4 (G, D, D, G) against the reference's modules driven by the loop of main.py:691-723 with Adam
     (betas 0 / 0.9) and the running-average generator (oracle/gen_golden_g.py:run_train4): parameter DELTAS after the first
     and the fourth iteration.  Adam's first step is lr * sign(g), so the cosine of the deltas is (agreeing - disagreeing)
@@ -313,19 +357,23 @@ def test_trainer_four_iterations_match_reference():
             for k in track_g:
                 dG, dA = gp[k].detach() - w0[("G", k)], ap[k].detach() - w0[("G", k)]
                 want, want_a = g[f"it{it}:G:{k}"], g[f"it{it}:avg:{k}"]
-                assert cos(dG, want) > (0.85 if it == 0 else 0.90), (it, k, cos(dG, want))
-                assert abs(float(dG.abs().max()) / np.abs(want).max() - 1) < 5e-2, (it, k)
+                _note(f"train it{it} dG {k}", cos(dG, want), abs(float(dG.abs().max()) / np.abs(want).max() - 1))
+                assert cos(dG, want) > (tol.tr_cos0 if it == 0 else tol.tr_cos), (it, k, cos(dG, want))
+                assert abs(float(dG.abs().max()) / np.abs(want).max() - 1) < tol.tr_mag, (it, k)
                 # the running average moved by (1 - alpha_epoch) of the generator's displacement (alpha ramp, main.py:433-438)
                 # (after four iterations the average's displacement is dominated by near-zero-gradient entries whose Adam sign
                 # flips with the fp32-atomic summation order of the wgrad: measured 0.895-0.99 over runs; bound 0.87)
-                assert cos(dA, want_a) > (0.85 if it == 0 else 0.87), (it, k, cos(dA, want_a))
-                assert abs(float(dA.norm()) / np.linalg.norm(want_a) - 1) < 5e-2, (it, k)
+                _note(f"train it{it} dAvg {k}", cos(dA, want_a), abs(float(dA.norm()) / np.linalg.norm(want_a) - 1))
+                assert cos(dA, want_a) > (tol.tr_cos0 if it == 0 else tol.tr_cos_avg), (it, k, cos(dA, want_a))
+                assert abs(float(dA.norm()) / np.linalg.norm(want_a) - 1) < tol.tr_mag, (it, k)
             if it > 0:
                 for k in track_d:
                     dD = dp[k].detach() - w0[("D", k)]
-                    assert cos(dD, g[f"it{it}:D:{k}"]) > 0.90, (it, k, cos(dD, g[f"it{it}:D:{k}"]))
+                    _note(f"train it{it} dD {k}", cos(dD, g[f"it{it}:D:{k}"]))
+                    assert cos(dD, g[f"it{it}:D:{k}"]) > tol.tr_cos, (it, k, cos(dD, g[f"it{it}:D:{k}"]))
             bn = tr.generator_running_avg.blk6.norm2.norm
-            assert np.abs(bn.running_mean.cpu().numpy() - g[f"it{it}:avg_bn_mean"]).max() < 2e-2
+            _note(f"train it{it} avg bn mean", np.abs(bn.running_mean.cpu().numpy() - g[f"it{it}:avg_bn_mean"]).max())
+            assert np.abs(bn.running_mean.cpu().numpy() - g[f"it{it}:avg_bn_mean"]).max() < tol.bn_mean
             assert int(bn.num_batches_tracked) == int(g[f"it{it}:avg_nbt"])
     # NOT sign-dominated: Adam's second-moment estimate after the last iteration (two optimiser steps each) is smooth in the
     # gradients -- exp_avg_sq = 0.9 * 0.1 g1^2 + 0.1 g2^2 (main.py:588-589: betas (0, 0.9)) -- a wrong beta2 / a squared-twice /
@@ -334,13 +382,15 @@ def test_trainer_four_iterations_match_reference():
         want = torch.from_numpy(g[f"it{int(g['iters']) - 1}:{kind}:exp_avg_sq:{k}"]).flatten().double()
         got = opt.state[mod_params[k]]["exp_avg_sq"].detach().cpu().flatten().double()
         rel = float((got - want).norm() / want.norm())
-        assert rel <= 0.10, (kind, k, rel)
-        assert abs(float(got.sum() / want.sum()) - 1) < 5e-2, (kind, k)
+        _note(f"train exp_avg_sq {kind}", rel, abs(float(got.sum() / want.sum()) - 1))
+        assert rel <= tol.tr_sq, (kind, k, rel)
+        assert abs(float(got.sum() / want.sum()) - 1) < tol.tr_sqsum, (kind, k)
         assert float(opt.state[mod_params[k]]["step"]) == 2.0
     # (the later losses are computed on weights that differ by the flipped first Adam steps: relative tolerance)
     # measured over repeated runs: first iteration <= 2e-3, later ones up to 3.7e-2 (lr_d = 4e-4 sign steps on flipped entries)
-    tol = np.array([[1e-2, 1e-2]] + [[8e-2, 8e-2]] * (len(losses) - 1))
-    assert (np.abs(np.array(losses) - g["losses"]) <= tol * np.maximum(1.0, np.abs(g["losses"]))).all(), (losses, g["losses"])
+    ltol = np.array([[tol.tr_loss0, tol.tr_loss0]] + [[tol.tr_loss, tol.tr_loss]] * (len(losses) - 1))
+    _note("train losses", (np.abs(np.array(losses) - g["losses"]) / np.maximum(1.0, np.abs(g["losses"]))).max())
+    assert (np.abs(np.array(losses) - g["losses"]) <= ltol * np.maximum(1.0, np.abs(g["losses"]))).all(), (losses, g["losses"])
 
 
 @pytest.mark.gpu
