@@ -14,8 +14,12 @@ namespace m355 {
 // EXACT build (-DM355_EXACT, csrc/conv_exact.hip): fp32 -- the same kernels with `act_t` = float, the eight-element vector a
 // 32-byte aggregate, and every "round to the storage type" helper the identity, so the formulas (statistics, affine, activation
 // backward, projection) are the ones the product runs, minus the bf16 roundings.
+// ... and `acc_t`, the type the reductions over pixels accumulate in: fp32 in the product build (the bf16 inputs are the noise), fp64
+// in the EXACT build -- ATen's CPU batch-norm / sum kernels accumulate fp32 data in double (at::acc_type<float, false>), and with
+// fp32 accumulators the gradients of a batch of 2 sat at 1e-3 of the reference's where fp64 gives 1e-4 (tests/test_exact_mode_gpu.py)
 #ifdef M355_EXACT
 typedef float act_t;
+typedef double acc_t;
 struct __attribute__((aligned(16))) bf16x8e {
     float v[8];
     __device__ __forceinline__ float operator[](int j) const { return v[j]; }
@@ -32,6 +36,7 @@ __device__ __forceinline__ bf16x8e pack8_e(const float (&z)[8])
 __device__ __forceinline__ float f2bf_e(float f) { return f; }
 #else
 typedef short act_t;
+typedef float acc_t;
 typedef __attribute__((ext_vector_type(8))) short bf16x8e;
 
 __device__ __forceinline__ float bf2f_e(short h) { return __uint_as_float(((unsigned int)(unsigned short)h) << 16); }
@@ -72,16 +77,16 @@ static inline int pix_per_block(size_t P, int C)
 template <int NV, typename F>
 __device__ __forceinline__ void pixel_reduce(int C, size_t pix0, int npix, float *part_blk, F f)
 {
-    __shared__ float red[256 * 8];
+    __shared__ acc_t red[256 * 8];
     const int tid = threadIdx.x;
     const int vecs = C >> 3;                 // 8-channel vectors per pixel
     const int lanes = 256 / vecs;            // pixel lanes
     const int v = tid % vecs, pl = tid / vecs;
-    float acc[NV][8];
+    acc_t acc[NV][8];
 #pragma unroll
     for (int k = 0; k < NV; ++k)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[k][j] = 0.0f;
+        for (int j = 0; j < 8; ++j) acc[k][j] = 0;
     if (pl < lanes) {
         // 4 independent 16-byte loads in flight per thread (the un-unrolled loop was latency bound at ~1.5 TB/s)
 #pragma unroll 4
@@ -96,9 +101,9 @@ __device__ __forceinline__ void pixel_reduce(int C, size_t pix0, int npix, float
         // thread t < C sums channel t over the pixel lanes
         for (int c = tid; c < C; c += 256) {
             const int vv = c >> 3, jj = c & 7;
-            float s = 0.0f;
+            acc_t s = 0;
             for (int l = 0; l < lanes; ++l) s += red[(l * vecs + vv) * 8 + jj];
-            part_blk[(size_t)k * C + c] = s;
+            part_blk[(size_t)k * C + c] = (float)s;
         }
     }
 }
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256) void k_chan_stats(const act_t *__restrict__ x,
 {
     const size_t pix0 = (size_t)blockIdx.x * ppb;
     const int npix = (int)min((size_t)ppb, P - pix0);
-    pixel_reduce<2>(C, pix0, npix, part + (size_t)blockIdx.x * 2 * C, [&](size_t p, int c0, float (&acc)[2][8]) {
+    pixel_reduce<2>(C, pix0, npix, part + (size_t)blockIdx.x * 2 * C, [&](size_t p, int c0, acc_t (&acc)[2][8]) {
         const bf16x8e v = *reinterpret_cast<const bf16x8e *>(x + p * C + c0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(256) void k_chan_sum(const act_t *__restrict__ x, f
 {
     const size_t pix0 = (size_t)blockIdx.x * ppb;
     const int npix = (int)min((size_t)ppb, P - pix0);
-    pixel_reduce<1>(C, pix0, npix, part + (size_t)blockIdx.x * C, [&](size_t p, int c0, float (&acc)[1][8]) {
+    pixel_reduce<1>(C, pix0, npix, part + (size_t)blockIdx.x * C, [&](size_t p, int c0, acc_t (&acc)[1][8]) {
         const bf16x8e v = *reinterpret_cast<const bf16x8e *>(x + p * C + c0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[0][j] += bf2f_e(v[j]);
@@ -137,19 +142,19 @@ __global__ __launch_bounds__(256) void k_chan_sum(const act_t *__restrict__ x, f
 __global__ __launch_bounds__(256) void k_sum_partials(const float *__restrict__ part, float *__restrict__ out, int nblk,
                                                       int W)
 {
-    __shared__ float red[8][32];
+    __shared__ acc_t red[8][32];
     const int g = blockIdx.y;
     const int i = blockIdx.x * 32 + (threadIdx.x & 31), l = threadIdx.x >> 5;
-    float s = 0.0f;
+    acc_t s = 0;
     if (i < W)
         for (int b = l; b < nblk; b += 8) s += part[((size_t)g * nblk + b) * W + i];
     red[l][threadIdx.x & 31] = s;
     __syncthreads();
     if (l == 0 && i < W) {
-        float t = 0.0f;
+        acc_t t = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x & 31];
-        out[(size_t)g * W + i] = t;
+        out[(size_t)g * W + i] = (float)t;
     }
 }
 
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(256) void k_act_bwd_reduce(const act_t *__restrict_
         bv[j] = b[(size_t)n * C + cg + j];
     }
     pixel_reduce<2>(C, pix0, npix, part + ((size_t)n * nblk + blockIdx.x) * 2 * C,
-                    [&](size_t p, int c0, float (&acc)[2][8]) {
+                    [&](size_t p, int c0, acc_t (&acc)[2][8]) {
                         const bf16x8e vx = *reinterpret_cast<const bf16x8e *>(x + (base + p) * C + c0);
                         const bf16x8e vd = *reinterpret_cast<const bf16x8e *>(dy + (base + p) * C + c0);
 #pragma unroll
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(256) void k_lrelu_bwd(const act_t *__restrict__ dy,
 {
     const size_t pix0 = (size_t)blockIdx.x * ppb;
     const int npix = (int)min((size_t)ppb, P - pix0);
-    pixel_reduce<1>(C, pix0, npix, part + (size_t)blockIdx.x * C, [&](size_t p, int c0, float (&acc)[1][8]) {
+    pixel_reduce<1>(C, pix0, npix, part + (size_t)blockIdx.x * C, [&](size_t p, int c0, acc_t (&acc)[1][8]) {
         const bf16x8e vy = *reinterpret_cast<const bf16x8e *>(y + p * C + c0);
         const bf16x8e vd = *reinterpret_cast<const bf16x8e *>(dy + p * C + c0);
         bf16x8e o;

@@ -210,6 +210,12 @@ __global__ __launch_bounds__(256) void k_sn_bwd_apply(const float *__restrict__ 
 // CW channels per workgroup, 1024 / CW row lanes: with 32 channels per workgroup a C = 64 layer ran on TWO workgroups, each
 // thread walking 32+ dependent-latency rounds of the up-to-1024 partial rows (~10 us per call, 42 calls per cycle); 8
 // channels per workgroup give 4x the workgroups and a quarter of the rows per thread.
+// accumulator type of the batch-norm finalising kernels: fp32 in the product build, fp64 in the EXACT build (csrc/gan_elem.hip acc_t)
+#ifdef M355_EXACT
+typedef double gacc_t;
+#else
+typedef float gacc_t;
+#endif
 template <int CW>
 __global__ __launch_bounds__(1024) void k_bn_finalize(const float *__restrict__ part, int nblk, float count_h,
                                                      const float *__restrict__ count_dev, const float *__restrict__ gamma,
@@ -219,14 +225,14 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float *__restrict__ 
                                                      float *__restrict__ b)
 {
     constexpr int RL = 1024 / CW;
-    __shared__ float red[2][RL][CW];
+    __shared__ gacc_t red[2][RL][CW];
     __shared__ float stat[2][CW];
     const int cl = threadIdx.x % CW, l = threadIdx.x / CW, c = blockIdx.x * CW + cl;
     const float count = count_dev ? *count_dev : count_h;   // SyncBN: the all-reduced pixel count, no host round trip
-    float s0 = 0.0f, s1 = 0.0f;
+    gacc_t s0 = 0, s1 = 0;
     if (c < C) {
         // 8 rows (16 loads) in flight per thread: a conv with fused statistics hands over one row per workgroup (up to 2048)
-        float p0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, p1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        gacc_t p0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, p1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int k = l; k < nblk; k += 8 * RL) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -252,10 +258,17 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float *__restrict__ 
         __syncthreads();
     }
     if (l == 0 && c < C) {
+#ifdef M355_EXACT
+        // (fp64 from the partial rows on: mean, E[x^2] - mean^2 and 1 / sqrt(var + eps) as ATen's CPU batch norm evaluates them)
+        const double t0 = red[0][0][cl], t1 = red[1][0][cl];
+        const double mean_d = t0 / (double)count, var_d = fmax(t1 / (double)count - mean_d * mean_d, 0.0);
+        const float mean = (float)mean_d, var = (float)var_d, rstd = (float)(1.0 / sqrt(var_d + (double)eps));
+#else
         const float t0 = red[0][0][cl], t1 = red[1][0][cl];
         const float mean = t0 / count;
         const float var = fmaxf(t1 / count - mean * mean, 0.0f);
         const float rstd = rsqrtf(var + eps);
+#endif
         stat[0][cl] = mean;
         stat[1][cl] = rstd;
         mean_o[c] = mean;
@@ -307,15 +320,15 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_finalize(const float *__restric
                                                          float *__restrict__ A, float *__restrict__ Bc, float *__restrict__ Cc,
                                                          float *__restrict__ m_out)
 {
-    __shared__ float red[2][32][32];
+    __shared__ gacc_t red[2][32][32];
     const int cl = threadIdx.x & 31, l = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
-    float m1 = 0.0f, m2 = 0.0f;
-    float mean = 0.0f, rstd = 1.0f;
+    gacc_t m1 = 0, m2 = 0;
+    gacc_t mean = 0, rstd = 1;
     if (c < C) {
         mean = mean_i[c];
         rstd = rstd_i[c];
         for (int n = l; n < N; n += 32) {
-            float q1[4] = {0.f, 0.f, 0.f, 0.f}, q2[4] = {0.f, 0.f, 0.f, 0.f};
+            gacc_t q1[4] = {0, 0, 0, 0}, q2[4] = {0, 0, 0, 0};
             const float *p = part + (size_t)n * nblk * 2 * C;
             for (int k = 0; k < nblk; k += 4) {
 #pragma unroll
@@ -325,12 +338,12 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_finalize(const float *__restric
                         q2[u] += p[((size_t)(k + u) * 2 + 1) * C + c];
                     }
             }
-            const float s1 = (q1[0] + q1[1]) + (q1[2] + q1[3]), s2 = (q2[0] + q2[1]) + (q2[2] + q2[3]);
-            const float sc = 1.0f + gamma[(size_t)n * gstride + c];
-            const float dg = rstd * (s2 - mean * s1);
-            dgamma[(size_t)n * C + c] = dg;
-            dbeta[(size_t)n * C + c] = s1;
-            A[(size_t)n * C + c] = rstd * sc;
+            const gacc_t s1 = (q1[0] + q1[1]) + (q1[2] + q1[3]), s2 = (q2[0] + q2[1]) + (q2[2] + q2[3]);
+            const gacc_t sc = (gacc_t)1 + gamma[(size_t)n * gstride + c];
+            const gacc_t dg = rstd * (s2 - mean * s1);
+            dgamma[(size_t)n * C + c] = (float)dg;
+            dbeta[(size_t)n * C + c] = (float)s1;
+            A[(size_t)n * C + c] = (float)(rstd * sc);
             m1 += sc * s1;
             m2 += sc * dg;
         }
@@ -339,20 +352,20 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_finalize(const float *__restric
     red[1][l][cl] = m2;
     __syncthreads();
     if (l == 0 && c < C) {
-        float t1 = 0.0f, t2 = 0.0f;
+        gacc_t t1 = 0, t2 = 0;
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
             t1 += red[0][k][cl];
             t2 += red[1][k][cl];
         }
         if (m_out) {  // SyncBN: the sums over the LOCAL samples; all-reduced, then m355_bn_bwd_coeffs
-            m_out[c] = t1;
-            m_out[C + c] = t2;
+            m_out[c] = (float)t1;
+            m_out[C + c] = (float)t2;
         } else if (batch_stats) {
             t1 /= count;
             t2 /= count;
-            Bc[c] = -rstd * rstd * t2;
-            Cc[c] = -rstd * t1 + rstd * rstd * mean * t2;
+            Bc[c] = (float)(-rstd * rstd * t2);
+            Cc[c] = (float)(-rstd * t1 + rstd * rstd * mean * t2);
         } else {
             Bc[c] = 0.0f;
             Cc[c] = 0.0f;

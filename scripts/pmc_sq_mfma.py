@@ -9,8 +9,23 @@ import sqlite3, sys
 db = sys.argv[1]
 cur = sqlite3.connect(db).cursor()
 dur = {}
-for name, g, s, e in cur.execute("select name, grid_size, start, end from kernels"):
-    dur.setdefault((name, g), []).append(e - s)
+rows = cur.execute("select * from kernels")
+cols = [c[0] for c in rows.description]
+print("# kernels view columns:", cols)
+ix = {c: i for i, c in enumerate(cols)}
+def grid_of(r):
+    for trip in (("grid_size",), ("grid_size_x", "grid_size_y", "grid_size_z"), ("grid_x", "grid_y", "grid_z")):
+        if all(t in ix for t in trip):
+            g = 1
+            for t in trip:
+                g *= int(r[ix[t]] or 1)
+            return g
+    return 0
+byname = {}
+for r in rows:
+    name, dt = r[ix["name"]], r[ix["end"]] - r[ix["start"]]
+    dur.setdefault((name, grid_of(r)), []).append(dt)
+    byname.setdefault(name, []).append(dt)
 tab = {}
 for k, g, c, v in cur.execute("select kernel_name, grid_size, counter_name, avg(value) from counters_collection group by kernel_name, grid_size, counter_name"):
     tab.setdefault((k, g), {})[c] = v
@@ -20,7 +35,7 @@ for (k, g), d in sorted(tab.items(), key=lambda kv: -sum(dur.get(kv[0], [0]))):
         continue
     wc = d.get("SQ_WAVE_CYCLES")
     pct = lambda c: ("%5.1f%%" % (100.0 * d[c] / wc)) if (wc and c in d) else "   n/a"
-    t = dur.get((k, g))
+    t = dur.get((k, g)) or dur.get((k, int(g))) or byname.get(k)   # (falls back to the instantiation's mean over all its shapes)
     avg_us = sum(t) / len(t) / 1e3 if t else float("nan")
     mf = d.get("SQ_VALU_MFMA_BUSY_CYCLES")
     busy = 100.0 * mf / (4 * 256 * avg_us * 2400.0) if (mf and t) else float("nan")

@@ -17,6 +17,7 @@ import torch
 import torch.nn.functional as F
 
 import test_gan_modules as tm
+from conftest import load_golden
 from test_conv_gpu import ref_conv
 
 pytestmark = pytest.mark.gpu
@@ -113,14 +114,90 @@ def test_exact_conv_matches_fp32_reference(exact, case):
 @pytest.mark.timeout(1200)
 @pytest.mark.parametrize("name", tm.G_CASES)
 def test_exact_g_step_and_d_step_match_reference(exact, name):
-    """the nine reference-executed goldens (one G step + one D step each; 128^2 / 256^2 / 512^2, nd 2 / 3, sync / batch /
+    """the nine reference-executed fp32 goldens (one G step + one D step each; 128^2 / 256^2 / 512^2, nd 2 / 3, sync / batch /
     instance / no norm, class / colour / text conditioning, no-mask) at the EXACT tolerances: logits and losses 1e-4, gradient
-    norms 1e-3, every stored gradient tensor relative L2 <= 1e-3 (they are kept as fp16: 3e-4 of that is storage)"""
+    norms 1e-3; the stored gradient tensors at relative L2 <= 3e-3 -- that bound is the GOLDENS' (fp16 storage 2e-4, and the
+    reference's own fp32 noise at batch 2: up to 2.4e-3, see the fp64 test below, which holds the same tensors at 2e-5)"""
     tm.REPORT.clear()
     try:
         tm.run_g_step_and_d_step(name, tm.EXACT)
     finally:
         _dump_report(name)
+
+
+@pytest.mark.parametrize("name", ["g_class128", "g_class256_sync", "g_uncond_circ"])
+def test_exact_steps_match_the_reference_run_in_fp64(exact, name):
+    """The fp32 goldens above carry the reference's OWN fp32 noise -- at batch 2 up to 2.4e-3 relative L2 on whole gradient tensors
+    (oracle/gen_golden_g64.py prints reference-fp32 against reference-fp64 per case; stored as `ref_fp32_noise`) -- so they cannot
+    hold anything tighter than that.  Against the reference executed in FLOAT64 (tests/golden/g64_*.npz) the EXACT build is held
+    at: logits and losses 5e-6, every parameter's gradient norm 2e-4, the stored full gradient tensors relative L2 6e-4 and at
+    most a fifth (generator) of the reference's own fp32-against-fp64 deviation."""
+    g = load_golden(name)
+    g64 = load_golden("g64_" + name[2:])
+    gan, args, G, D = tm.build(g)
+    G.to(DEV).train()
+    D.to(DEV).train()
+    crit = gan.GANLoss("hinge")
+    B, R = int(g["B"]), int(g["R"])
+    z, c, x_tex, x_alpha, x_mesh = [t.to(DEV) for t in tm.make_inputs(int(g["seed"]), B, R, 200)]
+    if not args.conditional_class:
+        c = None
+    w, nd = tm.d_weight(args), args.num_discriminators
+    rel = lambda got, want: float(np.abs(got.detach().cpu().numpy().astype(np.float64) - want).max() / max(1.0, np.abs(want).max()))
+
+    def grads(module, prefix, keys_k, norms_k):
+        named = dict(module.named_parameters())
+        worst_n, worst_l2 = 0.0, 0.0
+        for k, want in zip(g64[keys_k], g64[norms_k]):
+            if want > 1e-4 * g64[norms_k].max():
+                worst_n = max(worst_n, abs(float(named[str(k)].grad.norm()) / float(want) - 1))
+        for k in g64:
+            if k.startswith(prefix):
+                a = named[k[len(prefix):]].grad.detach().cpu().flatten().double()
+                b = torch.from_numpy(g64[k]).flatten().double()
+                if b.norm() > 0:
+                    worst_l2 = max(worst_l2, float((a - b).norm() / b.norm()))
+        return worst_n, worst_l2
+
+    pred_tex, pred_mesh = G(z, c, None)
+    ts = int(g64["tex_stride"])
+    assert rel(pred_tex[:, :, ::ts, ::ts], g64["pred_tex"].astype(np.float64)) < 5e-6
+    disc, mask = D(torch.cat((pred_tex * x_alpha, x_alpha), dim=1), pred_mesh, c, None)
+    e_logit = max(rel(a, g64[f"d{i + 1}"]) for i, a in enumerate(disc))
+    loss_g = crit(disc, True, for_discriminator=False, mask=mask if args.mask_output else None, weight=w)
+    e_loss = rel(loss_g, g64["loss_g"])
+    loss_g.mean().backward()
+    n_g, l2_g = grads(G, "gradG:", "gnorm_G_keys", "gnorm_G")
+    G.zero_grad()
+    D.zero_grad()
+    with torch.no_grad():
+        ft, fm = G(z, c, None)
+        xc = torch.cat((torch.cat((ft * x_alpha, x_alpha), 1), torch.cat((x_tex, x_alpha), 1)), 0)
+        cc = torch.cat((c, c), 0) if c is not None else None
+        mc = torch.cat((fm, x_mesh), 0)
+    disc2, mask2 = D(xc, mc, cc, None)
+    e_logit2 = max(rel(a, g64[f"dd{i + 1}"]) for i, a in enumerate(disc2))
+    fake, real = [t[:B] for t in disc2], [t[B:] for t in disc2]
+    mfake = [t[:B] for t in mask2] if args.mask_output else None
+    mreal = [t[B:] for t in mask2] if args.mask_output else None
+    loss_fake = crit(fake, False, for_discriminator=True, mask=mfake, weight=w)
+    loss_real = crit(real, True, for_discriminator=True, mask=mreal, weight=w)
+    e_loss2 = max(rel(loss_fake, g64["loss_fake"]), rel(loss_real, g64["loss_real"]))
+    (loss_fake + loss_real).mean().backward()
+    n_d, l2_d = grads(D, "gradD:", "gnorm_D_keys", "gnorm_D")
+    tm.REPORT.clear()
+    tm._note("vs fp64 reference: logits G / D step, losses G / D step", e_logit, e_logit2, e_loss, e_loss2)
+    tm._note("vs fp64 reference: worst gradient-norm ratio - 1 (G, D), worst full-tensor rel L2 (G, D)", n_g, n_d, l2_g, l2_d)
+    tm._note("reference fp32 vs fp64 gradient rel L2 (median, max) G | D", *g64["ref_fp32_noise"].flatten())
+    _dump_report("g64_" + name[2:])
+    assert max(e_logit, e_logit2, e_loss, e_loss2) < 5e-6, (e_logit, e_logit2, e_loss, e_loss2)
+    # measured (MI355X, round 5): 128^2 cases 5e-7 / 6e-6 on the full tensors, 6e-5 on the worst norm; the 256^2 case -- whose
+    # backward is conditioned badly enough for the reference's own fp32 run to sit at 2.4e-3 -- 1e-4 (G) / 3e-4 (D): the
+    # activations between the layers are still fp32 here, only the sums are fp64
+    assert max(n_g, n_d) < 2e-4 and max(l2_g, l2_d) < 6e-4, (n_g, n_d, l2_g, l2_d)
+    # ... and never worse than the reference's own fp32 run is against its fp64 run (generator: at least 5x better)
+    noise = g64["ref_fp32_noise"]
+    assert l2_g < 0.2 * noise[0][1] + 2e-5 and l2_d < 1.0 * min(noise[1][1], 1.0) + 2e-5, (l2_g, l2_d, noise)
 
 
 @pytest.mark.timeout(1200)
