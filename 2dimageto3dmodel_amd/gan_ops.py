@@ -992,12 +992,17 @@ class BatchNorm2d(nn.Module):
         from . import parallel
         return self.sync and parallel.collectives_on()
 
+    def _counts(self):
+        """does a training forward advance num_batches_tracked?  nn.BatchNorm2d does, the reference's SynchronizedBatchNorm2d never
+        does; a plain batch norm switched to global-batch statistics for data parallelism (recon_train.ReconTrainer) still does"""
+        return getattr(self, "_count_batches", not self.sync)
+
     def _update_running(self, mean, var, cnt):
         with torch.no_grad():
             unbiased = var * (cnt / (cnt - 1)) if float(cnt) > 1 else var
             self.running_mean.mul_(1 - self.momentum).add_(mean.detach(), alpha=self.momentum)
             self.running_var.mul_(1 - self.momentum).add_(unbiased.detach(), alpha=self.momentum)
-            if not self.sync:   # (the reference's SynchronizedBatchNorm2d.forward never counts, batchnorm.py:66-98)
+            if self._counts():   # (the reference's SynchronizedBatchNorm2d.forward never counts, batchnorm.py:66-98)
                 self.num_batches_tracked += 1
 
     def forward(self, x, gamma, beta, slope=1.0, res=None, out_slope=1.0, part=None):
@@ -1014,7 +1019,7 @@ class BatchNorm2d(nn.Module):
                 # (Generator.forward batches it over all layers) or here when used stand-alone
                 y = CbnActFn.apply(x, gamma, beta, self.running_mean, self.running_var, self.momentum, self.eps, slope, res,
                                    sync, out_slope, part)
-                if not getattr(self, "_defer_count", False) and not self.sync:
+                if not getattr(self, "_defer_count", False) and self._counts():
                     self.num_batches_tracked += 1
                 return y
         if out_slope != 1.0:

@@ -15,7 +15,8 @@ import torch
 import torch.nn as nn
 
 from . import mesh as M
-from .reconstruction import DatasetParams, ReconstructionNetwork
+from . import parallel as P
+from .reconstruction import BatchNorm1d, BatchNormAct2d, DatasetParams, ReconstructionNetwork
 from .render import Renderer
 
 
@@ -50,11 +51,23 @@ def transform_vertices(vtx, gt_scale, gt_translation, gt_rot, gt_idx=None, datas
 class ReconTrainer(nn.Module):
     """generator / mesh template / renderer / optimisers of run_reconstruction.py:79-89,332-355 and one call per loop iteration.
     Defaults are the script's argparse defaults (:37-64): texture 128, mesh map 32, image 256, MSE, lr 1e-4 for both
-    optimisers, mesh_regularization 5e-5 with the 10 -> 1 warm-up of :355,439-440, optimize_deltas on, optimize_z0 off."""
+    optimisers, mesh_regularization 5e-5 with the 10 -> 1 warm-up of :355,439-440, optimize_deltas on, optimize_z0 off.
+
+    Data parallel (one process per GPU, torch.distributed initialised -- parallel.init_from_env): the reference script is single-GPU,
+    so the N-rank step is defined as THE SAME STEP ON THE GLOBAL BATCH: every rank holds the whole model and the whole
+    DatasetParams table, takes its shard of the loader batch, and
+      * the network's batch norms take their statistics over the global batch (sync_bn: the fused [sum | sum of squares | count]
+        all-reduce of gan_ops, one message per layer and direction) -- without it a rank would normalise with its shard's
+        statistics, which is a different model from the single-GPU one;
+      * both losses are means over the rank's samples, equal shards: ONE flat all-reduce (MEAN) of the generator's and the
+        DatasetParams' gradients per iteration (parallel.FlatGradReducer) gives the global-batch gradient -- the per-image rows of
+        the DatasetParams table a rank did not touch contribute zeros, as they do in the single-GPU step;
+      * parameters are broadcast from rank 0 once; the optimisers then stay in lock step (identical gradients, identical state).
+    tests/test_distributed_gpu.py runs two ranks against the single-process step on the concatenated batch."""
 
     def __init__(self, mesh_template, dataset_size=None, symmetric=True, texture_resolution=128, mesh_resolution=32,
                  image_resolution=256, loss='mse', lr=1e-4, lr_dataset=1e-4, mesh_regularization=0.00005, optimize_deltas=True,
-                 optimize_z0=False, interpolation_mode='nearest', device='cuda'):
+                 optimize_z0=False, interpolation_mode='nearest', device='cuda', data_parallel=True, sync_bn=True):
         super().__init__()
         import argparse
         self.mesh_template = mesh_template
@@ -69,6 +82,20 @@ class ReconTrainer(nn.Module):
         self.criterion = {'mse': nn.MSELoss(), 'l1': nn.L1Loss()}[loss]
         self.mesh_regularization, self.flat_warmup = mesh_regularization, 10.0
         self.to(device)
+        self.data_parallel = bool(data_parallel)
+        self.reduce = None
+        if self.data_parallel:
+            for m in (self.generator, self.dataset_params):
+                if m is not None:
+                    P.broadcast_parameters(m)
+            if sync_bn:
+                for m in self.generator.modules():
+                    if isinstance(m, BatchNormAct2d):
+                        m.sync, m._count_batches = True, True   # global-batch statistics; still counts like nn.BatchNorm2d
+                    elif isinstance(m, BatchNorm1d):
+                        m.sync = True                           # (the two fully connected layers of the encoder)
+            self.reduce = P.FlatGradReducer(list(self.generator.parameters()) +
+                                            ([] if self.dataset_params is None else list(self.dataset_params.parameters())))
         self.optimizer = torch.optim.Adam(self.generator.parameters(), lr=lr)
         self.optimizer_dataset = None if self.dataset_params is None else torch.optim.Adam(self.dataset_params.parameters(),
                                                                                            lr=lr_dataset)
@@ -104,6 +131,8 @@ class ReconTrainer(nn.Module):
         total, recon_loss, flat_loss, miou, _ = self.losses(X_real, gt_scale, gt_translation, gt_rot, gt_idx)
         self.flat_warmup = max(self.flat_warmup - 0.1, 1)
         total.backward()
+        if self.reduce is not None:
+            self.reduce()          # (no-op unless more than one rank: the gradients become the global-batch means)
         self.optimizer.step()
         if self.optimizer_dataset is not None:
             self.optimizer_dataset.step()

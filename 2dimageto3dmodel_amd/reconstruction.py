@@ -38,6 +38,32 @@ class BatchNormAct2d(G.BatchNorm2d):
         return super().forward(x, gamma, beta, slope, res, out_slope)
 
 
+class BatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d of the encoder's two fully connected layers (code/models/reconstruction.py:64-68), same parameters / buffers /
+    state_dict.  `sync` (set by recon_train.ReconTrainer for data-parallel runs): training-mode statistics over the GLOBAL batch --
+    one all-reduce of [sum | sum of squares | count] per layer, its adjoint in the backward (gan_ops._SyncMoments) -- so that N
+    ranks with B / N samples each normalise exactly as one process with B samples does (a batch norm over a rank's 2-sample shard is a
+    different function).  Without sync, or outside training, this is nn.BatchNorm1d itself."""
+    sync = False
+
+    def forward(self, x):
+        from . import parallel
+        if not (self.sync and self.training and parallel.collectives_on()):
+            return super().forward(x)
+        cnt = x.new_tensor([float(x.shape[0])])
+        v = G._SyncMoments.apply(torch.cat((x.sum(0), (x * x).sum(0), cnt)))
+        c = x.shape[1]
+        n = v[2 * c]
+        mean = v[:c] / n
+        var = (v[c:2 * c] / n - mean * mean).clamp_min(0)
+        with torch.no_grad():
+            m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked + 1)
+            self.running_mean.mul_(1 - m).add_(mean.detach(), alpha=m)
+            self.running_var.mul_(1 - m).add_((var * (n / (n - 1))).detach() if float(n) > 1 else var.detach(), alpha=m)
+            self.num_batches_tracked += 1
+        return (x - mean) * torch.rsqrt(var + self.eps) * self.weight + self.bias
+
+
 class ResBlock(nn.Module):
     """models/reconstruction.py:7-26"""
 
@@ -127,9 +153,9 @@ class ReconstructionNetwork(nn.Module):
         self.conv5e = Conv2d(512, 64, 3, stride=2, pad_h=1, pad_w=1, bias=False)
         self.bn5e = BatchNormAct2d(64)
         self.fc1e = nn.Linear(64 * 8 * 8, bottleneck_dim, bias=False)
-        self.bnfc1e = nn.BatchNorm1d(bottleneck_dim)
+        self.bnfc1e = BatchNorm1d(bottleneck_dim)
         self.fc3e = nn.Linear(bottleneck_dim, 1024, bias=False)
-        self.bnfc3e = nn.BatchNorm1d(1024)
+        self.bnfc3e = BatchNorm1d(1024)
 
         # texture decoder: 4 x (2|4) seed, one x2 upsample after every block but the last (:72-90); texture_res 128 / 256
         # insert one / two more 256-channel blocks

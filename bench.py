@@ -693,8 +693,8 @@ def main():
 
 def bench_recon(args, pkg, par, dist, rank, world, dev):
     """The composed mesh-estimation step (2dimageto3dmodel_amd/recon_train.py): per-GPU batch --batch (the script's default is
-    50), 256 x 256 input and render, texture --res (script default 128), learnable per-image pose offsets.  Data-parallel
-    gradient averaging of this path is not wired (single-GPU workload: N > 1 runs N independent replicas)."""
+    50), 256 x 256 input and render, texture --res (script default 128), learnable per-image pose offsets.  N > 1: data
+    parallel (recon_train.ReconTrainer: global-batch batch-norm statistics + one flat gradient all-reduce per iteration)."""
     import tempfile
     rt = importlib.import_module("2dimageto3dmodel_amd.recon_train")
     mesh_mod = importlib.import_module("2dimageto3dmodel_amd.mesh")
@@ -754,7 +754,7 @@ def bench_recon(args, pkg, par, dist, rank, world, dev):
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": f"ReconstructionNetwork(texture {R}) -> 482-vertex template -> pose (+ learnable offsets) -> 256x256 DIB-R "
-                                   f"render -> MSE + flat loss, batch {B}/GPU", "per_gpu_batch": B, "parallelism": f"replicas x{world}",
+                                   f"render -> MSE + flat loss, batch {B}/GPU", "per_gpu_batch": B, "parallelism": f"dp{world}",
                        "losses": {k: float(v.detach() if torch.is_tensor(v) else v) for k, v in last.items()}},
             "kernel_ms_per_step": sum(v[1] for v in kt.values()) / args.steps,
             "all_conv_tflops": (conv_fl / (conv_ms * 1e-3) / 1e12) if conv_ms else None,
