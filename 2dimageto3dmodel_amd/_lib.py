@@ -47,6 +47,7 @@ SIGNATURES = {
     "m355_chamfer_nn_fwd_ws": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
     "m355_conv2d_out_hw": (c_int, [_P, _P, _P]),
     "m355_conv2d_dy_channels": (c_int, [c_int]),
+    "m355_conv2d_exec_ratio": (ctypes.c_double, [_P]),
     "m355_fold2x2": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "m355_conv2d_weight_elems": (c_size_t, [_P, c_int]),
     "m355_conv2d_weight_prep": (c_int, [_P, _P, c_int, _P, _P, _P, _P]),
@@ -217,11 +218,12 @@ def enable_kernel_timers(on):
 
 
 def collect_kernel_timers():
-    """-> {entry point: (launches, total_ms, total_work)}; call after torch.cuda.synchronize()."""
+    """-> {entry point: (launches, total_ms, total algorithmic work, total EXECUTED work)}; call after torch.cuda.synchronize().
+    (executed < algorithmic only where an algebraically cheaper form of the operator runs: the sub-pixel upsample convs)"""
     out = {}
-    for name, e0, e1, work in _TIMER_EVENTS:
-        c, t, w = out.get(name, (0, 0.0, 0.0))
-        out[name] = (c + 1, t + e0.elapsed_time(e1), w + work)
+    for name, e0, e1, work, work_x in _TIMER_EVENTS:
+        c, t, w, wx = out.get(name, (0, 0.0, 0.0, 0.0))
+        out[name] = (c + 1, t + e0.elapsed_time(e1), w + work, wx + work_x)
     _TIMER_EVENTS.clear()
     return out
 
@@ -229,7 +231,7 @@ def collect_kernel_timers():
 TIMER_TAGS = bool(os.environ.get("M355_TIMER_TAGS"))  # per-shape timer keys (scripts/layer_times.py)
 
 
-def launch(name, *args, work=0.0, tag=None):
+def launch(name, *args, work=0.0, tag=None, exec_ratio=1.0):
     """call m355_<name>(*args), raise on a non-zero status; optionally bracket it with HIP events"""
     fn = getattr(lib(), "m355_" + name)
     if _TIMERS_ON:
@@ -251,7 +253,9 @@ def launch(name, *args, work=0.0, tag=None):
             # label by the kernel family the C side dispatched to (what rocprofv3 lists), keeping the entry point
             fam = lib().m355_last_kernel().decode()
             name_t = fam + " [" + name_t + "]" if (TIMER_TAGS and tag) else fam
-        _TIMER_EVENTS.append((name_t, e0, e1, float(work)))
+        if callable(exec_ratio):
+            exec_ratio = exec_ratio()
+        _TIMER_EVENTS.append((name_t, e0, e1, float(work), float(work) * float(exec_ratio)))
     else:
         rc = fn(*args)
     check(rc, name)

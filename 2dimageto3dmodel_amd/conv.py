@@ -43,7 +43,7 @@ _OUT_HW, _DY_CH = {}, {}   # pure geometry (no environment switches behind them)
 
 def _reset_caches():
     """the memoised answers below belong to ONE build of the library (_lib.set_exact switches it)"""
-    for c in (_OUT_HW, _DY_CH, _HALVES, _FWD_WS, _WS_BYTES):
+    for c in (_OUT_HW, _DY_CH, _HALVES, _FWD_WS, _WS_BYTES, _EXEC_RATIO):
         c.clear()
 
 
@@ -73,6 +73,18 @@ def flops(d, cin_real=None):
     (zero-padded input channels do not count)"""
     ho, wo = out_hw(d)
     return 2.0 * d.N * ho * wo * d.Cout * (cin_real or d.Cin) * d.kh * d.kw
+
+
+_EXEC_RATIO = {}
+
+
+def exec_ratio(d):
+    """executed / algorithmic MACs of the layer's forward, dgrad and workspace / deterministic wgrad (4/9 in the sub-pixel form)"""
+    key = bytes(d)
+    r = _EXEC_RATIO.get(key)
+    if r is None:
+        r = _EXEC_RATIO[key] = float(lib().m355_conv2d_exec_ratio(ctypes.byref(d)))
+    return r
 
 
 def tag(d):
@@ -163,7 +175,7 @@ def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0, cin_real=Non
                work=lambda: flops(d, cin_real), tag=lambda: tag(d))
         return y, bits
     launch("conv2d_fwd", ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(b), ptr(y), int(out_f32_nchw), float(slope), stream(),
-           work=lambda: flops(d, cin_real), tag=lambda: tag(d))
+           work=lambda: flops(d, cin_real), tag=lambda: tag(d), exec_ratio=lambda: 1.0 if out_f32_nchw else exec_ratio(d))
     return y
 
 
@@ -201,7 +213,7 @@ def conv_fwd_stats(d, x, w_fwd, bias=None, cin_real=None, rows=None, _out=None):
     y, part = _out if _out is not None else (torch.empty((d.N, ho, wo, d.Cout), dtype=_lib.act_dtype(), device=x.device),
                                              torch.empty((rows, 2, d.Cout), dtype=torch.float32, device=x.device))
     launch("conv2d_fwd_stats", ctypes.byref(d), ptr(x), ptr(w_fwd), ptr(b), ptr(y), ptr(part), stream(),
-           work=lambda: flops(d, cin_real), tag=lambda: tag(d))
+           work=lambda: flops(d, cin_real), tag=lambda: tag(d), exec_ratio=lambda: exec_ratio(d))
     return y, part
 
 
@@ -229,7 +241,7 @@ def conv_dgrad(d, dy, w_dgrad, cin_real=None, mask_x=None, mask_slope=1.0, mask_
                stream(), work=lambda: flops(d, cin_real), tag=lambda: tag(d))
         return dx
     launch("conv2d_dgrad", ctypes.byref(d), ptr(dy), ptr(w_dgrad), ptr(dx), ptr(ws), ptr(mask_x), float(mask_slope), stream(),
-           work=lambda: flops(d, cin_real), tag=lambda: tag(d))
+           work=lambda: flops(d, cin_real), tag=lambda: tag(d), exec_ratio=lambda: exec_ratio(d))
     return dx
 
 
@@ -383,13 +395,13 @@ def conv_wgrad(d, x, dy, cin_real=None, raw=False, dbias=None, arena=False, dbia
         ws = torch.empty((nws,), dtype=torch.uint8, device=x.device)
         dw = torch.empty((d.Cout, d.kh, d.kw, d.Cin), dtype=torch.float32, device=x.device)
         launch("conv2d_wgrad_ws", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(ws), stream(),
-               work=lambda: flops(d, cin_real), tag=lambda: tag(d))
+               work=lambda: flops(d, cin_real), tag=lambda: tag(d), exec_ratio=lambda: exec_ratio(d))
         return dw if raw else dw.permute(0, 3, 1, 2)
     if _DETERMINISTIC:
         ws = torch.empty((lib().m355_conv2d_wgrad_det_ws_bytes(ctypes.byref(d)),), dtype=torch.uint8, device=x.device)
         dw = torch.empty((d.Cout, d.kh, d.kw, d.Cin), dtype=torch.float32, device=x.device)
         launch("conv2d_wgrad_det", ctypes.byref(d), ptr(x), ptr(dy), ptr(ws), ptr(dw), ptr(dbias), stream(),
-               work=lambda: flops(d, cin_real), tag=lambda: tag(d))
+               work=lambda: flops(d, cin_real), tag=lambda: tag(d), exec_ratio=lambda: exec_ratio(d))
         return dw if raw else dw.permute(0, 3, 1, 2)
     sl = WgradArena.take(n, x.device) if (arena and raw) else None
     if sl is not None:

@@ -958,6 +958,11 @@ static size_t up3_dgrad_off(const m355_conv_desc *d)
     return (size_t)m355::rows_padded(d->Cin) * m355::k_padded(9 * m355::dy_channels(d->Cout));
 }
 
+/* executed / algorithmic multiply-accumulates of this layer's forward, dgrad and workspace / deterministic wgrad: 4/9 where the
+ * layer runs in the sub-pixel form (an upsample + 3x3 conv: 4 taps on the stored tensor instead of 9 on the upsampled one), else 1.
+ * The benchmark accounts every conv at the OPERATOR's 2*M*N*K and reports the executed figure beside it. */
+extern "C" double m355_conv2d_exec_ratio(const m355_conv_desc *d) { return (d && subpixel(d)) ? 4.0 / 9.0 : 1.0; }
+
 extern "C" size_t m355_conv2d_weight_elems(const m355_conv_desc *d, int which)
 {
     // which 0: forward view [rows_padded(Cout)][ceil64(kh*kw*Cin)]; 1: dgrad views (stride 1: one

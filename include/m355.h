@@ -171,6 +171,10 @@ int m355_conv2d_out_hw(const m355_conv_desc *d, int *Ho, int *Wo);
 /*      adjoint of the nearest x2 upsample (gan.py:319) on NHWC bf16: g[N,2H,2W,C] -> dx[N,H,W,C] (2x2 block sums) */
 int m355_fold2x2(const void *g, void *dx, int N, int H, int W, int C, void *stream);
 int m355_conv2d_dy_channels(int cout);
+/*      executed / algorithmic multiply-accumulates of the layer (forward, dgrad, workspace / deterministic wgrad): 4/9 where an
+ *      upsample + 3x3 layer (models/gan.py:319,386-404 in front of ResBlockUp.conv1 :294,309) runs in the SUB-PIXEL form -- four 2x2
+ *      class convs of the stored tensor with pre-summed weights instead of nine taps on the upsampled one -- else 1 */
+double m355_conv2d_exec_ratio(const m355_conv_desc *d);
 /*      elements (bf16) of the weight views: which 0 forward [ceil64(Cout)][ceil32(kh*kw*Cin)], 1 dgrad */
 size_t m355_conv2d_weight_elems(const m355_conv_desc *d, int which);
 /*      w_oihw is the fp32 parameter [Cout][cin_w][kh][kw]; channels cin_w..Cin-1 of the views are zero. */

@@ -11,7 +11,7 @@ def header_functions():
     src = open(os.path.join(ROOT, "include", "m355.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(?:int|size_t|long long|const char \*)\s*\*?\s*(m355_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(?:int|size_t|double|long long|const char \*)\s*\*?\s*(m355_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = [a.strip() for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
         out[m.group(1)] = len(args)
     return out
