@@ -46,6 +46,7 @@ SIGNATURES = {
     "m355_chamfer_nn_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "m355_chamfer_nn_fwd_ws": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
     "m355_conv2d_out_hw": (c_int, [_P, _P, _P]),
+    "m355_conv2d_plan": (c_int, [_P, _P]),
     "m355_conv2d_dy_channels": (c_int, [c_int]),
     "m355_conv2d_exec_ratio": (ctypes.c_double, [_P]),
     "m355_fold2x2": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
@@ -137,6 +138,16 @@ class ConvDesc(ctypes.Structure):
     """m355_conv_desc (include/m355.h)"""
     _fields_ = [(n, c_int) for n in ("N", "H", "W", "Cin", "Cout", "kh", "kw", "stride", "pad_h", "pad_w",
                                       "pad_w_mode", "upsample")]
+
+
+class ConvPlan(ctypes.Structure):
+    """m355_conv_plan (include/m355.h): every pre-launch answer about a layer, one call per descriptor"""
+    _fields_ = [("Ho", c_int), ("Wo", c_int), ("dy_channels", c_int), ("act_bytes", c_int),
+                ("w_fwd_elems", c_size_t), ("w_dgrad_elems", c_size_t),
+                ("fwd_bits_ok", c_int), ("dgrad_bits_ok", c_int), ("dgrad_mask_ok", c_int), ("fwd_stats_rows", c_int),
+                ("fwd_ws_stats_rows", c_int), ("wgrad_fuses_dbias", c_int),
+                ("fwd_ws_bytes", c_size_t), ("dgrad_ws_bytes", c_size_t), ("wgrad_ws_bytes", c_size_t),
+                ("wgrad_det_ws_bytes", c_size_t), ("exec_ratio", ctypes.c_double)]
 
 
 class SnFinEntry(ctypes.Structure):

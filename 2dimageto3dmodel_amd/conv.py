@@ -39,11 +39,26 @@ def make_desc(N, H, W, Cin, Cout, kh, kw, stride=1, pad_h=0, pad_w=0, pad_w_mode
 
 
 _OUT_HW, _DY_CH = {}, {}   # pure geometry (no environment switches behind them): memoised, the hot loop calls them per launch
+_PLAN = {}
+
+
+def plan(d):
+    """m355_conv2d_plan: everything the binding has to know about a layer before it launches (output extent, buffer sizes, which
+    optional forms this build of the library runs the shape in), ONE library call per descriptor, memoised -- the selection rules
+    live in the library, the hot loop reads a struct.  (Environment switches the library reads are process-wide settings: change
+    them before the first launch, or call _reset_caches().)"""
+    key = bytes(d)
+    p = _PLAN.get(key)
+    if p is None:
+        p = _lib.ConvPlan()
+        check(lib().m355_conv2d_plan(ctypes.byref(d), ctypes.byref(p)), "conv2d_plan")
+        _PLAN[key] = p
+    return p
 
 
 def _reset_caches():
     """the memoised answers below belong to ONE build of the library (_lib.set_exact switches it)"""
-    for c in (_OUT_HW, _DY_CH, _HALVES, _FWD_WS, _WS_BYTES, _EXEC_RATIO):
+    for c in (_OUT_HW, _DY_CH, _HALVES, _FWD_WS, _WS_BYTES, _EXEC_RATIO, _PLAN):
         c.clear()
 
 
@@ -54,9 +69,8 @@ def out_hw(d):
     key = bytes(d)
     r = _OUT_HW.get(key)
     if r is None:
-        ho, wo = ctypes.c_int(), ctypes.c_int()
-        check(lib().m355_conv2d_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), "conv2d_out_hw")
-        r = _OUT_HW[key] = (ho.value, wo.value)
+        p = plan(d)
+        r = _OUT_HW[key] = (p.Ho, p.Wo)
     return r
 
 
@@ -83,7 +97,7 @@ def exec_ratio(d):
     key = bytes(d)
     r = _EXEC_RATIO.get(key)
     if r is None:
-        r = _EXEC_RATIO[key] = float(lib().m355_conv2d_exec_ratio(ctypes.byref(d)))
+        r = _EXEC_RATIO[key] = float(plan(d).exec_ratio)
     return r
 
 
@@ -103,10 +117,10 @@ def weight_prep(d, w_oihw, want_dgrad=True, sigma=None):
     """bf16 GEMM views of the fp32 parameter; `sigma` (1-element device tensor) divides it (spectral norm)"""
     w = _req(w_oihw.detach(), torch.float32, "weight")
     L = lib()
-    wf = torch.empty((L.m355_conv2d_weight_elems(ctypes.byref(d), 0),), dtype=torch.bfloat16, device=w.device)   # (2-byte elements)
+    wf = torch.empty((plan(d).w_fwd_elems,), dtype=torch.bfloat16, device=w.device)   # (2-byte elements)
     wd = None
     if want_dgrad:
-        wd = torch.empty((L.m355_conv2d_weight_elems(ctypes.byref(d), 1),), dtype=torch.bfloat16, device=w.device)
+        wd = torch.empty((plan(d).w_dgrad_elems,), dtype=torch.bfloat16, device=w.device)
     launch("conv2d_weight_prep", ctypes.byref(d), ptr(w), int(w.shape[1]), ptr(sigma), ptr(wf), ptr(wd), stream())
     return wf, wd
 
@@ -138,13 +152,13 @@ def _halves(d, out_bytes=2):
 def maskbits_ok(d, role):
     """role 0: the forward of this layer can write bit-packed activation masks; role 1: its dgrad can read them"""
     hv = _halves(d)
-    return maskbits_ok(hv[0], role) if hv else bool(lib().m355_conv2d_maskbits_ok(ctypes.byref(d), int(role)))
+    return maskbits_ok(hv[0], role) if hv else bool(plan(d).dgrad_bits_ok if role else plan(d).fwd_bits_ok)
 
 
 def dgrad_mask_ok(d):
     """can conv_dgrad(mask_x=...) apply the producer's LeakyReLU backward in its epilogue on this layer?"""
     hv = _halves(d)
-    return dgrad_mask_ok(hv[0]) if hv else bool(lib().m355_conv2d_dgrad_mask_ok(ctypes.byref(d)))
+    return dgrad_mask_ok(hv[0]) if hv else bool(plan(d).dgrad_mask_ok)
 
 
 def conv_fwd(d, x, w_fwd, bias=None, out_f32_nchw=False, slope=1.0, cin_real=None, emit_bits=False, _out=None):
@@ -187,6 +201,8 @@ def conv_stats_rows(d):
     nws, rows = _fwd_ws(d)
     if nws:
         return rows   # (split-K layers: the finishing pass emits them)
+    # (asked live, not from the memoised plan: the answer sizes the `part` buffer the kernel writes, and it follows the
+    # M355_HALO_WGS / M355_STATS_UPS_WGS test switches)
     return int(lib().m355_conv2d_fwd_stats_rows(ctypes.byref(d)))
 
 
@@ -233,8 +249,8 @@ def conv_dgrad(d, dy, w_dgrad, cin_real=None, mask_x=None, mask_slope=1.0, mask_
             conv_dgrad(dh, dy[sl], w_dgrad, cin_real, None if mask_x is None else mask_x[sl], mask_slope,
                        None if mask_bits is None else mask_bits[sl], _out=dx[sl])
         return dx
-    nws = lib().m355_conv2d_dgrad_ws_bytes(ctypes.byref(d))
-    ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device)
+    nws = plan(d).dgrad_ws_bytes
+    ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device) if nws else None
     if mask_bits is not None:
         assert tuple(mask_bits.shape) == (d.N, d.H, d.W, d.Cin // 64, 2), (tuple(mask_bits.shape), d.Cin)
         launch("conv2d_dgrad_bits", ctypes.byref(d), ptr(dy), ptr(w_dgrad), ptr(dx), ptr(ws), ptr(mask_bits), float(mask_slope),
@@ -254,7 +270,7 @@ def _fwd_ws(d):
     r = _FWD_WS.get(key)
     if r is None:
         L = lib()
-        r = _FWD_WS[key] = (int(L.m355_conv2d_fwd_ws_bytes(ctypes.byref(d))), int(L.m355_conv2d_fwd_ws_stats_rows(ctypes.byref(d))))
+        r = _FWD_WS[key] = (int(plan(d).fwd_ws_bytes), int(plan(d).fwd_ws_stats_rows))
     return r
 
 
@@ -276,13 +292,13 @@ def _wgrad_ws_bytes(d):
     key = bytes(d)
     r = _WS_BYTES.get(key)
     if r is None:
-        r = _WS_BYTES[key] = int(lib().m355_conv2d_wgrad_ws_bytes(ctypes.byref(d)))
+        r = _WS_BYTES[key] = int(plan(d).wgrad_ws_bytes)
     return r
 
 
 def wgrad_fuses_dbias(d):
     hv = _halves(d)
-    return wgrad_fuses_dbias(hv[0]) if hv else bool(lib().m355_conv2d_wgrad_fuses_dbias(ctypes.byref(d)))
+    return wgrad_fuses_dbias(hv[0]) if hv else bool(plan(d).wgrad_fuses_dbias)
 
 
 def _after_fill(st, device):
@@ -398,7 +414,7 @@ def conv_wgrad(d, x, dy, cin_real=None, raw=False, dbias=None, arena=False, dbia
                work=lambda: flops(d, cin_real), tag=lambda: tag(d), exec_ratio=lambda: exec_ratio(d))
         return dw if raw else dw.permute(0, 3, 1, 2)
     if _DETERMINISTIC:
-        ws = torch.empty((lib().m355_conv2d_wgrad_det_ws_bytes(ctypes.byref(d)),), dtype=torch.uint8, device=x.device)
+        ws = torch.empty((plan(d).wgrad_det_ws_bytes,), dtype=torch.uint8, device=x.device)
         dw = torch.empty((d.Cout, d.kh, d.kw, d.Cin), dtype=torch.float32, device=x.device)
         launch("conv2d_wgrad_det", ctypes.byref(d), ptr(x), ptr(dy), ptr(ws), ptr(dw), ptr(dbias), stream(),
                work=lambda: flops(d, cin_real), tag=lambda: tag(d), exec_ratio=lambda: exec_ratio(d))

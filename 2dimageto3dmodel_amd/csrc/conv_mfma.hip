@@ -2097,3 +2097,28 @@ static int conv_wgrad_impl(const m355_conv_desc *d, const void *x, const void *d
     m355::note_kernel("k_wgrad_mfma");
     return m355::check_launch("conv2d_wgrad");
 }
+
+/* the plan of a layer: every pre-launch query in one struct (include/m355.h m355_conv_plan) */
+extern "C" int m355_conv2d_plan(const m355_conv_desc *d, m355_conv_plan *p)
+{
+    M355_REQUIRE(p, "conv2d_plan: null pointer");
+    if (int rc = check_desc(d, "conv2d_plan")) return rc;
+    memset(p, 0, sizeof(*p));
+    conv_out_hw(d, &p->Ho, &p->Wo);
+    p->dy_channels = m355::dy_channels(d->Cout);
+    p->act_bytes = m355_act_bytes();
+    p->w_fwd_elems = m355_conv2d_weight_elems(d, 0);
+    p->w_dgrad_elems = m355_conv2d_weight_elems(d, 1);
+    p->fwd_bits_ok = m355_conv2d_maskbits_ok(d, 0);
+    p->dgrad_bits_ok = m355_conv2d_maskbits_ok(d, 1);
+    p->dgrad_mask_ok = m355_conv2d_dgrad_mask_ok(d);
+    p->fwd_stats_rows = m355_conv2d_fwd_stats_rows(d);
+    p->fwd_ws_bytes = m355_conv2d_fwd_ws_bytes(d);
+    p->fwd_ws_stats_rows = m355_conv2d_fwd_ws_stats_rows(d);
+    p->wgrad_fuses_dbias = m355_conv2d_wgrad_fuses_dbias(d);
+    p->dgrad_ws_bytes = m355_conv2d_dgrad_ws_bytes(d);
+    p->wgrad_ws_bytes = m355_conv2d_wgrad_ws_bytes(d);
+    p->wgrad_det_ws_bytes = m355_conv2d_wgrad_det_ws_bytes(d);
+    p->exec_ratio = m355_conv2d_exec_ratio(d);
+    return M355_OK;
+}

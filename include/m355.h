@@ -168,6 +168,28 @@ typedef struct {
 } m355_conv_desc;
 
 int m355_conv2d_out_hw(const m355_conv_desc *d, int *Ho, int *Wo);
+
+/* Everything a caller has to know about a layer BEFORE it launches -- output extent, buffer sizes, and which of the optional forms
+ * (bit masks, fused activation backward, fused statistics, split-K forward, workspace / deterministic weight gradient) this build
+ * of the library runs the shape in -- in ONE call (round 5; the individual queries below answer the same questions and remain).  The
+ * selection rules live in the library only: a binding asks for the plan once per descriptor and follows it. */
+typedef struct m355_conv_plan {
+    int Ho, Wo;                   /* m355_conv2d_out_hw */
+    int dy_channels;              /* m355_conv2d_dy_channels(Cout) */
+    int act_bytes;                /* m355_act_bytes */
+    size_t w_fwd_elems, w_dgrad_elems;   /* m355_conv2d_weight_elems(d, 0 / 1), 2-byte elements */
+    int fwd_bits_ok, dgrad_bits_ok;      /* m355_conv2d_maskbits_ok(d, 0 / 1) */
+    int dgrad_mask_ok;            /* m355_conv2d_dgrad_mask_ok */
+    int fwd_stats_rows;           /* m355_conv2d_fwd_stats_rows (0: no fused statistics) */
+    int fwd_ws_stats_rows;        /* m355_conv2d_fwd_ws_stats_rows */
+    int wgrad_fuses_dbias;        /* m355_conv2d_wgrad_fuses_dbias */
+    size_t fwd_ws_bytes;          /* m355_conv2d_fwd_ws_bytes (0: no split-K forward) */
+    size_t dgrad_ws_bytes;        /* m355_conv2d_dgrad_ws_bytes */
+    size_t wgrad_ws_bytes;        /* m355_conv2d_wgrad_ws_bytes (0: use m355_conv2d_wgrad / _acc / _det) */
+    size_t wgrad_det_ws_bytes;    /* m355_conv2d_wgrad_det_ws_bytes */
+    double exec_ratio;            /* m355_conv2d_exec_ratio */
+} m355_conv_plan;
+int m355_conv2d_plan(const m355_conv_desc *d, m355_conv_plan *plan);
 /*      adjoint of the nearest x2 upsample (gan.py:319) on NHWC bf16: g[N,2H,2W,C] -> dx[N,H,W,C] (2x2 block sums) */
 int m355_fold2x2(const void *g, void *dx, int N, int H, int W, int C, void *stream);
 int m355_conv2d_dy_channels(int cout);

@@ -27,3 +27,17 @@ def load_golden(name):
 
 
 P_CASES = ["p_cfg1", "p_b3_noscale", "p_oob", "p_s128", "p_n1", "p_dense", "p_sigma"]
+
+
+@pytest.fixture(autouse=True)
+def _fresh_conv_plans():
+    """conv.py memoises the library's per-layer answers (m355_conv2d_plan); several tests flip the library's environment
+    switches (monkeypatch.setenv: tile / workgroup / variant overrides), which are process-wide settings the memo cannot see --
+    every test starts, and leaves, with empty caches"""
+    conv = sys.modules.get("2dimageto3dmodel_amd.conv")
+    if conv is not None:
+        conv._reset_caches()
+    yield
+    conv = sys.modules.get("2dimageto3dmodel_amd.conv")
+    if conv is not None:
+        conv._reset_caches()

@@ -158,3 +158,29 @@ def test_two_gib_layers_are_halved_on_the_host():
     big, half = mk(256, ci=64, co=128, k=4, s=2, p=1), mk(128, ci=64, co=128, k=4, s=2, p=1)
     assert conv.dgrad_mask_ok(big) == conv.dgrad_mask_ok(half) and conv.wgrad_fuses_dbias(big) == conv.wgrad_fuses_dbias(half)
     assert conv.conv_stats_rows(mk(512, 256, 128, 64, 64, 3, 1, 1)) == 2 * conv.conv_stats_rows(mk(256, 256, 128, 64, 64, 3, 1, 1))
+
+
+def test_conv_plan_equals_the_individual_queries(pkg):
+    """m355_conv2d_plan (round 5): one call per layer answers what the individual pre-launch queries answer -- for every shape class
+    of the benchmarked networks, in the build that is loaded"""
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    L = pkg._lib.lib()
+    shapes = [(64, 128, 64, 128, 64, 3, 1, 1, 1, 1, 1), (64, 32, 16, 256, 128, 3, 1, 1, 1, 1, 1), (64, 8, 4, 512, 512, 3, 1, 1, 1, 1, 0),
+              (128, 256, 256, 8, 64, 5, 1, 2, 2, 2, 0), (128, 256, 256, 64, 128, 4, 2, 1, 1, 2, 0), (64, 256, 128, 64, 3, 5, 1, 2, 2, 1, 0),
+              (64, 128, 64, 128, 64, 1, 1, 0, 0, 0, 0), (128, 32, 32, 512, 1, 5, 1, 2, 2, 2, 0), (64, 256, 128, 64, 64, 3, 1, 1, 1, 1, 0)]
+    for N, H, W, Cin, Cout, k, s, ph, pw, mode, ups in shapes:
+        d = conv.make_desc(N, H, W, Cin, Cout, k, k, s, ph, pw, mode, ups)
+        p = conv.plan(d)
+        ho, wo = ctypes.c_int(), ctypes.c_int()
+        assert L.m355_conv2d_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) == 0 and (p.Ho, p.Wo) == (ho.value, wo.value)
+        assert p.dy_channels == L.m355_conv2d_dy_channels(Cout) and p.act_bytes == L.m355_act_bytes()
+        assert (p.w_fwd_elems, p.w_dgrad_elems) == (L.m355_conv2d_weight_elems(ctypes.byref(d), 0), L.m355_conv2d_weight_elems(ctypes.byref(d), 1))
+        assert (p.fwd_bits_ok, p.dgrad_bits_ok) == (L.m355_conv2d_maskbits_ok(ctypes.byref(d), 0), L.m355_conv2d_maskbits_ok(ctypes.byref(d), 1))
+        assert p.dgrad_mask_ok == L.m355_conv2d_dgrad_mask_ok(ctypes.byref(d)) and p.fwd_stats_rows == L.m355_conv2d_fwd_stats_rows(ctypes.byref(d))
+        assert (p.fwd_ws_bytes, p.fwd_ws_stats_rows) == (L.m355_conv2d_fwd_ws_bytes(ctypes.byref(d)), L.m355_conv2d_fwd_ws_stats_rows(ctypes.byref(d)))
+        assert p.wgrad_fuses_dbias == L.m355_conv2d_wgrad_fuses_dbias(ctypes.byref(d))
+        assert (p.dgrad_ws_bytes, p.wgrad_ws_bytes, p.wgrad_det_ws_bytes) == (L.m355_conv2d_dgrad_ws_bytes(ctypes.byref(d)),
+                                                                              L.m355_conv2d_wgrad_ws_bytes(ctypes.byref(d)),
+                                                                              L.m355_conv2d_wgrad_det_ws_bytes(ctypes.byref(d)))
+        assert p.exec_ratio == L.m355_conv2d_exec_ratio(ctypes.byref(d)) and p.exec_ratio == (4.0 / 9.0 if (ups and W % 32 == 0) else 1.0)
+    assert conv.plan(d) is p   # memoised per descriptor
