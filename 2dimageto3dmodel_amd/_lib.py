@@ -55,6 +55,7 @@ SIGNATURES = {
     "m355_conv2d_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P]),
     "m355_conv2d_dgrad_ws_bytes": (c_size_t, [_P]),
     "m355_conv2d_dgrad": (c_int, [_P, _P, _P, _P, _P, _P, c_float, _P]),
+    "m355_conv2d_dgrad_lead": (c_int, [_P, _P, _P, _P, _P, c_int, _P]),
     "m355_mesh_vertices_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "m355_mesh_vertices_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "m355_mesh_normals_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),

@@ -233,10 +233,11 @@ def conv_fwd_stats(d, x, w_fwd, bias=None, cin_real=None, rows=None, _out=None):
     return y, part
 
 
-def conv_dgrad(d, dy, w_dgrad, cin_real=None, mask_x=None, mask_slope=1.0, mask_bits=None, _out=None):
+def conv_dgrad(d, dy, w_dgrad, cin_real=None, mask_x=None, mask_slope=1.0, mask_bits=None, _out=None, lead=0):
     """mask_x: this conv's input x when it is the output of a fused conv+LeakyReLU(mask_slope): the returned gradient
     is then already multiplied by that activation's derivative; mask_bits: the same from the producer's bit masks
-    (conv_fwd(emit_bits=True)), 1/16 of the bytes"""
+    (conv_fwd(emit_bits=True)), 1/16 of the bytes.  lead > 0: the input channels beyond the first `lead` are constants of the model
+    (positional planes): only dx[..., :lead] is specified (m355_conv2d_dgrad_lead)"""
     dy = _req(dy, _lib.act_dtype(), "dy")
     ho, wo = out_hw(d)
     assert tuple(dy.shape) == (d.N, ho, wo, dy_channels(d.Cout)), tuple(dy.shape)
@@ -247,7 +248,7 @@ def conv_dgrad(d, dy, w_dgrad, cin_real=None, mask_x=None, mask_slope=1.0, mask_
         for i in (0, 1):
             sl = slice(i * h, (i + 1) * h)
             conv_dgrad(dh, dy[sl], w_dgrad, cin_real, None if mask_x is None else mask_x[sl], mask_slope,
-                       None if mask_bits is None else mask_bits[sl], _out=dx[sl])
+                       None if mask_bits is None else mask_bits[sl], _out=dx[sl], lead=lead)
         return dx
     nws = plan(d).dgrad_ws_bytes
     ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device) if nws else None
@@ -255,6 +256,11 @@ def conv_dgrad(d, dy, w_dgrad, cin_real=None, mask_x=None, mask_slope=1.0, mask_
         assert tuple(mask_bits.shape) == (d.N, d.H, d.W, d.Cin // 64, 2), (tuple(mask_bits.shape), d.Cin)
         launch("conv2d_dgrad_bits", ctypes.byref(d), ptr(dy), ptr(w_dgrad), ptr(dx), ptr(ws), ptr(mask_bits), float(mask_slope),
                stream(), work=lambda: flops(d, cin_real), tag=lambda: tag(d))
+        return dx
+    if lead and mask_x is None:
+        # (the work that is asked for: `lead` of the layer's input channels)
+        launch("conv2d_dgrad_lead", ctypes.byref(d), ptr(dy), ptr(w_dgrad), ptr(dx), ptr(ws), int(lead), stream(),
+               work=lambda: flops(d, min(int(lead), cin_real or d.Cin)), tag=lambda: tag(d) + f" lead{int(lead)}")
         return dx
     launch("conv2d_dgrad", ctypes.byref(d), ptr(dy), ptr(w_dgrad), ptr(dx), ptr(ws), ptr(mask_x), float(mask_slope), stream(),
            work=lambda: flops(d, cin_real), tag=lambda: tag(d), exec_ratio=lambda: exec_ratio(d))

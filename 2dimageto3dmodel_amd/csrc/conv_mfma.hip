@@ -862,7 +862,7 @@ int conv_c8_launch(const m355_conv_desc *d, const void *x, const void *w_fwd, co
                    size_t wbytes, unsigned *bits, hipStream_t st, const void *mask = nullptr, float mask_slope = 1.0f);
 bool dgrad_small_eligible(const m355_conv_desc *d, int Cy);
 int dgrad_small_launch(const m355_conv_desc *d, const void *dy, int Cy, const void *w_dgrad, int Kp, size_t wbytes, void *dx,
-                       hipStream_t st);
+                       hipStream_t st, int lead = 0);
 bool dgrad_c8_replicate_eligible(const m355_conv_desc *d, int Cy);  // csrc/conv_small.hip
 int dgrad_c8_replicate_launch(const m355_conv_desc *d, const void *dy, const void *w_dgrad, int Kp, size_t wbytes, void *dx,
                               hipStream_t st, const void *mask_x, float mask_slope);
@@ -1347,7 +1347,7 @@ extern "C" size_t m355_conv2d_dgrad_ws_bytes(const m355_conv_desc *d)
 }
 
 static int conv_dgrad_impl(const m355_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, void *ws, const void *mask_x,
-                           const unsigned *mask_bits, float mask_slope, void *stream, int probe)
+                           const unsigned *mask_bits, float mask_slope, void *stream, int probe, int lead = 0)
 {
     if (int rc = check_desc(d, "conv2d_dgrad")) return probe ? 0 : rc;
     if (!probe) M355_REQUIRE(dy && w_dgrad && dx, "conv2d_dgrad: null pointer");
@@ -1402,7 +1402,7 @@ static int conv_dgrad_impl(const m355_conv_desc *d, const void *dy, const void *
         return m355::dgrad_direct_replicate_launch(d, dy, cout32, w_dgrad, a.Kp, cin64, dx, st);
     }
     if (!probe && direct && !mask_x && !mask_bits && m355::dgrad_small_eligible(d, cout32) && !getenv("M355_NO_C8"))
-        return m355::dgrad_small_launch(d, dy, cout32, w_dgrad, a.Kp, (size_t)cin64 * a.Kp * 2, dx, st);
+        return m355::dgrad_small_launch(d, dy, cout32, w_dgrad, a.Kp, (size_t)cin64 * a.Kp * 2, dx, st, lead);
     // 5x5 "same" convs with <= 8 output channels and a zero / circular W pad (TextureDiscriminator.conv5): the gradient is a
     // conv of the 8-channel dy onto Cin channels with the same pad mode -- k_conv_c8, with the activation backward of the
     // producer of x (mask_x) in its epilogue (k_conv_glds pads the 1..8 channels of dy to a 64-wide K step)
@@ -1498,6 +1498,17 @@ extern "C" int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const 
                                  const void *mask_x, float mask_slope, void *stream)
 {
     return conv_dgrad_impl(d, dy, w_dgrad, dx, ws, mask_x, nullptr, mask_slope, stream, 0);
+}
+
+/* dgrad of a layer whose input channels beyond the first `lead` are CONSTANTS of the model (TextureDiscriminator.conv1,
+ * /root/reference/code/models/gan.py:204-213: image channels + the batch-constant positional encodings of gan.py:9-20): nothing reads their
+ * gradient, so only dx[..., 0 .. lead-1] is specified -- the other channels of dx hold zeros or the true gradient, whichever the
+ * dispatched kernel produces.  Same arguments as m355_conv2d_dgrad (no activation mask). */
+extern "C" int m355_conv2d_dgrad_lead(const m355_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, void *ws, int lead,
+                                      void *stream)
+{
+    M355_REQUIRE(d && lead >= 1 && lead <= d->Cin, "conv2d_dgrad_lead: lead=%d outside 1..Cin", lead);
+    return conv_dgrad_impl(d, dy, w_dgrad, dx, ws, nullptr, nullptr, 1.0f, stream, 0, lead);
 }
 
 /* dgrad whose epilogue applies the producer's LeakyReLU backward from the bit masks m355_conv2d_fwd_bits wrote

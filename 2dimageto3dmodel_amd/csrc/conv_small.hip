@@ -175,6 +175,7 @@ struct Head5Args {
     const unsigned short *w;  // bf16 forward view [rows][Kp], row = output channel, K ordered (kh, kw, ci)
     const float *bias;        // [Cout] or null
     float *y;                 // fp32 NCHW [N,Cout,H,W]
+    unsigned short *yb;       // OUT = 1: bf16 NHWC with 8 channels per pixel, channels 0 .. Cout-1 written, the rest zero
     int N, H, W, Cout, Kp;
     int nsx, nsy, rs;         // strips of 28 columns, row segments of rs rows
     float slope;
@@ -205,7 +206,12 @@ __device__ __forceinline__ float lane_from(float v)
     return __int_as_float(x);
 }
 
-template <int MODE>
+// OUT = 1 (round 5): the same kernel as the INPUT GRADIENT of TextureDiscriminator.conv1 (gan.py:204-213) in the G step: a 5x5 conv of
+// the 64-channel dy with the flipped, transposed weights onto the first <= 4 input channels -- the only ones whose gradient
+// anything reads (the other four are the batch-constant positional planes of gan.py:9-20) -- written as the 8-channel bf16 NHWC
+// pixel the loaders' backward expects (m355_conv2d_dgrad_lead).  k_conv_smallco produced all 8 with half of every MFMA's columns
+// unused: 302 us at batch 64 against ~2x the 88 us this form takes for the half-size conv_final.
+template <int MODE, int OUT = 0>
 __global__ __launch_bounds__(64) void k_head5(Head5Args a)
 {
     constexpr int SW = 28;   // output columns of a strip (32 lanes - 2 - 2)
@@ -288,7 +294,20 @@ __global__ __launch_bounds__(64) void k_head5(Head5Args a)
                 if (q + PD < qend) load_row(q + PD, buf[k]);
                 // output row q - 2 is complete
                 const int r = q - 2;
-                if (r >= r0 && r < r1 && st_col) {
+                if (OUT == 1) {
+                    // lane c of half 0 holds channels 0 / 2, its partner in half 1 channels 1 / 3 of the same pixel: one 16-byte store
+                    float v0 = R[0][0] + bv[0], v1 = R[0][1] + bv[1];
+                    v0 = v0 >= 0.0f ? v0 : v0 * a.slope;
+                    v1 = v1 >= 0.0f ? v1 : v1 * a.slope;
+                    const float p0 = __shfl_xor(v0, 32), p1 = __shfl_xor(v1, 32);
+                    if (r >= r0 && r < r1 && st_col && half == 0) {
+                        uint4 o;
+                        o.x = pack_bf16(v0, p0);
+                        o.y = pack_bf16(v1, p1);
+                        o.z = 0u; o.w = 0u;
+                        *reinterpret_cast<uint4 *>(a.yb + (((size_t)n * a.H + r) * a.W + gx) * 8) = o;
+                    }
+                } else if (r >= r0 && r < r1 && st_col) {
 #pragma unroll
                     for (int cp = 0; cp < 2; ++cp) {
                         const int co = 2 * cp + half;
@@ -906,8 +925,31 @@ bool dgrad_small_eligible(const m355_conv_desc *d, int Cy)
 }
 
 int dgrad_small_launch(const m355_conv_desc *d, const void *dy, int Cy, const void *w_dgrad, int Kp, size_t wbytes, void *dx,
-                       hipStream_t st)
+                       hipStream_t st, int lead)
 {
+    if (lead >= 1 && lead <= 4 && Cy == 64 && d->kh == 5 && !getenv("M355_NO_HEAD5")) {
+        // only the first `lead` input channels' gradient is wanted: the scatter form (k_head5<MODE, 1>), rows 0 .. lead-1 of the
+        // dgrad view (= a forward view of a 64 -> Cin conv with the taps already flipped)
+        Head5Args h = {};
+        h.x = (const unsigned short *)dy;
+        h.w = (const unsigned short *)w_dgrad;
+        h.yb = (unsigned short *)dx;
+        h.N = d->N; h.H = d->H; h.W = d->W; h.Cout = lead; h.Kp = Kp;
+        h.nsx = (d->W + 27) / 28;
+        long nsy = 2048 / ((long)d->N * h.nsx);
+        if (nsy < 1) nsy = 1;
+        if (nsy > (d->H + 7) / 8) nsy = (d->H + 7) / 8;
+        h.rs = (int)((d->H + nsy - 1) / nsy);
+        h.nsy = (d->H + h.rs - 1) / h.rs;
+        h.slope = 1.0f;
+        h.xbytes = (unsigned)((size_t)d->N * d->H * d->W * Cy * 2);
+        h.wbytes = (unsigned)wbytes;
+        const dim3 grid((unsigned)((long)d->N * h.nsx * h.nsy));
+        if (d->pad_w_mode == 0) hipLaunchKernelGGL((k_head5<0, 1>), grid, dim3(64), 0, st, h);
+        else hipLaunchKernelGGL((k_head5<2, 1>), grid, dim3(64), 0, st, h);
+        note_kernel("k_head5");
+        return check_launch("conv2d_dgrad (8 input channels, leading channels only)");
+    }
     m355_conv_desc t = *d;
     t.Cin = Cy;   // the "input" of this conv is dy
     t.Cout = 8;

@@ -64,6 +64,9 @@ class Conv2d(nn.Conv2d):
         # csrc/conv_mfma.hip `up3`; the owning SpectralNormGroup prepares them with the whole network's.)  Learnt from the calls:
         # a group whose views were built for the other setting serves one forward through the per-call weight_prep and rebuilds.
         self.m355_ups = 0
+        # > 0: the input channels beyond the first m355_dx_lead are constants of the model (positional encodings): the backward
+        # produces the gradient of the leading channels only (csrc: m355_conv2d_dgrad_lead)
+        self.m355_dx_lead = 0
         self._sn_state = None
         self._sn_own = None
 
@@ -82,7 +85,7 @@ class Conv2d(nn.Conv2d):
         else:
             weight = self.weight
         return G.conv2d(x, weight, self.bias, stride, pad_h, pad_w, mode, upsample, slope, out_f32_nchw, sn, in_slope,
-                        premasked, want_stats)
+                        premasked, want_stats, self.m355_dx_lead)
 
 
 def spectral_norm(conv):
@@ -508,6 +511,7 @@ class TextureDiscriminator(_DiscBase):
         self.circular = circular
         self.positional_embeddings = positional_embeddings
         mode = C.PAD_CIRCULAR if circular else C.PAD_ZERO
+        nc_image = nc
         if positional_embeddings:
             self.pos_emb = None
             nc += 4
@@ -517,6 +521,10 @@ class TextureDiscriminator(_DiscBase):
             self.conv1 = spectral_norm(Conv2d(nc, 64, 4, stride=2, pad_h=1, pad_w=1, pad_w_mode=mode))
         else:
             self.conv1 = spectral_norm(Conv2d(nc, 64, 5, pad_h=2, pad_w=2, pad_w_mode=mode))
+        if positional_embeddings and nc_image <= 4:
+            # conv1's input = the image channels + four batch-constant positional planes (gan.py:204-207): nothing reads the planes'
+            # gradient, the backward only produces the image channels' (the G step's dL/d texture)
+            self.conv1.m355_dx_lead = nc_image
         self.conv2 = spectral_norm(Conv2d(64, 128, 4, stride=2, pad_h=1, pad_w=1, pad_w_mode=mode, bias=bias))
         if n2 is not None:
             self.bn2 = n2

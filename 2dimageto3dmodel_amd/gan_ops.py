@@ -485,7 +485,7 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad_h, pad_w, mode, ups, slope, out_f32_nchw, sn, in_slope=1.0,
-                premasked=False, in_bits=None, want_stats=False):
+                premasked=False, in_bits=None, want_stats=False, dx_lead=0):
         n, h, w, cx = x.shape
         cout, cw, kh, kw = weight.shape
         if cx % 8 or cx < cw:
@@ -512,7 +512,7 @@ class Conv2dFn(torch.autograd.Function):
         else:
             y = C.conv_fwd(d, x.detach(), wf, None if bias is None else bias.detach(), out_f32_nchw, slope, cin_real=cw)
         ctx.d, ctx.cw, ctx.slope, ctx.f32, ctx.sn = d, cw, slope, out_f32_nchw, sn
-        ctx.in_slope, ctx.premasked = in_slope, premasked
+        ctx.in_slope, ctx.premasked, ctx.dx_lead = in_slope, premasked, int(dx_lead)
         # `bits` / `part` never get a gradient: without this autograd hands backward a zero-FILLED tensor of their shape for each
         # (17 fills per GAN cycle, the bit masks of D.conv2 at batch 128 alone 67 MB)
         ctx.set_materialize_grads(False)
@@ -526,7 +526,7 @@ class Conv2dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dbits=None, _dpart=None):
         if dy is None:   # (set_materialize_grads(False): nobody used y)
-            return (None,) * 15
+            return (None,) * 16
         x, wd, y, w_orig, in_bits = ctx.saved_tensors
         d = ctx.d
         if ctx.sn is not None:
@@ -577,7 +577,7 @@ class Conv2dFn(torch.autograd.Function):
             elif ctx.in_slope != 1.0:   # fold the LeakyReLU backward of the layer that produced x into the epilogue
                 dx = C.conv_dgrad(d, g, wd, cin_real=ctx.cw, mask_x=x, mask_slope=ctx.in_slope)
             else:
-                dx = C.conv_dgrad(d, g, wd, cin_real=ctx.cw)
+                dx = C.conv_dgrad(d, g, wd, cin_real=ctx.cw, lead=ctx.dx_lead)
         dw = None
         if ctx.needs_input_grad[1]:
             fused_db = db if (ctx.premasked and db is not None and C.wgrad_fuses_dbias(d)) else None
@@ -588,11 +588,11 @@ class Conv2dFn(torch.autograd.Function):
                 dw = C.wgrad_finish(d, graw, ctx.cw, param=ctx.wparam)
             else:
                 dw = C.wgrad_finish(d, graw, ctx.cw, w_orig, sn.u, sn.v, sn.sigma, param=ctx.wparam)
-        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias, stride, pad_h, pad_w, mode, upsample=0, slope=1.0, out_f32_nchw=False, sn=None, in_slope=1.0,
-           premasked=False, want_stats=False):
+           premasked=False, want_stats=False, dx_lead=0):
     """in_slope != 1: x is the output of a fused conv+LeakyReLU(in_slope) whose ONLY consumer is this conv: the
     returned grad_x is pre-multiplied by that activation's derivative, and that producer must be called with
     premasked=True (it then skips its own activation backward).  Both flags are set by the discriminators."""
@@ -600,7 +600,7 @@ def conv2d(x, weight, bias, stride, pad_h, pad_w, mode, upsample=0, slope=1.0, o
     norm's [rows,2,C] partial sums produced by the conv launch (else None); the caller passes it to BatchNorm2d.forward(part=)"""
     y, bits, part = Conv2dFn.apply(x, weight, bias, stride, pad_h, pad_w, mode, int(upsample), float(slope), bool(out_f32_nchw),
                                    sn, float(in_slope), bool(premasked),
-                                   getattr(x, "_m355_bits", None) if in_slope != 1.0 else None, bool(want_stats))
+                                   getattr(x, "_m355_bits", None) if in_slope != 1.0 else None, bool(want_stats), int(dx_lead))
     if bits is not None:
         y._m355_bits = bits  # picked up by the consumer conv (same Python tensor object, see the discriminators' _act)
     if want_stats:

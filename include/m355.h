@@ -232,6 +232,11 @@ size_t m355_conv2d_dgrad_ws_bytes(const m355_conv_desc *d);
 int m355_conv2d_dgrad(const m355_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, void *ws,
                       const void *mask_x, float mask_slope, void *stream);
 
+/*      the same for a layer whose input channels beyond the first `lead` are constants of the model (TextureDiscriminator.conv1,
+ *      models/gan.py:204-213: 4 image channels + the 4 positional planes of gan.py:9-20): only dx[..., 0 .. lead-1] is specified (the
+ *      other channels hold zeros or the true gradient, whichever the dispatched kernel produces); no activation mask */
+int m355_conv2d_dgrad_lead(const m355_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, void *ws, int lead, void *stream);
+
 /* Bit-packed activation masks between a conv+LeakyReLU forward and its (only) consumer's dgrad: 1 bit per element
  * instead of re-reading the 2-byte activation (D.conv2's dgrad read 1 GB just to test signs).  Layout
  * [N,H,W,C/64,2] uint32 in the register order of the epilogues (opaque: produce with _fwd_bits, consume with

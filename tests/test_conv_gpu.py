@@ -137,6 +137,37 @@ def test_conv_fwd_and_dgrad(pkg, case):
         assert (dxm.permute(0, 3, 1, 2) - want).abs().max().item() / want.abs().max().item() < 1.2e-2
 
 
+@pytest.mark.parametrize("case", [(3, 24, 64, 8, 64, 5, 1, 2, 2, 2, 0, 4),     # D.conv1: circular, several strips of 28 columns
+                                  (2, 40, 40, 8, 64, 5, 1, 2, 2, 0, 0, 3),     # zero W pad, ragged strips and row segments, 3 channels
+                                  (2, 16, 32, 8, 64, 5, 1, 2, 2, 2, 0, 1),     # one leading channel
+                                  (2, 16, 16, 8, 128, 5, 1, 2, 2, 2, 0, 4)])   # 128 output channels: not the scatter form's shape
+def test_dgrad_of_the_leading_input_channels(pkg, case):
+    """m355_conv2d_dgrad_lead (round 5): the input gradient of a layer whose trailing input channels are model constants
+    (TextureDiscriminator.conv1: image channels + positional planes, models/gan.py:204-213) -- the first `lead` channels of dx equal
+    the full dgrad's, whichever kernel runs (the scatter-form head kernel for 64 dy channels, else the general path)"""
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    N, H, W, Cin, Cout, k, stride, ph, pw, mode, ups, lead = case
+    g = torch.Generator().manual_seed(77)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).bfloat16().float()
+    xr = torch.zeros(N, Cin, H, W, requires_grad=True)
+    y_ref = ref_conv(xr, w, None, stride, ph, pw, mode, ups)
+    dy = torch.randn(y_ref.shape, generator=g).bfloat16().float()
+    y_ref.backward(dy)
+    d = conv.make_desc(N, H, W, Cin, Cout, k, k, stride, ph, pw, mode, ups)
+    _, wd = conv.weight_prep(d, w.to(DEV))
+    dyd = dy.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    for rep in range(2):
+        dx = conv.conv_dgrad(d, dyd, wd, lead=lead)
+        assert tuple(dx.shape) == (N, H, W, Cin)
+        got = dx.float().cpu().permute(0, 3, 1, 2)[:, :lead]
+        want = xr.grad[:, :lead]
+        assert (got - want).abs().max().item() / want.abs().max().item() < 1.2e-2
+    if Cout == 64:
+        assert conv.lib().m355_last_kernel().decode() == "k_head5"
+    full = conv.conv_dgrad(d, dyd, wd).float().cpu().permute(0, 3, 1, 2)
+    assert (full - xr.grad).abs().max().item() / xr.grad.abs().max().item() < 1.2e-2
+
+
 @pytest.mark.parametrize("tile", ["64x64", "128x128", "256x128", "256x256"])
 @pytest.mark.parametrize("case", [(3, 20, 12, 128, 256, 3, 1, 1, 1, 1, 1), (2, 32, 32, 128, 256, 4, 2, 1, 1, 2, 0),
                                   (2, 16, 16, 64, 128, 4, 2, 1, 1, 2, 0), (3, 12, 6, 96, 96, 3, 1, 1, 1, 0, 0)])
