@@ -82,6 +82,9 @@ SIGNATURES = {
     "m355_cproj_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "m355_cproj_bwd_ws_floats": (c_size_t, [c_int, c_int, c_int]),
     "m355_cproj_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
+    "m355_cproj_bwd_conv5_ok": (c_int, [c_int, c_int, c_int]),
+    "m355_cproj_bwd_conv5_ws_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "m355_cproj_bwd_conv5": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     "m355_conv2d_maskbits_ok": (c_int, [_P, c_int]),
     "m355_conv2d_dgrad_mask_ok": (c_int, [_P]),
     "m355_conv2d_fwd_bits": (c_int, [_P, _P, _P, _P, _P, c_float, _P, _P]),

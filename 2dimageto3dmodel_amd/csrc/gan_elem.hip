@@ -448,6 +448,115 @@ __global__ __launch_bounds__(256) void k_cproj_bwd(const act_t *__restrict__ fea
     }
 }
 
+// ---- the discriminators' tail in ONE backward pass (round 5).  feat = LeakyReLU(conv4(.)) has two consumers, the 5x5 one-channel
+// logit conv and the projection term (gan.py:110-116, 221-228); their input gradients were three passes over the 134 MB tensor (at
+// batch 128): the projection's dfeat (this file), the logit conv's masked dgrad (k_conv_c8 at 48 "TF": one output channel), and
+// autograd's bf16 add of the two.  Here:   dfeat[n,p,c] = mask(feat) * ( g[n,p] * emb[n,c] + sum_{a,b} dy[n, p + (a-2, b-2)] * w[c][a][b] )
+// with w = the logit conv's dgrad weights (taps already flipped, W / sigma): per element 1 + 25 multiply-adds on the VECTOR unit --
+// 3.4 GFLOP per launch, under the 268 MB the pass has to move anyway.  A thread owns one 8-channel vector and FOUR consecutive
+// pixels of a row: the 5 x 8 weights of a tap row sit in registers for the four pixels (LDS reads per pixel / 4), dy comes from the
+// sample's logit-gradient image in LDS (broadcast reads).  demb as in k_cproj_bwd.  W pad: zero or circular (wmode 0 / 2), H zero.
+// the logit conv's dgrad weights as [25 taps][C] in the activation type (bf16 / EXACT: fp32): gathered ONCE per launch from the dgrad view
+// (a workgroup of the main kernel copies the 25 C values coalesced; gathering them itself -- 2-byte reads 512 bytes apart -- cost
+// more than its arithmetic)
+__global__ __launch_bounds__(256) void k_conv5_wt(const void *__restrict__ wd, int Kp, int C, act_t *__restrict__ wt)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 25 * C) return;
+    const int tap = i / C, c = i - tap * C;
+#ifdef M355_EXACT
+    wt[i] = reinterpret_cast<const float *>(wd)[(size_t)(24 - tap) * C + c];   // fp32 conv weight [1][5][5][C] (W / sigma), unflipped
+#else
+    wt[i] = reinterpret_cast<const short *>(wd)[(size_t)c * Kp + tap * 8];     // bf16 dgrad view [row c][Kp], K = (a, b, co8), taps flipped
+#endif
+}
+
+__global__ __launch_bounds__(256) void k_cproj_bwd_conv5(const act_t *__restrict__ feat, const float *__restrict__ emb,
+                                                         const float *__restrict__ g, const float *__restrict__ dy5,
+                                                         const act_t *__restrict__ wt, act_t *__restrict__ dfeat,
+                                                         float *__restrict__ part, int H, int W, int C, int gpb, float mask_slope,
+                                                         int wmode)
+{
+    extern __shared__ float smem[];
+    const int HW = H * W;
+    float *dyl = smem;                                            // [H][W]
+    act_t *wl = reinterpret_cast<act_t *>(smem + HW);             // [25][C]
+    __shared__ float red[256 * 8];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int vecs = C >> 3, lanes = 256 / vecs, v = tid % vecs, pl = tid / vecs;
+    for (int i = tid; i < (25 * C) >> 3; i += 256)
+        *reinterpret_cast<bf16x8e *>(wl + i * 8) = *reinterpret_cast<const bf16x8e *>(wt + i * 8);
+    for (int i = tid; i < HW; i += 256) dyl[i] = dy5[(size_t)n * HW + i];
+    float ev[8];
+    acc_t acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ev[j] = emb[(size_t)n * C + v * 8 + j];
+        acc[j] = 0;
+    }
+    __syncthreads();
+    const int gpr = W >> 2, ngroups = H * gpr;                 // groups of four pixels along a row
+    const int g0 = blockIdx.x * gpb, g1 = min(ngroups, g0 + gpb);
+    if (pl < lanes)
+        for (int gi = g0 + pl; gi < g1; gi += lanes) {
+            const int y = gi / gpr, x0 = (gi - y * gpr) << 2;
+            float o[4][8];
+            bf16x8e xv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p = y * W + x0 + q;
+                const float gp = g[(size_t)n * HW + p];
+                xv[q] = *reinterpret_cast<const bf16x8e *>(feat + ((size_t)n * HW + p) * C + v * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    o[q][j] = gp * ev[j];
+                    acc[j] += gp * bf2f_e(xv[q][j]);
+                }
+            }
+            int xi[8];       // columns x0 - 2 .. x0 + 5 after the W pad rule (-1: zero padding), once per group
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                int xx = x0 - 2 + t;
+                if (wmode == 2) xx = xx < 0 ? xx + W : (xx >= W ? xx - W : xx);
+                xi[t] = (unsigned)xx < (unsigned)W ? xx : -1;
+            }
+#pragma unroll
+            for (int a = 0; a < 5; ++a) {
+                const int yy = y + a - 2;
+                if ((unsigned)yy >= (unsigned)H) continue;
+                float dv[8];   // dy[yy][x0 - 2 .. x0 + 5]
+#pragma unroll
+                for (int t = 0; t < 8; ++t) dv[t] = xi[t] >= 0 ? dyl[yy * W + xi[t]] : 0.0f;
+#pragma unroll
+                for (int b = 0; b < 5; ++b) {
+                    const bf16x8e w8 = *reinterpret_cast<const bf16x8e *>(wl + (a * 5 + b) * C + v * 8);
+                    float wv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) wv[j] = bf2f_e(w8[j]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[q][j] = fmaf(dv[q + b], wv[j], o[q][j]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[q][j] *= bf2f_e(xv[q][j]) > 0.0f ? 1.0f : mask_slope;
+                *reinterpret_cast<bf16x8e *>(dfeat + ((size_t)n * HW + y * W + x0 + q) * C + v * 8) = pack8_e(o[q]);
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = (float)acc[j];
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int vv = c >> 3, jj = c & 7;
+        acc_t sum = 0;
+        for (int l = 0; l < lanes; ++l) sum += red[(l * vecs + vv) * 8 + jj];
+        part[((size_t)n * gridDim.x + blockIdx.x) * C + c] = (float)sum;
+    }
+}
+
 }  // namespace m355
 
 using namespace m355;
@@ -619,4 +728,51 @@ extern "C" int m355_cproj_bwd(const void *feat, const float *emb, const float *g
                        HW, C, ppb, mask_slope);
     if (nblk > 1) hipLaunchKernelGGL(k_sum_partials, dim3((C + 31) / 32, N), dim3(256), 0, st, (const float *)ws, demb, nblk, C);
     return check_launch("cproj_bwd");
+}
+
+/* The tail of a discriminator in one backward pass (models/gan.py:110-116, 221-228: feat -> 5x5 one-channel logit conv + projection term):
+ * dfeat = mask(feat) * ( g_proj[n,p] * emb[n,c] + (5x5 "same" conv of the logit gradient dy5 [N,H,W] with the logit conv's dgrad weights) ),
+ * demb as m355_cproj_bwd.  w_dgrad = that conv's dgrad view (m355_conv2d_weight_prep; Kp = its row length) -- in the EXACT build its fp32
+ * weight array.  pad_w_mode 0 (zero) or 2 (circular); H zero padded.  m355_cproj_bwd_conv5_ok: C % 8 == 0, C <= 512 with C / 8 dividing
+ * 256, W % 4 == 0, H W floats + 25 C weights of LDS within the budget.  ws: m355_cproj_bwd_conv5_ws_floats(N, H, W, C) floats (0: none needed). */
+static int conv5_gpb(int N, int H, int W)   // groups of four pixels per workgroup: ~2048 workgroups per launch, at least 16 groups each
+{
+    const int ng = H * (W / 4);
+    int nblk = N > 0 ? 2048 / N : 1;   // (38 KB of LDS per workgroup: four resident per CU)
+    if (nblk < 1) nblk = 1;
+    int gpb = (ng + nblk - 1) / nblk;
+    if (gpb < 16) gpb = 16;
+    return gpb;
+}
+static size_t conv5_lds_bytes(int H, int W, int C) { return sizeof(float) * (size_t)H * W + sizeof(act_t) * (size_t)25 * C; }
+extern "C" int m355_cproj_bwd_conv5_ok(int H, int W, int C)
+{
+    // (LDS: 25 x C weights + the H x W logit-gradient image + the 8 KB reduction buffer within 64 KB)
+    return (C >= 8 && C % 8 == 0 && C <= 2048 && 256 % (C / 8) == 0 && W >= 4 && W % 4 == 0 && H >= 1 && (H * W) % 2 == 0 &&
+            conv5_lds_bytes(H, W, C) + 8192 <= 65536) ? 1 : 0;
+}
+extern "C" size_t m355_cproj_bwd_conv5_ws_floats(int N, int H, int W, int C)
+{
+    if (!m355_cproj_bwd_conv5_ok(H, W, C) || N <= 0) return 0;
+    const int ng = H * (W / 4), gpb = conv5_gpb(N, H, W), nblk = (ng + gpb - 1) / gpb;
+    // the [25][C] weight table (in activation elements, rounded up to whole floats) + the per-workgroup shares of demb
+    return (size_t)(25 * C * sizeof(act_t) + 3) / 4 + (nblk > 1 ? (size_t)N * nblk * C : 0);
+}
+extern "C" int m355_cproj_bwd_conv5(const void *feat, const float *emb, const float *g /*[N,HW]*/, const float *dy5 /*[N,H,W]*/,
+                                    const void *w_dgrad, int Kp, void *dfeat, float *demb /*[N,C]*/, float *ws, int N, int H, int W,
+                                    int C, float mask_slope, int pad_w_mode, void *stream)
+{
+    M355_REQUIRE(feat && emb && g && dy5 && w_dgrad && dfeat && demb && N > 0 && N <= 65535, "cproj_bwd_conv5: bad argument");
+    M355_REQUIRE(m355_cproj_bwd_conv5_ok(H, W, C) && (pad_w_mode == 0 || pad_w_mode == 2) && Kp >= 200,
+                 "cproj_bwd_conv5: shape not eligible (m355_cproj_bwd_conv5_ok)");
+    hipStream_t st = (hipStream_t)stream;
+    const int ng = H * (W / 4), gpb = conv5_gpb(N, H, W), nblk = (ng + gpb - 1) / gpb;
+    M355_REQUIRE(ws, "cproj_bwd_conv5: workspace required (m355_cproj_bwd_conv5_ws_floats)");
+    act_t *wt = reinterpret_cast<act_t *>(ws);
+    float *part = ws + (25 * C * sizeof(act_t) + 3) / 4;
+    hipLaunchKernelGGL(k_conv5_wt, dim3((25 * C + 255) / 256), dim3(256), 0, st, w_dgrad, Kp, C, wt);
+    hipLaunchKernelGGL(k_cproj_bwd_conv5, dim3(nblk, N), dim3(256), conv5_lds_bytes(H, W, C), st, (const act_t *)feat, emb, g, dy5,
+                       (const act_t *)wt, (act_t *)dfeat, nblk == 1 ? demb : part, H, W, C, gpb, mask_slope, pad_w_mode);
+    if (nblk > 1) hipLaunchKernelGGL(k_sum_partials, dim3((C + 31) / 32, N), dim3(256), 0, st, (const float *)part, demb, nblk, C);
+    return check_launch("cproj_bwd_conv5");
 }

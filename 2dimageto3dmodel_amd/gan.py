@@ -70,7 +70,7 @@ class Conv2d(nn.Conv2d):
         self._sn_state = None
         self._sn_own = None
 
-    def forward(self, x, upsample=0, slope=1.0, out_f32_nchw=False, in_slope=1.0, premasked=False, want_stats=False):
+    def forward(self, x, upsample=0, slope=1.0, out_f32_nchw=False, in_slope=1.0, premasked=False, want_stats=False, dx_pair=None):
         stride, pad_h, pad_w, mode = self.m355
         self.m355_ups = int(upsample)
         sn, weight = None, None
@@ -85,7 +85,7 @@ class Conv2d(nn.Conv2d):
         else:
             weight = self.weight
         return G.conv2d(x, weight, self.bias, stride, pad_h, pad_w, mode, upsample, slope, out_f32_nchw, sn, in_slope,
-                        premasked, want_stats, self.m355_dx_lead)
+                        premasked, want_stats, self.m355_dx_lead, dx_pair)
 
 
 def spectral_norm(conv):
@@ -413,17 +413,32 @@ class _DiscBase(nn.Module):
                                                      and 256 % (cf // 8) == 0)
             pm = bool(proj_ok and C.dgrad_mask_ok(d))
         h = self._act(conv_feat, norm_feat, h, in_act, pm)
+        # premasked + class projection: ONE kernel produces h's gradient from both consumers (gan_ops.TailPair).  The projection term
+        # is evaluated BEFORE the logit conv -- autograd runs the younger node's backward first, and the pair needs the conv's first
+        pair = None
+        if pm and a.conditional_class:
+            so, pho, pwo, mo = conv_out.m355
+            if G.tail_pair_ok(h, (conv_out.kernel_size[0], conv_out.kernel_size[1], so, pho, pwo), mo, conv_out.out_channels):
+                pair = G.TailPair()
+        if pair is not None:
+            p = self._projection_term(h, c, LRELU, pair)
+            y = conv_out(h, out_f32_nchw=True, in_slope=LRELU, dx_pair=pair)
+            return y + p.unsqueeze(1)
         y = conv_out(h, out_f32_nchw=True, in_slope=LRELU if pm else 1.0)
         return self._project(y, h, c, caption, LRELU if pm else 1.0)
+
+    def _projection_term(self, feat, c, in_slope=1.0, pair=None):
+        a = self.args
+        c_emb = self.projector(c[:, 0])
+        if a.conditional_color:
+            c_emb = c_emb + self.projector_col1(c[:, 1])
+        return G.class_projection(feat, c_emb, in_slope, pair)
 
     def _project(self, y, feat, c, caption, in_slope=1.0):
         """projection discriminator (gan.py:104-116, 216-228): y += sum_c feat * emb"""
         a = self.args
         if a.conditional_class:
-            c_emb = self.projector(c[:, 0])
-            if a.conditional_color:
-                c_emb = c_emb + self.projector_col1(c[:, 1])
-            y = y + G.class_projection(feat, c_emb, in_slope).unsqueeze(1)
+            y = y + self._projection_term(feat, c, in_slope).unsqueeze(1)
         elif a.conditional_text:
             att_out, _ = self.att(G.to_nchw_f32(feat), *caption)
             y = y + torch.sum(G.to_nchw_f32(feat) * att_out, dim=1, keepdim=True)

@@ -485,7 +485,7 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad_h, pad_w, mode, ups, slope, out_f32_nchw, sn, in_slope=1.0,
-                premasked=False, in_bits=None, want_stats=False, dx_lead=0):
+                premasked=False, in_bits=None, want_stats=False, dx_lead=0, dx_pair=None):
         n, h, w, cx = x.shape
         cout, cw, kh, kw = weight.shape
         if cx % 8 or cx < cw:
@@ -512,7 +512,7 @@ class Conv2dFn(torch.autograd.Function):
         else:
             y = C.conv_fwd(d, x.detach(), wf, None if bias is None else bias.detach(), out_f32_nchw, slope, cin_real=cw)
         ctx.d, ctx.cw, ctx.slope, ctx.f32, ctx.sn = d, cw, slope, out_f32_nchw, sn
-        ctx.in_slope, ctx.premasked, ctx.dx_lead = in_slope, premasked, int(dx_lead)
+        ctx.in_slope, ctx.premasked, ctx.dx_lead, ctx.dx_pair = in_slope, premasked, int(dx_lead), dx_pair
         # `bits` / `part` never get a gradient: without this autograd hands backward a zero-FILLED tensor of their shape for each
         # (17 fills per GAN cycle, the bit masks of D.conv2 at batch 128 alone 67 MB)
         ctx.set_materialize_grads(False)
@@ -526,7 +526,7 @@ class Conv2dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dbits=None, _dpart=None):
         if dy is None:   # (set_materialize_grads(False): nobody used y)
-            return (None,) * 16
+            return (None,) * 17
         x, wd, y, w_orig, in_bits = ctx.saved_tensors
         d = ctx.d
         if ctx.sn is not None:
@@ -535,6 +535,7 @@ class Conv2dFn(torch.autograd.Function):
             ctx.sn.check()
         c32 = C.dy_channels(d.Cout)
         db_zeroed = False
+        fused_tail = False
         if ctx.premasked:
             # the consumer's dgrad already applied this layer's LeakyReLU derivative (mask_x below): dy IS g
             assert not ctx.f32 and c32 == d.Cout
@@ -561,6 +562,14 @@ class Conv2dFn(torch.autograd.Function):
             db = dyc.sum((0, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[2] else None
             g = torch.empty((d.N, dyc.shape[2], dyc.shape[3], 8), dtype=_act(), device=dy.device)
             launch("pack_nhwc8", ptr(dyc), ptr(None), ptr(g), d.N, d.Cout, 0, dyc.shape[2], dyc.shape[3], stream())
+            pair = ctx.dx_pair
+            if (pair is not None and not pair.proj_done and ctx.needs_input_grad[0] and ctx.in_slope != 1.0 and in_bits is None
+                    and d.Cout == 1):
+                # the tail of a discriminator (TailPair): the projection term's backward, which runs next, produces the whole
+                # gradient of x in one pass from this conv's logit gradient and dgrad weights -- no dgrad launch here
+                kp = (d.kh * d.kw * c32 + 63) // 64 * 64      # row length of the stride-1 dgrad view (m355_conv2d_weight_elems)
+                pair.request = (dyc.view(d.N, dyc.shape[2], dyc.shape[3]), wd, kp, d.pad_w_mode, ctx.in_slope)
+                fused_tail = True
         else:
             g = dy.permute(0, 2, 3, 1) if ctx.f32 else dy       # -> NHWC view
             if ctx.slope != 1.0:
@@ -571,7 +580,7 @@ class Conv2dFn(torch.autograd.Function):
                 g = F.pad(g, (0, c32 - d.Cout))
             g = g.contiguous().to(_act())
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and not fused_tail:
             if ctx.in_slope != 1.0 and in_bits is not None:
                 dx = C.conv_dgrad(d, g, wd, cin_real=ctx.cw, mask_bits=in_bits, mask_slope=ctx.in_slope)
             elif ctx.in_slope != 1.0:   # fold the LeakyReLU backward of the layer that produced x into the epilogue
@@ -588,11 +597,11 @@ class Conv2dFn(torch.autograd.Function):
                 dw = C.wgrad_finish(d, graw, ctx.cw, param=ctx.wparam)
             else:
                 dw = C.wgrad_finish(d, graw, ctx.cw, w_orig, sn.u, sn.v, sn.sigma, param=ctx.wparam)
-        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias, stride, pad_h, pad_w, mode, upsample=0, slope=1.0, out_f32_nchw=False, sn=None, in_slope=1.0,
-           premasked=False, want_stats=False, dx_lead=0):
+           premasked=False, want_stats=False, dx_lead=0, dx_pair=None):
     """in_slope != 1: x is the output of a fused conv+LeakyReLU(in_slope) whose ONLY consumer is this conv: the
     returned grad_x is pre-multiplied by that activation's derivative, and that producer must be called with
     premasked=True (it then skips its own activation backward).  Both flags are set by the discriminators."""
@@ -600,7 +609,8 @@ def conv2d(x, weight, bias, stride, pad_h, pad_w, mode, upsample=0, slope=1.0, o
     norm's [rows,2,C] partial sums produced by the conv launch (else None); the caller passes it to BatchNorm2d.forward(part=)"""
     y, bits, part = Conv2dFn.apply(x, weight, bias, stride, pad_h, pad_w, mode, int(upsample), float(slope), bool(out_f32_nchw),
                                    sn, float(in_slope), bool(premasked),
-                                   getattr(x, "_m355_bits", None) if in_slope != 1.0 else None, bool(want_stats), int(dx_lead))
+                                   getattr(x, "_m355_bits", None) if in_slope != 1.0 else None, bool(want_stats), int(dx_lead),
+                                   dx_pair)
     if bits is not None:
         y._m355_bits = bits  # picked up by the consumer conv (same Python tensor object, see the discriminators' _act)
     if want_stats:
@@ -907,18 +917,39 @@ def _fused_ok(x):
     return x.is_cuda and x.dtype == _act() and c % 8 == 0 and c <= 2048 and 256 % (c // 8) == 0
 
 
+class TailPair:
+    """Links the two consumers of a discriminator's last feature map -- the one-channel 5x5 logit conv and the projection term --
+    so that ONE kernel produces the feature map's whole gradient (csrc/gan_elem.hip k_cproj_bwd_conv5) instead of the conv's dgrad,
+    the projection's dfeat and autograd's addition of the two.  Protocol: the projection term is created FIRST in the forward, the conv
+    second; autograd runs the younger node first, so the conv's backward finds the pair empty, leaves its dgrad request here (logit
+    gradient, dgrad weights, descriptor) and returns no input gradient; the projection's backward then runs the fused kernel.  Should
+    the engine ever run them the other way round, the projection marks `proj_done`, and the conv's backward sees it and computes its own
+    dgrad: both orders are correct, only the first is fused."""
+    __slots__ = ("request", "proj_done")
+
+    def __init__(self):
+        self.request, self.proj_done = None, False
+
+
+def tail_pair_ok(feat, conv_desc_kw, mode, cout):
+    """can the fused tail backward take this feature map / logit conv?  (5x5, one output channel, zero or circular W pad)"""
+    n, h, w, c = feat.shape
+    return (feat.is_cuda and _fused_ok(feat) and conv_desc_kw == (5, 5, 1, 2, 2) and cout == 1 and mode in (C.PAD_ZERO, C.PAD_CIRCULAR)
+            and not os.environ.get("M355_NO_TAIL_FUSION") and bool(lib().m355_cproj_bwd_conv5_ok(h, w, c)))
+
+
 class ClassProjection(torch.autograd.Function):
     """projection discriminator term (gan.py:104-116, 216-228): feat [N,H,W,C] bf16, emb [N,C] fp32 -> [N,H,W] fp32
     = sum_c feat * emb, on the bf16 feature map (csrc/gan_elem.hip k_cproj_*)"""
 
     @staticmethod
-    def forward(ctx, feat, emb, in_slope=1.0):
+    def forward(ctx, feat, emb, in_slope=1.0, pair=None):
         feat, emb = feat.detach().contiguous(), emb.detach().float().contiguous()
         n, h, w, c = feat.shape
         out = torch.empty((n, h, w), dtype=torch.float32, device=feat.device)
         launch("cproj_fwd", ptr(feat), ptr(emb), ptr(out), n, h * w, c, stream())
         ctx.save_for_backward(feat, emb)
-        ctx.in_slope = float(in_slope)
+        ctx.in_slope, ctx.pair = float(in_slope), pair
         return out
 
     @staticmethod
@@ -927,24 +958,38 @@ class ClassProjection(torch.autograd.Function):
         n, h, w, c = feat.shape
         dfeat = torch.empty_like(feat)
         demb = torch.empty((n, c), dtype=torch.float32, device=feat.device)
+        g = g.contiguous().float()
+        pair = ctx.pair
+        if pair is not None and pair.request is not None:
+            # the logit conv's backward ran first and left its dgrad here: the whole gradient of feat in one pass
+            dy5, wd, kp, mode, slope = pair.request
+            pair.request = None
+            assert slope == ctx.in_slope and tuple(dy5.shape) == (n, h, w)
+            nws = lib().m355_cproj_bwd_conv5_ws_floats(n, h, w, c)
+            ws = torch.empty((nws,), dtype=torch.float32, device=feat.device) if nws else None
+            launch("cproj_bwd_conv5", ptr(feat), ptr(emb), ptr(g), ptr(dy5), ptr(wd), int(kp), ptr(dfeat), ptr(demb), ptr(ws), n, h, w, c,
+                   ctx.in_slope, int(mode), stream())
+            return dfeat, demb, None, None
+        if pair is not None:
+            pair.proj_done = True   # (the conv's backward has not run yet: it will compute its own dgrad)
         nws = lib().m355_cproj_bwd_ws_floats(n, h * w, c)
         ws = torch.empty((nws,), dtype=torch.float32, device=feat.device) if nws else None
-        launch("cproj_bwd", ptr(feat), ptr(emb), ptr(g.contiguous().float()), ptr(dfeat), ptr(demb), ptr(ws), n, h * w, c,
+        launch("cproj_bwd", ptr(feat), ptr(emb), ptr(g), ptr(dfeat), ptr(demb), ptr(ws), n, h * w, c,
                ctx.in_slope, stream())
-        return dfeat, demb, None
+        return dfeat, demb, None, None
 
 
 def class_projection_fused(feat, emb):
     return _fused_ok(feat) and emb.dtype == torch.float32
 
 
-def class_projection(feat, emb, in_slope=1.0):
+def class_projection(feat, emb, in_slope=1.0, pair=None):
     """sum_c feat[n,h,w,c] * emb[n,c] -> [N,H,W] fp32.  in_slope != 1 (only where class_projection_fused): feat is a fused
     conv + LeakyReLU(in_slope) output whose producer was called with premasked=True -- the returned grad_feat is multiplied by
     that activation's derivative (every consumer of feat must do the same)"""
     if class_projection_fused(feat, emb):
-        return ClassProjection.apply(feat, emb, float(in_slope))
-    assert in_slope == 1.0
+        return ClassProjection.apply(feat, emb, float(in_slope), pair)
+    assert in_slope == 1.0 and pair is None   # (a TailPair needs the fused kernels: gan._tail checks tail_pair_ok first)
     return torch.einsum("nhwc,nc->nhw", feat.float(), emb)
 
 

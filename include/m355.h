@@ -489,6 +489,15 @@ int m355_cproj_fwd(const void *feat, const float *emb, float *out /*[N,HW]*/, in
 size_t m355_cproj_bwd_ws_floats(int N, int HW, int C);   /* scratch of _bwd (per-workgroup shares of demb, added in order); 0: none */
 int m355_cproj_bwd(const void *feat, const float *emb, const float *g /*[N,HW]*/, void *dfeat, float *demb /*[N,C]*/,
                    float *ws, int N, int HW, int C, float mask_slope, void *stream);
+/*      the whole tail of a discriminator in one backward pass (round 5): feat has two consumers, the 5x5 one-channel logit conv and the
+ *      projection term; dfeat = mask(feat) * (g[n,p] * emb[n,c] + the logit conv's input gradient), i.e. m355_cproj_bwd + the masked
+ *      m355_conv2d_dgrad of that conv + the addition of the two, without the two extra passes over feat.  dy5 [N,H,W] fp32 = the logit
+ *      gradient, w_dgrad / Kp = the logit conv's dgrad view and its row length; pad_w_mode 0 or 2. */
+int m355_cproj_bwd_conv5_ok(int H, int W, int C);
+size_t m355_cproj_bwd_conv5_ws_floats(int N, int H, int W, int C);
+int m355_cproj_bwd_conv5(const void *feat, const float *emb, const float *g, const float *dy5, const void *w_dgrad, int Kp,
+                         void *dfeat, float *demb, float *ws, int N, int H, int W, int C, float mask_slope, int pad_w_mode,
+                         void *stream);
 
 /* ---- mesh-template deformation, face normals, flat (smoothness) loss -- code/main.py:697-699 ----
  * Replaces MeshTemplate.get_vertex_positions / deform / compute_normals (code/rendering/mesh_template.py:106-149) and

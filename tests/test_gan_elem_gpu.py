@@ -161,6 +161,76 @@ def test_class_projection(pkg, shape):
     assert (ed.grad.cpu() - er.grad).abs().max().item() < 1e-4 * er.grad.abs().max().item()
 
 
+@pytest.mark.parametrize("case", [(3, 8, 8, 256, 2), (2, 32, 32, 512, 2), (2, 16, 32, 512, 0), (5, 12, 8, 64, 2)])
+def test_discriminator_tail_backward_in_one_pass(pkg, case, monkeypatch):
+    """gan._tail (models/gan.py:110-116, 221-228: last feature map -> LeakyReLU -> one-channel 5x5 logit conv + projection term) with
+    the TailPair fusion -- ONE kernel for the feature map's gradient (k_cproj_bwd_conv5) -- against (a) the same modules with the fusion
+    switched off (conv dgrad + projection backward + autograd's add) and (b) fp32 torch autograd of the reference's formulas on the
+    same bf16-rounded operands: logits, the gradient of the tail's INPUT, of the logit conv's weight / bias, of the embedding"""
+    import torch.nn.functional as F
+    gan = importlib.import_module("2dimageto3dmodel_amd.gan")
+    G = importlib.import_module("2dimageto3dmodel_amd.gan_ops")
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    n, h, w, cf, mode = case
+    g = torch.Generator().manual_seed(cf + h)
+    x = torch.randn(n, h, w, 64, generator=g).bfloat16()
+    c = torch.randint(0, 7, (n, 1), generator=g)
+    dy = torch.randn(n, 1, h, w, generator=g)
+
+    class Tail(gan._DiscBase):
+        def __init__(self):
+            super().__init__()
+            import argparse
+            self.args = argparse.Namespace(conditional_class=True, conditional_color=False, conditional_text=False)
+            self.conv_feat = gan.Conv2d(64, cf, 3, pad_h=1, pad_w=1, pad_w_mode=mode)
+            self.conv_out = gan.Conv2d(cf, 1, 5, pad_h=2, pad_w=2, pad_w_mode=mode)
+            self.projector = torch.nn.Embedding(7, cf)
+
+        def forward(self, x, c):
+            return self._tail(self.conv_feat, None, self.conv_out, x, False, c, None)
+
+    torch.manual_seed(5)
+    tail = Tail().to(DEV)
+    runs = {}
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("M355_NO_TAIL_FUSION", "1")
+        for p in tail.parameters():
+            p.grad = None
+        xd = x.to(DEV).requires_grad_()
+        y = tail(xd, c.to(DEV))
+        y.backward(dy.to(DEV))
+        runs[fused] = (y.detach().cpu(), xd.grad.float().cpu(), {k: p.grad.detach().cpu().clone() for k, p in tail.named_parameters()},
+                       conv.lib().m355_last_kernel().decode())
+    # (b) the reference's formulas in fp32 on the same operands (bf16 activations between the layers, as the product keeps them)
+    wf, bf_, wo, bo, emb = (t.detach().cpu().float() for t in (tail.conv_feat.weight, tail.conv_feat.bias, tail.conv_out.weight,
+                                                                tail.conv_out.bias, tail.projector.weight))
+    wf, wo, emb = wf.requires_grad_(), wo.requires_grad_(), emb.requires_grad_()
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_()
+
+    def padw(t, p):
+        return torch.cat((t[..., -p:], t, t[..., :p]), dim=3) if mode == 2 else F.pad(t, (p, p, 0, 0))
+    ste = lambda t: t.detach().bfloat16().float() + (t - t.detach())      # the bf16 weight view, straight-through
+    hf = F.leaky_relu(F.conv2d(padw(xr, 1), ste(wf), bf_, padding=(1, 0)), 0.2)
+    hq = hf + (hf.bfloat16().float() - hf).detach()                     # the stored bf16 activation, straight-through
+    yr = F.conv2d(padw(hq, 2), ste(wo), bo, padding=(2, 0)) + \
+        torch.einsum("nchw,nc->nhw", hq, emb[c[:, 0]]).unsqueeze(1)
+    yr.backward(dy)
+    yf, dxf, gf, _ = runs[True]
+    yu, dxu, gu, _ = runs[False]
+    assert torch.equal(yf, yu)                                           # the forward is the same arithmetic in the same order
+    assert (yf - yr.detach()).abs().max().item() < 2e-2 * yr.abs().max().item()
+    want_dx = xr.grad.permute(0, 2, 3, 1)
+    for dx in (dxf, dxu):
+        assert (dx - want_dx).abs().max().item() < 2.5e-2 * want_dx.abs().max().item()
+    assert (dxf - dxu).abs().max().item() < 1.5e-2 * dxu.abs().max().item()   # fused vs unfused: one bf16 rounding of dfeat instead of three
+    for k in gf:
+        scale = gu[k].abs().max().item()
+        assert (gf[k] - gu[k]).abs().max().item() < 1.5e-2 * max(scale, 1e-6), k
+    assert (gf["conv_out.weight"] - wo.grad).abs().max().item() < 2e-2 * wo.grad.abs().max().item()
+    assert (gf["projector.weight"] - emb.grad).abs().max().item() < 2e-2 * emb.grad.abs().max().item()
+
+
 @pytest.mark.parametrize("shape", [(4, 32, 32, 128, 64, 0), (3, 16, 32, 128, 128, 1)])
 def test_fused_conv_statistics_match_a_pass_over_the_tensor(pkg, shape, monkeypatch):
     """with conv_fwd_stats the batch-norm statistics come from the conv's fp32 accumulators, without it from the

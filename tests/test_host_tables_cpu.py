@@ -112,6 +112,11 @@ def test_workspace_queries(pkg):
     assert L.m355_conv2d_fwd_stats_rows(ctypes.byref(up)) == 4 * 128     # class pairs: 128 workgroups x 2 row parities, a row block per class
     assert L.m355_conv2d_fwd_stats_rows(ctypes.byref(desc(64, 64, 32, 128, 128, 3, ups=1))) == 4 * 64
     assert L.m355_cproj_bwd_ws_floats(128, 256, 512) == 128 * 2 * 512 and L.m355_cproj_bwd_ws_floats(128, 64, 256) == 0
+    # the fused discriminator tail (round 5): eligible shapes, workspace = the [25][C] bf16 weight table + the shares of demb
+    assert L.m355_cproj_bwd_conv5_ok(32, 32, 512) == 1 and L.m355_cproj_bwd_conv5_ok(8, 8, 256) == 1
+    assert L.m355_cproj_bwd_conv5_ok(32, 30, 512) == 0 and L.m355_cproj_bwd_conv5_ok(128, 128, 512) == 0   # W % 4, LDS budget
+    assert L.m355_cproj_bwd_conv5_ws_floats(128, 32, 32, 512) == 25 * 512 // 2 + 128 * 16 * 512            # 2048 / 128 = 16 workgroups per sample
+    assert L.m355_cproj_bwd_conv5_ws_floats(128, 8, 8, 256) == 25 * 256 // 2                                # one workgroup per sample: demb direct
     assert L.m355_sn_scratch_words(18, 512, 4608) == 18 * (72 + 128)
 
 
