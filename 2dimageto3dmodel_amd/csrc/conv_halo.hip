@@ -1249,8 +1249,6 @@ static int halo_grid_per(const ConvArgs &a)
     return (tiles + (tiles + per - 1) / per - 1) / ((tiles + per - 1) / per);  // same tiles-per-workgroup, fewer idle ones
 }
 
-// rows of partial sums a forward with fused batch-norm statistics writes (0: this problem has none -- the kernel that runs it
-// must be k_conv_halo with the plain unguarded epilogue, one class, whole 64-channel groups)
 // class pairs (see k_conv_halo PAIR): 2x2 class convs with 64 output channels -- the classes of a stride-2 dgrad with 64 input
 // channels (D.conv2), of a sub-pixel upsample conv with 64 output channels (G.blk6.conv1)
 static bool halo_pair(const ConvArgs &a)
@@ -1269,6 +1267,9 @@ static int halo_pair_per(const ConvArgs &a)   // workgroups along the pixel-tile
     return (tiles + (tiles + pp - 1) / pp - 1) / ((tiles + pp - 1) / pp);
 }
 
+// rows of partial sums a forward with fused batch-norm statistics writes (0: this problem has none -- the kernel that runs it
+// must be k_conv_halo with the plain unguarded epilogue and whole 64-channel groups: a 3x3 forward, or the four 2x2 classes of a
+// sub-pixel upsample conv on the 8-wave variants)
 int conv_halo_stats_rows(const ConvArgs &a)
 {
     if (!conv_halo_eligible(a) || a.stride != 1 || a.fold2 || a.Cout != a.CoutP || a.slope != 1.0f || a.mask_x ||
@@ -1301,9 +1302,7 @@ int conv_halo_launch(const ConvArgs &a_in, unsigned xb, unsigned wb, hipStream_t
         if (sp) a.stats = reinterpret_cast<float *>(strtoull(sp, nullptr, 0));
     }
 #endif
-    const int tiles = a.N * (a.Ho / 8) * (a.Wo / 32);
     const int nN = a.CoutP == 64 ? 1 : a.CoutP / 128;
-    const char *wgs = getenv("M355_HALO_WGS");
     const int per = halo_grid_per(a);
 #define M355_HL(BN_, NW_, KS_, UPS_, MD_)                                                                                      \
     do {                                                                                                                       \
