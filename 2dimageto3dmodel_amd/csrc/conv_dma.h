@@ -104,26 +104,59 @@ struct WgradArgs {
     int KH, KW, stride, pad_h, pad_w, pad_w_mode;
     int chunk;  // pixels per z-slice (multiple of WK)
     // deterministic form (m355_conv2d_wgrad_det): the partial tiles are accumulated as 64-bit FIXED-POINT integers (integer adds
-    // are associative, so the order in which the workgroups' atomics land does not matter); fix = [flag | dw (Cout*K) | db (Cout)]
+    // are associative, so the order in which the workgroups' atomics land does not matter); fix = [flag | dw (Cout*K) | db (Cout)],
+    // every cell kFixCell integers (wg_accum below)
     long long *fix;
 };
 
 // ---- split-K accumulation of the weight-gradient kernels.  Default: fp32 atomics into the zeroed dw (the result depends on
-// the order the workgroups finish in: two runs differ in the last bits).  DET: v * 2^36 rounded to int64 and added with a 64-bit
-// integer atomic -- |v| < 2^27 keeps the sum inside int64 for any realistic number of contributions, the resolution 2^-36 =
-// 1.5e-11 is below the fp32 rounding of any gradient above 1e-4 and an absolute 1.5e-11 per contribution below it; a
-// non-finite or out-of-range partial raises the flag word, and the conversion pass then writes NaN (nothing is hidden).
-constexpr float kFixScale = 68719476736.0f;          // 2^36
-constexpr double kFixInv = 1.0 / 68719476736.0;
+// the order the workgroups finish in: two runs differ in the last bits).  DET: the partial is added to the cell's fixed-point
+// integers with 64-bit INTEGER atomics -- integer adds are associative, so the order in which the workgroups' atomics land does not
+// matter.  A cell is THREE integers on the grids 1, 2^-50 and 2^-100, and a partial v goes where its bits are:
+//   |v| < 1 (every gradient of a healthy run): mid += round(v 2^50); the remainder (exact in fp32) is non-zero only below
+//   2^-27 = 7.5e-9, and only then small += round(remainder 2^50) -- ONE atomic per contribution in the common case;
+//   |v| >= 1: big += round(v), mid += the (exact) remainder when there is one.
+// The triple holds the EXACT sum of every partial above 2^-77 (its last mantissa bit is on the finest grid; below that an absolute
+// 8e-31 per contribution) and is converted with one rounding: the result has no preferred gradient magnitude -- Adam is scale free,
+// a layer whose gradients are 1e-12 matters as much as any other (rounds 4-5a used ONE cell on the grid 2^-36: everything under
+// 1e-4 was quantised at an absolute 1.5e-11).  4096 contributions per cell stay inside int64 (2^50 2^12); a non-finite partial, or
+// one beyond 1e8, raises the flag word and the conversion pass then writes NaN (nothing is hidden).
+constexpr float kFixMid = 1125899906842624.0f;        // 2^50
+constexpr float kFixSmall = 1125899906842624.0f;      // 2^50 (of the remainder, in units of 2^-50: the finest grid is 2^-100)
+constexpr double kFixMidInv = 1.0 / 1125899906842624.0;
+constexpr double kFixSmallInv = 1.0 / 1125899906842624.0 / 1125899906842624.0;
+constexpr int kFixCell = 3;                           // 64-bit integers per cell: (big, mid, small)
+// the value of a cell (the caller's cast to float is the one rounding)
+__device__ __forceinline__ double fix_value(long long big, long long mid, long long small)
+{
+    return (double)big + (double)mid * kFixMidInv + (double)small * kFixSmallInv;
+}
+// workspace layout: [flag | mid of the ncell cells | big of the ncell cells | small of the ncell cells] -- PLANES, the common case's one
+// atomic per contribution lands on consecutive 8-byte words for consecutive cells (interleaved triples measured 8 % of the whole
+// deterministic step slower: three times the cache lines per wave)
+__device__ __forceinline__ double fix_value(const long long *__restrict__ fix, size_t i, size_t ncell)   // cell i behind the flag word
+{
+    return fix_value(fix[1 + ncell + i], fix[1 + i], fix[1 + 2 * ncell + i]);
+}
+// ncell: the cells of the launch's workspace (weights + the Cout bias cells behind them)
 template <bool DET>
-__device__ __forceinline__ void wg_accum(float *dst, long long *fix, size_t idx, float v)
+__device__ __forceinline__ void wg_accum(float *dst, long long *fix, size_t idx, float v, size_t ncell)
 {
     if constexpr (DET) {
         if (!(fabsf(v) < 1.0e8f)) {
             atomicOr(reinterpret_cast<unsigned long long *>(fix), 1ull);
             return;
         }
-        atomicAdd(reinterpret_cast<unsigned long long *>(fix) + 1 + idx, (unsigned long long)__float2ll_rn(v * kFixScale));
+        unsigned long long *c = reinterpret_cast<unsigned long long *>(fix) + 1 + idx;
+        if (fabsf(v) >= 1.0f) {
+            const float b = rintf(v);
+            atomicAdd(c + ncell, (unsigned long long)(long long)b);
+            v -= b;                   // exact: |v| <= 0.5, a multiple of the original's last bit (>= 2^-23)
+        }
+        const float t = v * kFixMid, h = rintf(t);
+        if (h != 0.0f) atomicAdd(c, (unsigned long long)(long long)h);
+        const float r = t - h;        // exact
+        if (r != 0.0f) atomicAdd(c + 2 * ncell, (unsigned long long)__float2ll_rn(r * kFixSmall));
     } else {
         atomicAdd(dst + idx, v);
     }

@@ -1000,7 +1000,8 @@ __global__ __launch_bounds__(512, (TH == 4 && NCO == 1) ? 4 : 2) void k_wgrad_ha
 #pragma unroll
         for (int c = 0; c < NCO; ++c)
             if (co0 + 64 * c + dbc < a.Cout)
-                wg_accum<DET>(a.db, a.fix, (DET ? (size_t)a.Cout * (a.KH * a.KW * a.Cin) : 0) + co0 + 64 * c + dbc, dbacc[c]);
+                wg_accum<DET>(a.db, a.fix, (DET ? (size_t)a.Cout * (a.KH * a.KW * a.Cin) : 0) + co0 + 64 * c + dbc, dbacc[c],
+                              (size_t)a.Cout * (a.KH * a.KW * a.Cin) + a.Cout);
     }
     // acc[t][r]: co = co0 + 32 w_co + (r&3) + 8(r>>2) + 4(lane>>5), ci = ci0 + 32 w_ci + (lane&31)
     const int K = a.KH * a.KW * a.Cin;
@@ -1015,7 +1016,8 @@ __global__ __launch_bounds__(512, (TH == 4 && NCO == 1) ? 4 : 2) void k_wgrad_ha
                 for (int r = 0; r < 16; ++r) {
                     const int co = co0 + 64 * c + 32 * w_co + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     if (co < a.Cout)
-                        wg_accum<DET>(a.dw, a.fix, (size_t)co * K + (kh * a.KW + kw) * a.Cin + ci0 + 32 * w_ci + (lane & 31), acc[c][t][r]);
+                        wg_accum<DET>(a.dw, a.fix, (size_t)co * K + (kh * a.KW + kw) * a.Cin + ci0 + 32 * w_ci + (lane & 31), acc[c][t][r],
+                                      (size_t)a.Cout * K + a.Cout);
                 }
             }
         }

@@ -1672,7 +1672,7 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgradArgs a)
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wr * (TM / 2) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int col = col0 + wc * 64 + 32 * j + (lane & 31);
-                if (co < a.Cout && col < K) wg_accum<DET>(a.dw, a.fix, (size_t)co * K + col, acc[i][j][r]);
+                if (co < a.Cout && col < K) wg_accum<DET>(a.dw, a.fix, (size_t)co * K + col, acc[i][j][r], (size_t)a.Cout * K + a.Cout);
             }
 }
 
@@ -1830,9 +1830,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(WgradDmaArgs A)
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wr * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int col = col0 + wc * 64 + 32 * j + (lane & 31);
-                if (co < a.Cout && col < K) wg_accum<DET>(a.dw, a.fix, (size_t)co * K + col, acc[i][j][r]);
+                if (co < a.Cout && col < K) wg_accum<DET>(a.dw, a.fix, (size_t)co * K + col, acc[i][j][r], (size_t)a.Cout * K + a.Cout);
             }
-    if (do_db && co0 + dbc < a.Cout) wg_accum<DET>(a.db, a.fix, (DET ? (size_t)a.Cout * K : 0) + co0 + dbc, dbacc);
+    if (do_db && co0 + dbc < a.Cout) wg_accum<DET>(a.db, a.fix, (DET ? (size_t)a.Cout * K : 0) + co0 + dbc, dbacc, (size_t)a.Cout * K + a.Cout);
 }
 
 }  // namespace m355
@@ -1862,15 +1862,16 @@ static int conv_wgrad_impl(const m355_conv_desc *d, const void *x, const void *d
                            bool zero, long long *fix = nullptr, float *part = nullptr);
 
 namespace m355 {
-// fix = [flag | n fixed-point sums | nb fixed-point bias sums] -> dw[n], db[nb] fp32 (one rounding per element); a raised flag
+// fix = [flag | n fixed-point cells | nb fixed-point bias cells] (kFixCell integers each, conv_dma.h wg_accum) -> dw[n], db[nb] fp32 (one
+// rounding per element); a raised flag
 // (some partial tile was not finite) poisons the whole result with NaN, as an fp32 accumulation would have
 __global__ __launch_bounds__(256) void k_fix_to_f32(const long long *__restrict__ fix, float *__restrict__ dw, size_t n,
                                                     float *__restrict__ db, int nb)
 {
     const bool bad = fix[0] != 0;
-    const size_t total = n + (db ? (size_t)nb : 0);
+    const size_t total = n + (db ? (size_t)nb : 0), ncell = n + (size_t)nb;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const float v = bad ? __builtin_nanf("") : (float)((double)fix[1 + i] * kFixInv);
+        const float v = bad ? __builtin_nanf("") : (float)fix_value(fix, i, ncell);
         if (i < n) dw[i] = v;
         else db[i - n] = v;
     }
@@ -1888,10 +1889,10 @@ __global__ __launch_bounds__(256) void k_up16_to_9(const void *__restrict__ src,
     const float *sf = reinterpret_cast<const float *>(src);
     const long long *sx = reinterpret_cast<const long long *>(src);
     const bool bad = DET && sx[0] != 0;
-    const size_t n9 = (size_t)Cout * 9 * Cin, n16 = (size_t)Cout * 16 * Cin, total = n9 + (db ? (size_t)Cout : 0);
+    const size_t n9 = (size_t)Cout * 9 * Cin, n16 = (size_t)Cout * 16 * Cin, total = n9 + (db ? (size_t)Cout : 0), ncell = n16 + Cout;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         if (i >= n9) {
-            db[i - n9] = DET ? (bad ? __builtin_nanf("") : (float)((double)sx[1 + n16 + (i - n9)] * kFixInv)) : sf[n16 + (i - n9)];
+            db[i - n9] = DET ? (bad ? __builtin_nanf("") : (float)fix_value(sx, n16 + (i - n9), ncell)) : sf[n16 + (i - n9)];
             continue;
         }
         const int ci = (int)(i % Cin);
@@ -1899,8 +1900,15 @@ __global__ __launch_bounds__(256) void k_up16_to_9(const void *__restrict__ src,
         const int tap = (int)(t % 9), co = (int)(t / 9), kh = tap / 3, kw = tap - 3 * kh;
         const size_t b = (((size_t)co * 4 + kh) * 4 + kw) * Cin + ci;   // entry (kh, kw); (kh+1, .) is 4 Cin further, (., kw+1) Cin
         if (DET) {
-            const long long v = sx[1 + b] + sx[1 + b + Cin] + sx[1 + b + 4 * (size_t)Cin] + sx[1 + b + 5 * (size_t)Cin];
-            dw[i] = bad ? __builtin_nanf("") : (float)((double)v * kFixInv);
+            const size_t e[4] = {b, b + Cin, b + 4 * (size_t)Cin, b + 5 * (size_t)Cin};
+            long long big = 0, mid = 0, small = 0;   // (the four entries' integers are added BEFORE the one rounding)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                mid += sx[1 + e[k]];
+                big += sx[1 + ncell + e[k]];
+                small += sx[1 + 2 * ncell + e[k]];
+            }
+            dw[i] = bad ? __builtin_nanf("") : (float)fix_value(big, mid, small);
         } else {
             dw[i] = (sf[b] + sf[b + Cin]) + (sf[b + 4 * (size_t)Cin] + sf[b + 5 * (size_t)Cin]);
         }
@@ -1915,7 +1923,7 @@ static int subpixel_wgrad(const m355_conv_desc *d, const void *x, const void *dy
                           hipStream_t st)
 {
     const size_t cells = subpixel_ws_cells(d), n16 = (size_t)d->Cout * 16 * d->Cin;
-    const size_t bytes = det ? sizeof(long long) * (1 + cells) : sizeof(float) * cells;
+    const size_t bytes = det ? sizeof(long long) * (1 + m355::kFixCell * cells) : sizeof(float) * cells;
     if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) {
         m355::set_error("conv2d_wgrad (sub-pixel): memset failed");
         return M355_ERR_LAUNCH;
@@ -1945,8 +1953,9 @@ static int subpixel_wgrad(const m355_conv_desc *d, const void *x, const void *dy
 extern "C" size_t m355_conv2d_wgrad_det_ws_bytes(const m355_conv_desc *d)
 {
     if (!d || d->Cout <= 0 || d->Cin <= 0 || d->kh <= 0 || d->kw <= 0) return 0;
-    if (subpixel(d)) return sizeof(long long) * (1 + subpixel_ws_cells(d));   // the 16-entry effective gradient
-    return sizeof(long long) * (1 + (size_t)d->Cout * d->kh * d->kw * d->Cin + (size_t)d->Cout);
+    // the flag word + kFixCell 64-bit integers per cell (conv_dma.h wg_accum)
+    if (subpixel(d)) return sizeof(long long) * (1 + m355::kFixCell * subpixel_ws_cells(d));   // the 16-entry effective gradient
+    return sizeof(long long) * (1 + m355::kFixCell * ((size_t)d->Cout * d->kh * d->kw * d->Cin + (size_t)d->Cout));
 }
 
 extern "C" int m355_conv2d_wgrad_det(const m355_conv_desc *d, const void *x, const void *dy, void *ws, float *dw, float *dbias,

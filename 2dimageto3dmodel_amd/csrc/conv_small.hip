@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_smallco(SmallWgArgs a)
             if (co < a.Cout) {
                 const size_t e = ((size_t)co * TAPS + t) * a.Cin + cc * 64 + 16 * wave + (lane & 15);
                 if (a.part) a.part[(size_t)blockIdx.x * ((size_t)a.Cout * TAPS * a.Cin) + e] = acc[t][r];
-                else wg_accum<DET>(a.dw, a.fix, e, acc[t][r]);
+                else wg_accum<DET>(a.dw, a.fix, e, acc[t][r], (size_t)a.Cout * TAPS * a.Cin + a.Cout);
             }
         }
 }
@@ -1308,7 +1308,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_c8p(C8WgArgs a)
             float *const prow = a.part ? a.part + (size_t)blockIdx.x * ((size_t)a.Cout * 201) : nullptr;
             if (do_db && (lane & 15) == 0) {
                 if (prow) prow[(size_t)a.Cout * 200 + co] = accb[i][r];
-                else wg_accum<DET>(a.db, a.fix, (DET ? (size_t)a.Cout * 200 : 0) + co, accb[i][r]);
+                else wg_accum<DET>(a.db, a.fix, (DET ? (size_t)a.Cout * 200 : 0) + co, accb[i][r], (size_t)a.Cout * 201);
             }
 #pragma unroll
             for (int kp = 0; kp < 3; ++kp) {
@@ -1318,7 +1318,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_c8p(C8WgArgs a)
                 for (int kw = 0; kw < 5; ++kw) {
                     const size_t e = ((size_t)co * 25 + kh * 5 + kw) * 8 + bci;
                     if (prow) prow[e] = acc[i][kp * 5 + kw][r];
-                    else wg_accum<DET>(a.dw, a.fix, e, acc[i][kp * 5 + kw][r]);
+                    else wg_accum<DET>(a.dw, a.fix, e, acc[i][kp * 5 + kw][r], (size_t)a.Cout * 201);
                 }
             }
         }

@@ -278,9 +278,11 @@ int m355_conv2d_wgrad_acc(const m355_conv_desc *d, const void *x, const void *dy
 /*      DETERMINISTIC form of the same: every wgrad kernel splits the pixel axis over workgroups and adds the partial tiles with
  *      atomics -- fp32 atomics give run-to-run differences in the last bits (the reference's CPU path is bit-deterministic,
  *      SURVEY 8c; code/main.py:691-723).  Here the SAME kernels accumulate the partials as 64-bit fixed-point integers
- *      (value * 2^36: integer addition is associative, so the order the workgroups finish in cannot matter) in `ws`
- *      (m355_conv2d_wgrad_det_ws_bytes(d) bytes, zeroed by the call) and one pass converts to fp32.  dw and dbias are
- *      OVERWRITTEN.  A non-finite partial poisons the result with NaN, as fp32 accumulation would. */
+ *      (three per cell, on the grids 1, 2^-50 and 2^-100: integer addition is associative, so the order the workgroups finish
+ *      in cannot matter, and the triple holds the exact sum of the partial tiles whatever their magnitude; a partial touches one
+ *      of the three in the common case -- csrc/conv_dma.h wg_accum) in `ws`
+ *      (m355_conv2d_wgrad_det_ws_bytes(d) bytes, zeroed by the call) and one pass converts to fp32 with one rounding.  dw and
+ *      dbias are OVERWRITTEN.  A non-finite partial (or one beyond 1e8) poisons the result with NaN, nothing is hidden. */
 /*      The 8-input-channel layer (D.conv1, gan.py:163) with a workspace: every workgroup stores its partial tile and a second
  *      launch adds them in workgroup order -- no atomics, deterministic in every mode; dw / dbias are OVERWRITTEN.
  *      _ws_bytes == 0: the layer has no such form (the <= 8-output-channel heads measured slower with it). */

@@ -569,6 +569,55 @@ def test_persistent_tile_kernels_repeat_bit_identically_under_memory_pressure(pk
     assert (got - want).abs().max().item() / want.abs().max().item() < 1.2e-2
 
 
+@pytest.mark.parametrize("case", [
+    (2, 32, 64, 128, 256, 4, 2, 1, 1, 2, 0),   # 4x4 stride 2: the 2x2 class variant of k_wgrad_halo
+    (2, 16, 32, 128, 128, 3, 1, 1, 1, 1, 0),   # 3x3: k_wgrad_halo
+    (2, 8, 32, 128, 128, 3, 1, 1, 1, 1, 1),    # upsample + 3x3 in the sub-pixel form: 16-entry cells + the integer 16 -> 9 fold
+    (2, 16, 16, 32, 64, 5, 1, 2, 2, 2, 0),     # k_wgrad_dma
+    (3, 12, 6, 96, 96, 3, 1, 1, 1, 0, 0),      # the generic split-K kernel
+    (2, 16, 32, 64, 3, 5, 1, 2, 2, 1, 0),      # a 3-channel head: k_wgrad_smallco
+    (3, 24, 64, 8, 64, 5, 1, 2, 2, 2, 0),      # D.conv1 (ordered partial rows in every mode)
+])
+def test_deterministic_weight_gradient_is_scale_free(pkg, case):
+    """The deterministic weight gradient (integer cells, csrc/conv_dma.h wg_accum) must not have a preferred gradient magnitude: Adam
+    (betas 0, 0.9 -- main.py:588-589) is invariant to the gradient's scale, so a layer whose gradients are 1e-9 matters as much as one
+    at 1e-2.  Here dy is scaled by 2^-30 and by 2^12 -- exact in bf16, and exact through the MFMA partial tiles -- and the result must be
+    the scaled result of the unscaled run, to the bit (the (hi, lo) cell pair holds the exact sum of the partials; a single 2^-36 grid
+    gave 1e-3 relative error at 2^-30).  The unscaled run is also held to the fp64 sum of the same bf16 operands at fp32 accuracy."""
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    N, H, W, Cin, Cout, k, stride, ph, pw, mode, ups = case
+    g = torch.Generator().manual_seed(99)
+    d = conv.make_desc(N, H, W, Cin, Cout, k, k, stride, ph, pw, mode, ups)
+    ho, wo = conv.out_hw(d)
+    x = torch.randn(N, H, W, Cin, generator=g).bfloat16()
+    cy = conv.dy_channels(Cout)
+    dy = torch.zeros(N, ho, wo, cy, dtype=torch.bfloat16)
+    dy[..., :Cout] = torch.randn(N, ho, wo, Cout, generator=g).bfloat16()
+
+    def run(scale):
+        db = torch.zeros(Cout, dtype=torch.float32, device=DEV) if conv.wgrad_fuses_dbias(d) else None
+        dys = (dy.float() * scale).bfloat16()
+        assert torch.equal(dys.float(), dy.float() * scale)      # (a power of two: no rounding)
+        dw = conv.conv_wgrad(d, x.to(DEV), dys.to(DEV), raw=True, dbias=db).clone()
+        return dw.cpu(), (None if db is None else db.cpu())
+
+    prev = conv.set_deterministic(True)
+    try:
+        dw1, db1 = run(1.0)
+        for scale in (2.0 ** -30, 2.0 ** 12):
+            dws, dbs = run(scale)
+            assert torch.isfinite(dws).all()
+            assert torch.equal(dws, dw1 * scale), (scale, float(((dws - dw1 * scale).abs() / (dw1.abs() * scale + 1e-30)).max()))
+            if db1 is not None:
+                assert torch.equal(dbs, db1 * scale)
+    finally:
+        conv.set_deterministic(prev)
+    wr = w64 = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+    ref_conv(x.double().permute(0, 3, 1, 2), wr, None, stride, ph, pw, mode, ups).backward(dy[..., :Cout].double().permute(0, 3, 1, 2))
+    want = w64.grad.permute(0, 2, 3, 1)          # raw layout [Cout, kh, kw, Cin]
+    assert ((dw1.double() - want).abs().max() / want.abs().max()).item() < 2e-6
+
+
 @pytest.mark.timeout(900)
 def test_every_shape_class_repeats_bit_identically_under_memory_pressure(pkg):
     """the shape classes of CASES (every dispatch path: generic MFMA, LDS-DMA, halo, 8-channel, small-Cout, heads, odd-kernel

@@ -82,7 +82,7 @@ def test_workspace_queries(pkg):
 
     d = desc(64, 8, 4, 512, 512, 3)
     # deterministic wgrad: [flag | Cout*K fixed-point sums | Cout bias sums], 8 bytes each
-    assert L.m355_conv2d_wgrad_det_ws_bytes(ctypes.byref(d)) == 8 * (1 + 512 * 9 * 512 + 512)
+    assert L.m355_conv2d_wgrad_det_ws_bytes(ctypes.byref(d)) == 8 * (1 + 3 * (512 * 9 * 512 + 512))   # flag + three integers per cell
     # partial-sum wgrad: the 8-input-channel 5x5 layer only (one row of Cout * 201 floats per pixel-axis workgroup)
     c8 = desc(128, 256, 256, 8, 64, 5, mode=2)
     assert L.m355_conv2d_wgrad_ws_bytes(ctypes.byref(c8)) == 4 * 256 * 64 * 201
@@ -105,9 +105,9 @@ def test_workspace_queries(pkg):
     assert L.m355_conv2d_weight_elems(ctypes.byref(desc(64, 128, 64, 128, 64, 3)), 0) == 64 * 9 * 128
     # ... the 16-entry effective weight gradient (+ bias sums) only where the shape takes that form; its dgrad needs no frame
     assert L.m355_conv2d_wgrad_ws_bytes(ctypes.byref(up)) == 4 * (64 * 16 * 128 + 64)
-    assert L.m355_conv2d_wgrad_det_ws_bytes(ctypes.byref(up)) == 8 * (1 + 64 * 16 * 128 + 64)
+    assert L.m355_conv2d_wgrad_det_ws_bytes(ctypes.byref(up)) == 8 * (1 + 3 * (64 * 16 * 128 + 64))
     assert L.m355_conv2d_wgrad_ws_bytes(ctypes.byref(small)) == 0
-    assert L.m355_conv2d_wgrad_det_ws_bytes(ctypes.byref(small)) == 8 * (1 + 128 * 9 * 256 + 128)
+    assert L.m355_conv2d_wgrad_det_ws_bytes(ctypes.byref(small)) == 8 * (1 + 3 * (128 * 9 * 256 + 128))
     assert L.m355_conv2d_dgrad_ws_bytes(ctypes.byref(up)) == 0
     assert L.m355_conv2d_fwd_stats_rows(ctypes.byref(up)) == 4 * 128     # class pairs: 128 workgroups x 2 row parities, a row block per class
     assert L.m355_conv2d_fwd_stats_rows(ctypes.byref(desc(64, 64, 32, 128, 128, 3, ups=1))) == 4 * 64
