@@ -151,7 +151,7 @@ class ConvPlan(ctypes.Structure):
                 ("fwd_bits_ok", c_int), ("dgrad_bits_ok", c_int), ("dgrad_mask_ok", c_int), ("fwd_stats_rows", c_int),
                 ("fwd_ws_stats_rows", c_int), ("wgrad_fuses_dbias", c_int),
                 ("fwd_ws_bytes", c_size_t), ("dgrad_ws_bytes", c_size_t), ("wgrad_ws_bytes", c_size_t),
-                ("wgrad_det_ws_bytes", c_size_t), ("exec_ratio", ctypes.c_double)]
+                ("wgrad_det_ws_bytes", c_size_t), ("exec_ratio", ctypes.c_double), ("w_dgrad_row_elems", c_int), ("pad_", c_int)]
 
 
 class SnFinEntry(ctypes.Structure):
@@ -201,10 +201,18 @@ def is_exact():
 def set_exact(on):
     """Switch this process between the product library and the EXACT build (fp32 activations, fp32 convs with fp64 accumulation:
     SURVEY.md 8c's exact mode) -> the previous setting.  Tensors and modules created under one setting must not be used under the
-    other: networks keep no activation state between forwards, but build them (and their SpectralNormGroup views) AFTER switching."""
+    other: networks keep no activation state between forwards, but build them (and their SpectralNormGroup views) AFTER switching.
+    The returned token is the PATH of the library that was current (loaded, or the one M355_LIB / M355_EXACT select when nothing is
+    loaded yet); passing it back restores exactly that library, an M355_LIB A/B build included.  set_exact(False) = the product
+    library this process was configured with (M355_LIB, default libm355.so), never a hard-coded name."""
     global _lib, LIB_PATH, _ACT_DTYPE
-    prev = _lib is not None and is_exact()
-    want = os.path.join(_HERE, "lib", EXACT_LIB if on else "libm355.so")
+    prev = LIB_PATH
+    if isinstance(on, str):
+        want = on
+    elif on:
+        want = os.path.join(_HERE, "lib", EXACT_LIB)
+    else:
+        want = os.path.join(_HERE, "lib", os.environ.get("M355_LIB", "libm355.so"))
     if want != LIB_PATH or _lib is None:
         LIB_PATH, _lib, _ACT_DTYPE = want, None, None
         for h in _RESET_HOOKS:

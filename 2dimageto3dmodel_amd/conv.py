@@ -142,7 +142,10 @@ def _halves(d, out_bytes=2):
         r = None
         if d.N >= 2 and d.N % 2 == 0:
             ho, wo = out_hw(d)
-            big = max(d.N * d.H * d.W * d.Cin * 2, d.N * ho * wo * max(d.Cout, dy_channels(d.Cout)) * out_bytes)
+            # (activation bytes from the loaded build: 2, or 4 under the EXACT build -- one element size for every pass of the layer;
+            # only the fp32 NCHW output form of conv_fwd is wider than that)
+            ab = int(plan(d).act_bytes)
+            big = max(d.N * d.H * d.W * d.Cin * ab, d.N * ho * wo * max(d.Cout, dy_channels(d.Cout)) * max(out_bytes, ab))
             if big >= (1 << 31):
                 r = (make_desc(d.N // 2, d.H, d.W, d.Cin, d.Cout, d.kh, d.kw, d.stride, d.pad_h, d.pad_w, d.pad_w_mode, d.upsample), d.N // 2)
         _HALVES[key] = r
@@ -509,6 +512,8 @@ def wgrad_finish(d, g_khwc, cin_real, w_orig=None, u=None, v=None, sigma=None, p
     # e.g. 1024 channels x 4x4 -- take the per-layer launch below instead of failing the whole flush after the pass)
     fits = (d.Cin + 1) * d.kh * d.kw <= _lib.SNFIN_LDS_FLOATS
     if fits and _DeferredFinish.active and param is not None and param.is_leaf and param.requires_grad:
+        from . import gan_ops
+        gan_ops.note_side_work()   # (the raw gradient may be in flight on the second stream: flush_wgrad_finish joins it)
         _DeferredFinish.items.append(((ptr(g_khwc), ptr(w_orig), ptr(u), ptr(v), ptr(sigma), ptr(dw), d.Cout, cin_real, d.Cin,
                                        d.kh, d.kw), (g_khwc, w_orig, u, v, sigma, dw), param))
         return None

@@ -50,38 +50,10 @@ __device__ __forceinline__ void wait_vm()
 // X_pq[i][j] = xpad[2i+p][2j+q] of the input: out[o] = sum_{p,q} sum_{a,b} X_pq[o+(a,b)] . W[2a+p][2b+q].  The segment
 // stream of a tile is then (class, channel chunk) instead of (channel chunk): each segment has its own halo (the DMA
 // addresses the plane with pixel stride 2) and all of them accumulate into the same output tile.
-#ifndef M355_HALO_EARLY
-#define M355_HALO_EARLY 0
-#endif
-#ifndef M355_HALO_PIPE
-#define M355_HALO_PIPE 1
-#endif
-#ifndef M355_HALO_PIPE8
-#define M355_HALO_PIPE8 0
-#endif
-#ifndef M355_HALO_RB4
-#define M355_HALO_RB4 3
-#endif
-#ifndef M355_HALO_RB8
-#define M355_HALO_RB8 3
-#endif
-// weight slots of the 8-wave 2x2 variants.  Their LDS has room for a fourth (weights three steps ahead instead of two): measured
-// same-box, D.conv3 / conv4 forward 497 / 450 -> 496 / 450 us, all k_conv_halo launches of a cycle 10.41 -> 10.36 ms: the waits of
-// these kernels are not weight-DMA latency.  Left at three.
-#ifndef M355_HALO_RB8_K2
-#define M355_HALO_RB8_K2 3
-#endif
-#ifndef M355_NO_EPI_CREDIT
-#define M355_NO_EPI_CREDIT 0
-#endif
-// TG2 (A/B build option, OFF): the 8-wave 2x2 variants meet at a barrier every SECOND tap -- four weight slots instead of
-// three (two being read, two in flight), the weights of two steps and the whole next halo issued behind the barrier that
-// frees their slots, every wait a plain drain.  Bit-identical results; measured same-box against the three-slot, barrier-per-
-// tap scheme with its counted waits: GAN cycle 29.14 -> 29.26 ms, D.conv3 / conv4 forward 517 / 460 -> 519 / 468 us.  Half
-// the barriers do not pay for giving up the counted vmcnt (loads in flight across the barrier) and the slices' spread.
-#ifndef M355_HALO_TG2
-#define M355_HALO_TG2 0
-#endif
+// (Rounds 1-5 carried seven A/B build switches here -- whole next halo at tap 0, fragment look-ahead off / on for the 8-wave 3x3
+// variant, 4 instead of 3 weight slots, no epilogue credit in the counted waits, one barrier per two taps.  Every losing branch was
+// measured same-box and is recorded in DESIGN.md 5 ("Round 2", "Round 3"); the code keeps the winners only: slices spread over taps
+// 0 .. T-3, look-ahead for the 4-wave and the 2x2 variants, three weight slots, one barrier per tap with counted waits.)
 
 // halo DMAs one wave issues at tap t (slices of NAS on taps 0 .. T-3), and their sum over the D steps before tap t
 template <int T, int NAW, int NAS>
@@ -158,19 +130,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
     constexpr int NA = (HR + 7) / 8;                      // DMA instructions per halo
     constexpr int NAW = (NA + NW - 1) / NW;               //   ... per wave
     // halo-slice DMAs per step (taps 0 .. T-3 carry the slices); EARLY: the whole next halo at tap 0
-    constexpr bool TG2 = M355_HALO_TG2 && NW == 8 && KS == 2 && !RES;   // one barrier per two taps (see M355_HALO_TG2)
-    constexpr int NAS = (M355_HALO_EARLY || TG2) ? NAW : (NAW + T - 3) / (T - 2);
+    constexpr int NAS = (NAW + T - 3) / (T - 2);
     // RES: the WHOLE weight panel of the workgroup's output channels stays resident in LDS (64 channels x K <= 576: the
     // class convs of a stride-2 dgrad with <= 128 dy channels, a 3x3 conv of 64 channels) -- those layers are bound by
     // the bytes DMA'd into LDS per flop, and the weights were half of them or more.  No weight DMAs in the loop, and one
     // barrier per channel chunk (the one that publishes the next halo) instead of one per tap.
     static_assert(!RES || (BN == 64 && NW == 4 && SUB == 1 && !UPS), "resident weights: 4-wave variant only");
-    constexpr int RB = RES ? (KS == 2 ? 8 : 9)
-                           : (TG2 ? 4 : (NW == 4 ? M355_HALO_RB4 : (KS == 2 ? M355_HALO_RB8_K2 : M355_HALO_RB8)));  // weight slots (ring / panel)
+    constexpr int RB = RES ? (KS == 2 ? 8 : 9) : 3;   // weight slots (panel / ring: a fourth slot measured equal)
     // software pipeline (one wave per SIMD has no partner wave to hide its LDS-read latency): fragments of step s+1 are
     // read during step s.  The 8-wave variant (2 waves per SIMD, 256 registers each) does the same for the 2x2 class
     // convs (+3-5 %); with 9 taps unrolled it would spill ~30 registers (-5 %), so 3x3 reads them in the step itself.
-    constexpr int L = ((NW == 4 || KS == 2 || M355_HALO_PIPE8) && M355_HALO_PIPE) ? 1 : 0;
+    constexpr int L = (NW == 4 || KS == 2) ? 1 : 0;
     constexpr int NBW = BN / (8 * NW);                    // weight DMAs per wave per step
     constexpr int ABUF = NW * NAW * 1024, BBUF = BN * 128;
     constexpr int WGN = BN / 64, PI = 2, CJ = 2;          // waves along N; each wave 2 tile rows x 64 channels
@@ -431,7 +401,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
             static_for<0, T>([&](auto tapc) { issue_B(0, cc, tapc, cc * T + decltype(tapc)::value); });
     } else {
         int cls = 0, cc = 0;
-        static_for<0, TG2 ? RB - 1 : RB - 1 + L>([&](auto qc) {   // (TG2: step 0 itself issues steps RB-1 and RB)
+        static_for<0, RB - 1 + L>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
             issue_B(cls, cc, std::integral_constant<int, q % T>{}, q);
             if (q % T == T - 1) advance(cls, cc);
@@ -449,7 +419,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
     // VMEM operations one lane issues between the last step of a tile and the first step of the next that are NOT part of
     // the counted DMA stream: the epilogue's 8 stores in its plain forms (+2 mask-word stores when it emits bit masks; the
     // +2 mask-word loads at the top of a tile that reads them); other epilogue forms (guarded / bf16 mask reads): no credit
-    const bool epi_simple = !a.fold2 && a.Cout == a.CoutP && !a.mask_x && !M355_NO_EPI_CREDIT;
+    const bool epi_simple = !a.fold2 && a.Cout == a.CoutP && !a.mask_x;
     const int epi_vm = !epi_simple ? 0 : (((a.bits_out && a.slope != 1.0f) || a.bits_in) ? 10 : 8);
     int fresh = 0;                // steps of the current tile still awaiting pre-epilogue weights
     int cls_cur = 0, cc_cur = 0;  // (class, chunk) of the current segment
@@ -501,21 +471,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();
                     }
-                } else if (TG2) {
-                    // even taps: everything this wave has issued is awaited (the weights of this and the next step, issued
-                    // two steps ago, and at tap 2 the next halo, issued at tap 0) except, first thing in a tile, the previous
-                    // tile's epilogue stores, which are younger than the weights awaited there
-                    if (tap % 2 == 0) {
-                        if (fresh > 0) {
-                            --fresh;
-                            if (epi_vm == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-                            else if (epi_vm == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
-                            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                        } else {
-                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                        }
-                        __builtin_amdgcn_s_barrier();
-                    }
                 } else {
                     if (warm) {
                         --warm;
@@ -561,19 +516,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                 mma(0);  // the DMA issue below (scalar address work, M0 writes) runs in the shadow of these MFMAs
 #endif
                 __builtin_amdgcn_sched_barrier(0);
-                if (TG2) {
-                    // behind an even tap's barrier the slots of the previous and of this step are free (their fragments were
-                    // read one step before they are used): steps s+3 and s+4 go there, to be published two steps from now
-                    if (tap % 2 == 0) {
-                        constexpr int a1 = tap + RB - 1, a2 = tap + RB;
-                        int cls_b = cls_cur, cc_b = cc_cur;
-#pragma unroll
-                        for (int q = 0; q < a1 / T; ++q) advance(cls_b, cc_b);
-                        issue_B(cls_b, cc_b, std::integral_constant<int, a1 % T>{}, slot_p);
-                        if (a2 / T > a1 / T) advance(cls_b, cc_b);
-                        issue_B(cls_b, cc_b, std::integral_constant<int, a2 % T>{}, slot);
-                    }
-                } else if (!RES) {
+                if (!RES) {
                     constexpr int ahead = tap + RB - 1 + L;  // the weight stream's step, relative to this segment's tap 0
                     int cls_b = cls_cur, cc_b = cc_cur;
 #pragma unroll
@@ -748,7 +691,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
         // stores that are OLDER than the weights it awaits, i.e. it let up to 8-10 DMAs too many stay in flight -- its own
         // weights among them.  They had nearly always landed anyway (issued two steps earlier); about one GAN iteration in
         // ten at 256^2 read a stale weight slot in one tile: found by round 4's run-to-run determinism checks)
-        fresh = RES ? 0 : (TG2 ? 1 : RB - 1);
+        fresh = RES ? 0 : RB - 1;
     }
     wait_vm<0>();  // the trailing (unused) prefetches
 #ifdef M355_DBG_STAMP

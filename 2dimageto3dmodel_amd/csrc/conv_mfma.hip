@@ -2140,5 +2140,6 @@ extern "C" int m355_conv2d_plan(const m355_conv_desc *d, m355_conv_plan *p)
     p->wgrad_ws_bytes = m355_conv2d_wgrad_ws_bytes(d);
     p->wgrad_det_ws_bytes = m355_conv2d_wgrad_det_ws_bytes(d);
     p->exec_ratio = m355_conv2d_exec_ratio(d);
+    p->w_dgrad_row_elems = d->stride == 1 ? m355::k_padded(d->kh * d->kw * (int)m355::dy_channels(d->Cout)) : 0;
     return M355_OK;
 }

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void k_cproj_bwd(const act_t *__restrict__ fea
 // the logit conv's dgrad weights as [25 taps][C] in the activation type (bf16 / EXACT: fp32): gathered ONCE per launch from the dgrad view
 // (a workgroup of the main kernel copies the 25 C values coalesced; gathering them itself -- 2-byte reads 512 bytes apart -- cost
 // more than its arithmetic)
-__global__ __launch_bounds__(256) void k_conv5_wt(const void *__restrict__ wd, int Kp, int C, act_t *__restrict__ wt)
+__global__ __launch_bounds__(256) void k_conv5_wt(const void *__restrict__ wd, int Kp, int tap_stride, int C, act_t *__restrict__ wt)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= 25 * C) return;
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void k_conv5_wt(const void *__restrict__ wd, i
 #ifdef M355_EXACT
     wt[i] = reinterpret_cast<const float *>(wd)[(size_t)(24 - tap) * C + c];   // fp32 conv weight [1][5][5][C] (W / sigma), unflipped
 #else
-    wt[i] = reinterpret_cast<const short *>(wd)[(size_t)c * Kp + tap * 8];     // bf16 dgrad view [row c][Kp], K = (a, b, co8), taps flipped
+    wt[i] = reinterpret_cast<const short *>(wd)[(size_t)c * Kp + tap * tap_stride];   // bf16 dgrad view [row c][Kp], K = (a, b, co8), taps flipped
 #endif
 }
 
@@ -765,12 +765,17 @@ extern "C" int m355_cproj_bwd_conv5(const void *feat, const float *emb, const fl
     M355_REQUIRE(feat && emb && g && dy5 && w_dgrad && dfeat && demb && N > 0 && N <= 65535, "cproj_bwd_conv5: bad argument");
     M355_REQUIRE(m355_cproj_bwd_conv5_ok(H, W, C) && (pad_w_mode == 0 || pad_w_mode == 2) && Kp >= 200,
                  "cproj_bwd_conv5: shape not eligible (m355_cproj_bwd_conv5_ok)");
+    // the layout k_conv5_wt reads -- row length Kp, tap stride dy_channels(1) -- is the conv library's private rule: ask it, do not assume it
+    m355_conv_desc d5 = {N, H, W, C, 1, 5, 5, 1, 2, 2, pad_w_mode, 0};
+    m355_conv_plan p5;
+    M355_REQUIRE(m355_conv2d_plan(&d5, &p5) == M355_OK && p5.w_dgrad_row_elems == Kp,
+                 "cproj_bwd_conv5: Kp is not the row length of this logit conv's dgrad view (m355_conv_plan.w_dgrad_row_elems)");
     hipStream_t st = (hipStream_t)stream;
     const int ng = H * (W / 4), gpb = conv5_gpb(N, H, W), nblk = (ng + gpb - 1) / gpb;
     M355_REQUIRE(ws, "cproj_bwd_conv5: workspace required (m355_cproj_bwd_conv5_ws_floats)");
     act_t *wt = reinterpret_cast<act_t *>(ws);
     float *part = ws + (25 * C * sizeof(act_t) + 3) / 4;
-    hipLaunchKernelGGL(k_conv5_wt, dim3((25 * C + 255) / 256), dim3(256), 0, st, w_dgrad, Kp, C, wt);
+    hipLaunchKernelGGL(k_conv5_wt, dim3((25 * C + 255) / 256), dim3(256), 0, st, w_dgrad, Kp, p5.dy_channels, C, wt);
     hipLaunchKernelGGL(k_cproj_bwd_conv5, dim3(nblk, N), dim3(256), conv5_lds_bytes(H, W, C), st, (const act_t *)feat, emb, g, dy5,
                        (const act_t *)wt, (act_t *)dfeat, nblk == 1 ? demb : part, H, W, C, gpb, mask_slope, pad_w_mode);
     if (nblk > 1) hipLaunchKernelGGL(k_sum_partials, dim3((C + 31) / 32, N), dim3(256), 0, st, (const float *)part, demb, nblk, C);

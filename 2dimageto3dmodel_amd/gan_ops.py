@@ -44,16 +44,27 @@ STREAMS_ON = os.environ.get("M355_STREAMS", "auto") != "0"
 FORK_MAX_BATCH = 1 << 30 if os.environ.get("M355_STREAMS") == "1" else 32
 
 
-_FORKED = set()     # device indices whose side stream has run a branch since conv.flush_wgrad_finish last joined it
+_FORKED = set()     # device indices whose side stream has had work enqueued since conv.flush_wgrad_finish last joined it
+_SIDE_RAW = {}      # raw HIP stream handle of a side stream -> device index (the check in the launch path is one dict lookup)
 
 
 def side_streams():
     return list(_SIDE.values())
 
 
+def note_side_work():
+    """called where a deferred weight-gradient epilogue is QUEUED (conv.wgrad_finish): if the current stream is a side stream, the
+    raw gradient it will read is being produced there, and the next flush must join that stream.  Marking at the enqueue -- not
+    only in Fork.__enter__, i.e. the forward -- covers every backward of a forked graph: a second backward under retain_graph, or two
+    forwards followed by two backwards, find the mark cleared by the first flush."""
+    idx = _SIDE_RAW.get(stream())
+    if idx is not None:
+        _FORKED.add(idx)
+
+
 def side_streams_to_join():
-    """the side streams a backward pass may have put weight-gradient kernels on since the last join (Fork.__enter__ marks them),
-    minus -- while the current stream is being captured into a hipGraph -- those that are not part of that capture: waiting on
+    """the side streams a backward pass may have put weight-gradient kernels on since the last join (Fork.__enter__ and
+    note_side_work mark them), minus -- while the current stream is being captured into a hipGraph -- those that are not part of that capture: waiting on
     their (uncaptured) work from a capturing stream is a capture-isolation error, and nothing of this pass ran there"""
     out = []
     for idx in sorted(_FORKED):
@@ -77,6 +88,7 @@ class Fork:
         self.side = _SIDE.get(dev.index)
         if self.side is None:
             self.side = _SIDE[dev.index] = torch.cuda.Stream(dev)
+            _SIDE_RAW[self.side.cuda_stream] = dev.index
         self._ctx = None
 
     def __enter__(self):
@@ -567,7 +579,7 @@ class Conv2dFn(torch.autograd.Function):
                     and d.Cout == 1):
                 # the tail of a discriminator (TailPair): the projection term's backward, which runs next, produces the whole
                 # gradient of x in one pass from this conv's logit gradient and dgrad weights -- no dgrad launch here
-                kp = (d.kh * d.kw * c32 + 63) // 64 * 64      # row length of the stride-1 dgrad view (m355_conv2d_weight_elems)
+                kp = int(C.plan(d).w_dgrad_row_elems)        # row length of the stride-1 dgrad view: the library's rule, asked once
                 pair.request = (dyc.view(d.N, dyc.shape[2], dyc.shape[3]), wd, kp, d.pad_w_mode, ctx.in_slope)
                 fused_tail = True
         else:

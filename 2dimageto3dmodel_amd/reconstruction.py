@@ -92,7 +92,7 @@ def _up_bilinear(x_nhwc):
     """F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False) (models/reconstruction.py:44) of an NHWC bf16
     activation: the interpolation itself in fp32 (as the reference's fp32 activations), stored back as bf16"""
     y = torch.nn.functional.interpolate(x_nhwc.permute(0, 3, 1, 2).float(), scale_factor=2, mode='bilinear', align_corners=False)
-    return y.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+    return y.permute(0, 2, 3, 1).contiguous().to(G._act())   # (bf16, or fp32 under the EXACT build: _lib.act_dtype)
 
 
 class DatasetParams(nn.Module):

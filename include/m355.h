@@ -188,6 +188,9 @@ typedef struct m355_conv_plan {
     size_t wgrad_ws_bytes;        /* m355_conv2d_wgrad_ws_bytes (0: use m355_conv2d_wgrad / _acc / _det) */
     size_t wgrad_det_ws_bytes;    /* m355_conv2d_wgrad_det_ws_bytes */
     double exec_ratio;            /* m355_conv2d_exec_ratio */
+    int w_dgrad_row_elems;        /* row length (elements) of the stride-1 dgrad view [rows][taps * dy_channels, padded]: what a kernel that
+                                   * reads that view itself (m355_cproj_bwd_conv5's Kp) must be given; 0 for stride-2 / sub-pixel views */
+    int pad_;
 } m355_conv_plan;
 int m355_conv2d_plan(const m355_conv_desc *d, m355_conv_plan *plan);
 /*      adjoint of the nearest x2 upsample (gan.py:319) on NHWC bf16: g[N,2H,2W,C] -> dx[N,H,W,C] (2x2 block sums) */

@@ -97,7 +97,7 @@ def test_the_model_sees_the_round_2_3_hole():
 
 def test_the_source_carries_the_rule_the_model_proves():
     src = open(SRC).read()
-    m = re.search(r"fresh = RES \? 0 : \(TG2 \? 1 : ([^;]+)\);", src)
+    m = re.search(r"fresh = RES \? 0 : ([^;]+);", src)
     assert m and m.group(1).replace(" ", "") == "RB-1", m and m.group(1)
     # the formulas restated above, as they stand in the source
     assert "constexpr int cnt_b = (RB - 2) * NBW + halo_dmas_behind<T, NAW, NAS, RB - 1>(tap);" in src
