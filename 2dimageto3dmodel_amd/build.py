@@ -40,6 +40,18 @@ SOURCES = [
 ]
 
 
+def source_hash():
+    """sha256 over the kernel sources (csrc/*, include/m355.h), by sorted file name: ties a measured artefact (profiles/pmc_traffic.json:
+    HBM bytes per launch from rocprofv3 PMC passes) to the code it was measured on -- bench.py nulls `roofline.traffic` when they differ"""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(os.path.dirname(HERE), "include", "m355.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):

@@ -294,6 +294,12 @@ class Generator(nn.Module):
         parts = out.split([w.shape[0] for w in ws], dim=1)
         return {m: (parts[2 * i], parts[2 * i + 1]) for i, m in enumerate(layers)}
 
+    def state_dict(self, *args, **kwargs):
+        g = self.__dict__.get("_sn")
+        if g is not None:
+            g.cancel_prefetch()   # (a spectral-norm step computed ahead of its forward: a checkpoint holds the last FORWARD's u / v)
+        return super().state_dict(*args, **kwargs)
+
     def _apply(self, fn, *args, **kwargs):
         # .to() / .cuda() / .half() replace parameter and buffer tensors: the batching caches (device tables of the
         # spectral-norm group, the layer list and the num_batches_tracked references) must be rebuilt from the new ones
@@ -618,14 +624,27 @@ class MultiScaleDiscriminator(nn.Module):
         elif args.num_discriminators != 2:
             raise ValueError(f"num_discriminators={args.num_discriminators}")
 
-    def forward(self, x, mesh_map=None, c=None, caption=None):
+    def _sn_group(self):
         g = self.__dict__.get("_sn")
         if g is None:
             g = self.__dict__["_sn"] = G.SpectralNormGroup(sn_convs(self))
             for m in self.children():
                 if isinstance(m, _DiscBase):
                     m.__dict__["_sn_external"] = True
-        g.step(self.training)
+        return g
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_sn", None)   # (.to() / .cuda() replace the parameter and buffer tensors the group's tables point at)
+        return super()._apply(fn, *args, **kwargs)
+
+    def state_dict(self, *args, **kwargs):
+        g = self.__dict__.get("_sn")
+        if g is not None:
+            g.cancel_prefetch()   # (see Generator.state_dict)
+        return super().state_dict(*args, **kwargs)
+
+    def forward(self, x, mesh_map=None, c=None, caption=None):
+        self._sn_group().step(self.training)
         members = [self.d1, self.d2] + ([self.d3] if self.args.num_discriminators == 3 else [])
         # every member's input assembly (pooling, mesh / positional planes, masks, NHWC bf16 packing) from ONE read
         # interface: one launch per member, one backward launch for all of them (gan_ops.DiscInputsFn)

@@ -94,11 +94,15 @@ class GanTrainer(torch.nn.Module):
             self.finish_pending()                                       # (the previous D step's all-reduce + optimiser step)
             X_fake = O.MaskedInput(pred_tex, X_alpha)                  # cat((pred_tex * X_alpha, X_alpha), dim=1), built in D's loaders
             disc, mask = self.discriminator(X_fake, pred_mesh, C, caption)
+            if not self._pending_d:
+                self._prefetch_sn(self.discriminator)                  # (for the next D step, under this step's backward)
             loss = self.criterion_gan(disc, True, for_discriminator=False, mask=mask, weight=w)
             return loss, pred_tex, pred_mesh
         if mode == 'd':
             with torch.no_grad():
                 pred_tex, pred_mesh = self.generator(noise, C, caption)
+                # (the generator is not updated before its next forward -- the next D step's, or the next cycle's G step's)
+                self._prefetch_sn(self.generator, cross_cycle=(self.total_it + 1) % (1 + self.d_steps_per_g) == 0)
                 assert (X_mesh is None) == (pred_mesh is None)
                 # cat((cat((pred_tex * X_alpha, X_alpha), 1), cat((X_tex, X_alpha), 1)), 0) in one pass
                 X_comb = O.MaskedInput(pred_tex, X_alpha, X_tex)
@@ -119,9 +123,30 @@ class GanTrainer(torch.nn.Module):
             self._pending_d = False
             self.reduce_d.finish()
             self.optimizer_d.step()
+            self._prefetch_sn(self.discriminator)
+
+    # ---- spectral norm ahead of its forward (gan_ops.SpectralNormGroup.prefetch).  A network's power iteration + bf16 weight views
+    # depend on its weights and u / v only, so they are issued on a second stream as soon as those are final for the next forward:
+    #   discriminators: after optimizer_d.step() (for the next D forward) and, in the G step, right after the D forward (the G step
+    #                   does not update D: the step for D1 runs under the G step's backward);
+    #   generator:      after the no-grad forward of a D step (no generator update until after the next G forward).  NOT after
+    #                   optimizer_g.step(): the running-average update that follows it reads u / v (they are buffers of the
+    #                   generator's state_dict, main.py:431-447) and the next forward is the very next thing on the stream.
+    # Inside a hipGraph capture the prefetch that would cross into the NEXT cycle is skipped (the graph must end with every stream
+    # joined, and the next replay recomputes from the live u / v).
+    def _prefetch_sn(self, net, cross_cycle=False):
+        if cross_cycle and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return
+        net._sn_group().prefetch(net.training)
+
+    def cancel_sn_prefetch(self):
+        """put u / v back where the last FORWARD left them (checkpoints, snapshots, hipGraph capture)"""
+        for net in (self.generator, self.discriminator):
+            net._sn_group().cancel_prefetch()
 
     def state_dict(self, *args, **kwargs):
         self.finish_pending()
+        self.cancel_sn_prefetch()   # (u / v of a checkpoint are those of the last forward, as the reference's are)
         return super().state_dict(*args, **kwargs)
 
     def _apply(self, fn, *args, **kwargs):
@@ -219,6 +244,7 @@ class GanTrainer(torch.nn.Module):
             else:
                 self.reduce_d()
                 self.optimizer_d.step()
+                self._prefetch_sn(self.discriminator, cross_cycle=(self.total_it + 1) % (1 + self.d_steps_per_g) == 0)
             out = {"d_fake": loss_fake.detach(), "d_real": loss_real.detach()}
         self.total_it += 1
         return out
@@ -302,12 +328,14 @@ class CycleGraph:
         # real: inside the warm-up it would be rolled back with the snapshot (one update silently lost), and on the re-capture
         # path (warmup = 0) its finish() / step() would be recorded into the graph instead of executed
         self.trainer.finish_pending()
+        self.trainer.cancel_sn_prefetch()   # (a spectral-norm step computed ahead by eager iterations: the snapshot is of the last FORWARD's u / v)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             snap = self._snapshot() if (warmup and self.restore_after_warmup) else None
             for _ in range(warmup):
                 self._run()
+            self.trainer.cancel_sn_prefetch()   # (the warm-up's last D step prefetched for a G step the capture must compute itself)
             if snap is not None:
                 self._restore(snap)
         torch.cuda.current_stream().wait_stream(side)

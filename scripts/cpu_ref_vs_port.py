@@ -125,11 +125,20 @@ if __name__ == "__main__":
     ncpu = os.cpu_count()
     print(f"# host: {cpu_model()}, {ncpu} hardware threads (the build container, NOT the GPU box); torch {torch.__version__} CPU, fp32")
     print("# samples/s, the REAL reference (/root/reference/code executed) beside bench.py's ports, same tensors, same thread count")
+    js = {"host": cpu_model(), "hardware_threads": ncpu, "where": "build container (the reference tree does not exist on the GPU box)",
+          "how": "python -O scripts/cpu_ref_vs_port.py --json profiles/cpu_port_over_reference.json", "proj": {}, "gan": {}}
     for thr in (1, ncpu):
         r, nr, p, np_ = proj(thr)
+        js["proj"][str(thr)] = {"reference_samples_per_s": r, "port_samples_per_s": p, "port_over_reference": p / r,
+                                "note": "port = oracle/p_oracle.c, scalar, always 1 thread"}
         print(f"projection fwd+bwd, 8 x 2048 pts -> 128^3, {thr:2d} thread(s): reference {r:8.2f} ({nr} runs)   port oracle/p_oracle.c (always 1 thread) "
               f"{p:8.2f} ({np_} runs)   port / reference = {p / r:.2f}")
     for thr in (1, ncpu):
         r, nr, p, np_ = gan(thr)
+        js["gan"][str(thr)] = {"reference_samples_per_s": r, "port_samples_per_s": p, "port_over_reference": p / r,
+                               "note": "port = oracle/gan_cpu.py on the same thread count"}
         print(f"GAN cycle (1 G + 2 D steps, Adam), batch 2, 256^2, {thr:2d} thread(s): reference {r:8.3f} ({nr} cycles)   port oracle/gan_cpu.py "
               f"{p:8.3f} ({np_} cycles)   port / reference = {p / r:.2f}")
+    if "--json" in sys.argv:
+        import json
+        json.dump(js, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)

@@ -45,6 +45,14 @@ def main(fetch_csv, write_csv, stats_csv, out_json):
             e["rocprof_avg_us"] = dur[fam][1] / dur[fam][0] / 1e3
             e["rocprof_calls"] = dur[fam][0]
         out[fam] = e
+    # the sources these counters were collected on (2dimageto3dmodel_amd/build.py source_hash): bench.py reports the traffic only for this tree
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("m355_build", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                             "2dimageto3dmodel_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out["_csrc_sha256"] = mod.source_hash()
     json.dump(out, open(out_json, "w"), indent=1, sort_keys=True)
     print(json.dumps(out.get("k_conv_glds", {})))
 

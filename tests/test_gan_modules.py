@@ -652,6 +652,61 @@ def test_second_stream_branches_change_no_bit(monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
+def test_spectral_norm_prefetch_changes_no_bit(monkeypatch):
+    """gan_ops.SpectralNormGroup.prefetch (round 6): the power iteration + bf16 weight views of a network's NEXT forward issued on a
+    second stream as soon as its weights are final (train.GanTrainer._prefetch_sn).  An execution detail: three cycles with it must
+    be BIT-identical to three cycles without, eagerly and as hipGraph replays; a stale prefetch (weights written behind its back)
+    must be undone, not consumed; state_dict() must show the u / v of the last forward."""
+    pkg = importlib.import_module("2dimageto3dmodel_amd")
+    train = importlib.import_module("2dimageto3dmodel_amd.train")
+    gops = importlib.import_module("2dimageto3dmodel_amd.gan_ops")
+    batches = _cycle_batches(4, 128, seed0=6600)
+
+    def run(prefetch, graph=False, meddle=False):
+        monkeypatch.setattr(gops, "SN_PREFETCH_ON", prefetch)
+        torch.manual_seed(661)
+        tr = train.GanTrainer(_trainer_args(), device="cuda:0", mesh_template=None, capturable=graph)
+        tr.train()
+        losses = []
+        if graph:
+            cyc = tr.capture_cycle([b for b, _ in batches], epoch=0, noises=[z for _, z in batches])
+            for _ in range(3):
+                losses += [float(v) for v in cyc.replay().values()]
+        else:
+            for k in range(3):
+                for i, (b, z) in enumerate(batches):
+                    losses += [float(v) for v in tr.iteration(*b, noise=z, epoch=0).values()]
+                    if meddle and k == 1 and i == 1:
+                        # behind a pending prefetch's back: an in-place write (same values) bumps the version counters -> stale
+                        with torch.no_grad():
+                            for p in list(tr.generator.parameters()) + list(tr.discriminator.parameters()):
+                                p.mul_(1.0)
+        torch.cuda.synchronize()
+        pend = [net._sn_group()._pending is not None for net in (tr.generator, tr.discriminator)]
+        return _state_bits(tr), losses, pend        # (_state_bits -> Module.state_dict() undoes a pending step)
+
+    prev = pkg.set_deterministic(True)
+    try:
+        s_off, l_off, _ = run(False)
+        s_on, l_on, pend = run(True)
+        assert gops._SN_SIDE, "no prefetch ran"
+        assert all(pend), pend                      # (eager: the last D step prefetched for the next cycle's G step)
+        s_med, l_med, _ = run(True, meddle=True)
+        s_g_on, l_g_on, _ = run(True, graph=True)
+        s_g_off, l_g_off, _ = run(False, graph=True)
+    finally:
+        pkg.set_deterministic(prev)
+    assert l_on == l_off, (l_on, l_off)
+    _assert_bit_identical(s_on, s_off, "spectral-norm prefetch on vs off")
+    assert l_med == l_off
+    _assert_bit_identical(s_med, s_off, "stale prefetch undone")
+    assert l_g_on == l_g_off, (l_g_on, l_g_off)
+    _assert_bit_identical(s_g_on, s_g_off, "spectral-norm prefetch inside a captured cycle")
+    _assert_bit_identical(s_g_on, s_off, "captured cycle with prefetch vs eager without")
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
 def test_deterministic_cycles_at_256_in_every_execution_mode():
     """The benchmarked resolution (256^2; batch 16 keeps it short): eight training cycles run eagerly on one stream, eagerly with the
     small branches on the second stream, and as hipGraph replays with either -- four trainers from one seed on the same batches,
