@@ -135,6 +135,14 @@ SIGNATURES = {
     "m355_bn_bwd_finalize": (c_int, [_P, c_int, c_float, _P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P,
                                      _P]),
     "m355_bn_bwd_coeffs": (c_int, [_P, c_float, _P, _P, _P, c_int, _P, _P, _P]),
+    "m355_ipc_region_bytes": (c_size_t, []),
+    "m355_ipc_max_floats": (c_int, []),
+    "m355_ipc_alloc": (c_int, [_P, _P]),
+    "m355_ipc_open": (c_int, [_P, _P]),
+    "m355_ipc_close": (c_int, [_P]),
+    "m355_ipc_free": (c_int, [_P]),
+    "m355_ipc_channels": (c_int, []),
+    "m355_ipc_allreduce": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P]),
 }
 
 

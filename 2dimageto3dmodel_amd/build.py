@@ -35,6 +35,7 @@ SOURCES = [
     ("gan_elem.hip", []),
     ("gan_glue.hip", []),
     ("gan_io.hip", []),
+    ("ipc_exchange.hip", []),
     ("mesh_deform.hip", STRICT),
     ("dibr_raster.hip", STRICT),
 ]

@@ -24,7 +24,7 @@ void note_kernel(const char *name) { g_kernel = name; }
 extern "C" const char *m355_last_error(void) { return m355::g_err; }
 /* kernel family the calling thread's last conv2d entry point dispatched to (what rocprofv3 will list) */
 extern "C" const char *m355_last_kernel(void) { return m355::g_kernel; }
-extern "C" int m355_abi_version(void) { return 3; }
+extern "C" int m355_abi_version(void) { return 4; }
 /* bytes of an ACTIVATION element the conv / elementwise entry points of this build read and write: 2 = bf16 (the product), 4 = fp32
  * (the EXACT build, -DM355_EXACT: csrc/conv_exact.hip) */
 extern "C" int m355_act_bytes(void)

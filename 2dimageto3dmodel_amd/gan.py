@@ -171,6 +171,7 @@ class ResBlockUp(nn.Module):
 
 class Generator(nn.Module):
     """models/gan.py:314-426"""
+    grad_barrier = None   # callable run in the backward pass when the trunk's gradient arrives (gan_ops.GradBarrier)
 
     def __init__(self, args, emb_dim, symmetric=True, mesh_head=True):
         super().__init__()
@@ -232,6 +233,11 @@ class Generator(nn.Module):
         if a.conditional_text:
             att_out, attention_map = self.att(G.to_nchw_f32(x), *caption)
             x = x + G.to_nhwc_bf16(att_out)
+        # data parallel: every gradient of blk3a .. conv_final and of the mesh head flows back through x -- when x's gradient arrives,
+        # those layers' weight gradients are complete and their all-reduce can start under the backward of blk2 / blk1 / fc
+        # (train.GanTrainer sets grad_barrier; None on a single GPU)
+        if self.grad_barrier is not None and torch.is_grad_enabled() and x.requires_grad:
+            x = G.GradBarrier.apply(x, self.grad_barrier)
         # the mesh head (blk3_mesh + conv_mesh on 32 x 16 maps: small, latency-bound layers) does not depend on the texture branch
         # below it: it runs on the second stream and fills the gaps of blk3a .. conv_final (gan_ops.Fork)
         sym = G.HT_SYMM if self.symmetric else 0

@@ -113,6 +113,22 @@ class Fork:
                 t.record_stream(self.main)
 
 
+class GradBarrier(torch.autograd.Function):
+    """identity; its backward calls `fn()` before passing the gradient on.  Placed on a tensor every gradient of a sub-network flows
+    through (the generator's trunk), it marks the point of the backward pass where that sub-network's parameter gradients are
+    complete -- train.GanTrainer issues their all-reduce there, under the rest of the pass (parallel.BucketedGradReducer)"""
+
+    @staticmethod
+    def forward(ctx, x, fn):
+        ctx.fn = fn
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.fn()
+        return g, None
+
+
 def fork_ok(*ts):
     """run a branch that reads `ts` on the second stream?  (CUDA tensors, and a batch small enough to leave power headroom)"""
     return STREAMS_ON and all(t is None or (torch.is_tensor(t) and t.is_cuda) for t in ts) and ts[0] is not None and \
@@ -943,7 +959,7 @@ class CbnActFn(torch.autograd.Function):
             # device (ragged shards are handled like the reference's _data_parallel_master, no host round trip)
             vec = torch.empty(2 * c + 1, dtype=torch.float32, device=dev)
             launch("bn_sync_pack", ptr(part), nblk, c, count, ptr(vec), stream())
-            dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+            _sync_sum(vec, (running_mean.data_ptr(), "fwd"))
             _count_syncbn()
             part, nblk, cnt_dev = vec, 1, vec[2 * c:]
         coef = torch.empty((2 * n + 2, c), dtype=torch.float32, device=dev)   # a[N,C] | b[N,C] | mean | rstd
@@ -955,6 +971,7 @@ class CbnActFn(torch.autograd.Function):
                stream())
         ctx.save_for_backward(x, coef, gamma, cnt_dev)
         ctx.cfg = (slope, count, (0 if res is None else (2 if res_w else 1)), sync)
+        ctx.site = running_mean.data_ptr()   # (the layer: keys the exchange channel of its SyncBN messages, parallel.syncbn_all_reduce)
         return y
 
     @staticmethod
@@ -974,7 +991,7 @@ class CbnActFn(torch.autograd.Function):
         launch("bn_bwd_finalize", ptr(part), nblk, count, ptr(gamma), int(gamma.stride(0)), n, c, ptr(mean), ptr(rstd), 1,
                ptr(dgamma), ptr(dbeta), ptr(A), ptr(Bc), ptr(Cc), ptr(m), stream())
         if sync:
-            dist.all_reduce(m, op=dist.ReduceOp.SUM)
+            _sync_sum(m, (ctx.site, "bwd"))
             _count_syncbn()
             launch("bn_bwd_coeffs", ptr(m), count, ptr(cnt_dev), ptr(mean), ptr(rstd), c, ptr(Bc), ptr(Cc), stream())
         dx = torch.empty_like(x)
@@ -987,6 +1004,13 @@ class CbnActFn(torch.autograd.Function):
             dres = torch.empty((n, h // 2, w // 2, c), dtype=dy.dtype, device=dy.device)
             launch("fold2x2", ptr(dy), ptr(dres), n, h // 2, w // 2, c, stream())
         return (dx, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None, None, None, None, None, dres, None, None, None)
+
+
+def _sync_sum(vec, site):
+    """a SyncBN message: RCCL all-reduce, or -- M355_SYNCBN_IPC=1 -- the one-launch exchange over peer-mapped memory (`site`: layer and
+    direction, the exchange's channel)"""
+    from . import parallel
+    parallel.syncbn_all_reduce(vec, site)
 
 
 def _count_syncbn():

@@ -4,6 +4,7 @@ modules: schedule 1 generator step : d_steps_per_g discriminator steps, Adam(bet
 The mesh smoothness regulariser of the G step (main.py:697-705) is applied when the trainer is given a
 `mesh_template` (2dimageto3dmodel_amd.mesh.MeshTemplate).  Not reproduced: the text encoder."""
 import math
+import os
 import warnings
 
 import torch
@@ -61,13 +62,25 @@ class GanTrainer(torch.nn.Module):
         # betas=(0, 0.9) as main.py:588-589 (floats: torch >= 2.10 rejects the int/float mix)
         # capturable: the step counters live on the device, so a whole cycle can be recorded into a hipGraph
         # fused: one multi-tensor kernel per step instead of ~10 foreach kernels (same update rule, main.py:588-589)
-        import os
         fused = torch.device(device).type == "cuda" and not os.environ.get("M355_NO_FUSED_ADAM")
         self.optimizer_g = torch.optim.Adam(self.generator.parameters(), lr=lr_g, betas=(0.0, 0.9), capturable=capturable,
                                             fused=fused)
         self.optimizer_d = torch.optim.Adam(self.discriminator.parameters(), lr=lr_d, betas=(0.0, 0.9), capturable=capturable,
                                             fused=fused)
-        self.reduce_g = P.FlatGradReducer(self.generator.parameters())
+        # data parallel: the generator's gradients travel as TWO messages.  The convs of blk3a .. conv_final and of the mesh head are
+        # complete when the backward pass reaches the trunk (gan_ops.GradBarrier in Generator.forward): their all-reduce is issued
+        # there and runs under the backward of blk2 / blk1 / fc; everything else (fc, blk1, blk2, the embeddings and every conditioning
+        # Linear -- one batched GEMM whose backward runs last) is complete only at the end.  Same averages as one flat message.
+        early = []
+        for name, m in self.generator.named_children():
+            if name in ("blk3a", "blk3b", "blk3c", "blk4", "blk5", "blk6", "blk3_mesh"):
+                early += [p for c in (m.conv1, m.conv2, m.shortcut) for p in c.parameters()]
+            elif name in ("conv_final", "conv_mesh"):
+                early += list(m.parameters())
+        early_ids = {id(p) for p in early}
+        late = [p for p in self.generator.parameters() if id(p) not in early_ids]
+        self.reduce_g = P.BucketedGradReducer([early, late])
+        self.overlap_g = not os.environ.get("M355_NO_G_BUCKETS")
         self.reduce_d = P.FlatGradReducer(self.discriminator.parameters())
         self.total_it = 0
         # data parallel: the discriminator's gradient all-reduce (14 MB) is issued asynchronously after its backward and awaited
@@ -117,13 +130,21 @@ class GanTrainer(torch.nn.Module):
         with torch.no_grad():
             return self.generator_running_avg(noise, C, caption, return_attention=True)
 
+    def _early_grads_ready(self):
+        """(from the generator's backward, gan_ops.GradBarrier) the trunk's gradient has arrived: run the queued weight-gradient
+        epilogues -- they write the .grad of blk3a .. conv_final and the mesh head -- and send those gradients on their way"""
+        CV.flush_wgrad_finish()
+        self.reduce_g.start_bucket(0)
+
     def finish_pending(self):
         """complete a discriminator step whose gradient all-reduce is still in flight (see overlap_comm)"""
         if self._pending_d:
             self._pending_d = False
             self.reduce_d.finish()
             self.optimizer_d.step()
-            self._prefetch_sn(self.discriminator)
+            # (total_it already counts the pending step: a multiple of the cycle length = that step closed a cycle, and the forward this
+            # prefetch serves belongs to the next one -- not issued inside a hipGraph capture, which must end with every stream joined)
+            self._prefetch_sn(self.discriminator, cross_cycle=self.total_it % (1 + self.d_steps_per_g) == 0)
 
     # ---- spectral norm ahead of its forward (gan_ops.SpectralNormGroup.prefetch).  A network's power iteration + bf16 weight views
     # depend on its weights and u / v only, so they are issued on a second stream as soon as those are final for the next forward:
@@ -211,6 +232,7 @@ class GanTrainer(torch.nn.Module):
             d_params = [p for p in self.discriminator.parameters() if p.requires_grad]
             for p in d_params:
                 p.requires_grad_(False)
+            self.generator.grad_barrier = self._early_grads_ready if (self.overlap_g and P.collectives_on()) else None
             try:
                 loss, _, pred_mesh = self('g', None, X_alpha, None, C, caption, noise)
                 loss = loss.mean()
@@ -225,6 +247,7 @@ class GanTrainer(torch.nn.Module):
                     with CV.deferred_wgrad_finish():
                         loss.backward()
             finally:
+                self.generator.grad_barrier = None
                 for p in d_params:
                     p.requires_grad_(True)
             self.reduce_g()

@@ -255,7 +255,7 @@ def parity_check_gan(trainer, R):
     err_logit = max(float((got.cpu() - want).abs().max() / max(1.0, float(want.abs().max()))) for got, want in zip(disc, disc_r))
     # (the generator's hinge loss is minus the mean logit: its error is the logits' error -- a few 1e-3 of their magnitude, which
     # grows over the benchmarked cycles -- not the 1e-2 absolute of freshly initialised networks)
-    err_loss = abs(float(loss.mean()) - float(loss_r.mean())) / max(1.0, abs(float(loss_r.mean())))
+    err_loss = abs(float(loss.mean().detach()) - float(loss_r.mean().detach())) / max(1.0, abs(float(loss_r.mean().detach())))
     ok = bool(e.mean().item() < 9e-3 and e.max().item() < 1.8e-1 and err_logit < 6e-2 and err_loss < 4e-2)
     return {"ok": ok, "samples": B, "texture_mean_abs_err": e.mean().item(), "texture_max_abs_err": e.max().item(),
             "logit_rel_err": err_logit, "loss_rel_err": err_loss, "checker": "oracle/gan_cpu.py"}
@@ -321,7 +321,7 @@ def parity_check_gan_steps(trainer, R, exact=False):
         loss.mean().backward()
         rel = lambda a, b: float((a.detach().cpu() - b.detach()).abs().max() / max(1.0, float(b.detach().abs().max())))
         err_logit = max(rel(a, b) for a, b in zip(disc, disc_g_r))
-        err_loss = abs(float(loss.mean()) - float(loss_r.mean())) / max(1.0, abs(float(loss_r.mean())))
+        err_loss = abs(float(loss.mean().detach()) - float(loss_r.mean().detach())) / max(1.0, abs(float(loss_r.mean().detach())))
         named_g = dict(Gm.named_parameters())
 
         def cmp(named, ref):
@@ -345,8 +345,8 @@ def parity_check_gan_steps(trainer, R, exact=False):
         loss_fake, loss_real = crit.d_losses(disc2, mask2, trainer._d_weight())
         (loss_fake.mean() + loss_real.mean()).backward()
         err_logit_d = max(rel(a, b) for a, b in zip(disc2, disc_d_r))
-        err_loss_d = max(abs(float(loss_fake.mean()) - float(lf_r.mean())) / max(1.0, abs(float(lf_r.mean()))),
-                         abs(float(loss_real.mean()) - float(lr_r.mean())) / max(1.0, abs(float(lr_r.mean()))))
+        fl = lambda t: float(t.mean().detach())
+        err_loss_d = max(abs(fl(loss_fake) - fl(lf_r)) / max(1.0, abs(fl(lf_r))), abs(fl(loss_real) - fl(lr_r)) / max(1.0, abs(fl(lr_r))))
         cos_d, l2_d = cmp(dict(Dm.named_parameters()), ref_d)
         torch.cuda.synchronize()
     finally:
@@ -466,41 +466,48 @@ def exact_build_cycle(trainer, batches, gargs, template, dev):
     B = batches[0][0].shape[0]
     noises = [torch.randn(B, trainer.latent_dim, generator=torch.Generator().manual_seed(80 + i)).to(dev) for i in range(len(batches))]
 
+    def cycle(tr):
+        per_it = []
+        for b, z in zip(batches, noises):
+            per_it.append({k: float(v) for k, v in tr.iteration(*b, noise=z).items()})
+        tr.finish_pending()
+        return per_it
+
+    def fresh():
+        tr = train.GanTrainer(gargs, device=dev, mesh_template=template)
+        for m, sd in zip((tr.generator, tr.generator_running_avg, tr.discriminator), sds):
+            m.load_state_dict(sd)
+        tr.train()
+        tr.epoch = 0
+        return tr
+
     def one(exact):
         prev = lib.set_exact(True) if exact else None
         try:
-            tr = train.GanTrainer(gargs, device=dev, mesh_template=template)
-            for m, sd in zip((tr.generator, tr.generator_running_avg, tr.discriminator), sds):
-                m.load_state_dict(sd)
-            tr.train()
-            tr.epoch = 0
-            out = {}
-            if not exact:   # (the product build's first cycle pays allocator growth and lazy tables: one untimed cycle first)
-                for b, z in zip(batches, noises):
-                    tr.iteration(*b, noise=z)
-                tr.finish_pending()
-                for m, sd in zip((tr.generator, tr.generator_running_avg, tr.discriminator), sds):
-                    m.load_state_dict(sd)
-                tr.total_it = 0
+            if not exact:   # (the product build's first cycle pays allocator growth and lazily built tables: a throw-away trainer first)
+                cycle(fresh())
+            tr = fresh()   # fresh Adam state in BOTH builds: the same optimiser steps from the same weights
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for b, z in zip(batches, noises):
-                out.update(tr.iteration(*b, noise=z))
-            tr.finish_pending()
+            per_it = cycle(tr)
             torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) * 1e3
-            return ms, {k: float(v) for k, v in out.items()}
+            return (time.perf_counter() - t0) * 1e3, per_it
         finally:
             if exact:
                 lib.set_exact(prev)
 
-    ms_x, loss_x = one(True)
-    ms_p, loss_p = one(False)
-    rel = {k: abs(loss_p[k] - loss_x[k]) / max(1.0, abs(loss_x[k])) for k in loss_x}
-    return {"ms_per_cycle": ms_x, "batch": B, "library": lib.EXACT_LIB, "losses": loss_x,
-            "product_same_weights_same_noise": {"ms_per_cycle": ms_p, "losses": loss_p, "note": "one cycle, fresh Adam state, second cycle of a "
-                                                "fresh trainer (Adam's first step after a reload): not the steady-state figure of `gan_ms_per_cycle`"},
-            "product_vs_exact_loss_rel_err": rel, "product_vs_exact_loss_rel_err_max": max(rel.values()),
+    ms_x, it_x = one(True)
+    ms_p, it_p = one(False)
+    relerr = lambda a, b: {k: abs(a[k] - b[k]) / max(1.0, abs(b[k])) for k in b}
+    # iteration 0 = the G step: both builds evaluate the SAME weights on the same inputs (a pure forward comparison at the timed batch);
+    # iterations 1, 2 = the D steps, behind optimiser steps of Adam's first kind (lr * sign(g): near-zero gradients may flip between
+    # the builds, and the second D step sees the first one's update)
+    rel = [relerr(p_, x_) for p_, x_ in zip(it_p, it_x)]
+    return {"ms_per_cycle": ms_x, "batch": B, "library": lib.EXACT_LIB, "losses_per_iteration": it_x,
+            "product_same_weights_same_noise": {"ms_per_cycle": ms_p, "losses_per_iteration": it_p,
+                                                "note": "one cycle of a fresh trainer (Adam's first steps): not the steady-state `gan_ms_per_cycle`"},
+            "product_vs_exact_loss_rel_err_per_iteration": rel,
+            "product_vs_exact_loss_rel_err_g_step": max(rel[0].values()),
             "note": "the timed `value` is measured on the product library (bf16 MFMA, fp32 accumulate); the EXACT build is the one that "
                     "meets the 1e-4 loss / 1e-3 gradient contract against the reference (parity_gan_steps.exact: loss_rel_err vs "
                     "oracle/gan_cpu.py at batch 8) and costs ms_per_cycle at the timed batch"}
@@ -662,8 +669,11 @@ def main():
                     help="weak: --batch samples on EVERY GPU (global = N x batch); strong: --batch is the GLOBAL batch, split N ways "
                          "(SURVEY 8d cfg 4: global 64 split 8 ways)")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the GAN cycle from ONE captured hipGraph (GanTrainer.capture_cycle) instead of ~750 launches "
-                         "issued from Python: the host needs ~13 ms per cycle whatever the batch, which bounds small per-GPU batches")
+                    help="replay the GAN cycle from ONE captured hipGraph (GanTrainer.capture_cycle) instead of ~650 launches "
+                         "issued from Python: the host needs ~13 ms per cycle whatever the batch, which bounds small per-GPU batches.  "
+                         "ON BY DEFAULT at <= 32 samples per GPU on one GPU (BASELINE configs[2]: batch 16 eager 15.3 ms per cycle, "
+                         "replayed 10.0 ms, same box); at batch 64 the eager cycle is the faster one (26.3 vs 26.6-27.0 ms)")
+    ap.add_argument("--no-graph", action="store_true", help="issue the GAN cycle eagerly at every batch")
     args = ap.parse_args()
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
@@ -698,6 +708,10 @@ def main():
 
     B, N, S, R = (args.batch // world if args.scaling == "strong" else args.batch), args.points, args.grid, args.res
     do_p, do_g = args.workload in ("both", "proj"), args.workload in ("both", "gan")
+    # small per-GPU batches are host-bound when every kernel is launched from Python: replay the captured cycle instead (one GPU: RCCL
+    # collectives inside a capture have run on one rank only, tests/test_distributed_gpu.py -- N > 1 stays opt-in)
+    if do_g and not args.no_graph and B <= 32 and world == 1:
+        args.graph = True
 
     if do_p:
         pc, q, sc, mask = make_clouds(B, N, S, 1234 + 2 + 17 * rank, dev)
@@ -747,6 +761,8 @@ def main():
         def step_g():   # noqa: F811  (the timed region replays; the per-kernel HIP-event pass below runs the eager cycle)
             last.update(cyc.replay())
 
+    # (the two halves on two streams -- the projection half issued on its own stream and joined at the end of the step -- measured equal:
+    # 2477 / 2468 serial vs 2469 / 2480 samples/s overlapped, same box, scripts/r06_runs/r06_run5.sh: kept serial)
     def step():
         if do_p:
             step_p()
@@ -799,6 +815,7 @@ def main():
     torch.cuda.synchronize()
     kt = pkg._lib.collect_kernel_timers()  # name -> (launches, total_ms, total algorithmic work)
     allreduce_ms = par.allreduce_ms() / args.steps
+    allreduce_exposed_ms = par.allreduce_exposed_ms() / args.steps
     par.reset_stats()
     pkg._lib.enable_kernel_timers(False)
     gops.STREAMS_ON = streams_were_on
@@ -847,7 +864,11 @@ def main():
                        "gan_streams": 2 if (do_g and streams_were_on) else 1,
                        "deterministic": bool(pkg.is_deterministic()),
                        "losses": {k: float(v.detach() if torch.is_tensor(v) else v) for k, v in last.items()}},
+            # gradient all-reduces (G: two messages, the first issued inside the backward; D: one, left in flight under the next
+            # generator forward): issue-to-completion as the compute stream sees it, and the part of it that stream spent WAITING
             "allreduce_ms_per_step": allreduce_ms,
+            "allreduce_exposed_ms_per_step": allreduce_exposed_ms,
+            "allreduce_overlapped_ms_per_step": max(0.0, allreduce_ms - allreduce_exposed_ms),
             "grad_allreduces_per_step": coll["grad_allreduces"] / args.steps,
             "grad_allreduce_mb_per_step": coll["grad_allreduce_bytes"] / args.steps / 1e6,
             "syncbn_collectives_per_step": coll["syncbn_collectives"] / args.steps,
@@ -888,7 +909,7 @@ def main():
         if do_p:
             par_chk = parity_check(elf, crit, pc, q, sc, mask, S)
             out["parity_ok"], out["parity"] = par_chk["ok"], par_chk
-        if do_g and world == 1 and not args.graph:   # (N > 1: a rank-0-only forward would wait for the other ranks' SyncBN messages)
+        if do_g and world == 1:   # (N > 1: a rank-0-only forward would wait for the other ranks' SyncBN messages)
             gan_chk = parity_check_gan(trainer, R)
             out["parity_ok"] = bool(out.get("parity_ok", True) and gan_chk["ok"])
             out["parity_gan"] = gan_chk

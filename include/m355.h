@@ -34,7 +34,7 @@ typedef enum {
 const char *m355_last_error(void);
 /* name of the kernel family the calling thread's last m355_conv2d_* call dispatched to (profiling aid) */
 const char *m355_last_kernel(void);
-int m355_abi_version(void);   /* 2: deterministic reductions (round 4): workspaces on cproj_bwd / head_tail_bwd / mesh_flat_fwd, gather tables on the mesh backward, m355_conv2d_wgrad_det; 3 (round 5): m355_act_bytes */
+int m355_abi_version(void);   /* 2: deterministic reductions (round 4): workspaces on cproj_bwd / head_tail_bwd / mesh_flat_fwd, gather tables on the mesh backward, m355_conv2d_wgrad_det; 3 (round 5): m355_act_bytes; 4 (round 6): m355_conv_plan.w_dgrad_row_elems, m355_ipc_* */
 /* Bytes of an ACTIVATION element ("bf16" in the comments below) in this build of the library: 2 = bf16, the product; 4 = fp32, the
  * EXACT build (lib/libm355_exact.so, compiled from the same sources with -DM355_EXACT; SURVEY.md 8c "an fp32-accumulate exact mode
  * for 1e-4 checks").  Same entry points, same argument meaning; the GAN path's activation tensors, conv operands and weight views
@@ -533,6 +533,28 @@ int m355_mesh_normals_bwd(const float *pos, const int *faces, const float *dnorm
 int m355_mesh_flat_fwd(const float *normals, const int *ff, float *loss /*[1]*/, float *ws /*[B]*/, int B, int F, void *stream);
 int m355_mesh_flat_bwd(const float *normals, const int *ff, const int *rev_ptr, const int *rev_idx, const float *gloss /*[1]*/,
                        float *dnormals, int B, int F, void *stream);
+
+/* ---- small-message all-reduce over peer-mapped device memory (round 6; csrc/ipc_exchange.hip) -----------------------------------
+ * The SyncBN statistics exchange of the data-parallel GAN path -- [sum | sum of squares | count] forward, two moment sums backward,
+ * <= 4097 floats, 56 dependent messages per training cycle -- as ONE kernel launch on the compute stream instead of a collective-
+ * library call.  Replaces the master / slave pipes of /root/reference/code/sync_batchnorm/batchnorm.py:110-131 and comm.py:18-133
+ * (what the default build routes through an RCCL all-reduce).  Protocol: every rank owns one fine-grained device region, exports it
+ * (hipIpcGetMemHandle, 64 bytes, through any channel), maps the peers' (m355_ipc_open); a message publishes the local vector with a
+ * release-stored sequence flag, acquire-spins on the peers' flags, adds the W vectors in RANK order (same additions in the same order
+ * on every rank: bit-equal results, deterministic).  Messages are matched per CHANNEL (= call site: one SyncBN layer's forward or backward;
+ * different call sites may execute in different orders on different ranks when branches run on two streams); the per-channel sequence
+ * numbers live in the region, so a launch replays from a hipGraph.  Every wait is bounded (timeout_ms, default 2000): a missing peer raises a bit in *status and the kernel leaves. */
+#define M355_IPC_MAX_RANKS 16
+#define M355_IPC_CHANNELS 64
+size_t m355_ipc_region_bytes(void);
+int m355_ipc_max_floats(void);
+int m355_ipc_channels(void);
+int m355_ipc_alloc(void **region, void *handle64);
+int m355_ipc_open(const void *handle64, void **region);
+int m355_ipc_close(void *region);
+int m355_ipc_free(void *region);
+int m355_ipc_allreduce(float *inout, int n, void *const *regions /*[world], host array of device pointers*/, int rank, int world,
+                       int channel, unsigned *status /*device word*/, int timeout_ms, void *stream);
 
 #ifdef __cplusplus
 }

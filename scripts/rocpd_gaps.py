@@ -1,5 +1,6 @@
 """Busy / idle anatomy of a rocprofv3 kernel trace (rocpd SQLite): python scripts/rocpd_gaps.py in.db [tail_fraction]
-Over the last `tail_fraction` (default 0.5) of the trace -- the timed replays, past warm-up and capture -- prints the wall span, the
+Over the last `tail_fraction` (default 0.5) of the LAUNCHES (not of the time: a capture pass is a long pause without kernels) -- the
+timed replays, past warm-up and capture -- prints the wall span, the
 UNION of kernel intervals (two streams overlap), the idle time between kernels, the number of launches, and the kernels by total time."""
 import sqlite3
 import sys
@@ -8,8 +9,7 @@ import sys
 def main(db_path, frac=0.5):
     cur = sqlite3.connect(db_path).cursor()
     rows = sorted((s, e, name) for name, s, e in cur.execute("select name, start, end from kernels"))
-    t_lo = rows[0][0] + (rows[-1][1] - rows[0][0]) * (1.0 - frac)
-    rows = [r for r in rows if r[0] >= t_lo]
+    rows = rows[int(len(rows) * (1.0 - frac)):]
     span = rows[-1][1] - rows[0][0]
     busy, cur_s, cur_e = 0, rows[0][0], rows[0][1]
     gaps = []

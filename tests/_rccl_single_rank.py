@@ -84,7 +84,20 @@ def overlap_probe():
             torch.cuda.synchronize()
             states.append([v.detach().clone() for v in t.state_dict().values()] +
                           [sv.detach().clone() for p_ in t.discriminator.parameters() for sv in t.optimizer_d.state[p_].values() if torch.is_tensor(sv)])
-        return {"pending_after_last_iteration": pend, "bit_identical": all(torch.equal(a, b) for a, b in zip(*states))}
+        # the generator's gradients as two messages (the first issued from inside the backward, parallel.BucketedGradReducer) against
+        # one flat message at the end
+        torch.manual_seed(13)
+        t = train.GanTrainer(gargs, device=dev)
+        t.overlap_comm, t.overlap_g = False, False
+        t.train()
+        for _ in range(2):
+            for b, z in zip(batches, noises):
+                t.iteration(*b, noise=z, epoch=0)
+        torch.cuda.synchronize()
+        flat = [v.detach().clone() for v in t.state_dict().values()] + \
+               [sv.detach().clone() for p_ in t.discriminator.parameters() for sv in t.optimizer_d.state[p_].values() if torch.is_tensor(sv)]
+        return {"pending_after_last_iteration": pend, "bit_identical": all(torch.equal(a, b) for a, b in zip(*states)),
+                "buckets_bit_identical": all(torch.equal(a, b) for a, b in zip(states[1], flat))}
     finally:
         pkg.set_deterministic(prev)
 

@@ -37,7 +37,7 @@ def test_ctypes_table_mirrors_header(pkg):
 
 def test_bad_arguments_report_errors_not_crashes(pkg):
     L = pkg._lib.lib()
-    assert L.m355_abi_version() == 3 and L.m355_act_bytes() == 2
+    assert L.m355_abi_version() == 4 and L.m355_act_bytes() == 2
     rc = L.m355_proj_transform_fwd(None, None, None, 1, 1, 1.875, 2.0, None)
     assert rc == -1 and b"null" in L.m355_last_error()
     assert L.m355_proj_ntiles(128) == 256 and L.m355_proj_ntiles(64) == 64 and L.m355_proj_ntiles(512) == 16384

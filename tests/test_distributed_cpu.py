@@ -101,6 +101,42 @@ def _worker(rank, world, port, q):
         assert torch.allclose(pose_w.weight.grad, ref_lin.weight.grad, atol=1e-6)
         with pytest.raises(ValueError):
             par.check_image_groups(K * 3 + 1, 3, K)
+        # ---- BucketedGradReducer + GradBarrier (round 6): the "early" layers' all-reduce is issued from INSIDE the backward pass, when
+        # the gradient reaches the trunk; the averages are the flat reducer's bit for bit, and the barrier fired exactly once with the
+        # early gradients complete and the late ones not yet there
+        torch.manual_seed(300 + rank)
+        trunk, head_a, head_b = torch.nn.Linear(6, 8), torch.nn.Linear(8, 5), torch.nn.Linear(8, 3)
+        for m in (trunk, head_a, head_b):
+            par.broadcast_parameters(m, src=0)
+        early, late = list(head_a.parameters()) + list(head_b.parameters()), list(trunk.parameters())
+        red = par.BucketedGradReducer([early, late])
+        seen = []
+
+        def ready():
+            seen.append((all(p.grad is not None for p in early), any(p.grad is not None for p in late)))
+            assert red.start_bucket(0)
+
+        xin = torch.randn(4, 6) * (rank + 1)
+        t = G.GradBarrier.apply(torch.tanh(trunk(xin)), ready)
+        (head_a(t).pow(2).sum() + head_b(t).sum()).backward()
+        assert seen == [(True, False)], seen
+        local = [p.grad.clone() for p in early + late]
+        red()
+        assert red.started == [False, False]
+        flat_params = [torch.nn.Parameter(p.detach().clone()) for p in early + late]
+        for fp, g in zip(flat_params, local):
+            fp.grad = g.clone()
+        par.FlatGradReducer(flat_params)()
+        for p, fp in zip(early + late, flat_params):
+            assert torch.equal(p.grad, fp.grad)                       # bucketed == flat, bit for bit
+        assert par.stats["grad_allreduces"] >= 3
+        # exposed / overlapped accounting: the waits are a part of the issue-to-completion spans
+        par.reset_stats(time_allreduce=True)
+        for fp, g in zip(flat_params, local):
+            fp.grad = g.clone()
+        par.FlatGradReducer(flat_params)()
+        assert 0.0 <= par.allreduce_exposed_ms() <= par.allreduce_ms() + 1e-6
+        par.reset_stats()
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         import traceback

@@ -89,6 +89,7 @@ def _worker(rank, world, port, q):
         assert tr._pending_d
         tr.finish_pending()
         assert not tr._pending_d
+        assert tr.reduce_g.started == [False, False] and tr.generator.grad_barrier is None
         for p in list(tr.generator.parameters())[:6] + list(tr.discriminator.parameters())[:6]:
             both = [torch.zeros_like(p) for _ in range(world)]
             dist.all_gather(both, p.detach())
@@ -196,11 +197,13 @@ def test_rccl_single_rank():
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     # the asynchronous discriminator all-reduce (left in flight across the iteration boundary) against the synchronous order
-    assert out["overlap"] == {"pending_after_last_iteration": [True, False], "bit_identical": True}, out["overlap"]
+    assert out["overlap"]["pending_after_last_iteration"] == [True, False] and out["overlap"]["bit_identical"] is True, out["overlap"]
     # 1 G step (every CBN layer forward + backward) + 2 D steps (forward under no_grad): 4 SyncBN collectives per layer;
-    # 3 gradient all-reduces
+    # 4 gradient all-reduces (the generator's travel as two messages, the first issued inside its backward: round 6)
     assert out["n_cbn"] == 12
-    assert out["grad_allreduces"] == 3 and out["syncbn_collectives"] == 4 * out["n_cbn"] and out["plain_collectives"] == 0
+    assert out["grad_allreduces"] == 4 and out["syncbn_collectives"] == 4 * out["n_cbn"] and out["plain_collectives"] == 0
+    # ... and the two-message form leaves every weight and Adam moment where the one-message form does (deterministic mode)
+    assert out["overlap"]["buckets_bit_identical"] is True, out["overlap"]
     assert out["allreduce_ms"] > 0
     # two runs of the same cycle differ in the summation order of the split-K weight-gradient atomics, and Adam's first
     # step is lr * sign(g): a near-zero gradient may flip (a 2 * lr = 2e-4 difference on that weight).  The collectives
@@ -280,7 +283,177 @@ def test_bench_two_ranks_sharing_one_gpu():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
-    assert out["grad_allreduces_per_step"] == 3 and out["syncbn_collectives_per_step"] == 56
+    assert out["grad_allreduces_per_step"] == 4 and out["syncbn_collectives_per_step"] == 56
     assert abs(out["grad_allreduce_mb_per_step"] - 75.0) < 3.0 and out["allreduce_ms_per_step"] > 0
+    assert 0.0 <= out["allreduce_exposed_ms_per_step"] <= out["allreduce_ms_per_step"] + 1e-3   # (waits are a part of the spans)
     assert out["value"] > 0 and "cpu_baseline" not in out
     assert all(np.isfinite(v) for v in out["config"]["losses"].values())
+
+
+# ---- round 6: the SyncBN messages as ONE kernel launch over peer-mapped device memory (csrc/ipc_exchange.hip, parallel.IpcAllReduce)
+def _ipc_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        par = importlib.import_module("2dimageto3dmodel_amd.parallel")
+        G = importlib.import_module("2dimageto3dmodel_amd.gan_ops")
+        conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+        train = importlib.import_module("2dimageto3dmodel_amd.train")
+        dev = "cuda:0"
+        torch.cuda.set_device(0)
+        report = {}
+        # (a) the exchange itself: sums equal the rank-ordered sum of the ranks' vectors, bit for bit, on both ranks; more messages
+        # than slots; sizes 1 .. the largest SyncBN message
+        ex = par.IpcAllReduce(dev, timeout_ms=3000)
+        gcpu = torch.Generator().manual_seed(900)
+        for n in (1, 129, 1025, 4097):
+            data = [torch.randn(world, n, generator=gcpu) * 10 ** float(torch.randint(-3, 4, (1,), generator=gcpu)) for _ in range(11)]
+            outs = [ex(d[rank].to(dev).clone()) for d in data]
+            torch.cuda.synchronize()
+            ex.check()
+            for d, o in zip(data, outs):
+                want = d[0].clone()
+                for r in range(1, world):
+                    want = want + d[r]
+                assert torch.equal(o.cpu(), want), (n, (o.cpu() - want).abs().max())
+        # (a2) channels are independent: the ranks issue two call sites in OPPOSITE orders (rank 0 on two streams, as a forked branch
+        # does; rank 1 serially, the other way round) -- a global message order would pair the wrong vectors or wait forever
+        va, vb = torch.full((33,), float(rank + 1), device=dev), torch.full((77,), 10.0 * (rank + 1), device=dev)
+        if rank == 0:
+            s2 = torch.cuda.Stream()
+            s2.wait_stream(torch.cuda.current_stream())
+            ex(va, channel=1)
+            with torch.cuda.stream(s2):
+                ex(vb, channel=2)
+            torch.cuda.current_stream().wait_stream(s2)
+        else:
+            ex(vb, channel=2)
+            ex(va, channel=1)
+        torch.cuda.synchronize()
+        ex.check()
+        assert torch.equal(va.cpu(), torch.full((33,), 3.0)) and torch.equal(vb.cpu(), torch.full((77,), 30.0))
+        # (b) latency of a message as the stream sees it (two processes time-share ONE GPU here: an upper bound for xGMI peers)
+        v = torch.ones(513, device=dev)
+        for _ in range(20):
+            ex(v)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200):
+            ex(v)
+        e1.record()
+        torch.cuda.synchronize()
+        ex.check()
+        report["us_per_message"] = e0.elapsed_time(e1) * 1e3 / 200
+        # (c) a peer that does not show up: the wait is BOUNDED and reported (rank 1 skips one message, then catches up)
+        ex.timeout_ms = 300
+        if rank == 0:
+            ex(torch.ones(8, device=dev))
+            torch.cuda.synchronize()
+            with pytest.raises(RuntimeError, match="did not arrive"):
+                ex.check()
+        dist.barrier()
+        if rank == 1:
+            ex(torch.ones(8, device=dev))      # (finds rank 0's message of that sequence number in place: no wait)
+            torch.cuda.synchronize()
+            ex.check()
+        dist.barrier()
+        ex.timeout_ms = 3000
+        out = ex(torch.full((5,), float(rank + 1), device=dev))   # back in step
+        torch.cuda.synchronize()
+        ex.check()
+        assert torch.equal(out.cpu(), torch.full((5,), float(sum(range(1, world + 1)))))
+        ex.close()
+        # (d) SyncBN through the exchange == SyncBN through torch.distributed, bit for bit; then a training cycle
+        torch.manual_seed(7)
+        full = (torch.randn(2 * world, 12, 10, 64) * 1.3 + 0.2).bfloat16()
+        gamma, beta = 0.1 * torch.randn(2 * world, 64), 0.1 * torch.randn(2 * world, 64)
+        w_out = torch.randn(2 * world, 12, 10, 64).bfloat16()
+        sl = slice(2 * rank, 2 * rank + 2)
+
+        def sbn_pass():
+            xs = full[sl].to(dev).requires_grad_()
+            gs, bs = gamma[sl].to(dev).requires_grad_(), beta[sl].to(dev).requires_grad_()
+            sbn = G.SynchronizedBatchNorm2d(64).to(dev)
+            y = sbn(xs, gs, bs, 0.2)
+            y.backward(w_out[sl].to(dev))
+            torch.cuda.synchronize()
+            return [t.detach().clone() for t in (y, xs.grad, gs.grad, bs.grad, sbn.running_mean, sbn.running_var)]
+
+        os.environ["M355_SYNCBN_IPC"] = "0"
+        ref = sbn_pass()
+        os.environ["M355_SYNCBN_IPC"] = "1"
+        got = sbn_pass()
+        assert par.syncbn_ipc(torch.device(dev)) is not None and par.syncbn_ipc(torch.device(dev)).messages == 2
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+        gargs = argparse.Namespace(norm_g="syncbatch", norm_d="none", conditional_class=True, conditional_color=False,
+                                   conditional_text=False, n_classes=[200], texture_resolution=128, mask_output=True,
+                                   num_discriminators=2, texture_only=False, text_embedding_dim=256)
+        prev = conv.set_deterministic(True)
+
+        def cycle(ipc):
+            os.environ["M355_SYNCBN_IPC"] = "1" if ipc else "0"
+            torch.manual_seed(11)
+            tr = train.GanTrainer(gargs, device=dev)
+            tr.train()
+            g = torch.Generator().manual_seed(50 + rank)
+            B, R = 2, 128
+            for _ in range(3):
+                b = ((torch.rand(B, 3, R, R, generator=g) * 2 - 1).to(dev), (torch.rand(B, 1, R, R, generator=g) > 0.4).float().to(dev),
+                     (0.05 * torch.randn(B, 3, 32, 32, generator=g)).to(dev), torch.randint(0, 200, (B, 1), generator=g).to(dev))
+                z = torch.randn(B, 64, generator=g).to(dev)
+                tr.iteration(*b, noise=z, epoch=0)
+            tr.finish_pending()
+            torch.cuda.synchronize()
+            return [v.detach().clone() for v in tr.state_dict().values()]
+
+        s_rccl = cycle(False)
+        s_ipc = cycle(True)
+        exch = par.syncbn_ipc(torch.device(dev))
+        exch.check()
+        report["messages_per_cycle"] = exch.messages - 2
+        conv.set_deterministic(prev)
+        assert all(torch.equal(a, b) for a, b in zip(s_ipc, s_rccl)), "SyncBN over the exchange changed the training cycle's bits"
+        for t in s_ipc[:12]:
+            both = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(both, t)
+            assert torch.equal(both[0], both[1]), "ranks diverged"
+        os.environ["M355_SYNCBN_IPC"] = "0"
+        q.put((rank, "ok", report))
+    except Exception:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, traceback.format_exc(), {}))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_syncbn_messages_over_peer_mapped_memory():
+    """parallel.IpcAllReduce (csrc/ipc_exchange.hip) with two processes sharing cuda:0 -- rank-ordered sums bit
+    for bit, slot reuse, a bounded and reported wait when a peer is missing, SyncBN and a whole training cycle bit-identical to the
+    torch.distributed path, ranks in lock step.  Prints the per-message latency on this (time-shared) device."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ipc_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=840) for _ in procs]
+    for p in procs:
+        p.join(30)
+    for r, msg, rep in res:
+        assert msg == "ok", f"rank {r}:\n{msg}"
+    print("IpcAllReduce:", [rep for _, _, rep in res])
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "ipc_exchange_report.txt"), "w") as f:
+            f.write(repr([rep for _, _, rep in res]) + "\n")
+    except OSError:
+        pass
+    assert all(rep["messages_per_cycle"] == 4 * 12 for _, _, rep in res), res     # 12 CBN layers at 128^2: fwd x 3 forwards + bwd x 1

@@ -46,7 +46,7 @@ def _dump_report(tag):
 def test_exact_build_identity(exact):
     L = exact.lib()
     assert L.m355_act_bytes() == 4 and exact.act_dtype() == torch.float32 and exact.is_exact()
-    assert L.m355_abi_version() == 3
+    assert L.m355_abi_version() == 4
     conv = importlib.import_module("2dimageto3dmodel_amd.conv")
     d = conv.make_desc(2, 16, 32, 128, 64, 3, 3, 1, 1, 1, 1, 1)
     # no bit masks, no fused statistics, no workspaces: the callers take their generic paths
