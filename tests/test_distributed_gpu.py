@@ -334,6 +334,22 @@ def _ipc_worker(rank, world, port, q):
         torch.cuda.synchronize()
         ex.check()
         assert torch.equal(va.cpu(), torch.full((33,), 3.0)) and torch.equal(vb.cpu(), torch.full((77,), 30.0))
+        # (a3) inside a hipGraph: the per-channel sequence numbers live in device memory, so a captured launch replays (the kernel's
+        # arguments are the same every time; what pairs the ranks' messages is the counter in the region)
+        src, vg = torch.full((65,), float(rank + 1), device=dev), torch.zeros(65, device=dev)
+        torch.cuda.synchronize()
+        dist.barrier()
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph):
+            vg.copy_(src)
+            ex(vg, channel=3)
+            ex(vg, channel=4)
+        for _ in range(5):
+            vg.zero_()
+            gph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(vg.cpu(), torch.full((65,), 2.0 * sum(range(1, world + 1)))), vg[:4]
+        ex.check()
         # (b) latency of a message as the stream sees it (two processes time-share ONE GPU here: an upper bound for xGMI peers)
         v = torch.ones(513, device=dev)
         for _ in range(20):

@@ -652,6 +652,76 @@ def test_second_stream_branches_change_no_bit(monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
+def test_captured_cycle_at_batch16_256_follows_the_cpu_oracle_loop():
+    """BASELINE configs[2] as bench.py now runs it by default (batch 16, 256^2, nd = 2, class-conditional, syncbatch: the captured
+    cycle replayed from one hipGraph): ONE replayed cycle -- G step, D step, D step, each with its Adam(0, 0.9) update -- against the
+    loop of main.py:691-723 restated on the pinned CPU oracle (oracle/gan_cpu.py: g_step / d_step / adam_step) from the same weights,
+    batches and noise.  The G step's loss is a pure forward comparison; behind it every update is Adam's FIRST step (lr * sign(g)), so
+    parameter displacements are compared as tests/test_gan_modules.py::run_trainer_four_iterations compares g_train4: cosine = the
+    share of agreeing signs, and magnitude."""
+    import os
+    from oracle import gan_cpu as gc
+    train = importlib.import_module("2dimageto3dmodel_amd.train")
+    args = _trainer_args(texture_resolution=256)
+    B, R, seed = 16, 256, 9160
+    torch.manual_seed(seed)
+    tr = train.GanTrainer(args, device="cuda:0", mesh_template=None, capturable=True)
+    tr.train()
+    sd_g = {k: v.detach().cpu().clone() for k, v in tr.generator.state_dict().items()}
+    sd_d = {k: v.detach().cpu().clone() for k, v in tr.discriminator.state_dict().items()}
+    ins = [make_inputs(seed + 10 * it, B, R, 200) for it in range(3)]       # (z, c, x_tex, x_alpha, x_mesh)
+    batches = [tuple(t.to("cuda:0") for t in (x_tex, x_alpha, x_mesh, c)) for (_z, c, x_tex, x_alpha, x_mesh) in ins]
+    cyc = tr.capture_cycle(batches, epoch=0, noises=[i[0].to("cuda:0") for i in ins])
+    # (capturing trains nothing: the weights are still the initial ones)
+    assert torch.equal(tr.generator.state_dict()["blk6.conv2.weight_orig"].cpu(), sd_g["blk6.conv2.weight_orig"])
+    out = {k: float(v) for k, v in cyc.replay().items()}
+    torch.cuda.synchronize()
+    # ---- the reference loop on the CPU oracle
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(32, (os.cpu_count() or 1) // 8)))
+    try:
+        wg, wd = gc.Weights(sd_g), gc.Weights(sd_d)
+        pg = {k: v for k, v in wg.store.items() if v.requires_grad}
+        pd = {k: v for k, v in wd.store.items() if v.requires_grad}
+        sg, sdd = {}, {}
+        z, c, x_tex, x_alpha, x_mesh = ins[0]
+        loss_g = gc.g_step(wg, wd, args, z, c, x_alpha)[0].mean()
+        loss_g.backward()
+        gc.adam_step(pg, wg.grads(), sg, 1e-4, 1)
+        ref_d = []
+        for step, (z, c, x_tex, x_alpha, x_mesh) in enumerate(ins[1:], start=1):
+            wd.zero_grad()
+            lf, lr, _ = gc.d_step(wg, wd, args, z, c, x_tex, x_alpha, x_mesh)
+            (lf + lr).mean().backward()
+            gc.adam_step(pd, wd.grads(), sdd, 4e-4, step)
+            ref_d.append((float(lf.mean()), float(lr.mean())))
+    finally:
+        torch.set_num_threads(nthr)
+    _note("b16 graph g loss", abs(out["g"] - float(loss_g)), out["g"])
+    assert abs(out["g"] - float(loss_g)) < 2e-2 * max(1.0, abs(float(loss_g))), (out["g"], float(loss_g))
+    # (the replay returns the LAST D step's losses; that step ran on weights one sign-step of lr_d = 4e-4 away from the first one's)
+    for got, want in ((out["d_fake"], ref_d[-1][0]), (out["d_real"], ref_d[-1][1])):
+        assert abs(got - want) < 6e-2 * max(1.0, abs(want)), (out, ref_d)
+    gp, dp = dict(tr.generator.named_parameters()), dict(tr.discriminator.named_parameters())
+
+    def cos_mag(now, before, want_now):
+        dg = (now.detach().cpu() - before).flatten().double()
+        dw = (want_now.detach() - before).flatten().double()
+        return float(torch.dot(dg, dw) / (dg.norm() * dw.norm() + 1e-300)), float(dg.abs().max() / dw.abs().max())
+
+    for k in ("blk6.conv2.weight_orig", "blk4.conv1.weight_orig", "blk1.norm1.fc_beta.bias"):
+        cs, mg = cos_mag(gp[k], sd_g[k], wg.store[k])
+        _note(f"b16 graph dG {k}", cs, mg)
+        assert cs > 0.85 and abs(mg - 1) < 0.05, (k, cs, mg)          # one Adam step: +-lr on every entry
+    for k in ("d1.conv2.weight_orig", "d1.conv4.weight_orig", "d2.conv3.bias"):
+        cs, mg = cos_mag(dp[k], sd_d[k], wd.store[k])
+        _note(f"b16 graph dD {k}", cs, mg)
+        assert cs > 0.80 and abs(mg - 1) < 0.25, (k, cs, mg)          # two steps; the second on weights the first one's flips moved
+    assert tr.total_it == 3
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
 def test_spectral_norm_prefetch_changes_no_bit(monkeypatch):
     """gan_ops.SpectralNormGroup.prefetch (round 6): the power iteration + bf16 weight views of a network's NEXT forward issued on a
     second stream as soon as its weights are final (train.GanTrainer._prefetch_sn).  An execution detail: three cycles with it must
