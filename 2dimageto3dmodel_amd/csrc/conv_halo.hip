@@ -608,6 +608,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) wbits |= (v[e] > 0.0f ? 1u : 0u) << (16 * j + 4 * g + e);
                             }
+                            // (the cheaper forms -- one multiply + one v_med3 here, the bit-mask factor by v_bfe_i32 / v_bfi below: a quarter
+                            // fewer vector instructions in the masked epilogues, bit-identical outputs -- measured EQUAL on D.conv2-4, same
+                            // box, builds alternated: profiles/r06_epilogue_valu_ab.txt.  The epilogue's instruction count is not what the
+                            // tile's constant is made of.)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * a.slope;
                         }

@@ -195,8 +195,8 @@ class GanTrainer(torch.nn.Module):
                     other.append((v, src[k]))
             ema = self.__dict__["_ema_lists"] = (fl_dst, fl_src, other)
         fl_dst, fl_src, other = ema
-        for v, sv in other:
-            v.copy_(sv)
+        if other:   # (the integer buffers -- num_batches_tracked of every batch norm: one launch, not one device copy per layer)
+            torch._foreach_copy_([v for v, _ in other], [sv for _, sv in other])
         torch._foreach_mul_(fl_dst, alpha)
         torch._foreach_add_(fl_dst, fl_src, alpha=1 - alpha)
 
