@@ -425,8 +425,10 @@ def conv_wgrad(d, x, dy, cin_real=None, raw=False, dbias=None, arena=False, dbia
     if _DETERMINISTIC:
         ws = torch.empty((plan(d).wgrad_det_ws_bytes,), dtype=torch.uint8, device=x.device)
         dw = torch.empty((d.Cout, d.kh, d.kw, d.Cin), dtype=torch.float32, device=x.device)
+        # (issued-MAC ratio: the weight gradient takes the sub-pixel form only where the layer has the 16-entry workspace form -- the
+        # small stages' forward / dgrad do, their weight gradient is the 9-tap one)
         launch("conv2d_wgrad_det", ctypes.byref(d), ptr(x), ptr(dy), ptr(ws), ptr(dw), ptr(dbias), stream(),
-               work=lambda: flops(d, cin_real), tag=lambda: tag(d), exec_ratio=lambda: exec_ratio(d))
+               work=lambda: flops(d, cin_real), tag=lambda: tag(d), exec_ratio=lambda: exec_ratio(d) if _wgrad_ws_bytes(d) else 1.0)
         return dw if raw else dw.permute(0, 3, 1, 2)
     sl = WgradArena.take(n, x.device) if (arena and raw) else None
     if sl is not None:

@@ -941,7 +941,8 @@ static bool up3(const m355_conv_desc *d)
 {
     return d->upsample == 1 && d->stride == 1 && d->kh == 3 && d->kw == 3 && d->pad_h == 1 && d->pad_w == 1;
 }
-static bool subpixel(const m355_conv_desc *d)
+// subpixel_halo: the shapes whose class convs run on the halo kernels -- forward, dgrad AND the 16-entry weight gradient
+static bool subpixel_halo(const m355_conv_desc *d)
 {
 #ifdef M355_EXACT
     return false;
@@ -950,6 +951,25 @@ static bool subpixel(const m355_conv_desc *d)
     const size_t xb = (size_t)d->N * d->H * d->W * d->Cin * 2, yb = (size_t)d->N * d->H * d->W * 4 * d->Cout * 2;
     static const bool off = getenv("M355_NO_SUBPIXEL") != nullptr;   // A/B runs: the 9-tap kernels with the upsample in the halo load
     return xb < (1ull << 31) && yb < (1ull << 31) && !off;
+}
+// subpixel: ... plus (round 6) the SMALL stages whose 9-tap form is not a halo shape either (upsampled width not a multiple of 32 or
+// height not of 8: the generator's 16x8 -> 32x16 layers, blk3a.conv1 / blk3_mesh.conv1 at 256^2).  Their FORWARD and DGRAD take the
+// form on the generic implicit-GEMM kernel -- four class launches are what it already runs for a stride-2 dgrad, and the adjoint is a
+// plain 4x4 stride-2 conv of dy -- with 4/9 of the taps' pixel gathers and MACs; their weight gradient stays the 9-tap one (the
+// 16-entry form exists on the halo tiles only), which is the same operator's gradient.  Only from 4096 stored pixels per launch:
+// below that (the 8x4 stage at batch 64, everything at batch 16) the class GEMMs are a few dozen workgroups with a long K loop, and
+// the split-K form of the 9-tap conv -- whose finishing pass also emits the batch-norm sums -- is the faster one (measured same box,
+// profiles/r06_small_subpixel_ab.txt: blk2.conv1's dgrad 52 -> 96 us in the sub-pixel form; batch 16 +0.07 ms per cycle).
+static bool subpixel(const m355_conv_desc *d)
+{
+#ifdef M355_EXACT
+    return false;
+#endif
+    if (subpixel_halo(d)) return true;
+    if (!up3(d) || d->Cin % 64 || d->Cout % 64) return false;
+    static const bool off = getenv("M355_NO_SUBPIXEL") != nullptr || getenv("M355_NO_SUBPIXEL_SMALL") != nullptr;
+    const bool halo9 = (2 * d->W) % 32 == 0 && (2 * d->H) % 8 == 0;   // (the 9-tap form runs on k_conv_halo with fused statistics: keep it)
+    return !off && !halo9 && (long)d->N * d->H * d->W >= 4096;
 }
 // element offsets of the sub-pixel views inside the forward / dgrad weight buffers of an up3 layer (behind the 3x3 views)
 static size_t up3_fwd_off(const m355_conv_desc *d) { return (size_t)m355::rows_padded(d->Cout) * m355::k_padded(9 * d->Cin); }
@@ -1260,6 +1280,7 @@ static int fwd_splitk(const m355_conv_desc *d)
     if (!d || check_desc(d, "conv2d_fwd_ws")) return 0;
     if (m355::conv_small_eligible(d, 0) || m355::conv_c8_eligible(d, 0)) return 0;
     if (d->Cout % 8 || d->Cout > 2048 || 256 % (d->Cout / 8)) return 0;   // (the finishing pass: 8-channel vectors, 256 / vecs pixel lanes)
+    if (subpixel(d)) return 0;   // (four class launches with 4/9 of the taps instead of K slices of the 9-tap form)
     return m355::splitk_plan(fwd_args(d, nullptr, nullptr, nullptr, nullptr, 1.0f));
 }
 static int fwd_splitk_ppb(const m355_conv_desc *d, int M)   // pixels per workgroup of the finishing pass: ~512 workgroups, whole lanes
@@ -1954,7 +1975,7 @@ extern "C" size_t m355_conv2d_wgrad_det_ws_bytes(const m355_conv_desc *d)
 {
     if (!d || d->Cout <= 0 || d->Cin <= 0 || d->kh <= 0 || d->kw <= 0) return 0;
     // the flag word + kFixCell 64-bit integers per cell (conv_dma.h wg_accum)
-    if (subpixel(d)) return sizeof(long long) * (1 + m355::kFixCell * subpixel_ws_cells(d));   // the 16-entry effective gradient
+    if (subpixel_halo(d)) return sizeof(long long) * (1 + m355::kFixCell * subpixel_ws_cells(d));   // the 16-entry effective gradient
     return sizeof(long long) * (1 + m355::kFixCell * ((size_t)d->Cout * d->kh * d->kw * d->Cin + (size_t)d->Cout));
 }
 
@@ -1967,7 +1988,7 @@ extern "C" int m355_conv2d_wgrad_det(const m355_conv_desc *d, const void *x, con
 #ifdef M355_EXACT
     return conv_wgrad_impl(d, x, dy, dw, dbias, stream, true);   // (already a sequential fp64 sum per element)
 #endif
-    if (subpixel(d)) {
+    if (subpixel_halo(d)) {
         M355_REQUIRE(x && dy && dw, "conv2d_wgrad_det: null pointer");
         return subpixel_wgrad(d, x, dy, dw, dbias, ws, true, st);
     }
@@ -2012,7 +2033,7 @@ extern "C" size_t m355_conv2d_wgrad_ws_bytes(const m355_conv_desc *d)
     if (m355::wgrad_c8_eligible(d, cy)) return sizeof(float) * m355::wgrad_c8_ws_floats(d, cy);
     // upsample + 3x3 in the sub-pixel form: the 16-entry effective gradient (zeroed here, accumulated with fp32 atomics -- NOT the
     // ordered sum of the thin layers: m355_conv2d_wgrad_det is the run-to-run reproducible form of these layers)
-    if (subpixel(d)) return sizeof(float) * subpixel_ws_cells(d);
+    if (subpixel_halo(d)) return sizeof(float) * subpixel_ws_cells(d);
     // (the <= 8-output-channel heads keep their atomics: with up to 512 partial rows of a few thousand elements the ordered sum
     // is the longer tail -- conv_final's wgrad 117.7 -> 155.9 us, D.conv5's 60.0 -> 65.6 us, profiles/r04_thin_rate_b.txt)
     return 0;
@@ -2022,7 +2043,7 @@ extern "C" int m355_conv2d_wgrad_ws(const m355_conv_desc *d, const void *x, cons
                                     void *stream)
 {
     M355_REQUIRE(ws && m355_conv2d_wgrad_ws_bytes(d) > 0, "conv2d_wgrad_ws: this layer has no partial-sum form (m355_conv2d_wgrad_ws_bytes)");
-    if (subpixel(d)) {
+    if (subpixel_halo(d)) {
         M355_REQUIRE(x && dy && dw, "conv2d_wgrad_ws: null pointer");
         return subpixel_wgrad(d, x, dy, dw, dbias, ws, false, (hipStream_t)stream);
     }

@@ -63,6 +63,12 @@ CASES = [
     (1, 16, 64, 64, 128, 3, 1, 1, 1, 2, 1),   # circular W pad, two pixel tiles across W, one chunk
     (2, 8, 32, 64, 64, 3, 1, 1, 1, 0, 1),     # zero W pad, class pairs
     (1, 24, 32, 192, 256, 3, 1, 1, 1, 1, 1),  # three chunks, two 128-channel output tiles
+    # ---- (round 6) the SMALL upsample + 3x3 stages (upsampled width not a multiple of 32): forward and dgrad in the sub-pixel form on the
+    # generic implicit-GEMM kernel (four class launches / the adjoint 4x4 stride-2 conv), weight gradient 9-tap.  The replicate cases
+    # are above ((2, 8, 4, 64, 128), (3, 20, 12, 128, 256), (2, 16, 8, 256, 128)); here the other two W pads and 64 output channels
+    (2, 8, 4, 64, 64, 3, 1, 1, 1, 2, 1),      # circular, G.blk1 -> blk2 size
+    (2, 16, 8, 128, 128, 3, 1, 1, 1, 0, 1),   # zero W pad, two chunks
+    (3, 16, 8, 256, 64, 3, 1, 1, 1, 1, 1),    # G.blk3_mesh.conv1 shape class: 64 output channels, replicate
     # ---- odd kernels with stride 2 (the encoder of models/reconstruction.py:53-63): dgrad through the padded even kernel
     (2, 32, 32, 8, 64, 5, 2, 2, 2, 0, 0),     # conv1e: 5x5 s2 p2 on (4 -> 8) channels
     (2, 16, 16, 64, 128, 3, 2, 1, 1, 0, 0),   # conv2e: 3x3 s2 p1
