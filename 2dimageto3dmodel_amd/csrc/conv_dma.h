@@ -91,6 +91,9 @@ struct ConvArgs {
     // to skws[slice][M][CoutP] and a finishing pass (k_splitk_finish / k_fold_pad) adds them in slice order
     int sk;
     float *skws;
+#ifdef M355_DBG_STAMP
+    unsigned *stamp;   // debug build (scripts/stamp_halo.py): where workgroup (0,0) of k_conv_halo dumps its shader-clock stamps
+#endif
 };
 
 // launch description of the weight-gradient kernels (csrc/conv_mfma.hip, csrc/conv_halo.hip)

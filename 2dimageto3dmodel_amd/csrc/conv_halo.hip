@@ -326,8 +326,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
     constexpr int DBG_STEPS = 96;
     __shared__ unsigned dbg_lds[8 * DBG_STEPS * 4];
     unsigned dbg_i = 0, dbg_t0 = 0, dbg_t1 = 0, dbg_t2 = 0, dbg_t3 = 0, dbg_n0 = 0;
-    const bool dbg_on = NW == 8 && !STATS && a.stats != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
+    const bool dbg_on = NW == 8 && !STATS && a.stamp != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
     const unsigned long long dbg_c0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+    // ... and of the tile epilogue (round 6): per wave and tile [end of the last MFMA step | stores issued | accumulators re-initialised |
+    // next tile's prologue (origin, mask-word loads) done]
+    constexpr int DBG_TILES = 8;
+    __shared__ unsigned dbg_epi[8 * DBG_TILES * 4];
+    int dbg_tile = 0;
+#define HALO_ESTAMP(slot) do { if (dbg_on && dbg_tile < DBG_TILES && lane == 0) dbg_epi[(wave * DBG_TILES + dbg_tile) * 4 + (slot)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HALO_ESTAMP(slot) do { } while (0)
 #endif
 #pragma unroll
     for (int j = 0; j < CJ; ++j) st_tot[j] = 0.0f;
@@ -439,6 +447,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                 rbits_pf[i] = a.bits_in[(pix * (size_t)(a.Cs >> 6) + (size_t)(PAIR ? 0 : (n0 >> 6) + wn)) * 2 + half];
             }
         }
+#ifdef M355_DBG_STAMP
+        __builtin_amdgcn_sched_barrier(0);
+        if (dbg_tile > 0) { --dbg_tile; HALO_ESTAMP(3); ++dbg_tile; }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         for (int sg = 0; sg < NSEG; ++sg) {
             const unsigned char *ha = lds + hb * ABUF;
             // the chunk this segment's slices prefetch (their offsets aoff[] were prepared during the previous segment)
@@ -557,6 +570,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
             advance(cls_cur, cc_cur);
         }
 
+#ifdef M355_DBG_STAMP
+        __builtin_amdgcn_sched_barrier(0);
+        HALO_ESTAMP(0);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         // ---- epilogue of this tile (as k_conv_glds), while the next tile's halo and first weights are in flight:
         // acc[j][i][r] = channel n0 + 64wn + 32j + 8(r>>2) + 4half + (r&3), pixel (2wm+i, tx)
         if (a.fold2) {
@@ -686,8 +704,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                 }
             }
         }
+#ifdef M355_DBG_STAMP
+        __builtin_amdgcn_sched_barrier(0);
+        HALO_ESTAMP(1);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if (!has_next) break;
         init_acc();
+#ifdef M355_DBG_STAMP
+        __builtin_amdgcn_sched_barrier(0);
+        HALO_ESTAMP(2);
+        ++dbg_tile;
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         tp = tp_next;
         // Steps 0 .. RB-2 of the next tile await weights issued in steps -(RB-1) .. -1, i.e. BEFORE the epilogue above: only for
         // those are its stores the youngest operations in flight.  (Step s awaits the weights of step s+L, issued in step
@@ -701,8 +730,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
 #ifdef M355_DBG_STAMP
     if (dbg_on) {
         __syncthreads();
-        unsigned *out = reinterpret_cast<unsigned *>(a.stats);
+        unsigned *out = a.stamp;
         for (int k = tid; k < 8 * DBG_STEPS * 4; k += NW * 64) out[k] = dbg_lds[k];
+        for (int k = tid; k < 8 * DBG_TILES * 4; k += NW * 64) out[8 * DBG_STEPS * 4 + 2 + k] = dbg_epi[k];
         if (tid == 0) {   // whole-kernel shader cycles and 100 MHz reference ticks of this workgroup -> the effective clock
             out[8 * DBG_STEPS * 4] = (unsigned)(__builtin_amdgcn_s_memtime() - dbg_c0);
             out[8 * DBG_STEPS * 4 + 1] = (unsigned)(__builtin_amdgcn_s_memrealtime() - dbg_r0);
@@ -1246,10 +1276,7 @@ int conv_halo_launch(const ConvArgs &a_in, unsigned xb, unsigned wb, hipStream_t
 {
     ConvArgs a = a_in;
 #ifdef M355_DBG_STAMP
-    if (!a.stats && (a.KH == 2 || a.stride == 2)) {   // (KS 3 selects its instantiation by a.stats)
-        const char *sp = getenv("M355_STAMP_PTR");
-        if (sp) a.stats = reinterpret_cast<float *>(strtoull(sp, nullptr, 0));
-    }
+    if (const char *sp = getenv("M355_STAMP_PTR")) a.stamp = reinterpret_cast<unsigned *>(strtoull(sp, nullptr, 0));
 #endif
     const int nN = a.CoutP == 64 ? 1 : a.CoutP / 128;
     const int per = halo_grid_per(a);
