@@ -526,7 +526,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
                 };
 #ifndef M355_DBG_NO_MMA
                 if (!L) read_frags(cur, ha, slot, tapc);
-                mma(0);  // the DMA issue below (scalar address work, M0 writes) runs in the shadow of these MFMAs
+                // a tile without a bias starts from ZERO: its first MFMAs take the constant as their C operand instead of 64 registers
+                // cleared in the (exposed) epilogue of the tile before -- the stamps put that clearing at 1.0 k of a tile's 27-36 k cycles
+                // (profiles/r06_stamp_halo.txt); same box, builds alternated: D.conv2 / 3 / 4 dgrad 650 / 527 / 473 -> 644 / 521 / 468 us,
+                // bit-identical outputs (profiles/r06_zero_c_ab.txt)
+                if (tap == 0 && sg == 0 && !a.bias) {
+                    const f32x16 zero = {};
+#pragma unroll
+                    for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                        for (int i = 0; i < PI; ++i)
+                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.w[0][j], cur.p[0][i], zero, 0, 0, 0);
+                } else
+                    mma(0);  // the DMA issue below (scalar address work, M0 writes) runs in the shadow of these MFMAs
 #endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (!RES) {
@@ -710,7 +722,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv_halo(ConvArgs
         __builtin_amdgcn_sched_barrier(0);
 #endif
         if (!has_next) break;
-        init_acc();
+        if (a.bias) init_acc();   // (without a bias the next tile's first MFMAs start from the constant 0, see the main loop)
 #ifdef M355_DBG_STAMP
         __builtin_amdgcn_sched_barrier(0);
         HALO_ESTAMP(2);
