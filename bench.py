@@ -803,6 +803,10 @@ def main():
     # -- gan_ops.Fork -- is switched off here, otherwise two concurrent kernels would each be charged the other's time)
     gops = importlib.import_module("2dimageto3dmodel_amd.gan_ops")
     streams_were_on, gops.STREAMS_ON = gops.STREAMS_ON, False
+    # (likewise the spectral-norm steps that the timed region runs ahead of their forward on their own stream: in line here)
+    prefetch_was_on, gops.SN_PREFETCH_ON = gops.SN_PREFETCH_ON, False
+    if do_g:
+        trainer.cancel_sn_prefetch()
     pkg._lib.enable_kernel_timers(True)
     par.reset_stats(time_allreduce=True)
     for _ in range(args.steps):
@@ -819,6 +823,7 @@ def main():
     par.reset_stats()
     pkg._lib.enable_kernel_timers(False)
     gops.STREAMS_ON = streams_were_on
+    gops.SN_PREFETCH_ON = prefetch_was_on
 
     # (the same step count on every rank -- dt is the max over ranks, identical everywhere; only rank 0 samples)
     sustained = sample_clock_power(step, max(3, min(200, int(2.5 / max(dt / args.steps, 1e-4)))), sample=(rank == 0))
