@@ -110,6 +110,12 @@ struct WgradArgs {
     // are associative, so the order in which the workgroups' atomics land does not matter); fix = [flag | dw (Cout*K) | db (Cout)],
     // every cell kFixCell integers (wg_accum below)
     long long *fix;
+    // k_wgrad_halo, non-deterministic instantiations: per-workgroup PARTIAL ROWS instead of atomics -- part[blockIdx.x][Cout*K + Cout] fp32
+    // (every cell of a row has exactly one writer: the split-K replicas of a (co, ci, class) block differ in blockIdx.x only), added in row
+    // order by k_wgrad_part_sum: no contention on the weight tile (the 64-way same-address fp32 atomics of D.conv2's classes), no pre-zeroing,
+    // and the same bits on every run.  null: accumulate into dw / db (or fix).
+    float *part;
+    size_t part_stride;
 };
 
 // ---- split-K accumulation of the weight-gradient kernels.  Default: fp32 atomics into the zeroed dw (the result depends on

@@ -985,15 +985,75 @@ __global__ __launch_bounds__(512, (TH == 4 && NCO == 1) ? 4 : 2) void k_wgrad_ha
         if (KS == 3 && w_hi) tile_mma(std::integral_constant<int, 1>{});
         else tile_mma(std::integral_constant<int, 0>{});
     }
+    // partial rows (WgradArgs::part): this workgroup's row; every cell of it is written by exactly one workgroup of the launch
+    float *const prow = (!DET && a.part) ? a.part + (size_t)blockIdx.x * a.part_stride : nullptr;
     if (do_db) {
 #pragma unroll
         for (int c = 0; c < NCO; ++c)
-            if (co0 + 64 * c + dbc < a.Cout)
-                wg_accum<DET>(a.db, a.fix, (DET ? (size_t)a.Cout * (a.KH * a.KW * a.Cin) : 0) + co0 + 64 * c + dbc, dbacc[c],
-                              (size_t)a.Cout * (a.KH * a.KW * a.Cin) + a.Cout);
+            if (co0 + 64 * c + dbc < a.Cout) {
+                if (prow) {
+                    // (the 8 waves' column sums of a channel: one writer per cell -> through LDS, wave 0 adds them in wave order)
+                } else
+                    wg_accum<DET>(a.db, a.fix, (DET ? (size_t)a.Cout * (a.KH * a.KW * a.Cin) : 0) + co0 + 64 * c + dbc, dbacc[c],
+                                  (size_t)a.Cout * (a.KH * a.KW * a.Cin) + a.Cout);
+            }
+    }
+    if (prow && do_db) {
+        __syncthreads();   // (every wave is past its last fragment read: the stage buffers are free)
+        float *red = reinterpret_cast<float *>(lds);
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) red[(c * 8 + dbq) * 64 + dbc] = dbacc[c];
+        __syncthreads();
+        if (dbq == 0) {
+#pragma unroll
+            for (int c = 0; c < NCO; ++c) {
+                float t = 0.0f;
+#pragma unroll
+                for (int w8 = 0; w8 < 8; ++w8) t += red[(c * 8 + w8) * 64 + dbc];
+                if (co0 + 64 * c + dbc < a.Cout) prow[(size_t)a.Cout * (a.KH * a.KW * a.Cin) + co0 + 64 * c + dbc] = t;
+            }
+        }
     }
     // acc[t][r]: co = co0 + 32 w_co + (r&3) + 8(r>>2) + 4(lane>>5), ci = ci0 + 32 w_ci + (lane&31)
     const int K = a.KH * a.KW * a.Cin;
+    if (prow) {
+        if (KS == 2) {
+            // the two wave quartets hold the two pixel halves of the SAME cells: quartet 1 hands its sums over through LDS (the stage
+            // buffers are free: 4 waves x 64 values x 64 lanes = 64 KB), quartet 0 adds them -- in that order, every time
+            __syncthreads();
+            float *red = reinterpret_cast<float *>(lds);
+            if (w_hi == 1) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[(((wave & 3) * NT + t) * 16 + r) * 64 + lane] = acc[0][t][r];
+            }
+            __syncthreads();
+            if (w_hi == 0) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][t][r] += red[(((wave & 3) * NT + t) * 16 + r) * 64 + lane];
+            }
+        }
+        if (KS == 3 || w_hi == 0) {
+#pragma unroll
+            for (int c = 0; c < NCO; ++c)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int tap = KS == 3 ? w_hi * NT + t : t;
+                    if (tap < T) {
+                        const int kh = KS == 3 ? tap / 3 : 2 * (tap >> 1) + cp, kw = KS == 3 ? tap % 3 : 2 * (tap & 1) + cq;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int co = co0 + 64 * c + 32 * w_co + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            if (co < a.Cout) prow[(size_t)co * K + (kh * a.KW + kw) * a.Cin + ci0 + 32 * w_ci + (lane & 31)] = acc[c][t][r];
+                        }
+                    }
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < NCO; ++c)
 #pragma unroll
@@ -1023,22 +1083,51 @@ bool wgrad_halo_eligible(const WgradArgs &a)
            (a.Cin <= 64 || !getenv("M355_WGRAD_HALO_CIN64"));
 }
 
-int wgrad_halo_launch(const WgradArgs &a, unsigned xb, unsigned yb, hipStream_t st)
+int wgrad_part_sum_launch(const float *part, int rows, size_t stride, float *dw, size_t n, float *db, int nb, hipStream_t st);   // conv_small.hip
+
+// the launch shape of wgrad_halo_launch: (split-K replicas = partial rows, (co, ci) blocks, classes), tile rows, dy blocks per workgroup
+static void wgrad_halo_shape(const WgradArgs &a, int &per, int &ny, int &ncls, int &th, int &nco, bool &twin, bool &wide)
 {
+    const char *var = getenv("M355_WGRAD_HALO_VARIANT");
+    wide = a.stride == 2 && a.Cout % 128 == 0 && var && !strcmp(var, "wide");
+    twin = a.stride == 2 && !wide && !(var && !strcmp(var, "narrow"));
+    th = (wide || twin) ? 4 : 8;
+    nco = wide ? 2 : 1;
+    const int tiles = a.N * (a.Ho / th) * (a.Wo / 32);
+    ny = ((a.Cout + 64 * nco - 1) / (64 * nco)) * (a.Cin / 64);
+    ncls = a.stride == 2 ? 4 : 1;
+    per = (twin ? 512 : 256) / (ny * ncls);  // one 8-wave workgroup per CU; each walks a strided list of pixel tiles (split K)
+    if (per < 1) per = 1;
+    if (per > tiles) per = tiles;
+}
+
+// partial rows of the PARTIAL-ROW form of this weight gradient (0: it has none -- the deterministic instantiations keep their integer
+// cells, the two-dy-block variant has no room for the quartets' exchange): what m355_conv2d_wgrad_ws_bytes sizes the workspace from
+int wgrad_halo_part_rows(const WgradArgs &a)
+{
+    static const char *sw = getenv("M355_WGRAD_HALO_PART");   // "0": atomics everywhere (A/B), "2": also the stride-1 3x3 layers
+    const int mode = sw ? atoi(sw) : 1;
+    if (!mode || !wgrad_halo_eligible(a) || a.fix) return 0;
+    if (a.stride == 1 && mode < 2) return 0;
+    int per, ny, ncls, th, nco;
+    bool twin, wide;
+    wgrad_halo_shape(a, per, ny, ncls, th, nco, twin, wide);
+    return (nco == 1 && per >= 2) ? per : 0;
+}
+
+int wgrad_halo_launch(const WgradArgs &a_in, unsigned xb, unsigned yb, hipStream_t st)
+{
+    WgradArgs a = a_in;
+    a.part_stride = (size_t)a.Cout * (a.KH * a.KW * a.Cin) + a.Cout;
     // stride-2 classes with >= 128 output channels: 4 x 32 tiles, two 64-channel dy blocks per workgroup on one x halo
     // stride-2 classes: 4 x 32-pixel tiles, TWO workgroups per CU (80 KB of LDS, 128 registers each).  The class kernels
     // wait on their tile DMAs 46 % of the time (SQ_WAIT_ANY; L2 hit rate and HBM traffic are fine): with one tile of
     // prefetch a workgroup cannot cover an HBM round trip, two independent pipelines per CU can (+12-17 % over one
     // 8 x 32 workgroup, +10-14 % over 4 x 32 with two dy blocks on one x halo).  M355_WGRAD_HALO_VARIANT=narrow|wide: A/B.
-    const char *var = getenv("M355_WGRAD_HALO_VARIANT");
-    const bool wide = a.stride == 2 && a.Cout % 128 == 0 && var && !strcmp(var, "wide");
-    const bool twin = a.stride == 2 && !wide && !(var && !strcmp(var, "narrow"));
-    const int th = (wide || twin) ? 4 : 8, nco = wide ? 2 : 1;
-    const int tiles = a.N * (a.Ho / th) * (a.Wo / 32);
-    const int ny = ((a.Cout + 64 * nco - 1) / (64 * nco)) * (a.Cin / 64), ncls = a.stride == 2 ? 4 : 1;
-    int per = (twin ? 512 : 256) / (ny * ncls);  // one 8-wave workgroup per CU; each walks a strided list of pixel tiles (split K)
-    if (per < 1) per = 1;
-    if (per > tiles) per = tiles;
+    int per, ny, ncls, th, nco;
+    bool twin, wide;
+    wgrad_halo_shape(a, per, ny, ncls, th, nco, twin, wide);
+    if (a.part && (a.fix || nco != 1)) a.part = nullptr;
     const dim3 grid(per, ny, ncls);
 #define M355_WD(KS_, UPS_, MD_, TH_, NCO_)                                                                                           \
     do {                                                                                                                             \
@@ -1059,7 +1148,10 @@ int wgrad_halo_launch(const WgradArgs &a, unsigned xb, unsigned yb, hipStream_t 
 #undef M355_WD
 #undef M355_WM
     note_kernel("k_wgrad_halo");
-    return check_launch("conv2d_wgrad (halo)");
+    if (int rc = check_launch("conv2d_wgrad (halo)")) return rc;
+    if (a.part)   // the partial rows -> dw (+ db), added in row order
+        return wgrad_part_sum_launch(a.part, per, a.part_stride, a.dw, (size_t)a.Cout * (a.KH * a.KW * a.Cin), a.db, a.Cout, st);
+    return M355_OK;
 }
 
 // the four sub-pixel classes of an upsample + 3x3 layer (a.H x a.W = the stored extent = the class grid; dy is [N, 2H, 2W, Cy];

@@ -720,6 +720,7 @@ int dgrad_direct_replicate_launch(const m355_conv_desc *d, const void *dy, int C
 bool wgrad_halo_eligible(const WgradArgs &a);  // csrc/conv_halo.hip
 int wgrad_halo_launch(const WgradArgs &a, unsigned xb, unsigned yb, hipStream_t st);
 int wgrad_halo_up_launch(const WgradArgs &a, unsigned xb, unsigned yb, hipStream_t st);   // sub-pixel classes of upsample + 3x3
+int wgrad_halo_part_rows(const WgradArgs &a);   // partial rows of the no-atomics form of a halo weight gradient (0: none)
 int dgrad_edge_up4_launch(const m355_conv_desc *d, const void *dy, int Cy, const void *w4, int Kp, void *dx, hipStream_t st);
 
 static bool dma_eligible(const ConvArgs &a)
@@ -2023,6 +2024,26 @@ extern "C" int m355_conv2d_wgrad_acc(const m355_conv_desc *d, const void *x, con
  * addresses.  With a workspace every workgroup instead stores its partial tile and a second small launch adds the rows in
  * workgroup order: no atomics, deterministic in every mode, dw / dbias OVERWRITTEN (no pre-zeroing); 340 -> 335 us at batch 128.
  * m355_conv2d_wgrad_ws_bytes(d) == 0: this layer has no such form (use m355_conv2d_wgrad / _acc / _det). */
+// geometry of a weight-gradient launch (what conv_wgrad_impl fills in besides the pointers)
+static m355::WgradArgs wgrad_geometry(const m355_conv_desc *d)
+{
+    m355::WgradArgs a = {};
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ups = d->upsample;
+    a.Hl = d->H << d->upsample; a.Wl = d->W << d->upsample;
+    conv_out_hw(d, &a.Ho, &a.Wo);
+    a.Cout = d->Cout; a.Cy = m355::dy_channels(d->Cout);
+    a.KH = d->kh; a.KW = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
+    a.pad_w_mode = d->pad_w_mode;
+    return a;
+}
+// partial rows of the no-atomics form of a halo weight gradient (round 6; 0: this layer has none)
+static int wgrad_halo_rows(const m355_conv_desc *d)
+{
+    if (!wgrad_dma_ok(d) || m355::wgrad_c8_eligible(d, m355::dy_channels(d->Cout)) || m355::wgrad_small_eligible(d, m355::dy_channels(d->Cout)))
+        return 0;
+    return m355::wgrad_halo_part_rows(wgrad_geometry(d));
+}
+
 extern "C" size_t m355_conv2d_wgrad_ws_bytes(const m355_conv_desc *d)
 {
     if (!d || check_desc(d, "conv2d_wgrad_ws_bytes")) return 0;
@@ -2034,6 +2055,10 @@ extern "C" size_t m355_conv2d_wgrad_ws_bytes(const m355_conv_desc *d)
     // upsample + 3x3 in the sub-pixel form: the 16-entry effective gradient (zeroed here, accumulated with fp32 atomics -- NOT the
     // ordered sum of the thin layers: m355_conv2d_wgrad_det is the run-to-run reproducible form of these layers)
     if (subpixel_halo(d)) return sizeof(float) * subpixel_ws_cells(d);
+    // (round 6) the stride-2 class weight gradients on k_wgrad_halo (D.conv2-4): 64 / 16 / 4 split-K replicas per (co, ci, class) block
+    // used to meet in same-address fp32 atomics -- a per-launch constant of ~40 us (and ~250 us with the deterministic mode's integer
+    // cells); their partial tiles go to rows of this workspace and one small launch adds the rows in order
+    if (const int rows = wgrad_halo_rows(d)) return sizeof(float) * (size_t)rows * ((size_t)d->Cout * d->kh * d->kw * d->Cin + d->Cout);
     // (the <= 8-output-channel heads keep their atomics: with up to 512 partial rows of a few thousand elements the ordered sum
     // is the longer tail -- conv_final's wgrad 117.7 -> 155.9 us, D.conv5's 60.0 -> 65.6 us, profiles/r04_thin_rate_b.txt)
     return 0;
@@ -2087,8 +2112,10 @@ static int conv_wgrad_impl(const m355_conv_desc *d, const void *x, const void *d
     if (m355::wgrad_small_eligible(d, a.Cy)) return m355::wgrad_small_launch(d, x, dy, a.Cy, dw, st, fix, part);
     const size_t xbytes = (size_t)d->N * d->H * d->W * d->Cin * 2, ybytes = (size_t)P * a.Cy * 2;
     const int lgWo = m355::ilog2_exact(a.Wo), lgHo = m355::ilog2_exact(a.Ho);
-    if (wgrad_dma_ok(d) && m355::wgrad_halo_eligible(a))
+    if (wgrad_dma_ok(d) && m355::wgrad_halo_eligible(a)) {
+        if (part && wgrad_halo_rows(d)) a.part = part;   // (m355_conv2d_wgrad_ws: partial rows + ordered sum, dw / dbias overwritten)
         return m355::wgrad_halo_launch(a, (unsigned)xbytes, (unsigned)ybytes, st);
+    }
     if (wgrad_dma_ok(d)) {
         const int TM = d->Cout > 64 ? 128 : 64, TN = d->Cout > 64 ? 128 : 256;
         const int gx = (d->Cout + TM - 1) / TM, gy = (K + TN - 1) / TN;

@@ -801,6 +801,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// rows of per-workgroup partial sums [rows][n + nb] -> dw[n] (+ db[nb]), added in row order (used by the halo weight gradients too)
+int wgrad_part_sum_launch(const float *part, int rows, size_t stride, float *dw, size_t n, float *db, int nb, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_wgrad_part_sum, dim3((unsigned)((n + (db ? (size_t)nb : 0) + 255) / 256)), dim3(256), 0, st, part, rows, stride, dw, n, db, nb);
+    return check_launch("conv2d_wgrad (ordered sum of the partial rows)");
+}
+
 bool conv_c8_eligible(const m355_conv_desc *d, int y_f32_nchw)
 {
     return !y_f32_nchw && d->Cin == 8 && d->kh == 5 && d->kw == 5 && d->stride == 1 && d->upsample == 0 && d->pad_h == 2 &&

@@ -353,7 +353,38 @@ def test_head_dgrad_with_fused_activation_backward(pkg, case):
     assert (dxm - want).abs().max().item() / want.abs().max().item() < 1.2e-2
 
 
-@pytest.mark.parametrize("case", [(2, 32, 64, 128, 256, 4, 2, 1, 1, 2, 0), (2, 16, 16, 128, 64, 3, 1, 1, 1, 1, 1),
+@pytest.mark.parametrize("case", [(2, 32, 64, 128, 256, 4, 2, 1, 1, 2, 0), (2, 64, 64, 64, 128, 4, 2, 1, 1, 2, 0),
+                                  (3, 16, 64, 256, 512, 4, 2, 1, 1, 0, 0)])
+def test_class_weight_gradients_are_ordered_sums_of_partial_rows(pkg, case, monkeypatch):
+    """(round 6) the stride-2 class weight gradients on k_wgrad_halo (D.conv2-4) no longer meet in same-address fp32 atomics: every
+    workgroup stores its partial tile into a row of the workspace m355_conv2d_wgrad_ws_bytes sizes, one launch adds the rows in order.
+    The layer therefore has the workspace form, conv_wgrad takes it in EVERY mode, repeated launches give the same bits without the
+    deterministic mode, and the result (weights and the fused bias gradient) is the atomics path's up to summation order."""
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    monkeypatch.setattr(conv, "_DETERMINISTIC", False)
+    N, H, W, Cin, Cout, k, stride, ph, pw, mode, ups = case
+    g = torch.Generator().manual_seed(31)
+    d = conv.make_desc(N, H, W, Cin, Cout, k, k, stride, ph, pw, mode, ups)
+    assert conv.plan(d).wgrad_ws_bytes > 0
+    x = torch.randn(N, H, W, Cin, generator=g).bfloat16().to(DEV)
+    dy = torch.randn(N, H // 2, W // 2, Cout, generator=g).bfloat16().to(DEV)
+    runs = []
+    for _ in range(3):
+        db = torch.full((Cout,), 7.0, device=DEV)            # (overwritten, not accumulated)
+        dw = conv.conv_wgrad(d, x, dy, raw=True, dbias=db)
+        assert conv.lib().m355_last_kernel().decode() == "k_wgrad_halo"
+        runs.append((dw.clone(), db.clone()))
+    assert all(torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1]) for r in runs[1:])
+    # against the atomics form of the same kernel (m355_conv2d_wgrad: zero fill + fp32 atomics)
+    import ctypes
+    ref, refb = torch.empty_like(runs[0][0]), torch.empty(Cout, device=DEV)
+    conv.launch("conv2d_wgrad", ctypes.byref(d), conv.ptr(x), conv.ptr(dy), conv.ptr(ref), conv.ptr(refb), conv.stream())
+    torch.cuda.synchronize()
+    assert (runs[0][0] - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    assert (runs[0][1] - refb).abs().max().item() <= 2e-5 * max(1.0, refb.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [(2, 16, 32, 128, 128, 3, 1, 1, 1, 1, 0), (2, 16, 16, 128, 64, 3, 1, 1, 1, 1, 1),
                                   (2, 32, 32, 8, 64, 3, 1, 1, 1, 1, 0)])
 def test_wgrad_arena_accumulates_inside_backward(pkg, case, monkeypatch):
     """m355_conv2d_wgrad_acc (no zero fill) into the per-backward-pass arena: inside an autograd backward conv_wgrad(arena=True)
