@@ -159,7 +159,7 @@ class ConvPlan(ctypes.Structure):
                 ("fwd_bits_ok", c_int), ("dgrad_bits_ok", c_int), ("dgrad_mask_ok", c_int), ("fwd_stats_rows", c_int),
                 ("fwd_ws_stats_rows", c_int), ("wgrad_fuses_dbias", c_int),
                 ("fwd_ws_bytes", c_size_t), ("dgrad_ws_bytes", c_size_t), ("wgrad_ws_bytes", c_size_t),
-                ("wgrad_det_ws_bytes", c_size_t), ("exec_ratio", ctypes.c_double), ("w_dgrad_row_elems", c_int), ("pad_", c_int)]
+                ("wgrad_det_ws_bytes", c_size_t), ("exec_ratio", ctypes.c_double), ("w_dgrad_row_elems", c_int), ("wgrad_ws_ordered", c_int)]
 
 
 class SnFinEntry(ctypes.Structure):

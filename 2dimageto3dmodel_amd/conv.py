@@ -412,7 +412,7 @@ def conv_wgrad(d, x, dy, cin_real=None, raw=False, dbias=None, arena=False, dbia
             dbias.add_(db2)
         return dw if raw else dw.permute(0, 3, 1, 2)
     nws = _wgrad_ws_bytes(d)
-    if nws and not (_DETERMINISTIC and d.upsample):
+    if nws and (plan(d).wgrad_ws_ordered or not (_DETERMINISTIC and d.upsample)):
         # thin layers: per-workgroup partial tiles + an ordered sum instead of atomics (deterministic in every mode; dw / dbias
         # are overwritten, so neither the arena's zero fill nor a zeroed bias block is needed).  Also the sub-pixel form of the
         # upsample + 3x3 layers: its 16-entry effective gradient lives in ws (zeroed by the library, fp32 atomics -- in

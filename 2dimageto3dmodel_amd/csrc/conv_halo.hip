@@ -1010,7 +1010,9 @@ __global__ __launch_bounds__(512, (TH == 4 && NCO == 1) ? 4 : 2) void k_wgrad_ha
                 float t = 0.0f;
 #pragma unroll
                 for (int w8 = 0; w8 < 8; ++w8) t += red[(c * 8 + w8) * 64 + dbc];
-                if (co0 + 64 * c + dbc < a.Cout) prow[(size_t)a.Cout * (a.KH * a.KW * a.Cin) + co0 + 64 * c + dbc] = t;
+                // (sub-pixel classes: every class sums its own quarter of the dy pixels -> its own block of bias cells, added by the fold)
+                if (co0 + 64 * c + dbc < a.Cout)
+                    prow[(size_t)a.Cout * (a.KH * a.KW * a.Cin) + (UPC ? (size_t)blockIdx.z * a.Cout : 0) + co0 + 64 * c + dbc] = t;
             }
         }
     }
@@ -1105,13 +1107,18 @@ static void wgrad_halo_shape(const WgradArgs &a, int &per, int &ny, int &ncls, i
 // cells, the two-dy-block variant has no room for the quartets' exchange): what m355_conv2d_wgrad_ws_bytes sizes the workspace from
 int wgrad_halo_part_rows(const WgradArgs &a)
 {
-    static const char *sw = getenv("M355_WGRAD_HALO_PART");   // "0": atomics everywhere (A/B), "2": also the stride-1 3x3 layers
+    static const char *sw = getenv("M355_WGRAD_HALO_PART");   // "0": atomics everywhere (A/B), "2": every stride-1 3x3 layer, "3": none of them
     const int mode = sw ? atoi(sw) : 1;
     if (!mode || !wgrad_halo_eligible(a) || a.fix) return 0;
-    if (a.stride == 1 && mode < 2) return 0;
     int per, ny, ncls, th, nco;
     bool twin, wide;
     wgrad_halo_shape(a, per, ny, ncls, th, nco, twin, wide);
+    // the stride-1 3x3 layers: rows cost per x cells x 8 bytes of traffic against the atomics' fixed 38-41 us -- equal in a batch-64
+    // cycle, -0.06 ms at batch 16 (profiles/r06_wgrad_partial_rows_ab.txt): taken where a replica has at most 8 tiles
+    if (a.stride == 1 && mode != 2) {
+        const long tiles = (long)a.N * (a.Ho / th) * (a.Wo / 32);
+        if (mode == 3 || tiles > 8L * per) return 0;
+    }
     return (nco == 1 && per >= 2) ? per : 0;
 }
 
@@ -1156,17 +1163,35 @@ int wgrad_halo_launch(const WgradArgs &a_in, unsigned xb, unsigned yb, hipStream
 
 // the four sub-pixel classes of an upsample + 3x3 layer (a.H x a.W = the stored extent = the class grid; dy is [N, 2H, 2W, Cy];
 // a.dw / a.fix = the 16-entry effective gradient): 4 x 32-pixel tiles, two workgroups per CU, as the stride-2 classes
-int wgrad_halo_up_launch(const WgradArgs &a, unsigned xb, unsigned yb, hipStream_t st)
+static int wgrad_halo_up_per(const WgradArgs &a)
 {
-    if (a.Cin % 64 || a.Cy % 64 || a.Wo % 32 || a.Ho % 4 || a.KH != 4 || a.KW != 4) {
-        set_error("conv2d_wgrad (sub-pixel classes): shape not eligible");
-        return M355_ERR_BAD_ARG;
-    }
     const int tiles = a.N * (a.Ho / 4) * (a.Wo / 32);
     const int ny = ((a.Cout + 63) / 64) * (a.Cin / 64);
     int per = 512 / (ny * 4);
     if (per < 1) per = 1;
     if (per > tiles) per = tiles;
+    return per;
+}
+// partial rows of the sub-pixel weight gradient's no-atomics form (0: none): rows of [Cout*16*Cin effective-gradient cells | 4 x Cout bias cells]
+int wgrad_halo_up_part_rows(const WgradArgs &a)
+{
+    static const char *sw = getenv("M355_WGRAD_HALO_PART"), *up = getenv("M355_WGRAD_UP_PART");
+    if ((sw && atoi(sw) == 0) || (up && atoi(up) == 0) || a.Cin % 64 || a.Cy % 64 || a.Wo % 32 || a.Ho % 4) return 0;
+    const int per = wgrad_halo_up_per(a);
+    return per >= 2 ? per : 0;
+}
+
+int wgrad_halo_up_launch(const WgradArgs &a_in, unsigned xb, unsigned yb, hipStream_t st)
+{
+    WgradArgs a = a_in;
+    if (a.Cin % 64 || a.Cy % 64 || a.Wo % 32 || a.Ho % 4 || a.KH != 4 || a.KW != 4) {
+        set_error("conv2d_wgrad (sub-pixel classes): shape not eligible");
+        return M355_ERR_BAD_ARG;
+    }
+    const int ny = ((a.Cout + 63) / 64) * (a.Cin / 64);
+    const int per = wgrad_halo_up_per(a);
+    if (a.part && a.fix) a.part = nullptr;
+    a.part_stride = (size_t)a.Cout * 16 * a.Cin + 4 * (size_t)a.Cout;
     const dim3 grid(per, ny, 4);
 #define M355_WU(MD_)                                                                                                   \
     do {                                                                                                               \

@@ -721,6 +721,7 @@ bool wgrad_halo_eligible(const WgradArgs &a);  // csrc/conv_halo.hip
 int wgrad_halo_launch(const WgradArgs &a, unsigned xb, unsigned yb, hipStream_t st);
 int wgrad_halo_up_launch(const WgradArgs &a, unsigned xb, unsigned yb, hipStream_t st);   // sub-pixel classes of upsample + 3x3
 int wgrad_halo_part_rows(const WgradArgs &a);   // partial rows of the no-atomics form of a halo weight gradient (0: none)
+int wgrad_halo_up_part_rows(const WgradArgs &a);   // ... of the sub-pixel classes (rows of [Cout*16*Cin | 4 x Cout] cells)
 int dgrad_edge_up4_launch(const m355_conv_desc *d, const void *dy, int Cy, const void *w4, int Kp, void *dx, hipStream_t st);
 
 static bool dma_eligible(const ConvArgs &a)
@@ -1938,32 +1939,78 @@ __global__ __launch_bounds__(256) void k_up16_to_9(const void *__restrict__ src,
 }
 }  // namespace m355
 
+namespace m355 {
+// the same fold over per-workgroup PARTIAL ROWS (round 6: no atomics): part[rows][Cout*16*Cin + 4*Cout]; every output is the sum over the rows,
+// in row order, of its four effective-gradient entries (bias: of the four classes' cells) -- the same bits on every run
+__global__ __launch_bounds__(256) void k_up16_rows_to_9(const float *__restrict__ part, int rows, size_t stride, float *__restrict__ dw,
+                                                        float *__restrict__ db, int Cout, int Cin)
+{
+    const size_t n9 = (size_t)Cout * 9 * Cin, n16 = (size_t)Cout * 16 * Cin, total = n9 + (db ? (size_t)Cout : 0);
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        float s2[2] = {0.0f, 0.0f};
+        if (i >= n9) {
+            const size_t b = n16 + (i - n9);
+            for (int r = 0; r < rows; ++r) {
+                const float *p = part + (size_t)r * stride + b;
+                s2[r & 1] += (p[0] + p[Cout]) + (p[2 * (size_t)Cout] + p[3 * (size_t)Cout]);
+            }
+            db[i - n9] = s2[0] + s2[1];
+            continue;
+        }
+        const int ci = (int)(i % Cin);
+        const size_t t = i / Cin;
+        const int tap = (int)(t % 9), co = (int)(t / 9), kh = tap / 3, kw = tap - 3 * kh;
+        const size_t b = (((size_t)co * 4 + kh) * 4 + kw) * Cin + ci;   // entry (kh, kw); (kh+1, .) is 4 Cin further, (., kw+1) Cin
+        for (int r = 0; r < rows; ++r) {
+            const float *p = part + (size_t)r * stride + b;
+            s2[r & 1] += (p[0] + p[Cin]) + (p[4 * (size_t)Cin] + p[5 * (size_t)Cin]);
+        }
+        dw[i] = s2[0] + s2[1];
+    }
+}
+}  // namespace m355
+
 // ws of the sub-pixel weight gradient: fp32 (m355_conv2d_wgrad_ws) or fixed-point (m355_conv2d_wgrad_det) cells
 static size_t subpixel_ws_cells(const m355_conv_desc *d) { return (size_t)d->Cout * 16 * d->Cin + (size_t)d->Cout; }
+// geometry of the sub-pixel class launch, and the partial rows of its no-atomics form (0: none -> zeroed cells + fp32 atomics)
+static m355::WgradArgs subpixel_geometry(const m355_conv_desc *d)
+{
+    m355::WgradArgs a = {};
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Hl = d->H; a.Wl = d->W; a.ups = 0;
+    a.Ho = d->H; a.Wo = d->W;   // the class grid = the stored extent; dy is [N, 2 Ho, 2 Wo, Cy]
+    a.Cout = d->Cout; a.Cy = m355::dy_channels(d->Cout);
+    a.KH = a.KW = 4; a.stride = 1; a.pad_h = a.pad_w = 1; a.pad_w_mode = d->pad_w_mode;
+    return a;
+}
+static int subpixel_rows(const m355_conv_desc *d) { return m355::wgrad_halo_up_part_rows(subpixel_geometry(d)); }
+static size_t subpixel_row_cells(const m355_conv_desc *d) { return (size_t)d->Cout * 16 * d->Cin + 4 * (size_t)d->Cout; }
 
 static int subpixel_wgrad(const m355_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias, void *ws, bool det,
                           hipStream_t st)
 {
     const size_t cells = subpixel_ws_cells(d), n16 = (size_t)d->Cout * 16 * d->Cin;
+    const int rows = det ? 0 : subpixel_rows(d);   // (m355_conv2d_wgrad_ws: partial rows + an ordered sum where the launch has >= 2 replicas)
     const size_t bytes = det ? sizeof(long long) * (1 + m355::kFixCell * cells) : sizeof(float) * cells;
-    if (hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) {
+    if (!rows && hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) {
         m355::set_error("conv2d_wgrad (sub-pixel): memset failed");
         return M355_ERR_LAUNCH;
     }
-    m355::WgradArgs a = {};
+    m355::WgradArgs a = subpixel_geometry(d);
     a.x = (const unsigned short *)x;
     a.dy = (const unsigned short *)dy;
     a.dw = det ? nullptr : (float *)ws;
     a.db = dbias ? (det ? (float *)ws /* non-null marker */ : (float *)ws + n16) : nullptr;
     a.fix = det ? (long long *)ws : nullptr;
-    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Hl = d->H; a.Wl = d->W; a.ups = 0;
-    a.Ho = d->H; a.Wo = d->W;   // the class grid = the stored extent; dy is [N, 2 Ho, 2 Wo, Cy]
-    a.Cout = d->Cout; a.Cy = m355::dy_channels(d->Cout);
-    a.KH = a.KW = 4; a.stride = 1; a.pad_h = a.pad_w = 1; a.pad_w_mode = d->pad_w_mode;
+    a.part = rows ? (float *)ws : nullptr;
     const size_t xbytes = (size_t)d->N * d->H * d->W * d->Cin * 2, ybytes = (size_t)d->N * d->H * d->W * 4 * a.Cy * 2;
     if (int rc = m355::wgrad_halo_up_launch(a, (unsigned)xbytes, (unsigned)ybytes, st)) return rc;
     const size_t blocks = ((size_t)d->Cout * 9 * d->Cin + d->Cout + 255) / 256;
     const dim3 grid((unsigned)(blocks > 2048 ? 2048 : blocks));
+    if (rows) {
+        hipLaunchKernelGGL(m355::k_up16_rows_to_9, grid, dim3(256), 0, st, (const float *)ws, rows, subpixel_row_cells(d), dw, dbias, d->Cout,
+                           d->Cin);
+        return m355::check_launch("conv2d_wgrad (sub-pixel fold of the partial rows)");
+    }
     if (det) hipLaunchKernelGGL(m355::k_up16_to_9<true>, grid, dim3(256), 0, st, (const void *)ws, dw, dbias, d->Cout, d->Cin);
     else hipLaunchKernelGGL(m355::k_up16_to_9<false>, grid, dim3(256), 0, st, (const void *)ws, dw, dbias, d->Cout, d->Cin);
     return m355::check_launch("conv2d_wgrad (sub-pixel fold)");
@@ -2054,7 +2101,10 @@ extern "C" size_t m355_conv2d_wgrad_ws_bytes(const m355_conv_desc *d)
     if (m355::wgrad_c8_eligible(d, cy)) return sizeof(float) * m355::wgrad_c8_ws_floats(d, cy);
     // upsample + 3x3 in the sub-pixel form: the 16-entry effective gradient (zeroed here, accumulated with fp32 atomics -- NOT the
     // ordered sum of the thin layers: m355_conv2d_wgrad_det is the run-to-run reproducible form of these layers)
-    if (subpixel_halo(d)) return sizeof(float) * subpixel_ws_cells(d);
+    if (subpixel_halo(d)) {
+        const int rows = subpixel_rows(d);   // (round 6: per-workgroup partial rows, folded in row order; else zeroed cells + atomics)
+        return rows ? sizeof(float) * (size_t)rows * subpixel_row_cells(d) : sizeof(float) * subpixel_ws_cells(d);
+    }
     // (round 6) the stride-2 class weight gradients on k_wgrad_halo (D.conv2-4): 64 / 16 / 4 split-K replicas per (co, ci, class) block
     // used to meet in same-address fp32 atomics -- a per-launch constant of ~40 us (and ~250 us with the deterministic mode's integer
     // cells); their partial tiles go to rows of this workspace and one small launch adds the rows in order
@@ -2189,5 +2239,8 @@ extern "C" int m355_conv2d_plan(const m355_conv_desc *d, m355_conv_plan *p)
     p->wgrad_det_ws_bytes = m355_conv2d_wgrad_det_ws_bytes(d);
     p->exec_ratio = m355_conv2d_exec_ratio(d);
     p->w_dgrad_row_elems = d->stride == 1 ? m355::k_padded(d->kh * d->kw * (int)m355::dy_channels(d->Cout)) : 0;
+    // is the workspace form an ORDERED sum (run-to-run identical in every mode)?  Everything but a sub-pixel layer whose launch has a
+    // single replica per block (zeroed cells + fp32 atomics: the deterministic form of that one is m355_conv2d_wgrad_det)
+    p->wgrad_ws_ordered = p->wgrad_ws_bytes > 0 && (!subpixel_halo(d) || subpixel_rows(d) > 0);
     return M355_OK;
 }

@@ -859,7 +859,7 @@ def main():
             workload.append(f"GAN cycle (1 G + 2 D steps, Adam) at batch {B}/GPU, {R}x{R}, nd=2, class-conditional, "
                             f"syncbatch, mesh flat-loss regulariser in the G step")
         out = {
-            "metric": "train-step samples/sec (proj+loss+GAN fwd/bwd), batch 64", "value": world * B * args.steps / dt,
+            "metric": f"train-step samples/sec (proj+loss+GAN fwd/bwd), batch {B}", "value": world * B * args.steps / dt,
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "bf16" if do_g else "f32", "data": "synthetic",

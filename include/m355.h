@@ -34,7 +34,7 @@ typedef enum {
 const char *m355_last_error(void);
 /* name of the kernel family the calling thread's last m355_conv2d_* call dispatched to (profiling aid) */
 const char *m355_last_kernel(void);
-int m355_abi_version(void);   /* 2: deterministic reductions (round 4): workspaces on cproj_bwd / head_tail_bwd / mesh_flat_fwd, gather tables on the mesh backward, m355_conv2d_wgrad_det; 3 (round 5): m355_act_bytes; 4 (round 6): m355_conv_plan.w_dgrad_row_elems, m355_ipc_* */
+int m355_abi_version(void);   /* 2: deterministic reductions (round 4): workspaces on cproj_bwd / head_tail_bwd / mesh_flat_fwd, gather tables on the mesh backward, m355_conv2d_wgrad_det; 3 (round 5): m355_act_bytes; 4 (round 6): m355_conv_plan.w_dgrad_row_elems / .wgrad_ws_ordered, m355_ipc_* */
 /* Bytes of an ACTIVATION element ("bf16" in the comments below) in this build of the library: 2 = bf16, the product; 4 = fp32, the
  * EXACT build (lib/libm355_exact.so, compiled from the same sources with -DM355_EXACT; SURVEY.md 8c "an fp32-accumulate exact mode
  * for 1e-4 checks").  Same entry points, same argument meaning; the GAN path's activation tensors, conv operands and weight views
@@ -190,7 +190,8 @@ typedef struct m355_conv_plan {
     double exec_ratio;            /* m355_conv2d_exec_ratio */
     int w_dgrad_row_elems;        /* row length (elements) of the stride-1 dgrad view [rows][taps * dy_channels, padded]: what a kernel that
                                    * reads that view itself (m355_cproj_bwd_conv5's Kp) must be given; 0 for stride-2 / sub-pixel views */
-    int pad_;
+    int wgrad_ws_ordered;         /* 1: m355_conv2d_wgrad_ws adds per-workgroup partial rows in order -- the same bits on every run, in every
+                                   * mode (a binding takes it in deterministic mode too); 0: no workspace form, or zeroed cells + atomics */
 } m355_conv_plan;
 int m355_conv2d_plan(const m355_conv_desc *d, m355_conv_plan *plan);
 /*      adjoint of the nearest x2 upsample (gan.py:319) on NHWC bf16: g[N,2H,2W,C] -> dx[N,H,W,C] (2x2 block sums) */

@@ -384,7 +384,39 @@ def test_class_weight_gradients_are_ordered_sums_of_partial_rows(pkg, case, monk
     assert (runs[0][1] - refb).abs().max().item() <= 2e-5 * max(1.0, refb.abs().max().item())
 
 
-@pytest.mark.parametrize("case", [(2, 16, 32, 128, 128, 3, 1, 1, 1, 1, 0), (2, 16, 16, 128, 64, 3, 1, 1, 1, 1, 1),
+@pytest.mark.parametrize("case", [(8, 32, 32, 128, 64), (4, 16, 64, 128, 128), (8, 128, 64, 128, 64)])
+def test_subpixel_weight_gradients_are_ordered_sums_of_partial_rows(pkg, case, monkeypatch):
+    """(round 6) the same for the sub-pixel form of upsample + 3x3 (G.blk5.conv1, G.blk6.conv1): the four classes' workgroups store
+    partial rows of the 16-entry effective gradient (+ four blocks of bias cells, one per class), and the 16 -> 9 fold adds the rows in
+    order.  The plan says so (wgrad_ws_ordered), the deterministic mode takes the same path (no integer cells: the bits are already
+    run-to-run identical), and the result is the gradient of the stored-extent formulation (fp64 torch) at fp32 accuracy."""
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(37)
+    d = conv.make_desc(N, H, W, Cin, Cout, 3, 3, 1, 1, 1, 1, 1)
+    pl = conv.plan(d)
+    assert pl.wgrad_ws_bytes > 4 * (Cout * 16 * Cin + Cout) and pl.wgrad_ws_ordered == 1
+    x = torch.randn(N, H, W, Cin, generator=g).bfloat16()
+    dy = torch.randn(N, 2 * H, 2 * W, Cout, generator=g).bfloat16()
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    runs = []
+    for det in (False, False, True, True):
+        monkeypatch.setattr(conv, "_DETERMINISTIC", det)
+        db = torch.full((Cout,), 7.0, device=DEV)
+        dw = conv.conv_wgrad(d, xd, dyd, raw=True, dbias=db)
+        assert conv.lib().m355_last_kernel().decode() == "k_wgrad_halo"
+        runs.append((dw.clone(), db.clone()))
+    assert all(torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1]) for r in runs[1:])
+    w64 = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    ref_conv(x.double().permute(0, 3, 1, 2), w64, None, 1, 1, 1, 1, 1).backward(dy.double().permute(0, 3, 1, 2))
+    want = w64.grad.permute(0, 2, 3, 1)
+    assert ((runs[0][0].double().cpu() - want).abs().max() / want.abs().max()).item() < 2e-6
+    wantb = dy.double().sum((0, 1, 2))
+    assert ((runs[0][1].double().cpu() - wantb).abs().max() / wantb.abs().max()).item() < 2e-6
+
+
+# (16-column outputs: the 32-column 3x3 layers take ordered partial rows at small batches since round 6 -- no arena slice)
+@pytest.mark.parametrize("case", [(2, 16, 16, 128, 128, 3, 1, 1, 1, 1, 0), (2, 8, 8, 128, 64, 3, 1, 1, 1, 1, 1),
                                   (2, 32, 32, 8, 64, 3, 1, 1, 1, 1, 0)])
 def test_wgrad_arena_accumulates_inside_backward(pkg, case, monkeypatch):
     """m355_conv2d_wgrad_acc (no zero fill) into the per-backward-pass arena: inside an autograd backward conv_wgrad(arena=True)
@@ -532,7 +564,8 @@ def test_conv_fwd_stats_refused_where_not_fused(pkg):
     (32, 32, 32, 16, 64, 5, 1, 2, 2, 2, 0, "wgrad", "k_wgrad_dma"),         # MeshDiscriminator.conv1 weight gradient
     (16, 256, 128, 64, 3, 5, 1, 2, 2, 1, 0, "wgrad", "k_wgrad_smallco"),    # conv_final weight gradient
     # the sub-pixel form of upsample + 3x3 (round 5): forward on the class kernels with fused statistics, weight gradient on the
-    # class variant of k_wgrad_halo (dy addressed with stride 2) + the 16 -> 9 fold, fixed point in deterministic mode
+    # class variant of k_wgrad_halo (dy addressed with stride 2) + the 16 -> 9 fold (round 6: per-workgroup partial rows, the fold adds
+    # them in row order -- the same path in both modes)
     (16, 64, 32, 128, 128, 3, 1, 1, 1, 1, 1, "fwd_stats", "k_conv_halo"),   # G.blk5.conv1 forward: 8-wave 2x2 classes
     (16, 128, 64, 128, 64, 3, 1, 1, 1, 1, 1, "dgrad", "k_conv_halo"),       # G.blk6.conv1 dgrad: stride-2 forward variant on dy
     (16, 128, 64, 128, 64, 3, 1, 1, 1, 1, 1, "wgrad", "k_wgrad_halo"),      # G.blk6.conv1 weight gradient

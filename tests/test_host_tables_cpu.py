@@ -104,7 +104,12 @@ def test_workspace_queries(pkg):
         assert L.m355_conv2d_weight_elems(ctypes.byref(dd), 1) == rows_d * 9 * cout + rows_d * 16 * cout
     assert L.m355_conv2d_weight_elems(ctypes.byref(desc(64, 128, 64, 128, 64, 3)), 0) == 64 * 9 * 128
     # ... the 16-entry effective weight gradient (+ bias sums) only where the shape takes that form; its dgrad needs no frame
-    assert L.m355_conv2d_wgrad_ws_bytes(ctypes.byref(up)) == 4 * (64 * 16 * 128 + 64)
+    # (round 6: as per-workgroup partial rows -- 64 replicas of the class launch here, each [Cout*16*Cin | 4 x Cout] cells -- added
+    # in row order by the 16 -> 9 fold; the plan says the sum is ordered, so a binding takes it in deterministic mode too)
+    assert L.m355_conv2d_wgrad_ws_bytes(ctypes.byref(up)) == 4 * 64 * (64 * 16 * 128 + 4 * 64)
+    pl = pkg._lib.ConvPlan()
+    assert L.m355_conv2d_plan(ctypes.byref(up), ctypes.byref(pl)) == 0 and pl.wgrad_ws_ordered == 1
+    assert L.m355_conv2d_plan(ctypes.byref(small), ctypes.byref(pl)) == 0 and pl.wgrad_ws_ordered == 0
     assert L.m355_conv2d_wgrad_det_ws_bytes(ctypes.byref(up)) == 8 * (1 + 3 * (64 * 16 * 128 + 64))
     assert L.m355_conv2d_wgrad_ws_bytes(ctypes.byref(small)) == 0
     assert L.m355_conv2d_wgrad_det_ws_bytes(ctypes.byref(small)) == 8 * (1 + 3 * (128 * 9 * 256 + 128))
