@@ -2,6 +2,7 @@
 with the reference's pads (F.pad replicate gan.py:329, circpad rendering/utils.py:60-64) and nearest x2
 upsample (gan.py:319) materialised on the CPU side.  Only the accumulation order differs -> tight tolerance."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -360,6 +361,8 @@ def test_class_weight_gradients_are_ordered_sums_of_partial_rows(pkg, case, monk
     workgroup stores its partial tile into a row of the workspace m355_conv2d_wgrad_ws_bytes sizes, one launch adds the rows in order.
     The layer therefore has the workspace form, conv_wgrad takes it in EVERY mode, repeated launches give the same bits without the
     deterministic mode, and the result (weights and the fused bias gradient) is the atomics path's up to summation order."""
+    if os.environ.get("M355_WGRAD_HALO_PART") == "0" or os.environ.get("M355_WGRAD_UP_PART") == "0":
+        pytest.skip("the A/B switch puts these layers back on atomics")
     conv = importlib.import_module("2dimageto3dmodel_amd.conv")
     monkeypatch.setattr(conv, "_DETERMINISTIC", False)
     N, H, W, Cin, Cout, k, stride, ph, pw, mode, ups = case
@@ -390,6 +393,8 @@ def test_subpixel_weight_gradients_are_ordered_sums_of_partial_rows(pkg, case, m
     partial rows of the 16-entry effective gradient (+ four blocks of bias cells, one per class), and the 16 -> 9 fold adds the rows in
     order.  The plan says so (wgrad_ws_ordered), the deterministic mode takes the same path (no integer cells: the bits are already
     run-to-run identical), and the result is the gradient of the stored-extent formulation (fp64 torch) at fp32 accuracy."""
+    if os.environ.get("M355_WGRAD_HALO_PART") == "0" or os.environ.get("M355_WGRAD_UP_PART") == "0":
+        pytest.skip("the A/B switch puts these layers back on atomics")
     conv = importlib.import_module("2dimageto3dmodel_amd.conv")
     N, H, W, Cin, Cout = case
     g = torch.Generator().manual_seed(37)
