@@ -194,7 +194,14 @@ __global__ __launch_bounds__(256) void k_affine_act(const act_t *__restrict__ x,
         for (int u = 0; u < 4; ++u) {
             const size_t i = i0 + u * stride;
             ok[u] = i < total;
+            // x is read ONCE, right after the conv wrote it: a non-temporal load (streamed past the caches) runs this kernel 6.5 %
+            // faster (1.22 -> 1.14 ms per cycle; non-temporal STORES of y cost 2 %, and the backward kernels' loads are indifferent:
+            // profiles/r06_nt_loads_ab.txt).  The residual is read four times through the upsample: ordinary loads.
+#ifndef M355_EXACT
+            v4[u] = ok[u] ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8e *>(xn + i * 8)) : bf16x8e{0, 0, 0, 0, 0, 0, 0, 0};
+#else
             v4[u] = ok[u] ? *reinterpret_cast<const bf16x8e *>(xn + i * 8) : bf16x8e{0, 0, 0, 0, 0, 0, 0, 0};
+#endif
         }
         if (rn) {
 #pragma unroll
