@@ -127,6 +127,45 @@ def test_discriminator_convs_batch128_sampled_vs_torch_cpu(pkg):
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("case", [
+    (128, 256, 256, 64, 128, 4, 2, 1, 1, 2, 0),    # D.conv2, the D step's 128 images: 64 partial rows per (co, ci, class) block
+    (128, 64, 64, 256, 512, 4, 2, 1, 1, 2, 0),     # D.conv4: 4 rows
+    (64, 128, 64, 128, 64, 3, 1, 1, 1, 1, 1),      # G.blk6.conv1 (sub-pixel form): 64 rows of the 16-entry effective gradient
+    (64, 64, 32, 128, 128, 3, 1, 1, 1, 1, 1),      # G.blk5.conv1: 16 rows
+])
+def test_partial_row_weight_gradients_at_the_timed_batch_against_the_exact_integer_sums(pkg, case):
+    """(round 6) at the benchmark's own sizes, on DENSE random gradients: the ordered sum of per-workgroup partial rows
+    (m355_conv2d_wgrad_ws, what conv_wgrad takes for these layers in every mode) against the same kernel's deterministic form
+    (m355_conv2d_wgrad_det: the partial tiles added as exact integers, rounded once) -- only the fp32 additions of the rows lie
+    between the two, so they agree to fp32 rounding of the sum; the fused bias gradient likewise; two launches give the same bits"""
+    import ctypes
+    conv = importlib.import_module("2dimageto3dmodel_amd.conv")
+    N, H, W, Cin, Cout, k, stride, ph, pw, mode, ups = case
+    d = conv.make_desc(N, H, W, Cin, Cout, k, k, stride, ph, pw, mode, ups)
+    pl = conv.plan(d)
+    if not pl.wgrad_ws_ordered:
+        pytest.skip("partial rows switched off (M355_WGRAD_HALO_PART / M355_WGRAD_UP_PART)")
+    g = torch.Generator(device=DEV).manual_seed(41)
+    ho, wo = conv.out_hw(d)
+    x = torch.randn((N, H, W, Cin), generator=g, device=DEV).bfloat16()
+    dy = torch.randn((N, ho, wo, Cout), generator=g, device=DEV).bfloat16()
+    db1, db2 = torch.empty(Cout, device=DEV), torch.empty(Cout, device=DEV)
+    dw1 = conv.conv_wgrad(d, x, dy, raw=True, dbias=db1).clone()
+    assert conv.lib().m355_last_kernel().decode() == "k_wgrad_halo"
+    dw1b = conv.conv_wgrad(d, x, dy, raw=True, dbias=db2)
+    assert torch.equal(dw1, dw1b) and torch.equal(db1, db2)
+    ws = torch.empty((pl.wgrad_det_ws_bytes,), dtype=torch.uint8, device=DEV)
+    dw2 = torch.empty_like(dw1)
+    conv.launch("conv2d_wgrad_det", ctypes.byref(d), conv.ptr(x), conv.ptr(dy), conv.ptr(ws), conv.ptr(dw2), conv.ptr(db2), conv.stream())
+    torch.cuda.synchronize()
+    assert torch.isfinite(dw2).all()
+    assert ((dw1 - dw2).abs().max() / dw2.abs().max()).item() < 2e-6
+    assert ((db1 - db2).abs().max() / db2.abs().max().clamp_min(1.0)).item() < 2e-6
+    del x, dy, ws
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.timeout(900)
 def test_generator_blocks_batch64_sampled_vs_torch_cpu(pkg):
     """ResBlockUp conv1 (nearest x2 upsample folded in) / conv2 of blk4, blk5, blk6 (models/gan.py:294-312,386-404; symmetric
     generator: replicate W pad) at batch 64, the 1x1 shortcut of blk6, and the 64 -> 3 head at 256 x 128"""
