@@ -34,14 +34,18 @@ def _ceil(a, b):
 # its kernels fill the gaps of the main branch instead of extending the step.  Measured (profiles/r04_streams.txt): at batch 16
 # under the hipGraph 10.74 -> 10.59 ms per cycle (-1.5 %); at batch 64 26.5 -> 26.7 ms (+0.5 %, WORSE): every big kernel already
 # holds the socket at its 1400 W limit, so concurrent work only takes clock from it -- the time of a power-capped step is its
-# energy, and overlap saves none.  Hence the rule: fork only up to FORK_MAX_BATCH samples (M355_STREAMS=0 never, =1 always).
+# energy, and overlap saves none.  Hence the rule: fork only up to FORK_MAX_BATCH samples PER LAUNCH (M355_STREAMS=0 never, =1 always;
+# M355_FORK_MAX_BATCH overrides).  Round 6 re-measured where the line is (profiles/r06_fork_threshold.txt): the all-or-nothing A/B at
+# batch 64 hid that the generator's mesh head (G step: 64 samples per launch) gains what the mesh discriminator beside the 128-sample
+# D step loses -- threshold 32 / 64 / 96 / 128: 24.52 / 24.14 / 24.12 / 24.56 ms per cycle at batch 64; batch 48: 19.73 -> 19.33,
+# batch 40: 17.36 -> 17.01.  96 it is.
 # Autograd replays each node on the stream its forward ran on and synchronises gradients crossing streams itself; what it does
 # not know about is handled here and in conv.py: tensors shared across the streams are record_stream()ed (the caching allocator
 # must not hand their memory to the other stream's next allocation while a kernel still reads it), the per-pass zero fills of
 # conv.WgradArena / DbiasBlock carry an event the other stream waits for, and conv.flush_wgrad_finish joins the side streams.
 _SIDE = {}          # device index -> side stream
 STREAMS_ON = os.environ.get("M355_STREAMS", "auto") != "0"
-FORK_MAX_BATCH = 1 << 30 if os.environ.get("M355_STREAMS") == "1" else 32
+FORK_MAX_BATCH = 1 << 30 if os.environ.get("M355_STREAMS") == "1" else int(os.environ.get("M355_FORK_MAX_BATCH", "96"))
 
 
 _SN_SIDE = {}       # device index -> the stream spectral-norm steps are prefetched on (SpectralNormGroup.prefetch)
