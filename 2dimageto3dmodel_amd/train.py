@@ -36,6 +36,10 @@ def ema_alpha(alpha, epoch):
     return alpha
 
 
+# which of the three spectral-norm prefetch sites are taken (bit 0: the discriminator's chain under the G step's backward, bit 1: the
+# generator's under the D step, bit 2: the discriminator's after its optimiser step): A/B switch, all on by default
+_SN_SITES = int(os.environ.get("M355_SN_PREFETCH_SITES", "7"))
+
 class GanTrainer(torch.nn.Module):
     def __init__(self, args, latent_dim=64, lr_g=1e-4, lr_d=4e-4, d_steps_per_g=2, loss="hinge", device="cuda",
                  symmetric_g=True, use_mesh=True, ema_alpha=0.999, capturable=False, mesh_template=None,
@@ -108,14 +112,14 @@ class GanTrainer(torch.nn.Module):
             X_fake = O.MaskedInput(pred_tex, X_alpha)                  # cat((pred_tex * X_alpha, X_alpha), dim=1), built in D's loaders
             disc, mask = self.discriminator(X_fake, pred_mesh, C, caption)
             if not self._pending_d:
-                self._prefetch_sn(self.discriminator)                  # (for the next D step, under this step's backward)
+                self._prefetch_sn(self.discriminator, site=0)          # (for the next D step, under this step's backward)
             loss = self.criterion_gan(disc, True, for_discriminator=False, mask=mask, weight=w)
             return loss, pred_tex, pred_mesh
         if mode == 'd':
             with torch.no_grad():
                 pred_tex, pred_mesh = self.generator(noise, C, caption)
                 # (the generator is not updated before its next forward -- the next D step's, or the next cycle's G step's)
-                self._prefetch_sn(self.generator, cross_cycle=(self.total_it + 1) % (1 + self.d_steps_per_g) == 0)
+                self._prefetch_sn(self.generator, cross_cycle=(self.total_it + 1) % (1 + self.d_steps_per_g) == 0, site=1)
                 assert (X_mesh is None) == (pred_mesh is None)
                 # cat((cat((pred_tex * X_alpha, X_alpha), 1), cat((X_tex, X_alpha), 1)), 0) in one pass
                 X_comb = O.MaskedInput(pred_tex, X_alpha, X_tex)
@@ -144,7 +148,7 @@ class GanTrainer(torch.nn.Module):
             self.optimizer_d.step()
             # (total_it already counts the pending step: a multiple of the cycle length = that step closed a cycle, and the forward this
             # prefetch serves belongs to the next one -- not issued inside a hipGraph capture, which must end with every stream joined)
-            self._prefetch_sn(self.discriminator, cross_cycle=self.total_it % (1 + self.d_steps_per_g) == 0)
+            self._prefetch_sn(self.discriminator, cross_cycle=self.total_it % (1 + self.d_steps_per_g) == 0, site=2)
 
     # ---- spectral norm ahead of its forward (gan_ops.SpectralNormGroup.prefetch).  A network's power iteration + bf16 weight views
     # depend on its weights and u / v only, so they are issued on a second stream as soon as those are final for the next forward:
@@ -155,7 +159,9 @@ class GanTrainer(torch.nn.Module):
     #                   generator's state_dict, main.py:431-447) and the next forward is the very next thing on the stream.
     # Inside a hipGraph capture the prefetch that would cross into the NEXT cycle is skipped (the graph must end with every stream
     # joined, and the next replay recomputes from the live u / v).
-    def _prefetch_sn(self, net, cross_cycle=False):
+    def _prefetch_sn(self, net, cross_cycle=False, site=0):
+        if not (_SN_SITES >> site) & 1:
+            return
         if cross_cycle and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
             return
         net._sn_group().prefetch(net.training)
@@ -267,7 +273,7 @@ class GanTrainer(torch.nn.Module):
             else:
                 self.reduce_d()
                 self.optimizer_d.step()
-                self._prefetch_sn(self.discriminator, cross_cycle=(self.total_it + 1) % (1 + self.d_steps_per_g) == 0)
+                self._prefetch_sn(self.discriminator, cross_cycle=(self.total_it + 1) % (1 + self.d_steps_per_g) == 0, site=2)
             out = {"d_fake": loss_fake.detach(), "d_real": loss_real.detach()}
         self.total_it += 1
         return out
