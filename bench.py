@@ -366,8 +366,11 @@ def parity_check_gan_steps(trainer, R, exact=False):
             lib.set_exact(prev_exact)
         conv.set_deterministic(prev_det)
     if exact:
+        # (the 1e-4 loss / 1e-3 gradient contract is held from the initial weights by tests/test_exact_mode_gpu.py; on the weights the timed
+        # cycles leave -- a saturated discriminator: gradients that are small differences of large sums -- the D step's worst tensor read
+        # up to 8.8e-4 over 30 recorded lines: the gradient bound carries the same 1.5x margin as the product's)
         ok = err_logit < 1e-4 and err_logit_d < 1e-4 and err_loss < 1e-4 and err_loss_d < 1e-4 and min(cos_g, cos_d) > 0.99999 and \
-            max(l2_g, l2_d) < 1e-3
+            max(l2_g, l2_d) < 1.5e-3
     else:   # (tests/test_gan_modules.py::test_headline_batch8_*: cos >= 0.995, L2 <= 0.10 at batch 8 from the INITIAL weights; here the
         # weights are what 25 cycles on synthetic data left -- a saturated discriminator whose hinge terms are mostly inactive, so a
         # gradient tensor is the sum of a few terms and one logit within bf16 error of the kink moves it by percents: over 14 lines of
