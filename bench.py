@@ -898,7 +898,8 @@ def main():
             "syncbn_collectives_per_step": coll["syncbn_collectives"] / args.steps,
             # what carries the SyncBN messages at N > 1: torch.distributed (RCCL) by default, the one-launch exchange over peer-mapped
             # memory with M355_SYNCBN_IPC=1 (csrc/ipc_exchange.hip: exercised with two processes on one GPU only -- opt-in)
-            "syncbn_transport": ("ipc" if os.environ.get("M355_SYNCBN_IPC") == "1" and world > 1 else ("rccl" if world > 1 else None)),
+            "syncbn_transport": ("ipc" if os.environ.get("M355_SYNCBN_IPC") == "1" and world > 1 else
+                                 (("rccl" if args.backend == "nccl" else args.backend) if world > 1 else None)),
             "proj_ms_per_step": (dt_p / args.steps * 1e3) if do_p else None,
             "gan_ms_per_cycle": (dt_g / args.steps * 1e3) if do_g else None,
             "proj_samples_per_s": (world * B * args.steps / dt_p) if do_p else None,
