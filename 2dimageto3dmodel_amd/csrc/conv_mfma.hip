@@ -1961,6 +1961,7 @@ __global__ __launch_bounds__(256) void k_up16_rows_to_9(const float *__restrict_
         const size_t t = i / Cin;
         const int tap = (int)(t % 9), co = (int)(t / 9), kh = tap / 3, kw = tap - 3 * kh;
         const size_t b = (((size_t)co * 4 + kh) * 4 + kw) * Cin + ci;   // entry (kh, kw); (kh+1, .) is 4 Cin further, (., kw+1) Cin
+#pragma unroll 4
         for (int r = 0; r < rows; ++r) {
             const float *p = part + (size_t)r * stride + b;
             s2[r & 1] += (p[0] + p[Cin]) + (p[4 * (size_t)Cin] + p[5 * (size_t)Cin]);

@@ -461,22 +461,50 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_smallco(SmallWgArgs a)
         }
 }
 
-// dw[e] = part[0][e] + part[1][e] + ... (workgroup order: deterministic), e < n; optionally the same for a bias tail
+// dw[e] = sum over the rows of part[row][e], e < n; optionally the same for a bias tail.  A FIXED summation tree, the same on every run: a
+// workgroup owns 256 / RG outputs; RG groups of its threads take 1 / RG of the rows each (four interleaved accumulators per thread, added
+// in a fixed order), the groups are added in order through LDS.  RG = 4 for many rows (round 6: one thread per output walking all rows
+// -- RG = 1, n / 256 workgroups -- had 51 workgroups and four loads in flight per thread for D.conv1's 256 rows of 12.9 k floats: 22 us
+// for 13 MB; per-launch constant of that layer 36 -> 22 us, of the sub-pixel fold 31 -> 17 us); RG = 1 below 16 rows (D.conv4's 4 rows
+// of 2 M floats are bandwidth, not latency).
+template <int RG>
 __global__ __launch_bounds__(256) void k_wgrad_part_sum(const float *__restrict__ part, int nwg, size_t stride, float *__restrict__ dw, size_t n,
                                                         float *__restrict__ db, int nb)
 {
-    const size_t e = blockIdx.x * (size_t)256 + threadIdx.x;
-    if (e >= n + (db ? (size_t)nb : 0)) return;
+    constexpr int OUT = 256 / RG;
+    __shared__ float red[RG][OUT];
+    const int o = threadIdx.x % OUT, rg = threadIdx.x / OUT;
+    const size_t e = blockIdx.x * (size_t)OUT + o, total = n + (db ? (size_t)nb : 0);
+    const int q = (nwg + RG - 1) / RG, g0 = rg * q, g1 = min(nwg, g0 + q);
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-    int g = 0;
-    for (; g + 4 <= nwg; g += 4) {
+    if (e < total) {
+        int g = g0;
+        for (; g + 4 <= g1; g += 4) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) s[u] += part[(size_t)(g + u) * stride + e];
+            for (int u = 0; u < 4; ++u) s[u] += part[(size_t)(g + u) * stride + e];
+        }
+        for (; g < g1; ++g) s[0] += part[(size_t)g * stride + e];
     }
-    for (; g < nwg; ++g) s[0] += part[(size_t)g * stride + e];
-    const float t = (s[0] + s[1]) + (s[2] + s[3]);
-    if (e < n) dw[e] = t;
-    else db[e - n] = t;
+    float t = (s[0] + s[1]) + (s[2] + s[3]);
+    if (RG > 1) {
+        red[rg][o] = t;
+        __syncthreads();
+        if (rg != 0) return;
+        t = red[0][o];
+#pragma unroll
+        for (int k = 1; k < RG; ++k) t += red[k][o];
+    }
+    if (e < total) {
+        if (e < n) dw[e] = t;
+        else db[e - n] = t;
+    }
+}
+// (the choice is a function of the row count only: the same tree on every run)
+static void part_sum_launch(const float *part, int rows, size_t stride, float *dw, size_t n, float *db, int nb, hipStream_t st)
+{
+    const size_t total = n + (db ? (size_t)nb : 0);
+    if (rows >= 16) hipLaunchKernelGGL(k_wgrad_part_sum<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, part, rows, stride, dw, n, db, nb);
+    else hipLaunchKernelGGL(k_wgrad_part_sum<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, rows, stride, dw, n, db, nb);
 }
 
 bool wgrad_small_eligible(const m355_conv_desc *d, int Cy)
@@ -525,8 +553,7 @@ int wgrad_small_launch(const m355_conv_desc *d, const void *x, const void *dy, i
 #undef M355_SW
     if (part) {
         const size_t n = (size_t)d->Cout * d->kh * d->kw * d->Cin;
-        hipLaunchKernelGGL(k_wgrad_part_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float *)part, gx, n, dw, n,
-                           (float *)nullptr, 0);
+        part_sum_launch((const float *)part, gx, n, dw, n, nullptr, 0, st);
     }
     note_kernel("k_wgrad_smallco");
     return check_launch("conv2d_wgrad (small Cout)");
@@ -804,7 +831,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_c8(C8Args a)
 // rows of per-workgroup partial sums [rows][n + nb] -> dw[n] (+ db[nb]), added in row order (used by the halo weight gradients too)
 int wgrad_part_sum_launch(const float *part, int rows, size_t stride, float *dw, size_t n, float *db, int nb, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_wgrad_part_sum, dim3((unsigned)((n + (db ? (size_t)nb : 0) + 255) / 256)), dim3(256), 0, st, part, rows, stride, dw, n, db, nb);
+    part_sum_launch(part, rows, stride, dw, n, db, nb, st);
     return check_launch("conv2d_wgrad (ordered sum of the partial rows)");
 }
 
@@ -1377,8 +1404,7 @@ int wgrad_c8_launch(const m355_conv_desc *d, const void *x, const void *dy, int 
     if (part) {
         // every (pixel-axis workgroup) row holds the partial of ALL output channels (blockIdx.y writes its own 64): sum the rows
         const size_t n = (size_t)d->Cout * 200;
-        hipLaunchKernelGGL(k_wgrad_part_sum, dim3((unsigned)((n + d->Cout + 255) / 256)), dim3(256), 0, st, (const float *)part, gx,
-                           (size_t)d->Cout * 201, dw, n, db, d->Cout);
+        part_sum_launch((const float *)part, gx, (size_t)d->Cout * 201, dw, n, db, d->Cout, st);
     }
     note_kernel("k_wgrad_c8");
     return check_launch("conv2d_wgrad (8 input channels, planar)");
